@@ -1,0 +1,218 @@
+/*
+ * vits_mi355.h — C ABI of the MI355X-native VITS2 inference path.
+ *
+ * This is the drop-in boundary for ONE call in the reference:
+ *
+ *     audio = self.model.onnx.run(None, args)[0]          vosk_tts/synth.py:123-126
+ *
+ * where self.model.onnx is onnxruntime.InferenceSession(model.onnx)
+ * (vosk_tts/model.py:43-46) executing the graph exported from
+ * SynthesizerTrn.infer (training/vits2/models.py:1679-1704) by
+ * training/vits2/onnx_export.py:61-104.  Feed/outputs of that graph:
+ *   "input" int64 [B,T_x], "input_lengths" int64 [B], "scales" float32 [3] =
+ *   [noise_scale, length_scale, noise_scale_w] (onnx_export.py:62-64),
+ *   "sid" int64 [B]  ->  "output" float32 [B,1,1,S]   (onnx_export.py:65-72,97-98)
+ *
+ * All entry points are extern "C", take plain pointers and sizes, return an int
+ * status (0 = ok) and never throw.  Two libraries export this same ABI:
+ *   libvits_mi355.so  — the product: hand-written HIP kernels for gfx950
+ *   oracle/libvits_oracle.so — TEST INFRASTRUCTURE: scalar CPU restatement of the
+ *                              reference arithmetic (exports the vits_* stage symbols
+ *                              with the prefix vitsref_ instead of vits_)
+ *
+ * Layout conventions: every activation tensor is channel-major contiguous
+ * [B, C, T] float32 (the reference's layout), ids/lengths are int64 like the
+ * ONNX feed, durations are int32.
+ */
+#ifndef VITS_MI355_H
+#define VITS_MI355_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITS_ABI_VERSION 1
+#define VITS_MAX_UPS 4
+#define VITS_MAX_RESK 4
+#define VITS_MAX_RESD 4
+
+/* Status codes */
+#define VITS_OK 0
+#define VITS_ERR_ARG 1      /* bad argument (null pointer, bad size, id out of range) */
+#define VITS_ERR_BLOB 2     /* weight blob malformed / tensor missing / shape mismatch */
+#define VITS_ERR_DEVICE 3   /* HIP runtime error (message in vits_last_error) */
+#define VITS_ERR_UNSUPPORTED 4
+#define VITS_ERR_NOMEM 5
+
+/*
+ * Hyper-parameters of the graph; mirrors the "model"/"data" sections of
+ * training/vits2/configs/mb_istft_vits2_multi.json (line numbers in comments)
+ * plus the constants hard-coded in models.py.  All fields are 4 bytes; the struct
+ * is stored verbatim in the weight blob header.
+ */
+typedef struct vits_hparams {
+  int32_t abi_version;       /* VITS_ABI_VERSION */
+  int32_t n_vocab;           /* len(symbols); 62 for text/symbols.py */
+  int32_t hidden_channels;   /* json:57  192 */
+  int32_t inter_channels;    /* json:56  192 */
+  int32_t filter_channels;   /* json:58  768 */
+  int32_t n_heads;           /* json:59  2 */
+  int32_t n_layers;          /* json:60  6 */
+  int32_t kernel_size;       /* json:61  3  (text-encoder FFN) */
+  int32_t window_size;       /* attentions.py:15 default 4 */
+  int32_t gin_channels;      /* json:72  256 */
+  int32_t n_speakers;        /* json:37  200 */
+  int32_t enc_cond_layer;    /* attentions.py:38  2 (speaker add before this layer); -1 = no speaker-conditioned encoder */
+  int32_t dp_filter_channels;/* models.py:1625  256 */
+  int32_t dp_kernel_size;    /* models.py:1625  3 */
+  int32_t dp_n_flows;        /* models.py:1625  4 */
+  int32_t dp_num_bins;       /* modules.py:347  10 */
+  int32_t dp_dds_layers;     /* models.py:38  3 */
+  int32_t flow_n_flows;      /* models.py:636  4 */
+  int32_t flow_wn_layers;    /* models.py:1617  4 */
+  int32_t flow_kernel_size;  /* models.py:1615  5 (WN conv and pre-transformer FFN kernel) */
+  int32_t flow_dilation_rate;/* models.py:1616  1 */
+  int32_t dec_type;          /* 0 = Multiband_iSTFT_Generator (models.py:974), 1 = Generator (models.py:845) */
+  int32_t dec_initial_channel;/* json:67 512 */
+  int32_t n_ups;             /* len(json:66) 2 */
+  int32_t up_rates[VITS_MAX_UPS];   /* json:66 [4,4] */
+  int32_t up_kernels[VITS_MAX_UPS]; /* json:68 [16,16] */
+  int32_t n_resk;            /* len(json:64) 3 */
+  int32_t res_kernels[VITS_MAX_RESK];  /* json:64 [3,7,11] */
+  int32_t n_resd;            /* 3 */
+  int32_t res_dilations[VITS_MAX_RESK][VITS_MAX_RESD]; /* json:65 */
+  int32_t subbands;          /* json:53 4 */
+  int32_t istft_n_fft;       /* json:54 16 */
+  int32_t istft_hop;         /* json:55 4 */
+  int32_t pqmf_taps;         /* pqmf.py:53 62 */
+  float   pqmf_cutoff;       /* pqmf.py:53 0.15 */
+  float   pqmf_beta;         /* pqmf.py:53 9.0 */
+  float   dp_tail_bound;     /* modules.py:347 5.0 */
+  int32_t sampling_rate;     /* json:29 22050 */
+  int32_t hop_length;        /* json:31 256 */
+  int32_t reserved[8];
+} vits_hparams;
+
+/*
+ * Weight blob ("VITSW001"), little-endian, produced by vosk_tts_amd/weights.py:
+ *   char     magic[8]                      "VITSW001"
+ *   uint32   hparams_bytes                 sizeof(vits_hparams)
+ *   vits_hparams hp
+ *   uint32   n_tensors
+ *   n_tensors x vits_blob_entry
+ *   ... float32 data, each tensor 64-byte aligned, `offset` from start of blob
+ * Tensor names are the reference's state_dict keys after remove_weight_norm
+ * (onnx_export.py:77-80), e.g. "dec.resblocks.0.convs1.0.weight".
+ */
+typedef struct vits_blob_entry {
+  char     name[96];
+  uint32_t ndim;
+  uint32_t dims[4];
+  uint32_t pad_;
+  uint64_t offset;
+  uint64_t nelem;
+} vits_blob_entry;
+
+typedef struct vits_model vits_model; /* opaque */
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Parses the blob, uploads and re-lays-out weights for the MFMA kernels on
+ * HIP device `device`.  Replaces onnxruntime.InferenceSession(...) (model.py:46). */
+int vits_create(const void* blob, size_t blob_bytes, int device, vits_model** out);
+void vits_destroy(vits_model* m);
+/* Thread-local message for the last non-zero status returned on this thread. */
+const char* vits_last_error(void);
+int vits_get_hparams(const vits_model* m, vits_hparams* out);
+/* Returns 1 for the HIP library, 0 for the CPU oracle. */
+int vits_is_device_backend(void);
+
+/* ---- the hot path: one .run() --------------------------------------------- */
+
+/* Options beyond the ONNX feed.  All optional pointers may be NULL.
+ * The reference draws exactly two noise tensors per call (models.py:96 and :1700);
+ * parity runs inject them, production runs use the library's Philox stream. */
+typedef struct vits_synth_opts {
+  const float*   noise_dp;         /* [B,2,T_x]  replaces torch.randn at models.py:96 (before * noise_scale_w) */
+  const float*   noise_prior;      /* [B,inter,T_y_max] replaces randn_like at models.py:1700; row stride = noise_prior_stride */
+  int64_t        noise_prior_stride;/* T dimension stride of noise_prior (>= max T_y) */
+  const int32_t* forced_durations; /* [B,T_x] replaces w_ceil (models.py:1690); skips nothing else */
+  uint64_t       seed;             /* Philox seed when noise_* are NULL */
+  int32_t        max_frames;       /* 0 = unlimited; capacity bound on T_y per item (error if exceeded) */
+  int32_t        flags;            /* VITS_FLAG_* */
+} vits_synth_opts;
+
+#define VITS_FLAG_NONE 0
+
+/* Host-buffer entry point (what the Python Session.run adapter calls).
+ *   ids      int64 [B,T_x] (padded with anything past lengths[b])
+ *   lengths  int64 [B]
+ *   scales   float [3] = [noise_scale, length_scale, noise_scale_w]
+ *   sid      int64 [B] (ignored when n_speakers <= 1)
+ * On success *out_audio points to a library-owned float [B, *out_samples] buffer
+ * (row b valid for out_lengths[b] samples, rest is what the reference's padded
+ * batch produces), to be released with vits_free_output.  Re-entrant: each call
+ * uses its own workspace and HIP stream. */
+int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths,
+                    int32_t B, int32_t T_x, const float* scales, const int64_t* sid,
+                    const vits_synth_opts* opts,
+                    float** out_audio, int64_t* out_samples, int64_t* out_lengths);
+void vits_free_output(float* p);
+
+/* Device-resident variant used by bench.py: ids/lengths/sid already in HBM
+ * (int64 device pointers), audio written to a caller-provided device buffer
+ * [B, audio_capacity].  Durations must be forced (device int32 [B,T_x]) or
+ * opts->max_frames set so no host round trip is needed to size buffers; the
+ * call is asynchronous on `stream` (a hipStream_t) unless stream == NULL. */
+typedef struct vits_session vits_session; /* per-thread workspace + stream + graph cache */
+int vits_session_create(vits_model* m, int32_t max_B, int32_t max_Tx, int32_t max_Ty, vits_session** out);
+void vits_session_destroy(vits_session* s);
+int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const int64_t* d_lengths,
+                                   int32_t B, int32_t T_x, const float* scales, const int64_t* d_sid,
+                                   const int32_t* d_forced_durations, int32_t T_y_max, uint64_t seed,
+                                   float* d_audio, int64_t audio_capacity, void* stream);
+/* Elapsed device time (ms) of the last vits_session_synthesize_device call,
+ * measured with HIP events on the session stream (blocks until it completes). */
+int vits_session_last_ms(vits_session* s, float* ms);
+
+/* ---- stage-level entry points (parity tests; host buffers in/out) -------- */
+
+/* a2: TextEncoder.forward (models.py:317-326).  out x,m_p,logs_p: [B,hidden|inter,T_x] */
+int vits_stage_text_encoder(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t T_x,
+                            const int64_t* sid, float* x, float* m_p, float* logs_p);
+/* a6: StochasticDurationPredictor.forward(reverse=True) (models.py:56-63,93-101).
+ * x [B,hidden,T_x] (encoder output), noise [B,2,T_x] (unit normal), out logw [B,T_x] */
+int vits_stage_duration(vits_model* m, const float* x, const int64_t* lengths, int32_t B, int32_t T_x,
+                        const int64_t* sid, const float* noise, float noise_scale_w, float* logw);
+/* a10+a11: length regulator + prior sample (models.py:1689-1700).
+ * If forced_durations != NULL logw is ignored.  out durations int32 [B,T_x], y_lengths int64 [B];
+ * z_p [B,inter,T_y_cap] with row stride T_y_cap (noise has the same stride). */
+int vits_stage_regulate(vits_model* m, const float* logw, const int32_t* forced_durations,
+                        const int64_t* lengths, int32_t B, int32_t T_x, float length_scale,
+                        const float* m_p, const float* logs_p, const float* noise, float noise_scale,
+                        int32_t T_y_cap, int32_t* durations, int64_t* y_lengths, float* z_p);
+/* a12: ResidualCouplingTransformersBlock.forward(reverse=True) (models.py:750-757).
+ * z_p, z: [B,inter,T_y] contiguous */
+int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, int32_t B, int32_t T_y,
+                    const int64_t* sid, float* z);
+/* a15-a20: dec((z*y_mask)) (models.py:1016-1054, :1703).  z [B,inter,T_y] already masked.
+ * audio [B, T_y*hop_length]; audio_mb [B,subbands,T_y*hop/subbands] may be NULL. */
+int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t T_y, float* audio, float* audio_mb);
+
+/* Single generic op for kernel-level parity: y = conv1d(act(x)) with the library's
+ * main MFMA conv kernel.  x [B,C_in,T], w [C_out,C_in,K] (PyTorch layout), bias may be NULL.
+ * lrelu_slope == 1.0f means no activation. */
+int vits_op_conv1d(int device, const float* x, const float* w, const float* bias, int32_t B, int32_t C_in,
+                   int32_t C_out, int32_t T, int32_t K, int32_t dilation, float lrelu_slope, float* y);
+
+/* Algorithmic FLOPs of one forward (SURVEY.md §8a/§8d formula evaluated on the
+ * model's own hparams): used by bench.py for the roofline line. */
+double vits_algorithmic_flops(const vits_model* m, int32_t B, int32_t T_x, int32_t T_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITS_MI355_H */

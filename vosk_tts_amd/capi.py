@@ -1,0 +1,261 @@
+"""ctypes binding of the C ABI declared in include/vits_mi355.h.
+
+`VitsLib()` loads the product library (vosk_tts_amd/csrc/libvits_mi355.so, the
+hand-written HIP kernels) and fails loudly when it is missing — there is no CPU
+fallback in the product path.  The class takes an explicit (path, prefix) only
+so that tests can drive the CPU oracle (oracle/libvits_oracle.so, prefix
+"vitsref_") through the very same wrapper and compare results.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .weights import HParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libvits_mi355.so")
+
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class SynthOpts(ctypes.Structure):
+    """mirror of `struct vits_synth_opts`"""
+
+    _fields_ = [
+        ("noise_dp", c_f32p),
+        ("noise_prior", c_f32p),
+        ("noise_prior_stride", ctypes.c_int64),
+        ("forced_durations", c_i32p),
+        ("seed", ctypes.c_uint64),
+        ("max_frames", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+    ]
+
+
+class VitsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vits error {code}: {msg}")
+        self.code = code
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+EXPORTED = [
+    "create", "destroy", "last_error", "get_hparams", "is_device_backend", "synthesize", "free_output",
+    "stage_text_encoder", "stage_duration", "stage_regulate", "stage_flow", "stage_decoder", "op_conv1d",
+    "algorithmic_flops",
+]
+DEVICE_ONLY = ["session_create", "session_destroy", "session_synthesize_device", "session_last_ms"]
+
+
+class VitsLib:
+    def __init__(self, path=None, prefix="vits_"):
+        path = path or os.environ.get("VITS_MI355_LIB", DEFAULT_LIB)
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback in the product path."
+            )
+        self.path = path
+        self.prefix = prefix
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        f = self._fn
+        f("create").argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        f("destroy").argtypes = [ctypes.c_void_p]
+        f("destroy").restype = None
+        f("last_error").restype = ctypes.c_char_p
+        f("get_hparams").argtypes = [ctypes.c_void_p, ctypes.POINTER(HParams)]
+        f("synthesize").argtypes = [ctypes.c_void_p, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_i64p,
+                                    ctypes.POINTER(SynthOpts), ctypes.POINTER(c_f32p), c_i64p, c_i64p]
+        f("free_output").argtypes = [c_f32p]
+        f("free_output").restype = None
+        f("stage_text_encoder").argtypes = [ctypes.c_void_p, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p,
+                                            c_f32p, c_f32p, c_f32p]
+        f("stage_duration").argtypes = [ctypes.c_void_p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p,
+                                        ctypes.c_float, c_f32p]
+        f("stage_regulate").argtypes = [ctypes.c_void_p, c_f32p, c_i32p, c_i64p, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_float, ctypes.c_int32, c_i32p,
+                                        c_i64p, c_f32p]
+        f("stage_flow").argtypes = [ctypes.c_void_p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p]
+        f("stage_decoder").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p]
+        f("op_conv1d").argtypes = [ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p]
+        f("algorithmic_flops").argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        f("algorithmic_flops").restype = ctypes.c_double
+        self.is_device = bool(f("is_device_backend")())
+        if self.is_device:
+            f("session_create").argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.POINTER(ctypes.c_void_p)]
+            f("session_destroy").argtypes = [ctypes.c_void_p]
+            f("session_destroy").restype = None
+            f("session_synthesize_device").argtypes = [
+                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_f32p,
+                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64,
+                ctypes.c_void_p]
+            f("session_last_ms").argtypes = [ctypes.c_void_p, c_f32p]
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    def check(self, rc):
+        if rc != 0:
+            raise VitsError(rc, self._fn("last_error")().decode(errors="replace"))
+
+    def create(self, blob, device=0):
+        return VitsModel(self, blob, device)
+
+
+class VitsModel:
+    """Owns one vits_model* (weights resident on one device)."""
+
+    def __init__(self, lib, blob, device=0):
+        self.lib = lib
+        self._h = ctypes.c_void_p()
+        buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+        lib.check(lib._fn("create")(ctypes.cast(buf, ctypes.c_void_p), len(blob), device, ctypes.byref(self._h)))
+        self.hp = HParams()
+        lib.check(lib._fn("get_hparams")(self._h, ctypes.byref(self.hp)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self.lib._fn("destroy")(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path -----------------------------------------------------
+    def synthesize(self, ids, lengths, scales, sid, noise_dp=None, noise_prior=None, forced_durations=None, seed=0,
+                   max_frames=0):
+        """One .run(): returns (audio float32 [B,S], out_lengths int64 [B])."""
+        ids = _i64(ids)
+        B, Tx = ids.shape
+        lengths = _i64(lengths)
+        sid = _i64(sid)
+        scales = _f32(scales)
+        if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
+            raise ValueError("bad feed shapes")
+        opts = SynthOpts()
+        keep = []
+        if noise_dp is not None:
+            a = _f32(noise_dp); keep.append(a)
+            if a.shape != (B, 2, Tx):
+                raise ValueError("noise_dp must be [B,2,T_x]")
+            opts.noise_dp = _p(a, c_f32p)
+        if noise_prior is not None:
+            a = _f32(noise_prior); keep.append(a)
+            if a.ndim != 3 or a.shape[0] != B or a.shape[1] != self.hp.inter_channels:
+                raise ValueError("noise_prior must be [B,inter,T]")
+            opts.noise_prior = _p(a, c_f32p)
+            opts.noise_prior_stride = a.shape[2]
+        if forced_durations is not None:
+            a = _i32(forced_durations); keep.append(a)
+            if a.shape != (B, Tx):
+                raise ValueError("forced_durations must be [B,T_x]")
+            opts.forced_durations = _p(a, c_i32p)
+        opts.seed = seed
+        opts.max_frames = max_frames
+        out = c_f32p()
+        ns = ctypes.c_int64()
+        olen = np.zeros(B, dtype=np.int64)
+        self.lib.check(self.lib._fn("synthesize")(self._h, _p(ids, c_i64p), _p(lengths, c_i64p), B, Tx, _p(scales, c_f32p),
+                                                  _p(sid, c_i64p), ctypes.byref(opts), ctypes.byref(out),
+                                                  ctypes.byref(ns), _p(olen, c_i64p)))
+        try:
+            audio = np.ctypeslib.as_array(out, shape=(B, ns.value)).copy()
+        finally:
+            self.lib._fn("free_output")(out)
+        return audio, olen
+
+    # ---- stage-level entry points (parity tests) ---------------------------
+    def text_encoder(self, ids, lengths, sid):
+        ids = _i64(ids); lengths = _i64(lengths); sid = _i64(sid)
+        B, T = ids.shape
+        H, I = self.hp.hidden_channels, self.hp.inter_channels
+        x = np.empty((B, H, T), np.float32); m_p = np.empty((B, I, T), np.float32); logs_p = np.empty((B, I, T), np.float32)
+        self.lib.check(self.lib._fn("stage_text_encoder")(self._h, _p(ids, c_i64p), _p(lengths, c_i64p), B, T,
+                                                          _p(sid, c_i64p), _p(x, c_f32p), _p(m_p, c_f32p), _p(logs_p, c_f32p)))
+        return x, m_p, logs_p
+
+    def duration(self, x, lengths, sid, noise, noise_scale_w):
+        x = _f32(x); lengths = _i64(lengths); sid = _i64(sid); noise = _f32(noise)
+        B, _, T = x.shape
+        logw = np.empty((B, T), np.float32)
+        self.lib.check(self.lib._fn("stage_duration")(self._h, _p(x, c_f32p), _p(lengths, c_i64p), B, T, _p(sid, c_i64p),
+                                                      _p(noise, c_f32p), noise_scale_w, _p(logw, c_f32p)))
+        return logw
+
+    def regulate(self, logw, forced, lengths, length_scale, m_p, logs_p, noise, noise_scale, T_cap):
+        lengths = _i64(lengths)
+        B = lengths.shape[0]
+        logw = _f32(logw) if logw is not None else None
+        forced = _i32(forced) if forced is not None else None
+        T = (logw if logw is not None else forced).shape[-1]
+        m_p = _f32(m_p); logs_p = _f32(logs_p)
+        noise = _f32(noise) if noise is not None else None
+        I = self.hp.inter_channels
+        dur = np.zeros((B, T), np.int32); ylen = np.zeros(B, np.int64)
+        z_p = np.zeros((B, I, T_cap), np.float32)
+        self.lib.check(self.lib._fn("stage_regulate")(self._h, _p(logw, c_f32p), _p(forced, c_i32p), _p(lengths, c_i64p), B, T,
+                                                      length_scale, _p(m_p, c_f32p), _p(logs_p, c_f32p), _p(noise, c_f32p),
+                                                      noise_scale, T_cap, _p(dur, c_i32p), _p(ylen, c_i64p), _p(z_p, c_f32p)))
+        return dur, ylen, z_p
+
+    def flow(self, z_p, y_lengths, sid):
+        z_p = _f32(z_p); y_lengths = _i64(y_lengths); sid = _i64(sid)
+        B, _, T = z_p.shape
+        z = np.empty_like(z_p)
+        self.lib.check(self.lib._fn("stage_flow")(self._h, _p(z_p, c_f32p), _p(y_lengths, c_i64p), B, T, _p(sid, c_i64p),
+                                                  _p(z, c_f32p)))
+        return z
+
+    def decoder(self, z, want_mb=True):
+        z = _f32(z)
+        B, _, T = z.shape
+        hop = self.hp.hop_length
+        audio = np.empty((B, T * hop), np.float32)
+        mb = None
+        if want_mb and self.hp.dec_type == 0:
+            mb = np.empty((B, self.hp.subbands, T * hop // self.hp.subbands), np.float32)
+        self.lib.check(self.lib._fn("stage_decoder")(self._h, _p(z, c_f32p), B, T, _p(audio, c_f32p), _p(mb, c_f32p)))
+        return audio, mb
+
+    def algorithmic_flops(self, B, Tx, Ty):
+        return float(self.lib._fn("algorithmic_flops")(self._h, B, Tx, Ty))
+
+
+def op_conv1d(lib, x, w, bias, dilation=1, lrelu_slope=1.0, device=0):
+    x = _f32(x); w = _f32(w)
+    bias = _f32(bias) if bias is not None else None
+    B, Cin, T = x.shape
+    Cout, Cin2, K = w.shape
+    assert Cin == Cin2
+    y = np.empty((B, Cout, T), np.float32)
+    lib.check(lib._fn("op_conv1d")(device, _p(x, c_f32p), _p(w, c_f32p), _p(bias, c_f32p), B, Cin, Cout, T, K, dilation,
+                                   lrelu_slope, _p(y, c_f32p)))
+    return y
