@@ -1,0 +1,84 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_SO = os.path.join(ROOT, "oracle", "libvits_oracle.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle (test infrastructure).  Built on demand with gcc."""
+    from vosk_tts_amd.capi import VitsLib
+
+    src = os.path.join(ROOT, "oracle", "vits_oracle.c")
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    return VitsLib(ORACLE_SO, "vitsref_")
+
+
+@pytest.fixture(scope="session")
+def default_blob():
+    from vosk_tts_amd import weights as W
+
+    return W.synthetic_blob(W.default_hparams(), 1234)
+
+
+@pytest.fixture(scope="session")
+def tiny_blob():
+    from vosk_tts_amd import weights as W
+
+    return W.synthetic_blob(W.tiny_hparams(), 1234)
+
+
+@pytest.fixture(scope="session")
+def oracle_default(oracle_lib, default_blob):
+    return oracle_lib.create(default_blob)
+
+
+@pytest.fixture(scope="session")
+def oracle_tiny(oracle_lib, tiny_blob):
+    return oracle_lib.create(tiny_blob)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library (HIP kernels).  Fails loudly if it is not built."""
+    from vosk_tts_amd.capi import VitsLib
+
+    return VitsLib()
+
+
+@pytest.fixture(scope="session")
+def hip_default(hip_lib, default_blob):
+    return hip_lib.create(default_blob, 0)
+
+
+@pytest.fixture(scope="session")
+def hip_tiny(hip_lib, tiny_blob):
+    return hip_lib.create(tiny_blob, 0)
+
+
+def assert_close(name, ref, got, rtol, atol_frac=None):
+    """max|ref-got| <= rtol * max|ref| (the north_star's 'relative fp32 tolerance' is on
+    the tensor scale: per-element relative error is meaningless at zero crossings of audio)."""
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64).reshape(ref.shape)
+    assert np.isfinite(got).all(), f"{name}: non-finite values"
+    scale = np.abs(ref).max()
+    err = np.abs(ref - got).max()
+    assert err <= rtol * max(scale, 1e-30), f"{name}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / max(scale, 1e-30):.3e} > {rtol})"
+    return err / max(scale, 1e-30)

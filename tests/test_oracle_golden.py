@@ -1,0 +1,112 @@
+"""Pins the CPU oracle (oracle/vits_oracle.c) against fixtures produced by the
+reference's own PyTorch modules (oracle/gen_golden.py).  CPU-only, fast."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+# fp32 restatement vs PyTorch-CPU fp32: different summation order / libm => ~1e-6; bar 2e-5
+TOL = 2e-5
+
+
+def _full(model, g, tol=TOL):
+    ids, lengths, sid, scales = g["ids"], g["lengths"], g["sid"], g["scales"]
+    x, m_p, logs_p = model.text_encoder(ids, lengths, sid)
+    assert_close("x", g["x"], x, tol)
+    assert_close("m_p", g["m_p_tok"], m_p, tol)
+    assert_close("logs_p", g["logs_p_tok"], logs_p, tol)
+    logw = model.duration(g["x"], lengths, sid, g["noise_dp"], float(scales[2]))
+    assert_close("logw", g["logw"], logw, 5 * tol)
+    # free-running durations agree except where exp(logw)*ls sits within fp32 noise of an integer
+    dur_free, _, _ = model.regulate(g["logw"], None, lengths, float(scales[1]), g["m_p_tok"], g["logs_p_tok"], None, 0.0, 4096)
+    assert np.array_equal(dur_free, g["w_ceil_free"])
+    Ty = int(g["y_lengths"].max())
+    dur, ylen, z_p = model.regulate(None, g["forced_durations"], lengths, float(scales[1]), g["m_p_tok"], g["logs_p_tok"],
+                                    g["noise_prior"], float(scales[0]), Ty)
+    assert np.array_equal(ylen, g["y_lengths"])
+    assert_close("z_p", g["z_p"], z_p, tol)
+    z = model.flow(g["z_p"], g["y_lengths"], sid)
+    assert_close("z", g["z"], z, tol)
+    mask = (np.arange(Ty)[None, :] < g["y_lengths"][:, None])[:, None, :]
+    audio, mb = model.decoder(g["z"] * mask)
+    assert_close("audio_mb", g["audio_mb"], mb, tol)
+    assert_close("audio", g["audio"], audio, tol)
+    # whole path through the one-call entry point (what Session.run uses)
+    audio2, olen = model.synthesize(ids, lengths, scales, sid, noise_dp=g["noise_dp"], noise_prior=g["noise_prior"],
+                                    forced_durations=g["forced_durations"])
+    assert np.array_equal(olen, g["y_lengths"] * model.hp.hop_length)
+    assert_close("audio(e2e)", g["audio"], audio2, 5 * tol)
+
+
+def test_full_c1(oracle_default):
+    _full(oracle_default, golden("full_c1"))
+
+
+def test_full_b2_ragged(oracle_default):
+    _full(oracle_default, golden("full_b2"))
+
+
+def test_tiny_b3_ragged(oracle_tiny):
+    _full(oracle_tiny, golden("tiny_b3"))
+
+
+def test_free_running_infer(oracle_default):
+    """The real SynthesizerTrn.infer() call (free-running durations through ceil)."""
+    g = golden("free_c1")
+    audio, olen = oracle_default.synthesize(g["ids"], g["lengths"], g["scales"], g["sid"], noise_dp=g["noise_dp"],
+                                            noise_prior=g["noise_prior"])
+    assert olen[0] == g["y_lengths"][0] * 256
+    assert_close("audio", g["audio"], audio, 5 * TOL)
+
+
+def test_spline_linear_tails(oracle_default):
+    g = golden("tails")
+    logw = oracle_default.duration(g["x"], g["lengths"], g["sid"], g["noise_dp"], float(g["noise_scale_w"]))
+    assert np.abs(g["noise_dp"] * 6.0).max() > 5.0  # the fixture really exercises |z| > tail_bound
+    assert_close("logw", g["logw"], logw, 5 * TOL)
+
+
+@pytest.mark.parametrize("T", [1, 3, 4, 5, 9])
+def test_encoder_relative_window_edges(oracle_default, T):
+    g = golden(f"enc_T{T}")
+    x, m_p, logs_p = oracle_default.text_encoder(g["ids"], g["lengths"], g["sid"])
+    assert_close("x", g["x"], x, TOL)
+    assert_close("m_p", g["m_p_tok"], m_p, TOL)
+
+
+def test_constants(oracle_lib, oracle_default):
+    import ctypes
+
+    g = golden("consts")
+    L = oracle_lib.lib
+    L.vitsref_debug_istft_basis.restype = ctypes.POINTER(ctypes.c_float)
+    L.vitsref_debug_istft_basis.argtypes = [ctypes.c_void_p]
+    L.vitsref_debug_pqmf_filter.restype = ctypes.POINTER(ctypes.c_float)
+    L.vitsref_debug_pqmf_filter.argtypes = [ctypes.c_void_p]
+    basis = np.ctypeslib.as_array(L.vitsref_debug_istft_basis(oracle_default._h), shape=(18, 16))
+    filt = np.ctypeslib.as_array(L.vitsref_debug_pqmf_filter(oracle_default._h), shape=(4, 63))
+    assert_close("istft basis", g["istft_inverse_basis"], basis, 1e-6)
+    assert_close("pqmf filter", g["pqmf_synthesis_filter"], filt, 1e-6)
+
+
+def test_algorithmic_flops_match_survey(oracle_default):
+    """14.40 MFLOP/token (+4608*T_x) and 162.4 MFLOP/frame (+3072*T_y)."""
+    tok = oracle_default.algorithmic_flops(1, 1, 0)
+    frame = oracle_default.algorithmic_flops(1, 0, 1)
+    assert abs(tok - 14.40e6) / 14.40e6 < 0.01
+    assert abs(frame - 162.4e6) / 162.4e6 < 0.01
+    c2 = oracle_default.algorithmic_flops(1, 50, 150)
+    assert abs(c2 - 25.2e9) / 25.2e9 < 0.02
+
+
+def test_error_paths(oracle_lib, oracle_default, default_blob):
+    from vosk_tts_amd.capi import VitsError
+
+    with pytest.raises(VitsError):  # token id out of range
+        oracle_default.text_encoder(np.array([[999]]), np.array([1]), np.array([0]))
+    with pytest.raises(VitsError):  # speaker out of range
+        oracle_default.text_encoder(np.array([[1]]), np.array([1]), np.array([1000]))
+    with pytest.raises(VitsError):  # truncated blob
+        oracle_lib.create(default_blob[:4096])
+    with pytest.raises(VitsError):
+        oracle_lib.create(b"NOTABLOB" + default_blob[8:])
