@@ -178,6 +178,16 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
  * measured with HIP events on the session stream (blocks until it completes). */
 int vits_session_last_ms(vits_session* s, float* ms);
 
+/* Blocks until the session stream is idle; returns any deferred device-side error
+ * (bad token id, frame capacity exceeded). */
+int vits_session_sync(vits_session* s);
+/* use_graph: replay the forward as a cached hipGraph (default 1).  profile: run eagerly and
+ * bracket every kernel launch with HIP events (for vits_session_profile_report). */
+int vits_session_set_options(vits_session* s, int use_graph, int profile);
+/* Per-kernel-family totals of the profiled forwards since the last report, one line per family:
+ * "<name> <launches> <total_ms> <algorithmic_flops>". */
+int vits_session_profile_report(vits_session* s, char* buf, size_t cap);
+
 /* ---- stage-level entry points (parity tests; host buffers in/out) -------- */
 
 /* a2: TextEncoder.forward (models.py:317-326).  out x,m_p,logs_p: [B,hidden|inter,T_x] */

@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the product library loads, exports every symbol the
+header declares, and refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    hdr = open(os.path.join(ROOT, "include", "vits_mi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(vits_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _header_functions()
+    for must in ("vits_create", "vits_destroy", "vits_synthesize", "vits_free_output", "vits_last_error",
+                 "vits_session_create", "vits_session_synthesize_device", "vits_stage_text_encoder",
+                 "vits_stage_duration", "vits_stage_regulate", "vits_stage_flow", "vits_stage_decoder", "vits_op_conv1d"):
+        assert must in names
+
+
+def test_product_library_exports_every_declared_symbol(hip_lib):
+    missing = [n for n in _header_functions() if not hasattr(hip_lib.lib, n)]
+    assert not missing, f"libvits_mi355.so lacks {missing}"
+    assert hip_lib.is_device
+
+
+def test_oracle_exports_the_stage_abi(oracle_lib):
+    for n in ("create", "destroy", "synthesize", "free_output", "stage_text_encoder", "stage_duration", "stage_regulate",
+              "stage_flow", "stage_decoder", "op_conv1d", "algorithmic_flops"):
+        assert hasattr(oracle_lib.lib, "vitsref_" + n)
+    assert not oracle_lib.is_device
+
+
+def test_hparams_struct_matches_header():
+    from vosk_tts_amd.weights import BlobEntry, HParams
+
+    # 24 scalar ints + 4+4 ups + 1 + 4 resk + 1 + 16 resd + 4 ints + 3 floats + 2 ints + 8 reserved = 71 words
+    assert ctypes.sizeof(HParams) == 71 * 4
+    assert ctypes.sizeof(BlobEntry) == 96 + 4 + 16 + 4 + 8 + 8
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from vosk_tts_amd.capi import VitsLib
+
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        VitsLib(str(tmp_path / "nope.so"))
+
+
+def test_no_gpu_means_error_not_fallback(hip_lib, tiny_blob):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vosk_tts_amd.capi import VitsError
+
+    with pytest.raises(VitsError, match="no HIP device"):
+        hip_lib.create(tiny_blob, 0)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "vosk_tts_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "libvits_oracle" not in src or f == "capi.py", f
+                assert "vits_oracle.c" not in src, f
+                assert "import oracle" not in src and "from oracle" not in src, f

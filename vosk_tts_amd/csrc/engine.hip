@@ -1,0 +1,1352 @@
+// engine.hip — MI355X-native VITS2 inference engine behind the C ABI of include/vits_mi355.h.
+//
+// Replaces onnxruntime.InferenceSession.run() at vosk_tts/synth.py:123-126 for the graph that
+// training/vits2/onnx_export.py exports from SynthesizerTrn.infer (training/vits2/models.py:1679-1704).
+// One process per GPU; weights resident in HBM in MFMA-fragment order; every stage is a short
+// sequence of hand-written HIP kernels on one stream (no host round trip when durations are
+// forced or a frame capacity is given), optionally replayed as a hipGraph.
+//
+// There is NO CPU fallback here: every entry point either runs the HIP kernels or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/vits_mi355.h"
+#include "conv_mfma.hip.h"
+#include "kernels_misc.hip.h"
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512];
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(VITS_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define TRY(expr)              \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != VITS_OK) return rc_; \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------ weights
+struct ConvW {
+  float* w = nullptr;     // packed, MFMA fragment order
+  float* bias = nullptr;  // original row order
+  int M = 0, Mpad = 0, Cin = 0, K = 0, n_sg = 0;
+};
+struct EncLayerW {
+  ConvW qkv, o, f1, f2;
+  float *ek = nullptr, *ev = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+struct EncoderW {
+  std::vector<EncLayerW> layers;
+  int H = 0, F = 0, K = 0;
+};
+struct DDSW {
+  std::vector<float*> sw, sb, g1, b1, g2, b2;
+  std::vector<ConvW> pw;
+};
+struct ConvFlowW {
+  float *pre_w = nullptr, *pre_b = nullptr;
+  DDSW dds;
+  ConvW proj;
+};
+struct CouplingW {
+  ConvW pre, post;
+  EncoderW enc;
+  std::vector<ConvW> in_layers, rs_layers;
+  int cond_off = 0;
+};
+struct ResBlockW {
+  ConvW c1[VITS_MAX_RESD], c2[VITS_MAX_RESD];
+  int K = 0;
+  int dil[VITS_MAX_RESD] = {0};
+};
+struct UpW {
+  ConvW w;  // polyphase-packed: row = phase*cout + co, taps = Ku/u
+  int u = 0, Ku = 0, cout = 0, taps = 0, pad_l = 0, halo = 0;
+  int shift[8] = {0};
+};
+
+struct vits_session;
+
+struct vits_model {
+  vits_hparams hp;
+  int device = 0;
+  std::vector<void*> allocs;
+  const unsigned char* blob = nullptr;  // only during create
+  size_t blob_bytes = 0;
+  uint32_t n_entries = 0;
+  const vits_blob_entry* entries = nullptr;
+  bool missing = false;
+
+  float *emb = nullptr, *emb_g = nullptr;
+  float *cond_W = nullptr, *cond_b = nullptr;  // all cond(g)/Linear(g) matrices row-concatenated
+  int cond_rows = 0, cond_enc_off = -1, cond_dp_off = -1;
+  EncoderW enc_p;
+  ConvW enc_proj;
+  ConvW dp_pre, dp_proj;
+  DDSW dp_dds;
+  std::vector<ConvFlowW> cf;  // index k -> dp.flows.(2k+1), k = 1..n-1 (k = 0 unused)
+  float *ea_m = nullptr, *ea_logs = nullptr;
+  float ea_m_h[2] = {0, 0}, ea_logs_h[2] = {0, 0};
+  std::vector<CouplingW> flow;
+  ConvW conv_pre, conv_post;
+  std::vector<UpW> ups;
+  std::vector<ResBlockW> rb;
+  float *istft_basis = nullptr, *pqmf = nullptr;
+  bool use_g = false;
+
+  std::mutex pool_mu;
+  std::vector<vits_session*> pool;
+};
+
+static const float* tget(vits_model* m, int ndim, int d0, int d1, int d2, const char* fmt, ...) {
+  char name[160];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(name, sizeof name, fmt, ap);
+  va_end(ap);
+  for (uint32_t i = 0; i < m->n_entries; ++i) {
+    const vits_blob_entry* e = &m->entries[i];
+    if (strncmp(e->name, name, sizeof e->name) == 0) {
+      const int want[3] = {d0, d1, d2};
+      if ((int)e->ndim != ndim) { m->missing = true; fail(VITS_ERR_BLOB, "tensor %s: ndim %u != %d", name, e->ndim, ndim); return nullptr; }
+      for (int k = 0; k < ndim && k < 3; ++k)
+        if (want[k] >= 0 && (int)e->dims[k] != want[k]) {
+          m->missing = true;
+          fail(VITS_ERR_BLOB, "tensor %s: dim %d is %u, expected %d", name, k, e->dims[k], want[k]);
+          return nullptr;
+        }
+      return reinterpret_cast<const float*>(m->blob + e->offset);
+    }
+  }
+  m->missing = true;
+  fail(VITS_ERR_BLOB, "tensor %s missing from blob", name);
+  return nullptr;
+}
+
+static float* upload(vits_model* m, const float* host, size_t n) {
+  if (!host) return nullptr;
+  void* d = nullptr;
+  if (hipMalloc(&d, (n ? n : 1) * sizeof(float)) != hipSuccess) { m->missing = true; fail(VITS_ERR_NOMEM, "hipMalloc of %zu floats failed", n); return nullptr; }
+  m->allocs.push_back(d);
+  if (hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { m->missing = true; fail(VITS_ERR_DEVICE, "hipMemcpy H2D failed"); return nullptr; }
+  return static_cast<float*>(d);
+}
+
+// Generic packer: rows x Cin x K from a row-source functor (row may be remapped / zero padded).
+template <typename F>
+static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, F src) {
+  ConvW c;
+  c.M = M; c.Mpad = cdiv(M, 32) * 32; c.Cin = Cin; c.K = K;
+  if (Cin % CONV_CI_T != 0) { m->missing = true; fail(VITS_ERR_UNSUPPORTED, "conv C_in=%d is not a multiple of %d", Cin, CONV_CI_T); return c; }
+  c.n_sg = Cin / CONV_CI_T * 2 * K;
+  std::vector<float> packed((size_t)c.Mpad * Cin * K);
+  pack_conv_weights(packed.data(), c.Mpad, Cin, K, [&](int row, int ci, int kk) -> float { return row < M ? src(row, ci, kk) : 0.f; });
+  c.w = upload(m, packed.data(), packed.size());
+  c.bias = bias ? upload(m, bias, M) : nullptr;
+  return c;
+}
+
+// nn.Conv1d weight [Cout, Cin, K] (+ optional bias)
+static ConvW conv_from(vits_model* m, const char* name, int Cout, int Cin, int K, bool has_bias) {
+  const float* w = tget(m, 3, Cout, Cin, K, "%s.weight", name);
+  const float* b = has_bias ? tget(m, 1, Cout, -1, -1, "%s.bias", name) : nullptr;
+  if (m->missing) return ConvW();
+  return make_conv(m, Cout, Cin, K, b, [&](int r, int ci, int kk) { return w[((size_t)r * Cin + ci) * K + kk]; });
+}
+
+static void load_encoder(vits_model* m, EncoderW& E, const char* pfx, int n_layers, int H, int F, int K) {
+  const vits_hparams& hp = m->hp;
+  const int dk = H / hp.n_heads, NW = 2 * hp.window_size + 1;
+  E.H = H; E.F = F; E.K = K;
+  E.layers.resize(n_layers);
+  char nm[200];
+  for (int i = 0; i < n_layers && !m->missing; ++i) {
+    EncLayerW& L = E.layers[i];
+    // q,k,v 1x1 convs fused into one M = 3H GEMM (attentions.py:156-158)
+    const float* wq = tget(m, 3, H, H, 1, "%s.attn_layers.%d.conv_q.weight", pfx, i);
+    const float* wk = tget(m, 3, H, H, 1, "%s.attn_layers.%d.conv_k.weight", pfx, i);
+    const float* wv = tget(m, 3, H, H, 1, "%s.attn_layers.%d.conv_v.weight", pfx, i);
+    const float* bq = tget(m, 1, H, -1, -1, "%s.attn_layers.%d.conv_q.bias", pfx, i);
+    const float* bk = tget(m, 1, H, -1, -1, "%s.attn_layers.%d.conv_k.bias", pfx, i);
+    const float* bv = tget(m, 1, H, -1, -1, "%s.attn_layers.%d.conv_v.bias", pfx, i);
+    if (m->missing) return;
+    std::vector<float> b3(3 * H);
+    memcpy(b3.data(), bq, sizeof(float) * H); memcpy(b3.data() + H, bk, sizeof(float) * H); memcpy(b3.data() + 2 * H, bv, sizeof(float) * H);
+    L.qkv = make_conv(m, 3 * H, H, 1, b3.data(), [&](int r, int ci, int) {
+      const float* w = r < H ? wq : (r < 2 * H ? wk : wv);
+      return w[(size_t)(r % H) * H + ci];
+    });
+    snprintf(nm, sizeof nm, "%s.attn_layers.%d.conv_o", pfx, i);
+    L.o = conv_from(m, nm, H, H, 1, true);
+    L.ek = upload(m, tget(m, 3, 1, NW, dk, "%s.attn_layers.%d.emb_rel_k", pfx, i), (size_t)NW * dk);
+    L.ev = upload(m, tget(m, 3, 1, NW, dk, "%s.attn_layers.%d.emb_rel_v", pfx, i), (size_t)NW * dk);
+    snprintf(nm, sizeof nm, "%s.ffn_layers.%d.conv_1", pfx, i);
+    L.f1 = conv_from(m, nm, F, H, K, true);
+    snprintf(nm, sizeof nm, "%s.ffn_layers.%d.conv_2", pfx, i);
+    L.f2 = conv_from(m, nm, H, F, K, true);
+    L.g1 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_1.%d.gamma", pfx, i), H);
+    L.b1 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_1.%d.beta", pfx, i), H);
+    L.g2 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_2.%d.gamma", pfx, i), H);
+    L.b2 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_2.%d.beta", pfx, i), H);
+  }
+}
+
+static void load_dds(vits_model* m, DDSW& D, const char* pfx, int C, int K, int n) {
+  char nm[200];
+  for (int i = 0; i < n && !m->missing; ++i) {
+    D.sw.push_back(upload(m, tget(m, 3, C, 1, K, "%s.convs_sep.%d.weight", pfx, i), (size_t)C * K));
+    D.sb.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.convs_sep.%d.bias", pfx, i), C));
+    snprintf(nm, sizeof nm, "%s.convs_1x1.%d", pfx, i);
+    D.pw.push_back(conv_from(m, nm, C, C, 1, true));
+    D.g1.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_1.%d.gamma", pfx, i), C));
+    D.b1.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_1.%d.beta", pfx, i), C));
+    D.g2.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_2.%d.gamma", pfx, i), C));
+    D.b2.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_2.%d.beta", pfx, i), C));
+  }
+}
+
+static double bessel_i0(double x) {
+  double s = 1.0, term = 1.0, q = x * x / 4.0;
+  for (int k = 1; k < 200; ++k) { term *= q / ((double)k * k); s += term; if (term < 1e-18 * s) break; }
+  return s;
+}
+
+static int load_model(vits_model* m) {
+  const vits_hparams& hp = m->hp;
+  const int H = hp.hidden_channels, I = hp.inter_channels, F = hp.filter_channels, G = hp.gin_channels;
+  const int D = hp.dp_filter_channels;
+  if (hp.n_heads <= 0 || H % hp.n_heads) return fail(VITS_ERR_UNSUPPORTED, "hidden %% n_heads != 0");
+  const int dk = H / hp.n_heads;
+  if (dk != 32 && dk != 64 && dk != 96) return fail(VITS_ERR_UNSUPPORTED, "head dim %d not in {32,64,96}", dk);
+  if (hp.window_size > 4 || hp.window_size < 0) return fail(VITS_ERR_UNSUPPORTED, "window_size > 4");
+  if (H % 32 || I % 32 || (I / 2) % 16 || D % 32) return fail(VITS_ERR_UNSUPPORTED, "channel counts must be multiples of 32");
+  if (hp.dp_num_bins > 15 || hp.n_ups > VITS_MAX_UPS || hp.n_resk > 3 || hp.n_resd > VITS_MAX_RESD || hp.n_ups < 1)
+    return fail(VITS_ERR_UNSUPPORTED, "hparams out of range");
+  if (hp.flow_dilation_rate != 1) return fail(VITS_ERR_UNSUPPORTED, "flow dilation_rate != 1");
+  m->use_g = G > 0 && hp.n_speakers > 1;
+
+  m->emb = upload(m, tget(m, 2, hp.n_vocab, H, -1, "enc_p.emb.weight"), (size_t)hp.n_vocab * H);
+  load_encoder(m, m->enc_p, "enc_p.encoder", hp.n_layers, H, F, hp.kernel_size);
+  m->enc_proj = conv_from(m, "enc_p.proj", 2 * I, H, 1, true);
+  if (m->missing) return VITS_ERR_BLOB;
+
+  // ---- all speaker-conditioning matrices in one GEMV table
+  std::vector<float> cW, cB;
+  auto add_cond = [&](const float* w, const float* b, int rows) {
+    const int off = (int)cB.size();
+    if (!w || !b) return off;
+    cW.insert(cW.end(), w, w + (size_t)rows * G);
+    cB.insert(cB.end(), b, b + rows);
+    return off;
+  };
+  if (m->use_g) {
+    m->emb_g = upload(m, tget(m, 2, hp.n_speakers, G, -1, "emb_g.weight"), (size_t)hp.n_speakers * G);
+    if (hp.enc_cond_layer >= 0)
+      m->cond_enc_off = add_cond(tget(m, 2, H, G, -1, "enc_p.encoder.spk_emb_linear.weight"),
+                                 tget(m, 1, H, -1, -1, "enc_p.encoder.spk_emb_linear.bias"), H);
+    m->cond_dp_off = add_cond(tget(m, 3, D, G, 1, "dp.cond.weight"), tget(m, 1, D, -1, -1, "dp.cond.bias"), D);
+  }
+
+  // ---- duration predictor (reverse path)
+  m->dp_pre = conv_from(m, "dp.pre", D, H, 1, true);
+  m->dp_proj = conv_from(m, "dp.proj", D, D, 1, true);
+  load_dds(m, m->dp_dds, "dp.convs", D, hp.dp_kernel_size, hp.dp_dds_layers);
+  m->cf.resize(hp.dp_n_flows);
+  char nm[200];
+  const int P = 3 * hp.dp_num_bins - 1;
+  for (int k = 1; k < hp.dp_n_flows && !m->missing; ++k) {
+    ConvFlowW& c = m->cf[k];
+    c.pre_w = upload(m, tget(m, 3, D, 1, 1, "dp.flows.%d.pre.weight", 2 * k + 1), D);
+    c.pre_b = upload(m, tget(m, 1, D, -1, -1, "dp.flows.%d.pre.bias", 2 * k + 1), D);
+    snprintf(nm, sizeof nm, "dp.flows.%d.convs", 2 * k + 1);
+    load_dds(m, c.dds, nm, D, hp.dp_kernel_size, hp.dp_dds_layers);
+    snprintf(nm, sizeof nm, "dp.flows.%d.proj", 2 * k + 1);
+    c.proj = conv_from(m, nm, P, D, 1, true);
+  }
+  {
+    const float* em = tget(m, 2, 2, 1, -1, "dp.flows.0.m");
+    const float* el = tget(m, 2, 2, 1, -1, "dp.flows.0.logs");
+    if (m->missing) return VITS_ERR_BLOB;
+    m->ea_m = upload(m, em, 2); m->ea_logs = upload(m, el, 2);
+  }
+
+  // ---- flow
+  m->flow.resize(hp.flow_n_flows);
+  const int K5 = hp.flow_kernel_size, L = hp.flow_wn_layers;
+  for (int f = 0; f < hp.flow_n_flows && !m->missing; ++f) {
+    CouplingW& c = m->flow[f];
+    snprintf(nm, sizeof nm, "flow.flows.%d.pre", 2 * f);
+    c.pre = conv_from(m, nm, H, I / 2, 1, true);
+    snprintf(nm, sizeof nm, "flow.flows.%d.pre_transformer", 2 * f);
+    load_encoder(m, c.enc, nm, 1, H, H, K5);
+    for (int i = 0; i < L && !m->missing; ++i) {
+      // in_layer rows permuted to [tanh 32 | sigmoid 32] per 32 channels for the fused gate epilogue
+      const float* w = tget(m, 3, 2 * H, H, K5, "flow.flows.%d.enc.in_layers.%d.weight", 2 * f, i);
+      const float* b = tget(m, 1, 2 * H, -1, -1, "flow.flows.%d.enc.in_layers.%d.bias", 2 * f, i);
+      if (m->missing) break;
+      c.in_layers.push_back(make_conv(m, 2 * H, H, K5, b, [&](int r, int ci, int kk) {
+        const int j = r / 64, q = r % 64;
+        const int orig = q < 32 ? j * 32 + q : H + j * 32 + (q - 32);
+        return w[((size_t)orig * H + ci) * K5 + kk];
+      }));
+      snprintf(nm, sizeof nm, "flow.flows.%d.enc.res_skip_layers.%d", 2 * f, i);
+      c.rs_layers.push_back(conv_from(m, nm, i < L - 1 ? 2 * H : H, H, 1, true));
+    }
+    if (m->use_g)
+      c.cond_off = add_cond(tget(m, 3, 2 * H * L, G, 1, "flow.flows.%d.enc.cond_layer.weight", 2 * f),
+                            tget(m, 1, 2 * H * L, -1, -1, "flow.flows.%d.enc.cond_layer.bias", 2 * f), 2 * H * L);
+    snprintf(nm, sizeof nm, "flow.flows.%d.post", 2 * f);
+    c.post = conv_from(m, nm, I / 2, H, 1, true);
+  }
+  if (m->missing) return VITS_ERR_BLOB;
+  m->cond_rows = (int)cB.size();
+  if (m->cond_rows) { m->cond_W = upload(m, cW.data(), cW.size()); m->cond_b = upload(m, cB.data(), cB.size()); }
+
+  // ---- decoder
+  int C = hp.dec_initial_channel;
+  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true);
+  m->ups.resize(hp.n_ups);
+  m->rb.resize((size_t)hp.n_ups * hp.n_resk);
+  for (int i = 0; i < hp.n_ups && !m->missing; ++i) {
+    UpW& U = m->ups[i];
+    const int u = hp.up_rates[i], Ku = hp.up_kernels[i], Co = C / 2, p = (Ku - u) / 2;
+    if (u > 8 || Ku % u || (Ku - u) % 2 || C % 64) return fail(VITS_ERR_UNSUPPORTED, "upsample rate/kernel unsupported");
+    const float* w = tget(m, 3, C, Co, Ku, "dec.ups.%d.weight", i);  // [Cin, Cout, K]
+    const float* b = tget(m, 1, Co, -1, -1, "dec.ups.%d.bias", i);
+    if (m->missing) break;
+    U.u = u; U.Ku = Ku; U.cout = Co; U.taps = Ku / u;
+    // out[u*q + r] = sum_{delta} x[q + delta] * W[.., r + p - u*delta]; delta in [dmin(r), dmin(r)+taps-1]
+    int dmin[8], dmin_all = 1 << 30, dmax_all = -(1 << 30);
+    for (int r = 0; r < u; ++r) {
+      const int dmax = (r + p) / u;  // floor, r+p >= 0
+      dmin[r] = dmax - U.taps + 1;
+      if (dmin[r] < dmin_all) dmin_all = dmin[r];
+      if (dmax > dmax_all) dmax_all = dmax;
+    }
+    U.pad_l = -dmin_all;
+    U.halo = dmax_all - dmin_all;
+    for (int r = 0; r < u; ++r) U.shift[r] = dmin[r] + U.pad_l;
+    const int Cin = C;
+    U.w = make_conv(m, u * Co, Cin, U.taps, nullptr, [&](int row, int ci, int j) {
+      const int r = row / Co, co = row % Co;
+      const int k = r + p - u * (dmin[r] + j);
+      return (k >= 0 && k < Ku) ? w[((size_t)ci * Co + co) * Ku + k] : 0.f;
+    });
+    U.w.bias = upload(m, b, Co);
+    C = Co;
+    for (int j = 0; j < hp.n_resk && !m->missing; ++j) {
+      ResBlockW& R = m->rb[(size_t)i * hp.n_resk + j];
+      R.K = hp.res_kernels[j];
+      for (int d = 0; d < hp.n_resd; ++d) {
+        R.dil[d] = hp.res_dilations[j][d];
+        if ((R.K - 1) * R.dil[d] > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "resblock receptive field too wide");
+        snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", i * hp.n_resk + j, d);
+        R.c1[d] = conv_from(m, nm, C, C, R.K, true);
+        snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", i * hp.n_resk + j, d);
+        R.c2[d] = conv_from(m, nm, C, C, R.K, true);
+      }
+    }
+  }
+  if (m->missing) return VITS_ERR_BLOB;
+  if (hp.dec_type == 0) {
+    const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, cut = N / 2 + 1;
+    m->conv_post = conv_from(m, "dec.subband_conv_post", S * (N + 2), C, 7, false);
+    // OnnxSTFT inverse basis (stft.py:191-214): pinv(scale*[Re F;Im F]).T * hann == irfft synthesis rows / scale
+    std::vector<float> basis((size_t)2 * cut * N);
+    const double PI_D = 3.14159265358979323846, scale = (double)N / hop;
+    for (int n = 0; n < N; ++n) {
+      const double win = 0.5 - 0.5 * cos(2.0 * PI_D * n / N);
+      for (int k = 0; k < cut; ++k) {
+        const double wk = (k == 0 || k == N / 2) ? 1.0 : 2.0, th = 2.0 * PI_D * k * n / N;
+        basis[(size_t)k * N + n] = (float)(wk * cos(th) / N / scale) * (float)win;
+        basis[(size_t)(cut + k) * N + n] = (float)(-wk * sin(th) / N / scale) * (float)win;
+      }
+    }
+    m->istft_basis = upload(m, basis.data(), basis.size());
+    // PQMF synthesis filter (pqmf.py:15-43,64-75)
+    const int taps = hp.pqmf_taps, Lf = taps + 1;
+    std::vector<double> hpz(Lf);
+    for (int n = 0; n < Lf; ++n) {
+      const double xx = n - 0.5 * taps;
+      const double hi = (n == taps / 2) ? (double)hp.pqmf_cutoff : sin(PI_D * hp.pqmf_cutoff * xx) / (PI_D * xx);
+      const double r = (n - (Lf - 1) / 2.0) / ((Lf - 1) / 2.0), arg = 1.0 - r * r;
+      hpz[n] = hi * bessel_i0(hp.pqmf_beta * sqrt(arg < 0 ? 0 : arg)) / bessel_i0(hp.pqmf_beta);
+    }
+    std::vector<float> filt((size_t)S * Lf);
+    for (int k = 0; k < S; ++k)
+      for (int n = 0; n < Lf; ++n)
+        filt[(size_t)k * Lf + n] = (float)(2.0 * hpz[n] * cos((2 * k + 1) * (PI_D / (2.0 * S)) * (n - ((taps - 1) / 2.0)) - ((k % 2 == 0) ? 1.0 : -1.0) * PI_D / 4.0));
+    m->pqmf = upload(m, filt.data(), filt.size());
+  } else {
+    m->conv_post = conv_from(m, "dec.conv_post", 1, C, 7, false);
+  }
+  return m->missing ? VITS_ERR_BLOB : VITS_OK;
+}
+
+// ------------------------------------------------------------------------------------ sessions
+// A session owns one HIP stream and a bump-allocated activation workspace sized for
+// (B, T_x, T_y).  vits_synthesize() borrows one from the model's pool, so concurrent calls from
+// the gRPC server's worker threads (server/tts_server.py:39-40,57) never share buffers.
+struct ProfRec { std::string name; hipEvent_t e0, e1; double flops; };
+
+struct vits_session {
+  vits_model* m = nullptr;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  char* arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  int* d_err = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  bool profile = false;
+  std::vector<ProfRec> prof;
+  // graph cache for the device entry point
+  typedef std::tuple<const void*, const void*, const void*, const void*, void*, int, int, int, uint64_t, float, float, float> GKey;
+  std::map<GKey, hipGraphExec_t> graphs;
+  bool use_graph = true;
+
+  // named views (valid after plan())
+  int B = 0, Tx = 0, Ty = 0;
+  int *len_x = nullptr, *len_y = nullptr, *dur = nullptr, *cum = nullptr;
+  int64_t* ylen64 = nullptr;
+  float *x = nullptr, *qkv = nullptr, *att = nullptr, *y1 = nullptr, *ffh = nullptr, *stats = nullptr;
+  float *condv = nullptr;
+  float *dh = nullptr, *dy = nullptr, *dy2 = nullptr, *dc = nullptr, *dz = nullptr, *dpr = nullptr, *logw = nullptr, *dfh = nullptr;
+  float *zA = nullptr, *zB = nullptr, *fh = nullptr, *fx = nullptr, *facts = nullptr, *fskip = nullptr;
+  std::vector<float*> dec_bufs;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static T* bump(vits_session* s, size_t n) {
+  size_t off = align_up(s->arena_used, 256);
+  s->arena_used = off + n * sizeof(T);
+  return s->arena ? reinterpret_cast<T*>(s->arena + off) : nullptr;
+}
+
+// lays out every activation buffer for the given capacity; with arena == nullptr only measures
+static void plan(vits_session* s, int B, int Tx, int Ty) {
+  const vits_hparams& hp = s->m->hp;
+  const size_t H = hp.hidden_channels, I = hp.inter_channels, F = hp.filter_channels, D = hp.dp_filter_channels;
+  const size_t Fm = F > H ? F : H;
+  const size_t Tm = (size_t)(Tx > Ty ? Tx : Ty);
+  s->arena_used = 0;
+  s->B = B; s->Tx = Tx; s->Ty = Ty;
+  s->len_x = bump<int>(s, B); s->len_y = bump<int>(s, B);
+  s->ylen64 = bump<int64_t>(s, B);
+  s->dur = bump<int>(s, (size_t)B * Tx); s->cum = bump<int>(s, (size_t)B * Tx);
+  s->condv = bump<float>(s, (size_t)B * (s->m->cond_rows + 1));
+  // encoder-shaped scratch is shared by the text encoder (T_x) and the flow pre-transformers (T_y)
+  s->x = bump<float>(s, B * H * Tm);
+  s->qkv = bump<float>(s, B * 3 * H * Tm);
+  s->att = bump<float>(s, B * H * Tm);
+  s->y1 = bump<float>(s, B * H * Tm);
+  s->ffh = bump<float>(s, B * Fm * Tm);
+  s->stats = bump<float>(s, B * 2 * I * Tx);
+  s->dh = bump<float>(s, B * D * Tx); s->dy = bump<float>(s, B * D * Tx); s->dy2 = bump<float>(s, B * D * Tx);
+  s->dc = bump<float>(s, B * D * Tx); s->dfh = bump<float>(s, B * D * Tx);
+  s->dz = bump<float>(s, (size_t)B * 2 * Tx); s->dpr = bump<float>(s, (size_t)B * 32 * Tx); s->logw = bump<float>(s, (size_t)B * Tx);
+  s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
+  s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
+  s->facts = bump<float>(s, B * H * Ty); s->fskip = bump<float>(s, B * H * Ty);
+  // decoder: conv_pre out, then per stage: ups out + 3 tmp + 3 res-chain (models.py:1026-1036)
+  s->dec_bufs.clear();
+  size_t C = hp.dec_initial_channel, T = Ty;
+  s->dec_bufs.push_back(bump<float>(s, B * C * T));
+  size_t stage_max = 0;
+  {
+    size_t c = C, t = T;
+    for (int i = 0; i < hp.n_ups; ++i) { c /= 2; t *= hp.up_rates[i]; if (c * t > stage_max) stage_max = c * t; }
+  }
+  // two alternating sets of 7 stage buffers (stage i reads set (i-1)&1's res-chain, writes set i&1)
+  for (int k = 0; k < 14; ++k) s->dec_bufs.push_back(bump<float>(s, B * stage_max));
+  if (hp.dec_type == 0) {
+    size_t P = (size_t)hp.subbands * (hp.istft_n_fft + 2);
+    size_t t = T; for (int i = 0; i < hp.n_ups; ++i) t *= hp.up_rates[i];
+    s->dec_bufs.push_back(bump<float>(s, B * P * (t + 1)));
+    s->dec_bufs.push_back(bump<float>(s, B * hp.subbands * t * hp.istft_hop));
+  } else {
+    size_t t = T; for (int i = 0; i < hp.n_ups; ++i) t *= hp.up_rates[i];
+    s->dec_bufs.push_back(bump<float>(s, B * t));
+    s->dec_bufs.push_back(bump<float>(s, 64));
+  }
+}
+
+static void drop_graphs(vits_session* s) {
+  for (auto& kv : s->graphs) hipGraphExecDestroy(kv.second);
+  s->graphs.clear();
+}
+
+// (re)lays the workspace out for exactly (B,Tx,Ty) so every [B,C,T] tensor is dense; grows the
+// arena when needed.  Captured graphs hold raw workspace pointers, so a re-plan drops them.
+static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
+  if (s->arena && B == s->B && Tx == s->Tx && Ty == s->Ty) return VITS_OK;
+  drop_graphs(s);
+  char* keep = s->arena;
+  s->arena = nullptr;
+  plan(s, B, Tx, Ty);  // measure
+  const size_t need = s->arena_used + 4096;
+  s->arena = keep;
+  if (need > s->arena_bytes) {
+    if (s->arena) { hipStreamSynchronize(s->stream); hipFree(s->arena); s->arena = nullptr; s->arena_bytes = 0; }
+    const size_t want = need + need / 8;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) { s->B = s->Tx = s->Ty = 0; return fail(VITS_ERR_NOMEM, "workspace hipMalloc of %zu bytes failed", want); }
+    s->arena = static_cast<char*>(p);
+    s->arena_bytes = want;
+  }
+  plan(s, B, Tx, Ty);
+  return VITS_OK;
+}
+
+static int session_new(vits_model* m, vits_session** out) {
+  vits_session* s = new vits_session();
+  s->m = m;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void**)&s->d_err, sizeof(int)));
+  HIP_TRY(hipMemset(s->d_err, 0, sizeof(int)));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+  *out = s;
+  return VITS_OK;
+}
+
+static void session_free(vits_session* s) {
+  if (!s) return;
+  hipSetDevice(s->m->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  drop_graphs(s);
+  for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  if (s->arena) hipFree(s->arena);
+  if (s->d_err) hipFree(s->d_err);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->stream && s->own_stream) hipStreamDestroy(s->stream);
+  delete s;
+}
+
+static int pool_acquire(vits_model* m, vits_session** out) {
+  {
+    std::lock_guard<std::mutex> g(m->pool_mu);
+    if (!m->pool.empty()) { *out = m->pool.back(); m->pool.pop_back(); return VITS_OK; }
+  }
+  return session_new(m, out);
+}
+static void pool_release(vits_model* m, vits_session* s) {
+  std::lock_guard<std::mutex> g(m->pool_mu);
+  m->pool.push_back(s);
+}
+
+// ------------------------------------------------------------------------------------ launch helpers
+struct ProfScope {
+  vits_session* s; bool on;
+  ProfScope(vits_session* s_, const char* name, double flops) : s(s_), on(s_->profile) {
+    if (!on) return;
+    ProfRec r; r.name = name; r.flops = flops;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, s->stream);
+    s->prof.push_back(r);
+  }
+  ~ProfScope() { if (on) hipEventRecord(s->prof.back().e1, s->stream); }
+};
+
+enum TileCfg { T64 = 0, T128 = 1, T32W = 2, TGATE = 3, TGATE_BIG = 4 };
+
+template <int WM, int WN, int MI, int NI, int EPI>
+static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
+  constexpr int M_T = WM * MI * 32, N_T = WN * NI * 32;
+  P.ntiles_m = cdiv(P.M, M_T);
+  P.ntiles_n = cdiv(P.Tout, N_T);
+  P.row_len = N_T + halo;
+  const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
+  const size_t lds = (size_t)2 * CONV_CI_T * P.row_len * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MI, NI, EPI>), dim3(nblk), dim3(256), lds, st, P);
+}
+
+// dispatch on epilogue + tile heuristics.  halo = max over groups of (K-1)*dil (or polyphase spread)
+static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* name, int halo_override = -1) {
+  int halo = 0;
+  double macs = 0;
+  for (int g = 0; g < P.n_groups; ++g) {
+    const int hg = halo_override >= 0 ? halo_override : (P.g[g].K - 1) * P.g[g].dil;
+    if (hg > halo) halo = hg;
+    macs += (double)P.Cout * P.Cin * P.g[g].K;
+  }
+  ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
+  hipStream_t st = s->stream;
+  if (epi == EPI_GATE) { launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo); return; }
+  if (epi == EPI_RESSKIP) { launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(st, P, halo); return; }
+  if (epi == EPI_COUPLE) { launch_cfg<2, 2, 1, 1, EPI_COUPLE>(st, P, halo); return; }
+  if (P.ups_u && (P.ups_cout % 64)) { launch_cfg<1, 4, 1, 1, EPI_STORE>(st, P, halo); return; }
+  const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
+  const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
+  if (m_fits && big_blocks >= 512) { launch_cfg<2, 2, 2, 2, EPI_STORE>(st, P, halo); return; }
+  launch_cfg<2, 2, 1, 1, EPI_STORE>(st, P, halo);
+}
+
+// common-case parameter block: one group, same-length 'same'-padded Conv1d over [B,C,T]
+static ConvParams conv_params(const ConvW& W, const float* x, float* y, int B, int T, int dil, int pad_l) {
+  ConvParams P;
+  memset(&P, 0, sizeof P);
+  P.n_groups = 1;
+  P.g[0].x = x; P.g[0].w = W.w; P.g[0].bias = W.bias; P.g[0].y = y;
+  P.g[0].K = W.K; P.g[0].dil = dil; P.g[0].pad_l = pad_l; P.g[0].n_sg = W.n_sg;
+  P.B = B; P.Cin = W.Cin; P.x_ch_off = 0; P.x_ch_sign = 1;
+  P.x_bstride = (long long)W.Cin * T; P.Tin = T; P.Tin_stride = T;
+  P.M = W.Mpad; P.Cout = W.M; P.Tout = T; P.Tout_stride = T; P.y_bstride = (long long)W.M * T;
+  P.in_slope = 1.f; P.in_scale = 1.f;
+  return P;
+}
+
+static void launch_ln(vits_session* s, const float* a, const float* b, const float* base, float* y, const float* gamma,
+                      const float* beta, const int* len, int B, int C, int T, int gelu, int mask) {
+  ProfScope ps(s, "layernorm", 0);
+  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask};
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, s->stream, P);
+}
+
+static void launch_attention(vits_session* s, const float* qkv, const EncLayerW& L, const int* len, float* out, int B,
+                             int H, int T) {
+  const vits_hparams& hp = s->m->hp;
+  const int nh = hp.n_heads, dk = H / nh, W = hp.window_size;
+  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T);
+  dim3 grid(cdiv(T, 64), nh, B);
+  if (dk == 96) hipLaunchKernelGGL((relpos_attention_kernel<96, 16>), grid, dim3(64), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_kernel<64, 16>), grid, dim3(64), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+  else hipLaunchKernelGGL((relpos_attention_kernel<32, 16>), grid, dim3(64), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+}
+
+// attentions.Encoder.forward (attentions.py:48-65).  x in place [B,H,T]; final_base (optional):
+// out = final_base + encoder(x) (the VITS2 residual at models.py:377), written to final_out.
+static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int* len, int B, int T, int cond_layer,
+                        int cond_off, const float* final_base, float* final_out) {
+  vits_model* m = s->m;
+  const int H = E.H, F = E.F, K = E.K;
+  const int n = (int)E.layers.size();
+  for (int i = 0; i < n; ++i) {
+    const EncLayerW& L = E.layers[i];
+    if (i == cond_layer && cond_off >= 0)
+      hipLaunchKernelGGL(add_vec_mask_kernel, dim3(cdiv(T, 64), H, B), dim3(64), 0, s->stream, x, s->condv, m->cond_rows,
+                         cond_off, len, H, T);
+    ConvParams P = conv_params(L.qkv, x, s->qkv, B, T, 1, 0);
+    launch_conv(s, P, EPI_STORE, "enc.qkv");
+    launch_attention(s, s->qkv, L, len, s->att, B, H, T);
+    P = conv_params(L.o, s->att, s->y1, B, T, 1, 0);  // y1 = x + conv_o(att)
+    P.g[0].res = x;
+    launch_conv(s, P, EPI_STORE, "enc.o");
+    launch_ln(s, s->y1, nullptr, nullptr, x, L.g1, L.b1, len, B, H, T, 0, 0);
+    // FFN (attentions.py:308-317): conv_1(pad(x*mask)) -> relu -> *mask -> conv_2(pad(.)) -> *mask
+    P = conv_params(L.f1, x, s->ffh, B, T, 1, (K - 1) / 2);
+    P.in_mask = 1; P.len = len; P.relu = 1; P.out_mask = 1;
+    launch_conv(s, P, EPI_STORE, "enc.ffn1");
+    P = conv_params(L.f2, s->ffh, s->y1, B, T, 1, (K - 1) / 2);
+    P.in_mask = 1; P.len = len; P.out_mask = 1; P.g[0].res = x;  // y1 = x + ffn(x)
+    launch_conv(s, P, EPI_STORE, "enc.ffn2");
+    const bool lastl = i == n - 1;
+    launch_ln(s, s->y1, nullptr, lastl ? final_base : nullptr, (lastl && final_out) ? final_out : x, L.g2, L.b2, len, B, H,
+              T, 0, lastl ? 1 : 0);
+  }
+  (void)F;
+}
+
+static int check_err(vits_session* s) {
+  int e = 0;
+  HIP_TRY(hipMemcpyAsync(&e, s->d_err, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(VITS_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(le));
+  if (e) {
+    hipMemsetAsync(s->d_err, 0, sizeof(int), s->stream);
+    if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
+    if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
+    if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
+  }
+  return VITS_OK;
+}
+
+// ---- speaker conditioning vectors for the whole forward (one GEMV launch)
+static void run_cond(vits_session* s, const int64_t* d_sid, int B) {
+  vits_model* m = s->m;
+  if (!m->use_g || !m->cond_rows) return;
+  hipLaunchKernelGGL(cond_gemv_kernel, dim3(cdiv(m->cond_rows, 4), B), dim3(256), 0, s->stream, m->cond_W, m->cond_b, m->emb_g,
+                     d_sid, s->condv, m->cond_rows, m->hp.gin_channels, m->hp.n_speakers, s->d_err);
+}
+
+// ---- a2: TextEncoder.forward (models.py:317-326) -> s->x [B,H,Tx], s->stats [B,2I,Tx]
+static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int Tx) {
+  vits_model* m = s->m;
+  const vits_hparams& hp = m->hp;
+  const int H = hp.hidden_channels;
+  hipLaunchKernelGGL(embed_kernel, dim3(cdiv(Tx, 64), 8, B), dim3(64), 0, s->stream, d_ids, s->len_x, m->emb, s->x, H, Tx,
+                     hp.n_vocab, sqrtf((float)H), s->d_err);
+  run_encoder(s, m->enc_p, s->x, s->len_x, B, Tx, m->use_g ? hp.enc_cond_layer : -1, m->cond_enc_off, nullptr, nullptr);
+  ConvParams P = conv_params(m->enc_proj, s->x, s->stats, B, Tx, 1, 0);
+  P.out_mask = 1; P.len = s->len_x;
+  launch_conv(s, P, EPI_STORE, "enc.proj");
+}
+
+// DDSConv.forward (modules.py:96-108) on h [B,D,T] in place (h already includes +g)
+static void run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
+  const vits_hparams& hp = s->m->hp;
+  const int D = hp.dp_filter_channels, K = hp.dp_kernel_size;
+  int dil = 1;
+  for (size_t i = 0; i < W.pw.size(); ++i) {
+    DwLnParams dp{h, s->dy, W.sw[i], W.sb[i], W.g1[i], W.b1[i], s->len_x, D, T, K, dil};
+    hipLaunchKernelGGL(dwconv_ln_gelu_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, s->stream, dp);
+    ConvParams P = conv_params(W.pw[i], s->dy, s->dy2, B, T, 1, 0);
+    launch_conv(s, P, EPI_STORE, "dp.1x1");
+    // x = x + gelu(LN2(y)) ; masked every layer (equivalent at valid positions)
+    launch_ln(s, s->dy2, nullptr, h, h, W.g2[i], W.b2[i], s->len_x, B, D, T, 1, 1);
+    dil *= K;
+  }
+}
+
+// ---- a6: StochasticDurationPredictor.forward(reverse=True) (models.py:56-63,93-101) -> s->logw
+static void run_duration(vits_session* s, const float* x, const float* d_noise, float nsw, uint64_t seed, int B, int Tx) {
+  vits_model* m = s->m;
+  const vits_hparams& hp = m->hp;
+  const int D = hp.dp_filter_channels;
+  ConvParams P = conv_params(m->dp_pre, x, s->dh, B, Tx, 1, 0);
+  if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dp_off; }
+  launch_conv(s, P, EPI_STORE, "dp.pre");
+  run_dds(s, m->dp_dds, s->dh, B, Tx);
+  P = conv_params(m->dp_proj, s->dh, s->dc, B, Tx, 1, 0);
+  P.out_mask = 1; P.len = s->len_x;
+  launch_conv(s, P, EPI_STORE, "dp.proj");
+  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx);
+  int swap = 0;
+  const float cst = (float)log(exp(1.0 - 1e-3) - 1.0);
+  (void)cst;
+  for (int k = hp.dp_n_flows - 1; k >= 1; --k) {
+    swap ^= 1;  // Flip (modules.py:270-277) is a row relabel on the 2-channel z
+    const ConvFlowW& c = m->cf[k];
+    hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(Tx, 64), D, B), dim3(64), 0, s->stream, s->dz, swap, c.pre_w, c.pre_b,
+                       s->dc, s->dfh, D, Tx);
+    run_dds(s, c.dds, s->dfh, B, Tx);
+    P = conv_params(c.proj, s->dfh, s->dpr, B, Tx, 1, 0);
+    P.out_mask = 1; P.len = s->len_x;
+    launch_conv(s, P, EPI_STORE, "dp.cfproj");
+    hipLaunchKernelGGL(spline_inverse_kernel, dim3(cdiv(Tx, 64), B), dim3(64), 0, s->stream, s->dz, swap, s->dpr, c.proj.M,
+                       s->len_x, Tx, hp.dp_num_bins, hp.dp_tail_bound, 1.0f / sqrtf((float)D));
+  }
+  swap ^= 1;
+  hipLaunchKernelGGL(ea_logw_kernel, dim3(cdiv(Tx, 64), B), dim3(64), 0, s->stream, s->dz, swap, m->ea_m, m->ea_logs, s->len_x,
+                     s->logw, Tx);
+}
+
+// ---- a10: durations / cumsum / y_lengths
+static void run_durations(vits_session* s, const int* d_forced, float length_scale, int B, int Tx, int Tcap) {
+  hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s->stream, s->logw, d_forced, s->len_x, length_scale, Tx, s->dur,
+                     s->cum, s->len_y, s->ylen64, Tcap, s->d_err);
+}
+
+// ---- a10/a11: expand prior + sample -> z_p [B,I,Ty]
+static void run_expand(vits_session* s, const float* d_noise, long long noise_stride, float noise_scale, uint64_t seed,
+                       float* z_p, int B, int Tx, int Ty) {
+  const int I = s->m->hp.inter_channels;
+  hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(Ty, 64), 8, B), dim3(64), 0, s->stream, s->stats, s->cum, s->len_y, d_noise,
+                     noise_stride, noise_scale, seed, z_p, I, Tx, Ty);
+}
+
+// ---- a12-a14: ResidualCouplingTransformersBlock.forward(reverse=True) (models.py:750-757).
+// z in s->zA; result pointer returned (zA or zB).  Each Flip is folded into the next layer's
+// channel-reversed read (pre conv) and the EPI_COUPLE write.
+static float* run_flow(vits_session* s, int B, int Ty) {
+  vits_model* m = s->m;
+  const vits_hparams& hp = m->hp;
+  const int H = hp.hidden_channels, I = hp.inter_channels, half = I / 2, L = hp.flow_wn_layers, K5 = hp.flow_kernel_size;
+  float* u = s->zA;
+  float* v = s->zB;
+  for (int f = hp.flow_n_flows - 1; f >= 0; --f) {
+    const CouplingW& C = m->flow[f];
+    // h = pre(x0) * mask, x0[c] = u[I-1-c]  (models.py:375-376 after Flip)
+    ConvParams P = conv_params(C.pre, u, s->fh, B, Ty, 1, 0);
+    P.x_ch_off = I - 1; P.x_ch_sign = -1; P.x_bstride = (long long)I * Ty;
+    P.out_mask = 1; P.len = s->len_y;
+    launch_conv(s, P, EPI_STORE, "flow.pre");
+    // h = h + pre_transformer(h * mask)  (models.py:377)
+    hipMemcpyAsync(s->x, s->fh, sizeof(float) * (size_t)B * H * Ty, hipMemcpyDeviceToDevice, s->stream);
+    run_encoder(s, C.enc, s->x, s->len_y, B, Ty, -1, -1, s->fh, s->fx);
+    // WN (modules.py:148-176): fx is the running x, fskip the output accumulator
+    for (int i = 0; i < L; ++i) {
+      P = conv_params(C.in_layers[i], s->fx, s->facts, B, Ty, 1, (K5 - 1) / 2);
+      P.Cout = H; P.H = H; P.y_bstride = (long long)H * Ty;
+      if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = C.cond_off + i * 2 * H; }
+      launch_conv(s, P, EPI_GATE, "flow.wn_in");
+      P = conv_params(C.rs_layers[i], s->facts, nullptr, B, Ty, 1, 0);
+      P.io = s->fx; P.skip = s->fskip; P.H = H; P.first = i == 0; P.last = i == L - 1; P.len = s->len_y;
+      P.y_bstride = (long long)H * Ty;
+      launch_conv(s, P, EPI_RESSKIP, "flow.wn_rs");
+    }
+    // m = post(h) * mask ; x1 = (x1 - m) * mask ; cat (models.py:379-392)
+    P = conv_params(C.post, s->fskip, nullptr, B, Ty, 1, 0);
+    P.u = u; P.io = v; P.H = half; P.len = s->len_y; P.y_bstride = (long long)I * Ty;
+    launch_conv(s, P, EPI_COUPLE, "flow.post");
+    float* t = u; u = v; v = t;
+  }
+  return u;
+}
+
+// ---- a15-a20: decoder (models.py:1016-1054 / 872-891).  z [B,I,Ty] (masked at staging with len_y
+// when mask_in), audio -> d_audio [B, audio_bstride]
+static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, int Ty, float* d_audio, long long audio_bstride,
+                        float* d_mb) {
+  vits_model* m = s->m;
+  const vits_hparams& hp = m->hp;
+  int C = hp.dec_initial_channel, T = Ty;
+  float* cur = s->dec_bufs[0];
+  ConvParams P = conv_params(m->conv_pre, z, cur, B, Ty, 1, 3);
+  if (mask_in) { P.in_mask = 1; P.len = s->len_y; }  // (z * y_mask) models.py:1703
+  launch_conv(s, P, EPI_STORE, "dec.conv_pre");
+  const float* in1 = cur; const float* in2 = nullptr; const float* in3 = nullptr;
+  float in_scale = 1.f;
+  for (int i = 0; i < hp.n_ups; ++i) {
+    const UpW& U = m->ups[i];
+    float** set = &s->dec_bufs[1 + 7 * (i & 1)];
+    float* y = set[0];
+    const int Co = U.cout, To = T * U.u;
+    // x = leaky_relu(x, 0.1); x = ups[i](x)  (models.py:1027-1028), polyphase
+    memset(&P, 0, sizeof P);
+    P.n_groups = 1;
+    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = U.w.w; P.g[0].bias = U.w.bias; P.g[0].y = y;
+    P.g[0].K = U.taps; P.g[0].dil = 1; P.g[0].pad_l = U.pad_l; P.g[0].n_sg = U.w.n_sg;
+    P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
+    P.M = U.w.Mpad; P.Cout = U.w.M; P.Tout = T; P.Tout_stride = To; P.y_bstride = (long long)Co * To;
+    P.in_slope = 0.1f; P.in_scale = in_scale;
+    P.ups_u = U.u; P.ups_cout = Co;
+    for (int r = 0; r < U.u; ++r) P.ups_shift[r] = U.shift[r];
+    launch_conv(s, P, EPI_STORE, "dec.ups", U.halo);
+    C = Co; T = To;
+    // MRF: 3 ResBlock1 chains in grouped launches (modules.py:210-223)
+    const int nk = hp.n_resk;
+    for (int d = 0; d < hp.n_resd; ++d) {
+      memset(&P, 0, sizeof P);
+      P.n_groups = nk;
+      for (int j = 0; j < nk; ++j) {  // xt = c1(leaky_relu(x))
+        const ResBlockW& R = m->rb[(size_t)i * nk + j];
+        P.g[j].x = d == 0 ? y : set[4 + j];
+        P.g[j].w = R.c1[d].w; P.g[j].bias = R.c1[d].bias; P.g[j].y = set[1 + j];
+        P.g[j].K = R.K; P.g[j].dil = R.dil[d]; P.g[j].pad_l = (R.K - 1) * R.dil[d] / 2; P.g[j].n_sg = R.c1[d].n_sg;
+      }
+      P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
+      P.M = m->rb[(size_t)i * nk].c1[d].Mpad; P.Cout = C; P.Tout = T; P.Tout_stride = T; P.y_bstride = (long long)C * T;
+      P.in_slope = 0.1f; P.in_scale = 1.f;
+      launch_conv(s, P, EPI_STORE, "dec.res_c1");
+      for (int j = 0; j < nk; ++j) {  // x = c2(leaky_relu(xt)) + x
+        const ResBlockW& R = m->rb[(size_t)i * nk + j];
+        P.g[j].x = set[1 + j];
+        P.g[j].w = R.c2[d].w; P.g[j].bias = R.c2[d].bias; P.g[j].y = set[4 + j];
+        P.g[j].res = d == 0 ? y : set[4 + j];
+        P.g[j].K = R.K; P.g[j].dil = 1; P.g[j].pad_l = (R.K - 1) / 2; P.g[j].n_sg = R.c2[d].n_sg;
+      }
+      launch_conv(s, P, EPI_STORE, "dec.res_c2");
+    }
+    in1 = set[4]; in2 = nk > 1 ? set[5] : nullptr; in3 = nk > 2 ? set[6] : nullptr;
+    in_scale = 1.0f / (float)nk;  // x = xs / num_kernels (models.py:1036), folded into the next staging
+  }
+  float* post = s->dec_bufs[15];
+  float* mb = d_mb ? d_mb : s->dec_bufs[16];
+  if (hp.dec_type == 0) {
+    // leaky_relu(0.01) -> ReflectionPad1d((1,0)) -> subband_conv_post (models.py:1038-1040)
+    const int Tp = T + 1, Pc = m->conv_post.M;
+    memset(&P, 0, sizeof P);
+    P.n_groups = 1;
+    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = m->conv_post.w; P.g[0].y = post;
+    P.g[0].K = 7; P.g[0].dil = 1; P.g[0].pad_l = 4; P.g[0].n_sg = m->conv_post.n_sg;
+    P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
+    P.M = m->conv_post.Mpad; P.Cout = Pc; P.Tout = Tp; P.Tout_stride = Tp; P.y_bstride = (long long)Pc * Tp;
+    P.in_slope = 0.01f; P.in_scale = in_scale; P.reflect = 1;
+    launch_conv(s, P, EPI_STORE, "dec.conv_post");
+    const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, Tm = T * hop;
+    {
+      ProfScope ps(s, "istft", 0);
+      hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm);
+    }
+    {
+      ProfScope ps(s, "pqmf", 0);
+      hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3(cdiv(Tm * S, 256), B), dim3(256), 0, s->stream, mb, m->pqmf, d_audio, S,
+                         hp.pqmf_taps, Tm, audio_bstride);
+    }
+  } else {
+    memset(&P, 0, sizeof P);
+    P.n_groups = 1;
+    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = m->conv_post.w; P.g[0].y = post;
+    P.g[0].K = 7; P.g[0].dil = 1; P.g[0].pad_l = 3; P.g[0].n_sg = m->conv_post.n_sg;
+    P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
+    P.M = m->conv_post.Mpad; P.Cout = 1; P.Tout = T; P.Tout_stride = T; P.y_bstride = T;
+    P.in_slope = 0.01f; P.in_scale = in_scale;
+    launch_conv(s, P, EPI_STORE, "dec.conv_post");
+    hipLaunchKernelGGL(tanh_copy_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s->stream, post, d_audio, T, (long long)T, audio_bstride);
+  }
+}
+
+// ---- helpers for the host-buffer stage entry points
+struct HostStage {
+  vits_model* m; vits_session* s = nullptr; std::vector<void*> tmp;
+  explicit HostStage(vits_model* m_) : m(m_) {}
+  ~HostStage() {
+    if (s) { hipStreamSynchronize(s->stream); pool_release(m, s); }
+    for (void* p : tmp) hipFree(p);
+  }
+  template <typename T> T* to_dev(const T* h, size_t n) {
+    if (!h) return nullptr;
+    void* d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    tmp.push_back(d);
+    hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s->stream);
+    return static_cast<T*>(d);
+  }
+  template <typename T> T* dev_alloc(size_t n) {
+    void* d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    tmp.push_back(d);
+    return static_cast<T*>(d);
+  }
+};
+
+static int begin_stage(HostStage& hs, int B, int Tx, int Ty) {
+  hipError_t e = hipSetDevice(hs.m->device);
+  if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
+  TRY(pool_acquire(hs.m, &hs.s));
+  TRY(session_reserve(hs.s, B, Tx, Ty));
+  return VITS_OK;
+}
+
+static void set_lengths(vits_session* s, const int64_t* d_len64, int* d_len32, int B, int clamp) {
+  hipLaunchKernelGGL(lengths_to_i32_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, d_len64, d_len32, B, clamp);
+}
+
+
+static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t* d_len, int B, int Tx, const float* scales,
+                           const int64_t* d_sid, const int32_t* d_forced, int Ty, uint64_t seed, float* d_audio, int64_t cap) {
+  set_lengths(s, d_len, s->len_x, B, Tx);
+  run_cond(s, d_sid, B);
+  run_text_encoder(s, d_ids, B, Tx);
+  if (!d_forced) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx);
+  run_durations(s, d_forced, scales[1], B, Tx, Ty);
+  run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
+  float* z = run_flow(s, B, Ty);
+  run_decoder(s, z, true, B, Ty, d_audio, cap, nullptr);
+}
+
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int vits_is_device_backend(void) { return 1; }
+const char* vits_last_error(void) { return g_err; }
+
+int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
+  if (!blob || !out || bytes < 16 + sizeof(vits_hparams)) return fail(VITS_ERR_ARG, "bad blob argument");
+  const unsigned char* p = static_cast<const unsigned char*>(blob);
+  if (memcmp(p, "VITSW001", 8) != 0) return fail(VITS_ERR_BLOB, "bad magic");
+  uint32_t hb;
+  memcpy(&hb, p + 8, 4);
+  if (hb != sizeof(vits_hparams)) return fail(VITS_ERR_BLOB, "hparams size %u != %zu", hb, sizeof(vits_hparams));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VITS_ERR_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(VITS_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  vits_model* m = new vits_model();
+  memcpy(&m->hp, p + 12, sizeof(vits_hparams));
+  m->device = device;
+  if (m->hp.abi_version != VITS_ABI_VERSION) { delete m; return fail(VITS_ERR_BLOB, "abi version mismatch"); }
+  m->blob = p; m->blob_bytes = bytes;
+  memcpy(&m->n_entries, p + 12 + hb, 4);
+  m->entries = reinterpret_cast<const vits_blob_entry*>(p + 16 + hb);
+  if (16 + hb + (size_t)m->n_entries * sizeof(vits_blob_entry) > bytes) { delete m; return fail(VITS_ERR_BLOB, "truncated table"); }
+  for (uint32_t i = 0; i < m->n_entries; ++i)
+    if (m->entries[i].offset + m->entries[i].nelem * 4 > bytes) { delete m; return fail(VITS_ERR_BLOB, "truncated data"); }
+  int rc = load_model(m);
+  m->blob = nullptr; m->entries = nullptr;
+  if (rc != VITS_OK) { for (void* a : m->allocs) hipFree(a); delete m; return rc; }
+  hipDeviceSynchronize();
+  *out = m;
+  return VITS_OK;
+}
+
+void vits_destroy(vits_model* m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  for (vits_session* s : m->pool) session_free(s);
+  for (void* a : m->allocs) hipFree(a);
+  delete m;
+}
+
+int vits_get_hparams(const vits_model* m, vits_hparams* out) {
+  if (!m || !out) return fail(VITS_ERR_ARG, "null argument");
+  *out = m->hp;
+  return VITS_OK;
+}
+
+double vits_algorithmic_flops(const vits_model* m, int32_t B, int32_t Tx, int32_t Ty) {
+  const vits_hparams* hp = &m->hp;
+  double H = hp->hidden_channels, I = hp->inter_channels, F = hp->filter_channels, D = hp->dp_filter_channels;
+  double NW = 2 * hp->window_size + 1;
+  double enc_layer = 2 * (4 * H * H) + 2 * (2 * H * F * hp->kernel_size) + 2 * 2 * NW * H;
+  double tok = hp->n_layers * enc_layer + 2 * H * 2 * I;
+  double dds = hp->dp_dds_layers * (2 * D * hp->dp_kernel_size + 2 * D * D);
+  tok += 2 * H * D + 2 * D * D + dds + (hp->dp_n_flows - 1) * (2 * D + dds + 2 * D * (3 * hp->dp_num_bins - 1));
+  double tok_quad = hp->n_layers * 4 * H;
+  double K5 = hp->flow_kernel_size;
+  double fl = 2 * (I / 2) * H + (2 * (4 * H * H) + 2 * (2 * H * H * K5) + 2 * 2 * NW * H);
+  for (int i = 0; i < hp->flow_wn_layers; ++i) fl += 2 * H * 2 * H * K5 + 2 * H * (i < hp->flow_wn_layers - 1 ? 2 * H : H);
+  fl += 2 * H * (I / 2);
+  double frame = hp->flow_n_flows * fl, frame_quad = hp->flow_n_flows * 4 * H;
+  double C = hp->dec_initial_channel, rate = 1, dec = 2 * I * C * 7;
+  for (int i = 0; i < hp->n_ups; ++i) {
+    dec += rate * 2 * C * (C / 2) * hp->up_kernels[i];
+    rate *= hp->up_rates[i];
+    C /= 2;
+    for (int j = 0; j < hp->n_resk; ++j) dec += rate * hp->n_resd * 2 * (2 * C * C * hp->res_kernels[j]);
+  }
+  if (hp->dec_type == 0) {
+    double P = hp->subbands * (hp->istft_n_fft + 2);
+    dec += rate * 2 * C * P * 7;
+    dec += rate * hp->subbands * 2 * (hp->istft_n_fft + 2) * hp->istft_n_fft;
+    dec += rate * hp->subbands * hp->istft_hop * 2 * (hp->pqmf_taps + 1);
+  } else {
+    dec += rate * 2 * C * 7;
+  }
+  frame += dec;
+  return (double)B * ((double)Tx * (tok + tok_quad * Tx) + (double)Ty * (frame + frame_quad * Ty));
+}
+
+int vits_stage_text_encoder(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const int64_t* sid,
+                            float* x, float* m_p, float* logs_p) {
+  if (!m || !ids || !lengths || !x || !m_p || !logs_p || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+  HostStage hs(m);
+  TRY(begin_stage(hs, B, Tx, 1));
+  vits_session* s = hs.s;
+  const int H = m->hp.hidden_channels, I = m->hp.inter_channels;
+  int64_t* d_ids = hs.to_dev(ids, (size_t)B * Tx);
+  int64_t* d_len = hs.to_dev(lengths, B);
+  int64_t* d_sid = hs.to_dev(sid, B);
+  if (!d_ids || !d_len) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  set_lengths(s, d_len, s->len_x, B, Tx);
+  run_cond(s, d_sid, B);
+  run_text_encoder(s, d_ids, B, Tx);
+  HIP_TRY(hipMemcpyAsync(x, s->x, sizeof(float) * (size_t)B * H * Tx, hipMemcpyDeviceToHost, s->stream));
+  for (int b = 0; b < B; ++b) {
+    HIP_TRY(hipMemcpyAsync(m_p + (size_t)b * I * Tx, s->stats + (size_t)b * 2 * I * Tx, sizeof(float) * (size_t)I * Tx, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(logs_p + (size_t)b * I * Tx, s->stats + ((size_t)b * 2 * I + I) * Tx, sizeof(float) * (size_t)I * Tx, hipMemcpyDeviceToHost, s->stream));
+  }
+  return check_err(s);
+}
+
+int vits_stage_duration(vits_model* m, const float* x, const int64_t* lengths, int32_t B, int32_t Tx, const int64_t* sid,
+                        const float* noise, float noise_scale_w, float* logw) {
+  if (!m || !x || !lengths || !noise || !logw || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  HostStage hs(m);
+  TRY(begin_stage(hs, B, Tx, 1));
+  vits_session* s = hs.s;
+  const int H = m->hp.hidden_channels;
+  float* d_x = hs.to_dev(x, (size_t)B * H * Tx);
+  int64_t* d_len = hs.to_dev(lengths, B);
+  int64_t* d_sid = hs.to_dev(sid, B);
+  float* d_noise = hs.to_dev(noise, (size_t)B * 2 * Tx);
+  if (!d_x || !d_len || !d_noise) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  set_lengths(s, d_len, s->len_x, B, Tx);
+  run_cond(s, d_sid, B);
+  run_duration(s, d_x, d_noise, noise_scale_w, 0, B, Tx);
+  HIP_TRY(hipMemcpyAsync(logw, s->logw, sizeof(float) * (size_t)B * Tx, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
+}
+
+int vits_stage_regulate(vits_model* m, const float* logw, const int32_t* forced, const int64_t* lengths, int32_t B, int32_t Tx,
+                        float length_scale, const float* m_p, const float* logs_p, const float* noise, float noise_scale,
+                        int32_t Tcap, int32_t* durations, int64_t* y_lengths, float* z_p) {
+  if (!m || !lengths || !durations || !y_lengths || (!logw && !forced) || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  if (z_p && (!m_p || !logs_p || Tcap <= 0)) return fail(VITS_ERR_ARG, "m_p/logs_p/T_cap required");
+  HostStage hs(m);
+  TRY(begin_stage(hs, B, Tx, Tcap > 0 ? Tcap : 1));
+  vits_session* s = hs.s;
+  const int I = m->hp.inter_channels;
+  int64_t* d_len = hs.to_dev(lengths, B);
+  int* d_forced = hs.to_dev(forced, (size_t)B * Tx);
+  if (logw) HIP_TRY(hipMemcpyAsync(s->logw, logw, sizeof(float) * (size_t)B * Tx, hipMemcpyHostToDevice, s->stream));
+  set_lengths(s, d_len, s->len_x, B, Tx);
+  run_durations(s, d_forced, length_scale, B, Tx, z_p ? Tcap : 0);
+  if (z_p) {
+    for (int b = 0; b < B; ++b) {
+      HIP_TRY(hipMemcpyAsync(s->stats + (size_t)b * 2 * I * Tx, m_p + (size_t)b * I * Tx, sizeof(float) * (size_t)I * Tx, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(s->stats + ((size_t)b * 2 * I + I) * Tx, logs_p + (size_t)b * I * Tx, sizeof(float) * (size_t)I * Tx, hipMemcpyHostToDevice, s->stream));
+    }
+    float* d_noise = hs.to_dev(noise, (size_t)B * I * Tcap);
+    float* d_zero = nullptr;
+    if (!d_noise) {  // noise == NULL means eps = 0 here (stage API), not Philox
+      d_zero = hs.dev_alloc<float>((size_t)B * I * Tcap);
+      if (!d_zero) return fail(VITS_ERR_NOMEM, "device alloc failed");
+      HIP_TRY(hipMemsetAsync(d_zero, 0, sizeof(float) * (size_t)B * I * Tcap, s->stream));
+      d_noise = d_zero;
+    }
+    run_expand(s, d_noise, Tcap, noise_scale, 0, s->zA, B, Tx, Tcap);
+    HIP_TRY(hipMemcpyAsync(z_p, s->zA, sizeof(float) * (size_t)B * I * Tcap, hipMemcpyDeviceToHost, s->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(durations, s->dur, sizeof(int) * (size_t)B * Tx, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(y_lengths, s->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
+}
+
+int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, int32_t B, int32_t Ty, const int64_t* sid, float* z) {
+  if (!m || !z_p || !y_lengths || !z || B <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  HostStage hs(m);
+  TRY(begin_stage(hs, B, 1, Ty));
+  vits_session* s = hs.s;
+  const int I = m->hp.inter_channels;
+  int64_t* d_len = hs.to_dev(y_lengths, B);
+  int64_t* d_sid = hs.to_dev(sid, B);
+  HIP_TRY(hipMemcpyAsync(s->zA, z_p, sizeof(float) * (size_t)B * I * Ty, hipMemcpyHostToDevice, s->stream));
+  set_lengths(s, d_len, s->len_y, B, Ty);
+  run_cond(s, d_sid, B);
+  float* r = run_flow(s, B, Ty);
+  HIP_TRY(hipMemcpyAsync(z, r, sizeof(float) * (size_t)B * I * Ty, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
+}
+
+int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, float* audio, float* audio_mb) {
+  if (!m || !z || !audio || B <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  HostStage hs(m);
+  TRY(begin_stage(hs, B, 1, Ty));
+  vits_session* s = hs.s;
+  const vits_hparams& hp = m->hp;
+  const int I = hp.inter_channels;
+  const long long S = (long long)Ty * hp.hop_length;
+  HIP_TRY(hipMemcpyAsync(s->zA, z, sizeof(float) * (size_t)B * I * Ty, hipMemcpyHostToDevice, s->stream));
+  float* d_audio = hs.dev_alloc<float>((size_t)B * S);
+  if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  run_decoder(s, s->zA, false, B, Ty, d_audio, S, nullptr);
+  HIP_TRY(hipMemcpyAsync(audio, d_audio, sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream));
+  if (audio_mb && hp.dec_type == 0)
+    HIP_TRY(hipMemcpyAsync(audio_mb, s->dec_bufs[16], sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
+}
+
+// ---- the hot path, host buffers (SynthesizerTrn.infer, models.py:1679-1704)
+int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                    const int64_t* sid, const vits_synth_opts* opts, float** out_audio, int64_t* out_samples, int64_t* out_lengths) {
+  if (!m || !ids || !lengths || !scales || !out_audio || !out_samples || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+  const vits_hparams& hp = m->hp;
+  const int I = hp.inter_channels;
+  const float noise_scale = scales[0], length_scale = scales[1], noise_scale_w = scales[2];
+  const uint64_t seed = opts ? opts->seed : 0;
+  HostStage hs(m);
+  TRY(begin_stage(hs, B, Tx, 1));
+  vits_session* s = hs.s;
+  int64_t* d_ids = hs.to_dev(ids, (size_t)B * Tx);
+  int64_t* d_len = hs.to_dev(lengths, B);
+  int64_t* d_sid = hs.to_dev(sid, B);
+  if (!d_ids || !d_len) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  set_lengths(s, d_len, s->len_x, B, Tx);
+  run_cond(s, d_sid, B);
+  run_text_encoder(s, d_ids, B, Tx);
+  int* d_forced = nullptr;
+  if (opts && opts->forced_durations) {
+    d_forced = hs.to_dev(opts->forced_durations, (size_t)B * Tx);
+  } else {
+    float* d_ndp = (opts && opts->noise_dp) ? hs.to_dev(opts->noise_dp, (size_t)B * 2 * Tx) : nullptr;
+    run_duration(s, s->x, d_ndp, noise_scale_w, seed, B, Tx);
+  }
+  run_durations(s, d_forced, length_scale, B, Tx, 0);
+  // the one host round trip of the free-running path: T_y sizes everything downstream
+  std::vector<int64_t> ylen(B);
+  HIP_TRY(hipMemcpyAsync(ylen.data(), s->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s->stream));
+  TRY(check_err(s));
+  int64_t Ty = 1;
+  for (int b = 0; b < B; ++b) if (ylen[b] > Ty) Ty = ylen[b];
+  if (opts && opts->max_frames > 0 && Ty > opts->max_frames) return fail(VITS_ERR_ARG, "T_y %lld exceeds max_frames %d", (long long)Ty, opts->max_frames);
+  if (Ty > (1 << 24)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  // grow the workspace for T_y: encoder outputs live in the arena, so keep them across the re-plan
+  const int H = hp.hidden_channels;
+  float* keep_stats = hs.dev_alloc<float>((size_t)B * 2 * I * Tx);
+  int* keep_cum = hs.dev_alloc<int>((size_t)B * Tx);
+  if (!keep_stats || !keep_cum) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  HIP_TRY(hipMemcpyAsync(keep_stats, s->stats, sizeof(float) * (size_t)B * 2 * I * Tx, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(keep_cum, s->cum, sizeof(int) * (size_t)B * Tx, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  TRY(session_reserve(s, B, Tx, (int)Ty));
+  HIP_TRY(hipMemcpyAsync(s->stats, keep_stats, sizeof(float) * (size_t)B * 2 * I * Tx, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->cum, keep_cum, sizeof(int) * (size_t)B * Tx, hipMemcpyDeviceToDevice, s->stream));
+  std::vector<int> ylen32(B);
+  for (int b = 0; b < B; ++b) ylen32[b] = (int)ylen[b];
+  HIP_TRY(hipMemcpyAsync(s->len_y, ylen32.data(), sizeof(int) * B, hipMemcpyHostToDevice, s->stream));
+  set_lengths(s, d_len, s->len_x, B, Tx);
+  run_cond(s, d_sid, B);
+  (void)H;
+  float* d_npr = nullptr;
+  long long nstride = Ty;
+  if (opts && opts->noise_prior) {
+    if (opts->noise_prior_stride < Ty) return fail(VITS_ERR_ARG, "noise_prior stride %lld < T_y %lld", (long long)opts->noise_prior_stride, (long long)Ty);
+    nstride = opts->noise_prior_stride;
+    d_npr = hs.to_dev(opts->noise_prior, (size_t)B * I * nstride);
+    if (!d_npr) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  }
+  run_expand(s, d_npr, nstride, noise_scale, seed, s->zA, B, Tx, (int)Ty);
+  float* z = run_flow(s, B, (int)Ty);
+  const int64_t S = Ty * hp.hop_length;
+  float* d_audio = hs.dev_alloc<float>((size_t)B * S);
+  if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr);
+  float* h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)B * S));
+  if (!h_audio) return fail(VITS_ERR_NOMEM, "host alloc failed");
+  hipError_t e = hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream);
+  int rc = e == hipSuccess ? check_err(s) : fail(VITS_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e));
+  if (rc != VITS_OK) { free(h_audio); return rc; }
+  *out_audio = h_audio;
+  *out_samples = S;
+  if (out_lengths) for (int b = 0; b < B; ++b) out_lengths[b] = ylen[b] * hp.hop_length;
+  return VITS_OK;
+}
+
+void vits_free_output(float* p) { free(p); }
+
+// ---- device-resident sessions (bench / serving loop)
+int vits_session_create(vits_model* m, int32_t max_B, int32_t max_Tx, int32_t max_Ty, vits_session** out) {
+  if (!m || !out || max_B <= 0 || max_Tx <= 0 || max_Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(m->device));
+  vits_session* s = nullptr;
+  TRY(session_new(m, &s));
+  int rc = session_reserve(s, max_B, max_Tx, max_Ty);
+  if (rc != VITS_OK) { session_free(s); return rc; }
+  *out = s;
+  return VITS_OK;
+}
+
+void vits_session_destroy(vits_session* s) { session_free(s); }
+
+int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const int64_t* d_lengths, int32_t B, int32_t Tx,
+                                   const float* scales, const int64_t* d_sid, const int32_t* d_forced, int32_t Ty, uint64_t seed,
+                                   float* d_audio, int64_t cap, void* stream) {
+  if (!s || !d_ids || !d_lengths || !scales || !d_audio || B <= 0 || Tx <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  vits_model* m = s->m;
+  if (cap < (int64_t)Ty * m->hp.hop_length) return fail(VITS_ERR_ARG, "audio capacity %lld < T_y*hop", (long long)cap);
+  HIP_TRY(hipSetDevice(m->device));
+  (void)stream;  // sessions run on their own stream; the argument is reserved
+  TRY(session_reserve(s, B, Tx, Ty));
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  if (s->use_graph && !s->profile) {
+    vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed, scales[0], scales[1], scales[2]);
+    auto it = s->graphs.find(key);
+    if (it == s->graphs.end()) {
+      hipGraph_t g = nullptr;
+      HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+      forward_device(s, d_ids, d_lengths, B, Tx, scales, d_sid, d_forced, Ty, seed, d_audio, cap);
+      HIP_TRY(hipStreamEndCapture(s->stream, &g));
+      hipGraphExec_t ge = nullptr;
+      HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+      it = s->graphs.emplace(key, ge).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, s->stream));
+  } else {
+    forward_device(s, d_ids, d_lengths, B, Tx, scales, d_sid, d_forced, Ty, seed, d_audio, cap);
+  }
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  s->timed = true;
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(VITS_ERR_DEVICE, "launch failed: %s", hipGetErrorString(le));
+  return VITS_OK;
+}
+
+int vits_session_last_ms(vits_session* s, float* ms) {
+  if (!s || !ms || !s->timed) return fail(VITS_ERR_ARG, "no timed call");
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return check_err(s);
+}
+
+int vits_session_sync(vits_session* s) {
+  if (!s) return fail(VITS_ERR_ARG, "null session");
+  return check_err(s);
+}
+
+int vits_session_set_options(vits_session* s, int use_graph, int profile) {
+  if (!s) return fail(VITS_ERR_ARG, "null session");
+  s->use_graph = use_graph != 0;
+  s->profile = profile != 0;
+  return VITS_OK;
+}
+
+// Per-kernel-family device time from HIP events recorded around every launch of the last
+// profiled (eager) forwards.  Writes lines "name launches total_ms flops" into buf.
+int vits_session_profile_report(vits_session* s, char* buf, size_t cap) {
+  if (!s || !buf || !cap) return fail(VITS_ERR_ARG, "bad argument");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::map<std::string, std::tuple<int, double, double>> agg;
+  for (auto& r : s->prof) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    auto& a = agg[r.name];
+    std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += r.flops;
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  s->prof.clear();
+  size_t off = 0;
+  buf[0] = 0;
+  for (auto& kv : agg) {
+    int n = snprintf(buf + off, cap - off, "%s %d %.6f %.0f\n", kv.first.c_str(), std::get<0>(kv.second), std::get<1>(kv.second), std::get<2>(kv.second));
+    if (n < 0 || (size_t)n >= cap - off) break;
+    off += n;
+  }
+  return VITS_OK;
+}
+
+// ---- single generic op (kernel-level parity): y = conv1d(lrelu(x)), 'same' padding
+int vits_op_conv1d(int device, const float* x, const float* w, const float* bias, int32_t B, int32_t Cin, int32_t Cout, int32_t T,
+                   int32_t K, int32_t dil, float slope, float* y) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || K <= 0 || dil <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  if (Cin % CONV_CI_T) return fail(VITS_ERR_UNSUPPORTED, "C_in must be a multiple of %d", CONV_CI_T);
+  if ((K - 1) * dil > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "(K-1)*dil > %d", CONV_MAX_HALO);
+  HIP_TRY(hipSetDevice(device));
+  vits_model tmp;
+  tmp.device = device;
+  ConvW W = make_conv(&tmp, Cout, Cin, K, bias, [&](int r, int ci, int kk) { return w[((size_t)r * Cin + ci) * K + kk]; });
+  int rc = VITS_OK;
+  float *dx = nullptr, *dy = nullptr;
+  vits_session s;
+  s.m = &tmp;
+  if (tmp.missing) rc = VITS_ERR_NOMEM;
+  if (rc == VITS_OK && hipMalloc((void**)&dx, sizeof(float) * (size_t)B * Cin * T) != hipSuccess) rc = fail(VITS_ERR_NOMEM, "alloc");
+  if (rc == VITS_OK && hipMalloc((void**)&dy, sizeof(float) * (size_t)B * Cout * T) != hipSuccess) rc = fail(VITS_ERR_NOMEM, "alloc");
+  if (rc == VITS_OK) {
+    hipMemcpy(dx, x, sizeof(float) * (size_t)B * Cin * T, hipMemcpyHostToDevice);
+    ConvParams P = conv_params(W, dx, dy, B, T, dil, (K - 1) * dil / 2);
+    P.in_slope = slope;
+    launch_conv(&s, P, EPI_STORE, "op.conv1d");
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = fail(VITS_ERR_DEVICE, "conv kernel failed: %s", hipGetErrorString(e));
+    else hipMemcpy(y, dy, sizeof(float) * (size_t)B * Cout * T, hipMemcpyDeviceToHost);
+  }
+  if (dx) hipFree(dx);
+  if (dy) hipFree(dy);
+  for (void* a : tmp.allocs) hipFree(a);
+  return rc;
+}
+
+}  // extern "C"

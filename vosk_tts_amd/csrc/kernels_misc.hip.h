@@ -1,0 +1,451 @@
+// kernels_misc.hip.h — the non-GEMM kernels of the VITS2 inference path (gfx950, wave64).
+// All tensors are channel-major [B,C,T] fp32; threads map to consecutive t so every global
+// access is coalesced along time.  Reference lines are cited per kernel
+// (paths relative to /root/reference/training/vits2/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PI_F 3.14159265358979323846f
+
+// ----------------------------------------------------------------------------- Philox normals
+// Counter-based noise for the two randn draws of infer() (models.py:96, :1700) when the caller
+// does not inject noise.  (The CPU checker under oracle/ restates the same definition.)
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ inline float philox_normal(uint64_t seed, uint32_t stream, uint32_t row, uint32_t t) {
+  uint32_t c[4] = {t, row, stream, 0};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float u1 = ((float)c[0] + 0.5f) * (1.0f / 4294967296.0f);
+  float u2 = ((float)c[1] + 0.5f) * (1.0f / 4294967296.0f);
+  if (u1 < 1e-12f) u1 = 1e-12f;
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// ----------------------------------------------------------------------------- small utilities
+__global__ void lengths_to_i32_kernel(const int64_t* in, int* out, int n, int clamp_max) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    long long v = in[i];
+    if (v < 0) v = 0;
+    if (v > clamp_max) v = clamp_max;
+    out[i] = (int)v;
+  }
+}
+
+// x[b,c,t] = emb[ids[b,t]][c] * sqrt(H) * mask  (models.py:318-322).  err[0] set on bad id.
+__global__ void embed_kernel(const int64_t* ids, const int* len, const float* emb, float* x, int H, int T, int n_vocab,
+                             float scale, int* err) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+  if (t >= T) return;
+  long long id = ids[(long long)b * T + t];
+  const bool valid = t < len[b];
+  if (valid && (id < 0 || id >= n_vocab)) { atomicOr(err, 1); id = 0; }
+  for (int c = blockIdx.y; c < H; c += gridDim.y)
+    x[((long long)b * H + c) * T + t] = valid ? emb[id * H + c] * scale : 0.f;
+}
+
+// out[b][r] = bias[r] + sum_j W[r][j] * emb_g[sid[b]][j]   — every cond(g) / Linear(g) on the path
+// in one launch: enc spk_emb_linear (attentions.py:52-56), dp.cond (models.py:60), WN cond_layer
+// (modules.py:152-153).  W is the row-concatenation built at load time.  One wave per row.
+__global__ void cond_gemv_kernel(const float* W, const float* bias, const float* emb_g, const int64_t* sid, float* out,
+                                 int rows, int G, int n_speakers, int* err) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), b = blockIdx.y;
+  if (row >= rows) return;
+  long long s = sid ? sid[b] : 0;
+  if (s < 0 || s >= n_speakers) { if (lane == 0) atomicOr(err, 2); s = 0; }
+  const float* g = emb_g + s * G;
+  float a = 0.f;
+  for (int j = lane; j < G; j += 64) a += W[(long long)row * G + j] * g[j];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if (lane == 0) out[(long long)b * rows + row] = a + bias[row];
+}
+
+// x = (x + v[b][c]) * mask   (attentions.py:55-56)
+__global__ void add_vec_mask_kernel(float* x, const float* v, int v_stride, int v_off, const int* len, int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const long long o = ((long long)b * C + c) * T + t;
+  x[o] = t < len[b] ? x[o] + v[(long long)b * v_stride + v_off + c] : 0.f;
+}
+
+// ----------------------------------------------------------------------------- LayerNorm over C
+// modules.LayerNorm (modules.py:29-32): y = LN_c(a [+ b]) ; optional GELU ; optional out = base + y ;
+// optional mask.  One thread per (b,t): three coalesced sweeps over C (two-pass variance).
+struct LNParams {
+  const float* a; const float* b; const float* base; float* y;
+  const float* gamma; const float* beta; const int* len;
+  int C, T; int gelu; int mask;
+};
+__global__ void layernorm_c_kernel(const LNParams P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= P.T) return;
+  const long long o0 = (long long)b * P.C * P.T + t;
+  float mean = 0.f;
+  for (int c = 0; c < P.C; ++c) {
+    float v = P.a[o0 + (long long)c * P.T];
+    if (P.b) v += P.b[o0 + (long long)c * P.T];
+    mean += v;
+  }
+  mean /= (float)P.C;
+  float var = 0.f;
+  for (int c = 0; c < P.C; ++c) {
+    float v = P.a[o0 + (long long)c * P.T];
+    if (P.b) v += P.b[o0 + (long long)c * P.T];
+    v -= mean;
+    var += v * v;
+  }
+  const float rstd = 1.0f / sqrtf(var / (float)P.C + 1e-5f);
+  const bool zero = P.mask && t >= P.len[b];
+  for (int c = 0; c < P.C; ++c) {
+    float v = P.a[o0 + (long long)c * P.T];
+    if (P.b) v += P.b[o0 + (long long)c * P.T];
+    v = (v - mean) * rstd * P.gamma[c] + P.beta[c];
+    if (P.gelu) v = gelu_erf(v);
+    if (P.base) v += P.base[o0 + (long long)c * P.T];
+    P.y[o0 + (long long)c * P.T] = zero ? 0.f : v;
+  }
+}
+
+// DDSConv first half (modules.py:100-102): y = gelu(LN1(dwconv_k,dil(x * mask))).
+// The depthwise conv is recomputed per sweep (K taps) instead of being materialised.
+struct DwLnParams {
+  const float* x; float* y; const float* w; const float* bias; const float* gamma; const float* beta; const int* len;
+  int C, T, K, dil;
+};
+__global__ void dwconv_ln_gelu_kernel(const DwLnParams P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= P.T) return;
+  const int L = P.len[b], pad = (P.K * P.dil - P.dil) / 2;
+  const long long o0 = (long long)b * P.C * P.T;
+  auto conv = [&](int c) {
+    float a = P.bias[c];
+    for (int k = 0; k < P.K; ++k) {
+      const int s = t + k * P.dil - pad;
+      if (s >= 0 && s < L && s < P.T) a += P.w[c * P.K + k] * P.x[o0 + (long long)c * P.T + s];
+    }
+    return a;
+  };
+  float mean = 0.f;
+  for (int c = 0; c < P.C; ++c) mean += conv(c);
+  mean /= (float)P.C;
+  float var = 0.f;
+  for (int c = 0; c < P.C; ++c) { float v = conv(c) - mean; var += v * v; }
+  const float rstd = 1.0f / sqrtf(var / (float)P.C + 1e-5f);
+  for (int c = 0; c < P.C; ++c)
+    P.y[o0 + (long long)c * P.T + t] = gelu_erf((conv(c) - mean) * rstd * P.gamma[c] + P.beta[c]);
+}
+
+// ----------------------------------------------------------------------------- attention
+// MultiHeadAttention.attention (attentions.py:165-196) with the relative-position key/value terms
+// (attentions.py:198-260) in exact banded form: O(T) memory, no [T,2T-1] skew.
+//   s[i,j] = q~_i.k_j + (|j-i|<=W ? q~_i.E_k[j-i+W] : 0),  masked keys (-1e4) carry weight exp(-1e4-m) == 0
+//   out_i  = sum_j p_ij v_j + sum_{|j-i|<=W} p_ij E_v[j-i+W]
+// One thread per query, fp32, online softmax per TK-key tile staged in LDS (broadcast reads).
+// Rows past len[b] are written as 0 (the reference's uniform-softmax junk there is multiplied by
+// x_mask before it can reach any valid position; see DESIGN.md "masked rows").
+// qkv: [B, 3H, T] (q rows [0,H), k rows [H,2H), v rows [2H,3H)), out [B,H,T].
+template <int DK, int TK>
+__global__ void __launch_bounds__(64) relpos_attention_kernel(const float* qkv, const float* ek, const float* ev,
+                                                               const int* len, float* out, int H, int T, int W) {
+  __shared__ float kt[DK * TK];
+  __shared__ float vt[DK * TK];
+  __shared__ float qe[9 * 64];  // [r][lane], W <= 4
+  const int lane = threadIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * 64 + lane;
+  const int L = len[b] < T ? len[b] : T;
+  const int NW = 2 * W + 1;
+  const float* qb = qkv + ((long long)b * 3 * H + (long long)hd * DK) * T;
+  const float* kb = qb + (long long)H * T;
+  const float* vb = kb + (long long)H * T;
+  const bool active = i < L;
+  const int ic = active ? i : 0;
+  const float scale = 1.0f / sqrtf((float)DK);
+  float q[DK];
+#pragma unroll
+  for (int d = 0; d < DK; ++d) q[d] = qb[(long long)d * T + ic] * scale;
+  for (int r = 0; r < NW; ++r) {
+    float e = 0.f;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) e += q[d] * ek[r * DK + d];
+    qe[r * 64 + lane] = e;
+  }
+  float acc[DK];
+#pragma unroll
+  for (int d = 0; d < DK; ++d) acc[d] = 0.f;
+  float m = -3.0e38f, l = 0.f;
+  for (int j0 = 0; j0 < L; j0 += TK) {
+    __syncthreads();
+    for (int e = lane; e < DK * TK; e += 64) {
+      const int d = e / TK, jj = e % TK;
+      const int j = j0 + jj;
+      kt[e] = j < L ? kb[(long long)d * T + j] : 0.f;
+      vt[e] = j < L ? vb[(long long)d * T + j] : 0.f;
+    }
+    __syncthreads();
+    float s[TK];
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int jj = 0; jj < TK; ++jj) {
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < DK; ++d) a += q[d] * kt[d * TK + jj];
+      const int r = j0 + jj - i;
+      if (r >= -W && r <= W) a += qe[(r + W) * 64 + lane];
+      if (j0 + jj >= L) a = -3.0e38f;
+      s[jj] = a;
+      tmax = fmaxf(tmax, a);
+    }
+    const float mn = fmaxf(m, tmax);
+    const float alpha = __expf(m - mn);
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) acc[d] *= alpha;
+#pragma unroll
+    for (int jj = 0; jj < TK; ++jj) {
+      const float p = (j0 + jj < L) ? __expf(s[jj] - mn) : 0.f;
+      l += p;
+#pragma unroll
+      for (int d = 0; d < DK; ++d) acc[d] += p * vt[d * TK + jj];
+    }
+    m = mn;
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+  for (int d = 0; d < DK; ++d) acc[d] *= inv;
+  // relative-value band: recompute the <= 2W+1 in-band probabilities (attentions.py:191-194)
+  if (active) {
+    for (int r = -W; r <= W; ++r) {
+      const int j = i + r;
+      if (j < 0 || j >= L) continue;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < DK; ++d) a += q[d] * kb[(long long)d * T + j];
+      a += qe[(r + W) * 64 + lane];
+      const float p = __expf(a - m) * inv;
+#pragma unroll
+      for (int d = 0; d < DK; ++d) acc[d] += p * ev[(r + W) * DK + d];
+    }
+  }
+  if (i < T) {
+    float* ob = out + ((long long)b * H + (long long)hd * DK) * T + i;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) ob[(long long)d * T] = active ? acc[d] : 0.f;
+  }
+}
+
+// ----------------------------------------------------------------------------- duration predictor
+// z[b,c,t] = noise * noise_scale_w  (models.py:96)
+__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const long long o = ((long long)b * 2 + c) * T + t;
+  const float e = noise ? noise[o] : philox_normal(seed, 1, (uint32_t)(b * 2 + c), (uint32_t)t);
+  z[o] = e * nsw;
+}
+
+// ConvFlow head (modules.py:365-366): h = pre(x0) + g   (Conv1d(1,D,1) is a per-channel affine; the
+// DDSConv that follows starts with x = x + g, modules.py:97-98)
+__global__ void convflow_pre_kernel(const float* z, int x0_row, const float* pw, const float* pb, const float* cond,
+                                    float* h, int D, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const long long o = ((long long)b * D + c) * T + t;
+  h[o] = pw[c] * z[((long long)b * 2 + x0_row) * T + t] + pb[c] + cond[o];
+}
+
+__device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+// Inverse rational-quadratic spline with linear tails, one element per thread
+// (transforms.py:55-177, inverse branch 152-167; searchsorted :47-52), then cat(x0,x1)*mask
+// (modules.py:386).  pr: [B, 3*nb-1 (padded rows ignored), T] = proj(h)*mask.
+__global__ void spline_inverse_kernel(float* z, int x0_row, const float* pr, int pr_rows, const int* len, int T, int nb,
+                                      float bound, float inv_sqrt_d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const int x1_row = 1 - x0_row;
+  float* p0 = &z[((long long)b * 2 + x0_row) * T + t];
+  float* p1 = &z[((long long)b * 2 + x1_row) * T + t];
+  if (t >= len[b]) { *p0 = 0.f; *p1 = 0.f; return; }
+  const float y = *p1;
+  if (!(y >= -bound && y <= bound)) return;  // identity outside the interval (transforms.py:65-77)
+  const float* pp = pr + (long long)b * pr_rows * T + t;
+  const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+  constexpr int NB = 16;
+  float w[NB], cw[NB + 1], hh[NB], ch[NB + 1];
+  float mx = -3.0e38f;
+  for (int i = 0; i < nb; ++i) { w[i] = pp[(long long)i * T] * inv_sqrt_d; mx = fmaxf(mx, w[i]); }
+  float sum = 0.f;
+  for (int i = 0; i < nb; ++i) { w[i] = expf(w[i] - mx); sum += w[i]; }
+  float acc = 0.f;
+  cw[0] = -bound;
+  for (int i = 0; i < nb; ++i) {
+    acc += min_w + (1.f - min_w * nb) * (w[i] / sum);
+    cw[i + 1] = 2.f * bound * acc - bound;
+  }
+  cw[nb] = bound;
+  mx = -3.0e38f;
+  for (int i = 0; i < nb; ++i) { hh[i] = pp[(long long)(nb + i) * T] * inv_sqrt_d; mx = fmaxf(mx, hh[i]); }
+  sum = 0.f;
+  for (int i = 0; i < nb; ++i) { hh[i] = expf(hh[i] - mx); sum += hh[i]; }
+  acc = 0.f;
+  ch[0] = -bound;
+  for (int i = 0; i < nb; ++i) {
+    acc += min_h + (1.f - min_h * nb) * (hh[i] / sum);
+    ch[i + 1] = 2.f * bound * acc - bound;
+  }
+  ch[nb] = bound;
+  int bin = -1;
+  for (int i = 0; i <= nb; ++i) {
+    const float loc = ch[i] + (i == nb ? 1e-6f : 0.f);
+    if (y >= loc) bin++;
+  }
+  bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+  float in_cw = 0.f, in_w = 1.f, in_ch = 0.f, in_h = 1.f;
+  for (int i = 0; i < nb; ++i)
+    if (i == bin) { in_cw = cw[i]; in_w = cw[i + 1] - cw[i]; in_ch = ch[i]; in_h = ch[i + 1] - ch[i]; }
+  const float cst = logf(expf(1.f - min_d) - 1.f);
+  const float ud0 = (bin == 0) ? cst : pp[(long long)(2 * nb + bin - 1) * T];
+  const float ud1 = (bin == nb - 1) ? cst : pp[(long long)(2 * nb + bin) * T];
+  const float d0 = min_d + softplus_f(ud0), d1 = min_d + softplus_f(ud1);
+  const float delta = in_h / in_w;
+  const float t1 = (y - in_ch) * (d0 + d1 - 2.f * delta);
+  const float a = t1 + in_h * (delta - d0);
+  const float bq = in_h * d0 - t1;
+  const float c = -delta * (y - in_ch);
+  const float disc = bq * bq - 4.f * a * c;
+  const float root = (2.f * c) / (-bq - sqrtf(disc));
+  *p1 = root * in_w + in_cw;
+}
+
+// ElementwiseAffine reverse + logw = z0 (modules.py:293-295, models.py:99-100)
+__global__ void ea_logw_kernel(const float* z, int row, const float* m, const float* logs, const int* len, float* logw, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  // `row` is the physical row currently holding logical channel 0 (Flips are row relabels)
+  const float v = (z[((long long)b * 2 + row) * T + t] - m[0]) * expf(-logs[0]);
+  logw[(long long)b * T + t] = t < len[b] ? v : 0.f;
+}
+
+// ----------------------------------------------------------------------------- length regulator
+// w = exp(logw)*mask*length_scale; w_ceil; y_len = max(1, sum) (models.py:1689-1691); inclusive
+// cumsum for generate_path (commons.py:128-143).  One block per batch item.
+__global__ void durations_kernel(const float* logw, const int* forced, const int* len, float length_scale, int T,
+                                 int* dur, int* cum, int* ylen32, int64_t* ylen64, int Tcap, int* err) {
+  __shared__ int part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int L = len[b];
+  const int per = (T + 255) / 256;
+  const int t0 = tid * per;
+  int s = 0;
+  for (int t = t0; t < t0 + per && t < T; ++t) {
+    int d = 0;
+    if (t < L) d = forced ? forced[(long long)b * T + t] : (int)ceilf(expf(logw[(long long)b * T + t]) * length_scale);
+    if (d < 0) d = 0;
+    dur[(long long)b * T + t] = d;
+    s += d;
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { int v = part[i]; part[i] = run; run += v; }
+    int yl = run < 1 ? 1 : run;
+    if (Tcap > 0 && yl > Tcap) { atomicOr(err, 4); yl = Tcap; }
+    ylen32[b] = yl;
+    if (ylen64) ylen64[b] = yl;
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int t = t0; t < t0 + per && t < T; ++t) {
+    run += dur[(long long)b * T + t];
+    cum[(long long)b * T + t] = run;
+  }
+}
+
+// expand m_p/logs_p to frame rate by gather (instead of the reference's one-hot matmul,
+// models.py:1696-1698) and sample the prior z_p = m_p + eps*exp(logs_p)*noise_scale (:1700).
+// stats: [B, 2I, Tx] (m rows [0,I), logs rows [I,2I)).  Frames >= y_len: z_p = eps*noise_scale.
+__global__ void expand_prior_kernel(const float* stats, const int* cum, const int* ylen, const float* noise,
+                                    long long noise_stride, float noise_scale, uint64_t seed, float* z_p, int I, int Tx,
+                                    int Ty) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+  if (f >= Ty) return;
+  const int* cb = cum + (long long)b * Tx;
+  int tok = -1;
+  if (f < ylen[b] && f < cb[Tx - 1]) {
+    int lo = 0, hi = Tx - 1;  // first j with cum[j] > f
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cb[mid] > f) hi = mid; else lo = mid + 1; }
+    tok = lo;
+  }
+  for (int c = blockIdx.y; c < I; c += gridDim.y) {
+    const float mu = tok >= 0 ? stats[((long long)b * 2 * I + c) * Tx + tok] : 0.f;
+    const float ls = tok >= 0 ? stats[((long long)b * 2 * I + I + c) * Tx + tok] : 0.f;
+    const float e = noise ? noise[((long long)b * I + c) * noise_stride + f]
+                          : philox_normal(seed, 2, (uint32_t)(b * I + c), (uint32_t)f);
+    z_p[((long long)b * I + c) * Ty + f] = mu + e * expf(ls) * noise_scale;
+  }
+}
+
+// ----------------------------------------------------------------------------- decoder tail
+// spec = exp(x[:, :, :cut]); phase = pi*sin(x[:, :, cut:]) (models.py:1043-1044);
+// OnnxSTFT.inverse (stft.py:246-262): conv_transpose1d with the windowed pinv-DFT basis, stride hop,
+// * n_fft/hop, trim n_fft/2 both sides.  One thread per sub-band output sample.
+// post: [B, S*(N+2), Tp]; mb: [B, S, Tm], Tm = (Tp-1)*hop.  basis: [N+2][N].
+__global__ void istft_kernel(const float* post, const float* basis, float* mb, int S, int N, int hop, int Tp, int Tm) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, b = blockIdx.z;
+  if (n >= Tm) return;
+  const int cut = N / 2 + 1, C = S * (N + 2);
+  const int np = n + N / 2;
+  int t_hi = np / hop;
+  if (t_hi > Tp - 1) t_hi = Tp - 1;
+  int t_lo = (np - N + hop) / hop;  // ceil((np-N+1)/hop)
+  if (np - N + 1 <= 0) t_lo = 0;
+  const float* pb = post + ((long long)b * C + (long long)s * (N + 2)) * Tp;
+  float a = 0.f;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int j = np - t * hop;
+    for (int k = 0; k < cut; ++k) {
+      const float mag = expf(pb[(long long)k * Tp + t]);
+      const float ph = PI_F * sinf(pb[(long long)(cut + k) * Tp + t]);
+      float sn, cs;
+      sincosf(ph, &sn, &cs);
+      a += mag * cs * basis[k * N + j] + mag * sn * basis[(cut + k) * N + j];
+    }
+  }
+  mb[((long long)b * S + s) * Tm + n] = a * ((float)N / (float)hop);
+}
+
+// PQMF.synthesis (pqmf.py:105-116) in polyphase form: zero-stuffing by S with gain S, pad taps/2,
+// FIR [1,S,taps+1].  One thread per output sample: (taps+1)/S * S MACs instead of S*(taps+1).
+__global__ void pqmf_synthesis_kernel(const float* mb, const float* filt, float* audio, int S, int taps, int Tm,
+                                      long long audio_bstride) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int To = Tm * S, L = taps + 1, padl = taps / 2;
+  if (t >= To) return;
+  const int j0 = ((padl - t) % S + S) % S;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* xb = mb + ((long long)b * S + s) * Tm;
+    for (int j = j0; j < L; j += S) {
+      const int u = t + j - padl;
+      if (u >= 0 && u < To) a += filt[s * L + j] * (xb[u / S] * (float)S);
+    }
+  }
+  audio[(long long)b * audio_bstride + t] = a;
+}
+
+// plain HiFi-GAN tail: tanh (models.py:889)
+__global__ void tanh_copy_kernel(const float* x, float* y, int T, long long x_bstride, long long y_bstride) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t < T) y[(long long)b * y_bstride + t] = tanhf(x[(long long)b * x_bstride + t]);
+}
