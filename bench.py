@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X-native VITS2 hot path (BASELINE.json metric: audio
+samples/sec + real-time factor).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5            # default workload = BASELINE configs[1] (C2)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full forward of SynthesizerTrn.infer (text encoder -> duration path -> length
+regulator -> flow -> decoder) over one synthetic batch whose inputs are already resident in HBM;
+each rank is an independent replica (no collective on the data path) and `value`
+is the whole-job aggregate.  Weights are seeded synthetic tensors of the ru-0.9-multi-shaped
+MB-iSTFT-VITS2 architecture (the real checkpoint cannot be downloaded offline).
+
+Workloads (SURVEY.md §8 sizes; durations pinned to 3 frames/token so the work is fixed):
+  c2  B=1,  T_x=50            -> T_y=150,  38 400 samples (1.74 s)      [default: BASELINE configs[1]]
+  c3  B=32, T_x in [20,200]   -> padded to max, ragged masks             [configs[2], fp32 throughout]
+  c5  B=1,  T_x=2000          -> T_y=6000, 69.7 s of audio               [configs[4]]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+SAMPLE_RATE = 22050
+
+
+def make_workload(name, rng):
+    if name == "c2":
+        lengths = np.array([50], np.int64)
+    elif name == "c3":
+        lengths = rng.integers(20, 201, size=32).astype(np.int64)
+    elif name == "c5":
+        lengths = np.array([2000], np.int64)
+    elif name == "c1":
+        lengths = np.array([10], np.int64)
+    else:
+        raise ValueError(name)
+    B, Tx = len(lengths), int(lengths.max())
+    ids = rng.integers(1, 62, size=(B, Tx)).astype(np.int64)
+    dur = np.where(np.arange(Tx)[None] < lengths[:, None], 3, 0).astype(np.int32)
+    return ids, lengths, dur
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget for the CPU-oracle baseline leg")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist = dist_mod
+
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.capi import VitsDeviceSession, VitsLib
+
+    hp = W.default_hparams()
+    blob = W.synthetic_blob(hp, 1234)
+    lib = VitsLib()
+    model = lib.create(blob, local_rank)
+
+    rng = np.random.default_rng(1234)
+    ids, lengths, dur = make_workload(args.workload, rng)
+    B, Tx = ids.shape
+    Ty = int(dur.sum(1).max())
+    S = Ty * hp.hop_length
+    valid_samples = int(dur.sum()) * hp.hop_length
+    scales = np.array([0.8, 1.0, 0.8], np.float32)  # runtime defaults (vosk_tts/synth.py:50-54)
+    dev = torch.device("cuda", local_rank)
+    d_ids = torch.from_numpy(ids).to(dev)
+    d_len = torch.from_numpy(lengths).to(dev)
+    d_sid = torch.full((B,), 2, dtype=torch.int64, device=dev)
+    d_dur = torch.from_numpy(dur).to(dev)
+    d_audio = torch.empty((B, S), dtype=torch.float32, device=dev)
+    sess = VitsDeviceSession(model, B, Tx, Ty)
+    sess.set_options(use_graph=not args.no_graph, profile=False)
+
+    def step():
+        sess.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), B, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 7,
+                               d_audio.data_ptr(), S)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sess.sync()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sess.sync()  # surfaces any deferred device-side error
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(d_audio).all().item(), "non-finite audio"
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_samples = valid_samples * args.steps * world
+    value = total_samples / elapsed
+    audio_sec_per_step = valid_samples / SAMPLE_RATE
+    rtf = (elapsed / args.steps) / audio_sec_per_step
+
+    # ---- per-kernel device time with HIP events on the session stream (eager, profiled forwards)
+    flops_fwd = model.algorithmic_flops(B, Tx, Ty)
+    sess.set_options(use_graph=False, profile=True)
+    nprof = 3
+    for _ in range(nprof):
+        step()
+    rep = sess.profile_report()
+    sess.set_options(use_graph=not args.no_graph, profile=False)
+    conv = {k: v for k, v in rep.items() if v[2] > 0 and k != "attention"}
+    dom_name, dom = max(conv.items(), key=lambda kv: kv[1][1]) if conv else ("none", (1, 1.0, 0.0))
+    # the ResBlock convolutions (c1 + c2 launches run the same kernel instantiation) are one family
+    fam = [v for k, v in rep.items() if k.startswith("dec.res_")] if dom_name.startswith("dec.res_") else [dom]
+    fam_ms = sum(v[1] for v in fam)
+    fam_flops = sum(v[2] for v in fam)
+    fam_launches = sum(v[0] for v in fam)
+    achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+    dev_ms_all = sum(v[1] for v in rep.values()) / nprof
+    roofline = {
+        "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "kernel": "conv_mfma_kernel (" + ("dec.res_c1+dec.res_c2" if dom_name.startswith("dec.res_") else dom_name) + ")",
+        "avg_launch_us": round(fam_ms / max(fam_launches, 1) * 1e3, 2),
+        "algorithmic_flops_per_launch": fam_flops / max(fam_launches, 1),
+        "forward": {"algorithmic_gflop": round(flops_fwd / 1e9, 3),
+                    "achieved_tflops": round(flops_fwd / (elapsed / args.steps) / 1e12, 3),
+                    "frac": round(flops_fwd / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "sum_kernel_ms_eager": round(dev_ms_all, 4)},
+        "by_family_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])},
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # TEST-INFRASTRUCTURE leg: the CPU oracle (plain C restatement of the reference arithmetic)
+        # timed on this box's host cores on a bounded sample of the same workload.
+        so = os.path.join(ROOT, "oracle", "libvits_oracle.so")
+        if os.path.exists(so):
+            import ctypes
+
+            ref_lib = VitsLib(so, "vitsref_")
+            ref = ref_lib.create(blob)
+            ref_lib.lib.vitsref_num_threads.restype = ctypes.c_int
+            cores = int(ref_lib.lib.vitsref_num_threads())
+            nb = min(B, 2)  # bounded sample: at most 2 utterances of the batch per call
+            sub = (ids[:nb], lengths[:nb], dur[:nb])
+            sub_samples = int(sub[2].sum()) * hp.hop_length
+            n, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds and n < 50:
+                c0 = time.perf_counter()
+                ref.synthesize(sub[0], sub[1], scales, np.full(nb, 2), forced_durations=sub[2], seed=7)
+                t_cpu += time.perf_counter() - c0
+                n += 1
+            cpu_baseline = {"value": round(sub_samples * n / t_cpu, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+                            "sample": f"{n} forward(s) of {nb} utterance(s) of workload {args.workload} "
+                                      f"({sub_samples} samples each) through oracle/libvits_oracle.so (OpenMP), {t_cpu:.1f} s",
+                            "x_realtime": round(sub_samples * n / t_cpu / SAMPLE_RATE, 2)}
+
+    if rank == 0:
+        line = {
+            "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": round(rtf, 6), "x_realtime": round(1.0 / rtf, 1),
+            "config": {"workload": f"{args.workload}: MB-iSTFT-VITS2 (ru-0.9-multi-shaped, seeded synthetic weights), "
+                                   f"B={B} T_x={Tx} (lengths {int(lengths.min())}..{int(lengths.max())}), durations pinned 3/token "
+                                   f"-> T_y={Ty}, {valid_samples} valid samples/step/GPU, sid=2, scales=[0.8,1.0,0.8]",
+                       "batch": B, "T_x": Tx, "T_y": Ty, "samples_per_step_per_gpu": valid_samples,
+                       "parallelism": f"replicas x{world} (no collective)", "hipgraph": not args.no_graph},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

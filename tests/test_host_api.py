@@ -1,0 +1,219 @@
+"""Host-side mirror of the reference API (vosk_tts.Model / Synth / g2p): CPU tests use a stub in
+place of the session so the feed construction, defaults, int16 conversion and WAV output are
+checked exactly as vosk_tts/synth.py:47-150 does them; GPU tests run the real thing."""
+import json
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+
+def test_g2p_known_answers():
+    from vosk_tts_amd.g2p import convert
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g2p.npz"))
+    for w, want in zip(g["words"], g["phonemes"]):
+        assert convert(str(w)) == str(want), w
+    # the three examples in the reference header (vosk_tts/g2p.py:5-11)
+    assert convert("абстракцион+истов") == "a0 b s t r a0 k c i0 o0 nj i1 s t o0 v"
+    assert convert("абстр+акцию") == "a0 b s t r a1 k c i0 j u0"
+    assert convert("абстр+акция") == "a0 b s t r a1 k c i0 j a0"
+
+
+class _StubSession:
+    def __init__(self):
+        self.feeds = []
+
+    def run(self, names, feed):
+        self.feeds.append((names, feed))
+        T = 512
+        return [np.linspace(-2.0, 2.0, T, dtype=np.float32)[None, None, None, :]]
+
+
+class _StubModel:
+    def __init__(self, id_map, dic=None, inference=None):
+        self.onnx = _StubSession()
+        self.dic = dic or {}
+        self.tokenizer = None
+        self.config = {"phoneme_id_map": id_map, "inference": inference or {}}
+
+
+def test_g2p_noembed_dictionary_fallback_and_blanks():
+    from vosk_tts_amd.synth import Synth
+    from vosk_tts_amd.toymodel import phoneme_id_map
+
+    ids = phoneme_id_map()
+    s = Synth(_StubModel(ids, dic={"мир": "mj i1 r"}))
+    phon = s.phonemize("Прив+ет мир!")
+    assert phon == ["^", "p", "rj", "i0", "vj", "e1", "t", " ", "mj", "i1", "r", "!", "$"]
+    out = s.g2p_noembed("Прив+ет мир!")
+    assert out[0::2] == [ids[p] for p in phon] and set(out[1::2]) == {0} and len(out) == 2 * len(phon) - 1
+    # list-valued id maps (synth.py:239-244)
+    s2 = Synth(_StubModel({k: [v, v + 100] for k, v in ids.items()}))
+    out2 = s2.g2p_noembed("м+ир")
+    assert out2[:2] == [ids["^"], ids["^"] + 100] and out2[2] == 0
+
+
+def test_unknown_phoneme_raises_keyerror_before_the_boundary():
+    from vosk_tts_amd.synth import Synth
+    from vosk_tts_amd.toymodel import phoneme_id_map
+
+    s = Synth(_StubModel(phoneme_id_map()))
+    with pytest.raises(KeyError):
+        s.synth_audio("latin q")  # 'q' is not in the map (reference: KeyError at synth.py:243)
+    assert s.model.onnx.feeds == []
+
+
+def test_synth_audio_feed_defaults_and_int16(tmp_path):
+    from vosk_tts_amd.synth import Synth
+    from vosk_tts_amd.toymodel import phoneme_id_map
+
+    m = _StubModel(phoneme_id_map(), inference={"noise_level": 0.5, "scale": 0.5})
+    s = Synth(m)
+    pcm = s.synth_audio("  м+ир — да  ", speaker_id=None, speech_rate=2.0)
+    names, feed = m.onnx.feeds[0]
+    assert names is None
+    assert set(feed) == {"input", "input_lengths", "scales", "sid", "bert", "phone_duration_extra"}  # synth.py:113-120
+    assert feed["bert"] is None and feed["phone_duration_extra"] is None
+    assert feed["input"].dtype == np.int64 and feed["input"].shape[0] == 1
+    assert feed["input_lengths"].tolist() == [feed["input"].shape[1]]
+    np.testing.assert_allclose(feed["scales"], [0.5, 0.5, 0.8])  # [noise, 1/rate, duration noise] synth.py:106
+    assert feed["sid"].tolist() == [0] and feed["sid"].dtype == np.int64
+    # '—' -> '-' (synth.py:59) is kept as a phoneme
+    assert phoneme_id_map()["-"] in feed["input"][0].tolist()
+    # scale 0.5 then clip to +-32767 and truncate to int16 (synth.py:16-23,128-130)
+    want = np.clip(np.linspace(-2.0, 2.0, 512, dtype=np.float32) * 0.5 * 32767.0, -32767.0, 32767.0).astype("int16")
+    assert pcm.dtype == np.int16 and np.array_equal(pcm, want)
+    out = tmp_path / "o.wav"
+    s.synth("м+ир", str(out), speaker_id=3)
+    with wave.open(str(out)) as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 22050, 512)
+    assert m.onnx.feeds[-1][1]["sid"].tolist() == [3]
+
+
+def test_toy_model_directory_layout(tmp_path):
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "vosk-model-tts-xx-0.1"), W.tiny_hparams(n_vocab=len(PHONEMES)))
+    assert sorted(os.listdir(d)) == ["config.json", "dictionary", "model.vitsw"]
+    hp, tens = W.unpack_blob(open(os.path.join(d, "model.vitsw"), "rb").read())
+    assert hp.n_vocab == len(PHONEMES) and "enc_p.emb.weight" in tens
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    assert cfg["phoneme_id_map"]["_"] == 0 and cfg["inference"]["noise_level"] == 0.8
+
+
+def test_blob_roundtrip_and_determinism():
+    from vosk_tts_amd import weights as W
+
+    hp = W.tiny_hparams()
+    a = W.make_synthetic_weights(hp, 1234)
+    b = W.make_synthetic_weights(hp, 1234)
+    c = W.make_synthetic_weights(hp, 1235)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert any(not np.array_equal(a[k], c[k]) for k in a)
+    hp2, t2 = W.unpack_blob(W.pack_blob(hp, a))
+    assert bytes(hp2) == bytes(hp) and all(np.array_equal(a[k], t2[k]) for k in a)
+    # the generator must keep producing the tensors the golden fixtures were made with
+    g = golden("full_c1")
+    assert g["x"].shape == (1, 192, 10)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    hp = W.tiny_hparams(n_vocab=len(PHONEMES))
+    d = write_toy_model(str(tmp_path / "m"), hp)
+    model = Model(model_path=d, device=0)
+    assert model.dic["мир"] == "mj i1 r"  # highest-probability pronunciation (model.py:48-55)
+    synth = Synth(model)
+    out = tmp_path / "o.wav"
+    synth.synth("прив+ет, м+ир!", str(out), speaker_id=2)
+    with wave.open(str(out)) as f:
+        n = f.getnframes()
+        assert f.getframerate() == 22050 and n > 0 and n % 256 == 0
+    # session.run contract (synth.py:113-126): None feeds ignored, unknown names rejected, [B,1,1,S] out
+    ids = np.array([synth.g2p_noembed("м+ир")], np.int64)
+    feed = {"input": ids, "input_lengths": np.array([ids.shape[1]], np.int64), "scales": np.array([0.0, 1.0, 0.0], np.float32),
+            "sid": np.array([1], np.int64), "bert": None, "phone_duration_extra": None}
+    a1 = model.onnx.run(None, feed)[0]
+    a2 = model.onnx.run(None, feed)[0]
+    assert a1.ndim == 4 and a1.shape[:3] == (1, 1, 1) and a1.squeeze().ndim == 1
+    assert np.array_equal(a1, a2)  # scales=[0,.,0] -> deterministic
+    ref = oracle_lib.create(open(os.path.join(d, "model.vitsw"), "rb").read())
+    want, _ = ref.synthesize(ids, [ids.shape[1]], [0.0, 1.0, 0.0], [1])
+    assert_close("run() vs oracle", want, a1.reshape(want.shape), 5e-4)
+    with pytest.raises(ValueError):
+        model.onnx.run(None, dict(feed, bogus=np.zeros(1)))
+    with pytest.raises(NotImplementedError):
+        model.onnx.run(None, dict(feed, bert=np.zeros((1, 768, ids.shape[1]), np.float32)))
+    with pytest.raises(ValueError):
+        model.onnx.run(None, {k: v for k, v in feed.items() if k != "scales"})
+
+
+@pytest.mark.gpu
+def test_session_is_reentrant_from_threads(hip_tiny, oracle_tiny):
+    """gRPC server shares one Synth across a thread pool (server/tts_server.py:39-40,57)."""
+    import threading
+
+    rng = np.random.default_rng(0)
+    jobs = []
+    for i in range(8):
+        Tx = int(rng.integers(5, 30))
+        ids = rng.integers(1, 20, size=(1, Tx)).astype(np.int64)
+        dur = rng.integers(1, 4, size=(1, Tx)).astype(np.int32)
+        jobs.append((ids, dur, i))
+    want = [oracle_tiny.synthesize(ids, [ids.shape[1]], [0.5, 1.0, 0.5], [i % 5], forced_durations=dur, seed=i)[0] for ids, dur, i in jobs]
+    got = [None] * len(jobs)
+
+    def work(k):
+        ids, dur, i = jobs[k]
+        for _ in range(3):
+            got[k] = hip_tiny.synthesize(ids, [ids.shape[1]], [0.5, 1.0, 0.5], [i % 5], forced_durations=dur, seed=i)[0]
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(len(jobs)):
+        assert_close(f"job {k}", want[k], got[k], 5e-4)
+
+
+@pytest.mark.gpu
+def test_device_session_graph_replay_matches_host_path(hip_default):
+    """The bench/serving entry point (device pointers, hipGraph replay) produces the same audio as
+    the host-buffer entry point for the same seed."""
+    import torch
+
+    from vosk_tts_amd.capi import VitsDeviceSession
+
+    rng = np.random.default_rng(11)
+    lengths = np.array([23, 40, 31], np.int64)
+    B, Tx = 3, 40
+    ids = rng.integers(1, 62, size=(B, Tx)).astype(np.int64)
+    dur = np.where(np.arange(Tx)[None] < lengths[:, None], rng.integers(1, 4, size=(B, Tx)), 0).astype(np.int32)
+    Ty = int(dur.sum(1).max())
+    scales = np.array([0.8, 1.0, 0.8], np.float32)
+    sid = np.array([2, 7, 100], np.int64)
+    want, wl = hip_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=9)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_ids, d_len, d_sid, d_dur = t(ids), t(lengths), t(sid), t(dur)
+    d_audio = torch.zeros((B, Ty * 256), dtype=torch.float32, device=dev)
+    s = VitsDeviceSession(hip_default, B, Tx, Ty)
+    for use_graph in (True, False, True):
+        s.set_options(use_graph=use_graph)
+        d_audio.zero_()
+        for _ in range(2):  # second call replays the captured graph
+            s.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), B, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 9,
+                                d_audio.data_ptr(), Ty * 256)
+        s.sync()
+        assert s.last_ms() > 0
+        assert_close("device session", want, d_audio.cpu().numpy(), 1e-6)
+    s.close()

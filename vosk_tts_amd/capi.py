@@ -259,3 +259,60 @@ def op_conv1d(lib, x, w, bias, dilation=1, lrelu_slope=1.0, device=0):
     lib.check(lib._fn("op_conv1d")(device, _p(x, c_f32p), _p(w, c_f32p), _p(bias, c_f32p), B, Cin, Cout, T, K, dilation,
                                    lrelu_slope, _p(y, c_f32p)))
     return y
+
+
+class VitsDeviceSession:
+    """Device-resident serving loop (vits_session_*): inputs and outputs are raw HBM pointers
+    (e.g. torch tensors' data_ptr()); the forward runs asynchronously on the session's own HIP
+    stream and is replayed as a cached hipGraph."""
+
+    def __init__(self, model, max_B, max_Tx, max_Ty):
+        self.model = model
+        self.lib = model.lib
+        if not self.lib.is_device:
+            raise RuntimeError("device sessions exist only in the HIP library")
+        self._h = ctypes.c_void_p()
+        self.lib.check(self.lib._fn("session_create")(model._h, max_B, max_Tx, max_Ty, ctypes.byref(self._h)))
+        L = self.lib
+        L._fn("session_sync").argtypes = [ctypes.c_void_p]
+        L._fn("session_set_options").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L._fn("session_profile_report").argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+
+    def close(self):
+        if self._h:
+            self.lib._fn("session_destroy")(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synthesize_device(self, d_ids, d_lengths, B, Tx, scales, d_sid, d_forced, Ty, seed, d_audio, audio_capacity):
+        scales = _f32(scales)
+        self.lib.check(self.lib._fn("session_synthesize_device")(
+            self._h, ctypes.c_void_p(d_ids), ctypes.c_void_p(d_lengths), B, Tx, _p(scales, c_f32p),
+            ctypes.c_void_p(d_sid) if d_sid else None, ctypes.c_void_p(d_forced) if d_forced else None, Ty, seed,
+            ctypes.c_void_p(d_audio), audio_capacity, None))
+
+    def last_ms(self):
+        ms = ctypes.c_float()
+        self.lib.check(self.lib._fn("session_last_ms")(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        self.lib.check(self.lib._fn("session_sync")(self._h))
+
+    def set_options(self, use_graph=True, profile=False):
+        self.lib.check(self.lib._fn("session_set_options")(self._h, int(use_graph), int(profile)))
+
+    def profile_report(self):
+        """-> {family: (launches, total_ms, flops)}"""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self.lib.check(self.lib._fn("session_profile_report")(self._h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms, fl = line.split()
+            out[name] = (int(n), float(ms), float(fl))
+        return out

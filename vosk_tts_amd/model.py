@@ -1,0 +1,99 @@
+"""`Model` — mirror of vosk_tts.Model (vosk_tts/model.py:33-63) with the ONNX Runtime session
+replaced by the MI355X-native engine.
+
+A model directory holds (reference layout, model.py:46-63):
+    model.vitsw   weight blob for the HIP engine (replaces model.onnx; see vosk_tts_amd/weights.py)
+    dictionary    word prob phonemes... ; the highest-probability pronunciation wins (model.py:48-55)
+    config.json   inference defaults, phoneme_id_map, model_type, no_blank (synth.py:50-56,64,88,177)
+Attributes kept: .onnx (object with .run(None, feed)), .dic, .config, .tokenizer.
+There is no network in this build: models are looked up locally only (same search path).
+"""
+import json
+import logging
+import os
+import re
+import sys
+from pathlib import Path
+
+MODEL_DIRS = [os.getenv("VOSK_MODEL_PATH"), Path("/usr/share/vosk"), Path.home() / "AppData/Local/vosk",
+              Path.home() / ".cache/vosk"]
+
+
+def _local_models():
+    for directory in MODEL_DIRS:
+        if directory is None or not Path(directory).exists():
+            continue
+        for name in sorted(os.listdir(directory)):
+            yield Path(directory, name)
+
+
+def list_models():
+    for p in _local_models():
+        print(p.name)
+
+
+def list_languages():
+    langs = set()
+    for p in _local_models():
+        m = re.match(r"vosk-model(-small)?-tts-([a-z]{2}(-[a-z]{2})?)", p.name) or re.match(r"vosk-model(-small)?-([a-z]{2}(-[a-z]{2})?)", p.name)
+        if m:
+            langs.add(m.group(2))
+    for lang in sorted(langs):
+        print(lang)
+
+
+class Model:
+    def __init__(self, model_path=None, model_name=None, lang=None, device=None):
+        from .session import VitsSession
+
+        if model_path is None:
+            model_path = self.get_model_path(model_name, lang)
+        else:
+            model_path = Path(model_path)
+        if device is None:
+            device = int(os.getenv("VOSK_TTS_DEVICE", os.getenv("LOCAL_RANK", "0")))
+        logging.info(f"Loading model from {model_path}")
+        blob_path = model_path / "model.vitsw"
+        if not blob_path.exists():
+            raise FileNotFoundError(
+                f"{blob_path} not found: this engine loads VITSW001 weight blobs (see vosk_tts_amd/weights.py); "
+                "an ONNX importer is listed as next work in SURVEY.md §8f")
+        with open(blob_path, "rb") as f:
+            self.onnx = VitsSession(f.read(), device=device)
+
+        self.dic = {}
+        probs = {}
+        with open(model_path / "dictionary", encoding="utf-8") as f:
+            for line in f:
+                items = line.split(maxsplit=2)
+                if len(items) < 3:
+                    continue
+                prob = float(items[1])
+                if probs.get(items[0], 0) < prob:
+                    self.dic[items[0]] = items[2]
+                    probs[items[0]] = prob
+
+        with open(model_path / "config.json") as f:
+            self.config = json.load(f)
+        if os.path.exists(model_path / "bert/vocab.txt"):
+            logging.warning("bert/ found but BERT-conditioned flavours are not built (SURVEY.md §8f); ignoring it")
+        self.tokenizer = None
+
+    def get_model_path(self, model_name, lang):
+        if model_name is None:
+            return self.get_model_by_lang(lang)
+        return self.get_model_by_name(model_name)
+
+    def get_model_by_name(self, model_name):
+        for p in _local_models():
+            if p.name == model_name:
+                return p
+        print("model name %s does not exist" % (model_name))
+        sys.exit(1)
+
+    def get_model_by_lang(self, lang):
+        for p in _local_models():
+            if re.match(r"vosk-model(-small)?-{}".format(lang), p.name):
+                return p
+        print("lang %s does not exist" % (lang))
+        sys.exit(1)

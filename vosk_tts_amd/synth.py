@@ -1,0 +1,99 @@
+"""`Synth` — mirror of vosk_tts.Synth (vosk_tts/synth.py:11-150) for the VITS flavour
+(`g2p_noembed`, synth.py:223-255): same signature, defaults, feed construction, int16 conversion,
+RTF log line and WAV output.  The only change is what sits behind `self.model.onnx.run`.
+"""
+import logging
+import re
+import time
+import wave
+
+import numpy as np
+
+from .g2p import convert
+
+_SPLIT = "([,.?!;:\"() ])"
+
+
+class Synth:
+    def __init__(self, model):
+        self.model = model
+
+    def audio_float_to_int16(self, audio, max_wav_value=32767.0):
+        """Normalize audio and convert to int16 range (synth.py:16-23)"""
+        audio_norm = np.clip(audio * max_wav_value, -max_wav_value, max_wav_value)
+        return audio_norm.astype("int16")
+
+    def synth_audio(self, text, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None):
+        inf = self.model.config.get("inference", {})
+        if noise_level is None:
+            noise_level = inf.get("noise_level", 0.8)
+        if speech_rate is None:
+            speech_rate = inf.get("speech_rate", 1.0)
+        if duration_noise_level is None:
+            duration_noise_level = inf.get("duration_noise_level", 0.8)
+        if scale is None:
+            scale = inf.get("scale", 1.0)
+
+        text = re.sub("—", "-", text.strip())
+        model_type = self.model.config.get("model_type")
+        if self.model.tokenizer is not None or (model_type or "").startswith("multistream"):
+            raise NotImplementedError("BERT / multistream flavours (synth.py:64-99) are outside the VITS2 hot path; "
+                                      "see SURVEY.md §8f")
+        phoneme_ids = self.g2p_noembed(text)
+        ids = np.expand_dims(np.array(phoneme_ids, dtype=np.int64), 0)
+        lengths = np.array([ids.shape[1]], dtype=np.int64)
+        scales = np.array([noise_level, 1.0 / speech_rate, duration_noise_level], dtype=np.float32)
+        if speaker_id is None:
+            speaker_id = 0
+        sid = np.array([speaker_id], dtype=np.int64)
+        args = {"input": ids, "input_lengths": lengths, "scales": scales, "sid": sid, "bert": None,
+                "phone_duration_extra": None}
+
+        start_time = time.perf_counter()
+        audio = self.model.onnx.run(None, args)[0]
+        audio = audio.squeeze()
+        audio = audio * scale
+        audio = self.audio_float_to_int16(audio)
+        end_time = time.perf_counter()
+
+        audio_duration_sec = audio.shape[-1] / 22050
+        infer_sec = end_time - start_time
+        real_time_factor = infer_sec / audio_duration_sec if audio_duration_sec > 0 else 0.0
+        logging.info("Real-time factor: %0.2f (infer=%0.2f sec, audio=%0.2f sec)" % (real_time_factor, infer_sec, audio_duration_sec))
+        return audio
+
+    def synth(self, text, oname, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None):
+        audio = self.synth_audio(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
+        with wave.open(oname, "w") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(22050)
+            f.writeframes(audio.tobytes())
+
+    def phonemize(self, text):
+        """Words -> dictionary lookup or rule G2P, punctuation kept, '^' ... '$' (synth.py:224-236)."""
+        phonemes = ["^"]
+        for word in re.split(_SPLIT, text.lower()):
+            if word == "":
+                continue
+            if re.match(_SPLIT, word) or word == "-":
+                phonemes.append(word)
+            elif word in self.model.dic:
+                phonemes.extend(self.model.dic[word].split())
+            else:
+                phonemes.extend(convert(word).split())
+        phonemes.append("$")
+        return phonemes
+
+    def g2p_noembed(self, text):
+        phonemes = self.phonemize(text)
+        # ids interspersed with blank 0; id-map values may be lists (synth.py:238-251)
+        id_map = self.model.config["phoneme_id_map"]
+        as_list = (lambda v: list(v)) if isinstance(id_map[phonemes[0]], list) else (lambda v: [v])
+        phoneme_ids = as_list(id_map[phonemes[0]])
+        for p in phonemes[1:]:
+            phoneme_ids.append(0)
+            phoneme_ids.extend(as_list(id_map[p]))
+        logging.info(f"Text: {text}")
+        logging.info(f"Phonemes: {phonemes}")
+        return phoneme_ids

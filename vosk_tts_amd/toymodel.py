@@ -1,0 +1,34 @@
+"""Writes a self-contained model directory (model.vitsw + dictionary + config.json) with seeded
+synthetic weights, in the layout vosk_tts.Model reads (vosk_tts/model.py:46-63).  Used by tests,
+smoke() and the docs example, because the real voices cannot be downloaded offline."""
+import json
+import os
+
+from . import weights as W
+
+_CONS = ["b", "v", "g", "d", "z", "k", "l", "m", "n", "p", "r", "s", "t", "f", "h"]
+PHONEMES = (["_", "^", "$", " ", ",", ".", "?", "!", ";", ":", '"', "(", ")", "-"] + _CONS + [c + "j" for c in _CONS] +
+            ["zh", "c", "ch", "sh", "sch", "j"] + [v + s for v in "aoueiy" for s in "01"])
+
+
+def phoneme_id_map():
+    return {p: i for i, p in enumerate(PHONEMES)}
+
+
+def write_toy_model(path, hp=None, seed=1234, dictionary=None, inference=None):
+    os.makedirs(path, exist_ok=True)
+    hp = hp or W.default_hparams(n_vocab=len(PHONEMES))
+    if hp.n_vocab < len(PHONEMES):
+        raise ValueError("n_vocab too small for the phoneme inventory")
+    W.save_blob(os.path.join(path, "model.vitsw"), hp, W.make_synthetic_weights(hp, seed))
+    dictionary = dictionary or {"привет": [(1.0, "p rj i0 vj e1 t")], "мир": [(0.4, "mj i0 r"), (0.9, "mj i1 r")]}
+    with open(os.path.join(path, "dictionary"), "w", encoding="utf-8") as f:
+        for word, prons in dictionary.items():
+            for prob, ph in prons:
+                f.write(f"{word} {prob} {ph}\n")
+    cfg = {"audio": {"sample_rate": hp.sampling_rate},
+           "inference": inference or {"noise_level": 0.8, "speech_rate": 1.0, "duration_noise_level": 0.8, "scale": 1.0},
+           "phoneme_id_map": phoneme_id_map(), "num_speakers": hp.n_speakers, "model_type": "vits"}
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, ensure_ascii=False)
+    return path
