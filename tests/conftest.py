@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+# torch bundles its own HIP runtime; import it BEFORE the product library is dlopen'ed so that one
+# process holds exactly one libamdhip64 (bench.py does the same: torch is the plumbing for device
+# tensors and torch.distributed).
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
