@@ -218,6 +218,10 @@ int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t T_y, fl
 int vits_op_conv1d(int device, const float* x, const float* w, const float* bias, int32_t B, int32_t C_in,
                    int32_t C_out, int32_t T, int32_t K, int32_t dilation, float lrelu_slope, float* y);
 
+/* Test hook: 0 = choose the conv kernel by problem size (default), 1 = always the big-tile kernel,
+ * 2 = always the K-split small-N kernel.  Process-wide. */
+void vits_debug_force_tile(int mode);
+
 /* Algorithmic FLOPs of one forward (SURVEY.md §8a/§8d formula evaluated on the
  * model's own hparams): used by bench.py for the roofline line. */
 double vits_algorithmic_flops(const vits_model* m, int32_t B, int32_t T_x, int32_t T_y);

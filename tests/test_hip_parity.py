@@ -100,6 +100,18 @@ def test_stages_tiny_b3_ragged(hip_tiny, oracle_tiny):
     _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_every_epilogue_on_both_conv_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny, mode):
+    """The size heuristic picks the K-split kernel for these small fixtures; force each kernel in turn so
+    the gate / res-skip / coupling / polyphase epilogues of BOTH implementations are checked."""
+    hip_lib.lib.vits_debug_force_tile(mode)
+    try:
+        _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)
+        _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
+    finally:
+        hip_lib.lib.vits_debug_force_tile(0)
+
+
 def test_free_running_infer_golden(hip_default):
     g = golden("free_c1")
     audio, olen = hip_default.synthesize(g["ids"], g["lengths"], g["scales"], g["sid"], noise_dp=g["noise_dp"],

@@ -99,6 +99,64 @@ __device__ __forceinline__ float conv_act_in(float v, float scale, float slope) 
   return v > 0.f ? v : v * slope;
 }
 
+// ---- shared epilogue: one accumulator element (row, col) of the output tile --------------------
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue_elem(const ConvParams& P, const ConvGroup& G, int b, int lenb, int row, int col, float v) {
+  if (row >= P.Cout || col >= P.Tout) return;
+  if (EPI == EPI_STORE) {
+    if (P.ups_u) {
+      const int phase = row / P.ups_cout, co = row - phase * P.ups_cout;
+      if (G.bias) v += G.bias[co];
+      G.y[(long long)b * P.y_bstride + (long long)co * P.Tout_stride + (long long)col * P.ups_u + phase] = v;
+    } else {
+      if (G.bias) v += G.bias[row];
+      if (P.bias_b) v += P.bias_b[(long long)b * P.bias_b_stride + P.bias_b_off + row];
+      if (P.relu) v = v > 0.f ? v : 0.f;
+      if (P.out_mask && col >= lenb) v = 0.f;
+      const long long o = (long long)b * P.y_bstride + (long long)row * P.Tout_stride + col;
+      if (G.res) v += G.res[o];
+      G.y[o] = v;
+    }
+  } else if (EPI == EPI_RESSKIP) {
+    v += G.bias[row];
+    const bool valid = col < lenb;
+    if (P.last || row >= P.H) {
+      const int sr = P.last ? row : row - P.H;
+      const long long o = (long long)b * P.y_bstride + (long long)sr * P.Tout_stride + col;
+      float s = P.first ? v : P.skip[o] + v;
+      if (P.last && !valid) s = 0.f;  // output * x_mask (modules.py:176)
+      P.skip[o] = s;
+    } else {
+      const long long o = (long long)b * P.y_bstride + (long long)row * P.Tout_stride + col;
+      P.io[o] = valid ? P.io[o] + v : 0.f;  // x = (x + res_acts) * x_mask (modules.py:171)
+    }
+  } else if (EPI == EPI_COUPLE) {
+    // previous z = u (before the Flip that precedes this layer); this layer's logical input is
+    // flip(u): x0[c] = u[I-1-c], x1[c] = u[half-1-c].  new z = cat(x0, (x1 - m)*mask).
+    v += G.bias[row];
+    const int half = P.H, I2 = 2 * P.H;
+    const long long bo = (long long)b * P.y_bstride + col;
+    const float x1 = P.u[bo + (long long)(half - 1 - row) * P.Tout_stride];
+    const float x0 = P.u[bo + (long long)(I2 - 1 - row) * P.Tout_stride];
+    P.io[bo + (long long)(half + row) * P.Tout_stride] = col < lenb ? (x1 - v) : 0.f;
+    P.io[bo + (long long)row * P.Tout_stride] = x0;
+  }
+}
+// WN gate (commons.py:100-107): channel ch of batch b at column col from the tanh / sigmoid pre-activations
+__device__ __forceinline__ void conv_epilogue_gate(const ConvParams& P, const ConvGroup& G, int b, int ch, int col, float at, float as) {
+  if (ch >= P.H || col >= P.Tout) return;
+  at += G.bias[ch];
+  as += G.bias[P.H + ch];
+  if (P.bias_b) {
+    const float* bb = P.bias_b + (long long)b * P.bias_b_stride + P.bias_b_off;
+    at += bb[ch];
+    as += bb[P.H + ch];
+  }
+  const float tv = tanhf(at);
+  const float sv = 1.0f / (1.0f + __expf(-as));
+  G.y[(long long)b * P.y_bstride + (long long)ch * P.Tout_stride + col] = tv * sv;
+}
+
 template <int WM, int WN, int MI, int NI, int EPI>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
   static_assert(WM * WN == 4, "256-thread workgroups");
@@ -246,25 +304,13 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
   const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
   if (EPI == EPI_GATE) {
     // packed m-blocks alternate [tanh 32 rows | sigmoid 32 rows] of the same 32 channels
-    if (MI == 2) {
-      const int j = (m0 >> 6) + wm;  // channel block of 32
-      const float* bb = P.bias_b ? P.bias_b + (long long)b * P.bias_b_stride + P.bias_b_off : nullptr;
+    const int j = (m0 >> 6) + wm;  // channel block of 32
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + wn * (NI * 32) + ni * 32 + l31;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = n0 + wn * (NI * 32) + ni * 32 + l31;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int ch = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (ch < P.H && col < P.Tout) {
-            float at = acc[0][ni][e] + G.bias[ch];
-            float as = acc[MI - 1][ni][e] + G.bias[P.H + ch];
-            if (bb) { at += bb[ch]; as += bb[P.H + ch]; }
-            const float tv = tanhf(at);
-            const float sv = 1.0f / (1.0f + __expf(-as));
-            G.y[(long long)b * P.y_bstride + (long long)ch * P.Tout_stride + col] = tv * sv;
-          }
-        }
-      }
+      for (int e = 0; e < 16; ++e)
+        conv_epilogue_gate(P, G, b, j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][ni][e], acc[MI - 1][ni][e]);
     }
     return;
   }
@@ -275,48 +321,191 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
       const int col = n0 + wn * (NI * 32) + ni * 32 + l31;
       const int rbase = m0 + (wm * MI + mi) * 32 + 4 * h;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        if (row >= P.Cout || col >= P.Tout) continue;
-        float v = acc[mi][ni][e];
-        if (EPI == EPI_STORE) {
-          if (P.ups_u) {
-            const int phase = row / P.ups_cout, co = row - phase * P.ups_cout;
-            if (G.bias) v += G.bias[co];
-            G.y[(long long)b * P.y_bstride + (long long)co * P.Tout_stride + (long long)col * P.ups_u + phase] = v;
-          } else {
-            if (G.bias) v += G.bias[row];
-            if (P.bias_b) v += P.bias_b[(long long)b * P.bias_b_stride + P.bias_b_off + row];
-            if (P.relu) v = v > 0.f ? v : 0.f;
-            if (P.out_mask && col >= lenb) v = 0.f;
-            const long long o = (long long)b * P.y_bstride + (long long)row * P.Tout_stride + col;
-            if (G.res) v += G.res[o];
-            G.y[o] = v;
-          }
-        } else if (EPI == EPI_RESSKIP) {
-          v += G.bias[row];
-          const bool valid = col < lenb;
-          if (P.last || row >= P.H) {
-            const int sr = P.last ? row : row - P.H;
-            const long long o = (long long)b * P.y_bstride + (long long)sr * P.Tout_stride + col;
-            float s = P.first ? v : P.skip[o] + v;
-            if (P.last && !valid) s = 0.f;  // output * x_mask (modules.py:176)
-            P.skip[o] = s;
-          } else {
-            const long long o = (long long)b * P.y_bstride + (long long)row * P.Tout_stride + col;
-            P.io[o] = valid ? P.io[o] + v : 0.f;  // x = (x + res_acts) * x_mask (modules.py:171)
-          }
-        } else if (EPI == EPI_COUPLE) {
-          // previous z = u (before the Flip that precedes this layer); this layer's logical input is
-          // flip(u): x0[c] = u[I-1-c], x1[c] = u[half-1-c].  new z = cat(x0, (x1 - m)*mask).
-          v += G.bias[row];
-          const int half = P.H, I2 = 2 * P.H;
-          const long long bo = (long long)b * P.y_bstride + col;
-          const float x1 = P.u[bo + (long long)(half - 1 - row) * P.Tout_stride];
-          const float x0 = P.u[bo + (long long)(I2 - 1 - row) * P.Tout_stride];
-          P.io[bo + (long long)(half + row) * P.Tout_stride] = col < lenb ? (x1 - v) : 0.f;
-          P.io[bo + (long long)row * P.Tout_stride] = x0;
+      for (int e = 0; e < 16; ++e) conv_epilogue_elem<EPI>(P, G, b, lenb, rbase + (e & 3) + 8 * (e >> 2), col, acc[mi][ni][e]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-N variant ("K-split"): one workgroup owns a (MI*32) x (NI*32) output tile and its 4 waves
+// split the CONTRACTION (input-channel chunks c = wave, wave+4, ...).  Every wave stages its own
+// chunks into a wave-private LDS region and streams its own weight fragments with a 3-deep register
+// prefetch, so the main loop has no workgroup barrier and a single utterance (N = 50..2400 columns)
+// still spreads over hundreds of waves, each pulling a distinct weight slab from L2/HBM.  The four
+// partial accumulators are summed through LDS; wave w then finishes rows e in [4w, 4w+4) of every
+// 32x32 fragment through the shared epilogue.
+// ---------------------------------------------------------------------------------------------
+template <int MI, int NI, int EPI>
+__global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
+  constexpr int M_T = MI * 32;
+  constexpr int N_T = NI * 32;
+  constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
+  extern __shared__ float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  int id;
+  {
+    const int nblk = gridDim.x, L = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, within = L >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mt = id % P.ntiles_m; id /= P.ntiles_m;
+  const int grp = id % P.n_groups; id /= P.n_groups;
+  const int nt = id % P.ntiles_n;
+  const int b = id / P.ntiles_n;
+  const ConvGroup& G = P.g[grp];
+
+  const int ROW = P.row_len;
+  const int n0 = nt * N_T, m0 = mt * M_T;
+  const int K = G.K, dil = G.dil;
+  int tap_base = 0;
+  if (P.ups_u) tap_base = P.ups_shift[m0 / P.ups_cout];
+  const int nchunks = P.Cin / CONV_CI_T;
+  int t_lim = P.Tin;
+  if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
+
+  float stg[CONV_CI_T][JT];
+  const float* xb = G.x + (long long)b * P.x_bstride;
+  const float* xb2 = G.x2 ? G.x2 + (long long)b * P.x_bstride : nullptr;
+  const float* xb3 = G.x3 ? G.x3 + (long long)b * P.x_bstride : nullptr;
+  const float in_scale = P.in_scale, in_slope = P.in_slope;
+  const int t_base = n0 - G.pad_l;
+  float* wlds = lds + wave * (2 * CONV_CI_T * ROW);  // wave-private double buffer
+
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int rr = 0; rr < CONV_CI_T; ++rr) {
+      const int ci = c * CONV_CI_T + rr;
+      const long long roff = (long long)(P.x_ch_off + ci * P.x_ch_sign) * P.Tin_stride;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int col = lane + 64 * j;
+        int t = t_base + col;
+        if (P.reflect && t == -1) t = (P.Tin > 1) ? 1 : 0;
+        float v = 0.f;
+        if (col < ROW && t >= 0 && t < t_lim) {
+          v = xb[roff + t];
+          if (xb2) v += xb2[roff + t];
+          if (xb3) v += xb3[roff + t];
+          v = conv_act_in(v, in_scale, in_slope);
         }
+        stg[rr][j] = v;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* dst = wlds + buf * (CONV_CI_T * ROW);
+#pragma unroll
+    for (int rr = 0; rr < CONV_CI_T; ++rr) {
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int col = lane + 64 * j;
+        if (col < ROW) dst[rr * ROW + col] = stg[rr][j];
+      }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int n_mblocks = P.M >> 5;
+  const f32x4* wp[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int mb = (m0 >> 5) + mi;
+    if (mb >= n_mblocks) mb = 0;
+    wp[mi] = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
+  }
+  // this wave's taps in order: (c, kk) for c = wave, wave+4, ... ; tap -> first step-group 2*(c*K+kk)
+  const int my_chunks = wave < nchunks ? (nchunks - wave + 3) / 4 : 0;
+  const int my_taps = my_chunks * K;
+  auto tap_sg = [&](int tp) { const int ci = tp / K, kk = tp - ci * K; return 2 * ((wave + 4 * ci) * K + kk); };
+  f32x4 a0[MI][2], a1[MI][2], a2[MI][2];  // taps tp, tp+1, tp+2
+  auto fetch = [&](f32x4 (&dst)[MI][2], int tp) {
+    if (tp < my_taps) {
+      const int sg = tap_sg(tp);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        dst[mi][0] = wp[mi][(size_t)sg * 64];
+        dst[mi][1] = wp[mi][(size_t)(sg + 1) * 64];
+      }
+    }
+  };
+  fetch(a0, 0);
+  fetch(a1, 1);
+  if (my_chunks > 0) { load_chunk(wave); store_chunk(0); }
+  int tp = 0;
+  for (int ci = 0; ci < my_chunks; ++ci) {
+    const int cn = wave + 4 * (ci + 1);
+    if (ci + 1 < my_chunks) load_chunk(cn);
+    const float* lb = wlds + (ci & 1) * (CONV_CI_T * ROW) + h * ROW + l31 + tap_base;
+#pragma unroll 1
+    for (int kk = 0; kk < K; ++kk, ++tp) {
+      fetch(a2, tp + 2);
+      const float* lk = lb + kk * dil;
+      float bv[8][NI];
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[p][ni] = lk[2 * p * ROW + ni * 32];
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi][p >> 2][p & 3], bv[p][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        a0[mi][0] = a1[mi][0]; a0[mi][1] = a1[mi][1];
+        a1[mi][0] = a2[mi][0]; a1[mi][1] = a2[mi][1];
+      }
+    }
+    if (ci + 1 < my_chunks) store_chunk((ci + 1) & 1);
+  }
+
+  // ---- cross-wave reduction through LDS (staging regions are dead after the barrier)
+  __syncthreads();
+  float* red = lds;  // [wave][mi][ni][e][64]
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[(((wave * MI + mi) * NI + ni) * 16 + e) * 64 + lane] = acc[mi][ni][e];
+  __syncthreads();
+  const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
+  float sum[MI][NI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        const int e = 4 * wave + ee;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += red[(((w * MI + mi) * NI + ni) * 16 + e) * 64 + lane];
+        sum[mi][ni][ee] = a;
+      }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + ni * 32 + l31;
+#pragma unroll
+    for (int ee = 0; ee < 4; ++ee) {
+      const int e = 4 * wave + ee;
+      const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;  // row inside the 32-row fragment
+      if (EPI == EPI_GATE) {
+        conv_epilogue_gate(P, G, b, (m0 >> 6) * 32 + rin, col, sum[0][ni][ee], sum[MI - 1][ni][ee]);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) conv_epilogue_elem<EPI>(P, G, b, lenb, m0 + mi * 32 + rin, col, sum[mi][ni][ee]);
       }
     }
   }

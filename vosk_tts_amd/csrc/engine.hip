@@ -242,6 +242,7 @@ static int load_model(vits_model* m) {
   if (dk != 32 && dk != 64 && dk != 96) return fail(VITS_ERR_UNSUPPORTED, "head dim %d not in {32,64,96}", dk);
   if (hp.window_size > 4 || hp.window_size < 0) return fail(VITS_ERR_UNSUPPORTED, "window_size > 4");
   if (H % 32 || I % 32 || (I / 2) % 16 || D % 32) return fail(VITS_ERR_UNSUPPORTED, "channel counts must be multiples of 32");
+  if (H > LN_MAXV * LN_CG || D > LN_MAXV * LN_CG) return fail(VITS_ERR_UNSUPPORTED, "LayerNorm width > %d", LN_MAXV * LN_CG);
   if (hp.dp_num_bins > 15 || hp.n_ups > VITS_MAX_UPS || hp.n_resk > 3 || hp.n_resd > VITS_MAX_RESD || hp.n_ups < 1)
     return fail(VITS_ERR_UNSUPPORTED, "hparams out of range");
   if (hp.flow_dilation_rate != 1) return fail(VITS_ERR_UNSUPPORTED, "flow dilation_rate != 1");
@@ -574,7 +575,8 @@ struct ProfScope {
   ~ProfScope() { if (on) hipEventRecord(s->prof.back().e1, s->stream); }
 };
 
-enum TileCfg { T64 = 0, T128 = 1, T32W = 2, TGATE = 3, TGATE_BIG = 4 };
+// 0 = size heuristic, 1 = force the big-tile kernel, 2 = force the K-split kernel (tests only)
+static int g_force_tile = 0;
 
 template <int WM, int WN, int MI, int NI, int EPI>
 static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
@@ -587,7 +589,22 @@ static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
   hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MI, NI, EPI>), dim3(nblk), dim3(256), lds, st, P);
 }
 
-// dispatch on epilogue + tile heuristics.  halo = max over groups of (K-1)*dil (or polyphase spread)
+template <int MI, int NI, int EPI>
+static void launch_ks(hipStream_t st, ConvParams& P, int halo) {
+  constexpr int M_T = MI * 32, N_T = NI * 32;
+  P.ntiles_m = cdiv(P.M, M_T);
+  P.ntiles_n = cdiv(P.Tout, N_T);
+  P.row_len = N_T + halo;
+  const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
+  size_t lds = (size_t)4 * 2 * CONV_CI_T * P.row_len * sizeof(float);
+  const size_t red = (size_t)4 * MI * NI * 16 * 64 * sizeof(float);
+  if (red > lds) lds = red;
+  hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI>), dim3(nblk), dim3(256), lds, st, P);
+}
+
+// dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
+// Large problems (>= 2 workgroups per CU with 64x64 tiles) use the big-tile kernel (more operand
+// reuse); everything smaller uses the K-split kernel so that one utterance still fills the chip.
 static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* name, int halo_override = -1) {
   int halo = 0;
   double macs = 0;
@@ -598,9 +615,25 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
   hipStream_t st = s->stream;
-  if (epi == EPI_GATE) { launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo); return; }
-  if (epi == EPI_RESSKIP) { launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(st, P, halo); return; }
-  if (epi == EPI_COUPLE) { launch_cfg<2, 2, 1, 1, EPI_COUPLE>(st, P, halo); return; }
+  const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
+  const bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < 512);
+  if (epi == EPI_GATE) {
+    if (small) launch_ks<2, 1, EPI_GATE>(st, P, halo); else launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo);
+    return;
+  }
+  if (epi == EPI_RESSKIP) {
+    if (small) launch_ks<1, 1, EPI_RESSKIP>(st, P, halo); else launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(st, P, halo);
+    return;
+  }
+  if (epi == EPI_COUPLE) {
+    if (small) launch_ks<1, 1, EPI_COUPLE>(st, P, halo); else launch_cfg<2, 2, 1, 1, EPI_COUPLE>(st, P, halo);
+    return;
+  }
+  if (small) {
+    const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
+    if (blocks32 > 2048) launch_ks<1, 2, EPI_STORE>(st, P, halo); else launch_ks<1, 1, EPI_STORE>(st, P, halo);
+    return;
+  }
   if (P.ups_u && (P.ups_cout % 64)) { launch_cfg<1, 4, 1, 1, EPI_STORE>(st, P, halo); return; }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
@@ -626,7 +659,7 @@ static void launch_ln(vits_session* s, const float* a, const float* b, const flo
                       const float* beta, const int* len, int B, int C, int T, int gelu, int mask) {
   ProfScope ps(s, "layernorm", 0);
   LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask};
-  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, s->stream, P);
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, P);
 }
 
 static void launch_attention(vits_session* s, const float* qkv, const EncLayerW& L, const int* len, float* out, int B,
@@ -634,10 +667,10 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
   const vits_hparams& hp = s->m->hp;
   const int nh = hp.n_heads, dk = H / nh, W = hp.window_size;
   ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T);
-  dim3 grid(cdiv(T, 64), nh, B);
-  if (dk == 96) hipLaunchKernelGGL((relpos_attention_kernel<96, 16>), grid, dim3(64), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
-  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_kernel<64, 16>), grid, dim3(64), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
-  else hipLaunchKernelGGL((relpos_attention_kernel<32, 16>), grid, dim3(64), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+  dim3 grid(cdiv(T, ATT_TQ), nh, B);
+  if (dk == 96) hipLaunchKernelGGL((relpos_attention_kernel<96>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_kernel<64>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+  else hipLaunchKernelGGL((relpos_attention_kernel<32>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
 }
 
 // attentions.Encoder.forward (attentions.py:48-65).  x in place [B,H,T]; final_base (optional):
@@ -716,7 +749,7 @@ static void run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
   int dil = 1;
   for (size_t i = 0; i < W.pw.size(); ++i) {
     DwLnParams dp{h, s->dy, W.sw[i], W.sb[i], W.g1[i], W.b1[i], s->len_x, D, T, K, dil};
-    hipLaunchKernelGGL(dwconv_ln_gelu_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, s->stream, dp);
+    hipLaunchKernelGGL(dwconv_ln_gelu_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, dp);
     ConvParams P = conv_params(W.pw[i], s->dy, s->dy2, B, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "dp.1x1");
     // x = x + gelu(LN2(y)) ; masked every layer (equivalent at valid positions)
@@ -1280,6 +1313,8 @@ int vits_session_last_ms(vits_session* s, float* ms) {
   HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
   return check_err(s);
 }
+
+void vits_debug_force_tile(int mode) { g_force_tile = mode; }
 
 int vits_session_sync(vits_session* s) {
   if (!s) return fail(VITS_ERR_ARG, "null session");

@@ -80,69 +80,110 @@ __global__ void add_vec_mask_kernel(float* x, const float* v, int v_stride, int 
 
 // ----------------------------------------------------------------------------- LayerNorm over C
 // modules.LayerNorm (modules.py:29-32): y = LN_c(a [+ b]) ; optional GELU ; optional out = base + y ;
-// optional mask.  One thread per (b,t): three coalesced sweeps over C (two-pass variance).
+// optional mask.  Block = 256 threads = 16 time lanes x 16 channel groups: every thread keeps its
+// C/16 channel values in registers (one coalesced 64-byte segment per 16 lanes per channel), the
+// 16 groups combine through LDS (two-pass mean / variance, like F.layer_norm).
+#define LN_TL 16
+#define LN_CG 16
+#define LN_MAXV 24  // C <= 384
 struct LNParams {
   const float* a; const float* b; const float* base; float* y;
   const float* gamma; const float* beta; const int* len;
   int C, T; int gelu; int mask;
 };
-__global__ void layernorm_c_kernel(const LNParams P) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (t >= P.T) return;
-  const long long o0 = (long long)b * P.C * P.T + t;
-  float mean = 0.f;
-  for (int c = 0; c < P.C; ++c) {
-    float v = P.a[o0 + (long long)c * P.T];
-    if (P.b) v += P.b[o0 + (long long)c * P.T];
-    mean += v;
+__device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
+  red[cg * LN_TL + tl] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < LN_CG; ++g) s += red[g * LN_TL + tl];
+  __syncthreads();
+  return s;
+}
+__global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
+  __shared__ float red[LN_CG * LN_TL];
+  const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
+  const int t = blockIdx.x * LN_TL + tl;
+  const bool in = t < P.T;
+  const long long o0 = (long long)b * P.C * P.T + (in ? t : 0);
+  float v[LN_MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG;
+    float x = 0.f;
+    if (in && c < P.C) {
+      x = P.a[o0 + (long long)c * P.T];
+      if (P.b) x += P.b[o0 + (long long)c * P.T];
+    }
+    v[i] = x;
+    sum += x;
   }
-  mean /= (float)P.C;
-  float var = 0.f;
-  for (int c = 0; c < P.C; ++c) {
-    float v = P.a[o0 + (long long)c * P.T];
-    if (P.b) v += P.b[o0 + (long long)c * P.T];
-    v -= mean;
-    var += v * v;
+  const float mean = ln_group_sum(sum, red, tl, cg) / (float)P.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG;
+    if (c < P.C) { const float d = v[i] - mean; sq += d * d; }
   }
-  const float rstd = 1.0f / sqrtf(var / (float)P.C + 1e-5f);
+  const float rstd = 1.0f / sqrtf(ln_group_sum(sq, red, tl, cg) / (float)P.C + 1e-5f);
+  if (!in) return;
   const bool zero = P.mask && t >= P.len[b];
-  for (int c = 0; c < P.C; ++c) {
-    float v = P.a[o0 + (long long)c * P.T];
-    if (P.b) v += P.b[o0 + (long long)c * P.T];
-    v = (v - mean) * rstd * P.gamma[c] + P.beta[c];
-    if (P.gelu) v = gelu_erf(v);
-    if (P.base) v += P.base[o0 + (long long)c * P.T];
-    P.y[o0 + (long long)c * P.T] = zero ? 0.f : v;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG;
+    if (c < P.C) {
+      float x = (v[i] - mean) * rstd * P.gamma[c] + P.beta[c];
+      if (P.gelu) x = gelu_erf(x);
+      if (P.base) x += P.base[o0 + (long long)c * P.T];
+      P.y[o0 + (long long)c * P.T] = zero ? 0.f : x;
+    }
   }
 }
 
-// DDSConv first half (modules.py:100-102): y = gelu(LN1(dwconv_k,dil(x * mask))).
-// The depthwise conv is recomputed per sweep (K taps) instead of being materialised.
+// DDSConv first half (modules.py:100-102): y = gelu(LN1(dwconv_k,dil(x * mask))), same block shape;
+// the depthwise conv result stays in registers between the statistics and the normalisation.
 struct DwLnParams {
   const float* x; float* y; const float* w; const float* bias; const float* gamma; const float* beta; const int* len;
   int C, T, K, dil;
 };
-__global__ void dwconv_ln_gelu_kernel(const DwLnParams P) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (t >= P.T) return;
-  const int L = P.len[b], pad = (P.K * P.dil - P.dil) / 2;
+__global__ void __launch_bounds__(256) dwconv_ln_gelu_kernel(const DwLnParams P) {
+  __shared__ float red[LN_CG * LN_TL];
+  const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
+  const int t = blockIdx.x * LN_TL + tl;
+  const bool in = t < P.T;
+  const int L = P.len[b] < P.T ? P.len[b] : P.T, pad = (P.K * P.dil - P.dil) / 2;
   const long long o0 = (long long)b * P.C * P.T;
-  auto conv = [&](int c) {
-    float a = P.bias[c];
-    for (int k = 0; k < P.K; ++k) {
-      const int s = t + k * P.dil - pad;
-      if (s >= 0 && s < L && s < P.T) a += P.w[c * P.K + k] * P.x[o0 + (long long)c * P.T + s];
+  float v[LN_MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG;
+    float a = 0.f;
+    if (in && c < P.C) {
+      a = P.bias[c];
+      for (int k = 0; k < P.K; ++k) {
+        const int s = t + k * P.dil - pad;
+        if (s >= 0 && s < L) a += P.w[c * P.K + k] * P.x[o0 + (long long)c * P.T + s];
+      }
     }
-    return a;
-  };
-  float mean = 0.f;
-  for (int c = 0; c < P.C; ++c) mean += conv(c);
-  mean /= (float)P.C;
-  float var = 0.f;
-  for (int c = 0; c < P.C; ++c) { float v = conv(c) - mean; var += v * v; }
-  const float rstd = 1.0f / sqrtf(var / (float)P.C + 1e-5f);
-  for (int c = 0; c < P.C; ++c)
-    P.y[o0 + (long long)c * P.T + t] = gelu_erf((conv(c) - mean) * rstd * P.gamma[c] + P.beta[c]);
+    v[i] = a;
+    sum += a;
+  }
+  const float mean = ln_group_sum(sum, red, tl, cg) / (float)P.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG;
+    if (c < P.C) { const float d = v[i] - mean; sq += d * d; }
+  }
+  const float rstd = 1.0f / sqrtf(ln_group_sum(sq, red, tl, cg) / (float)P.C + 1e-5f);
+  if (!in) return;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG;
+    if (c < P.C) P.y[o0 + (long long)c * P.T + t] = gelu_erf((v[i] - mean) * rstd * P.gamma[c] + P.beta[c]);
+  }
 }
 
 // ----------------------------------------------------------------------------- attention
@@ -150,20 +191,23 @@ __global__ void dwconv_ln_gelu_kernel(const DwLnParams P) {
 // (attentions.py:198-260) in exact banded form: O(T) memory, no [T,2T-1] skew.
 //   s[i,j] = q~_i.k_j + (|j-i|<=W ? q~_i.E_k[j-i+W] : 0),  masked keys (-1e4) carry weight exp(-1e4-m) == 0
 //   out_i  = sum_j p_ij v_j + sum_{|j-i|<=W} p_ij E_v[j-i+W]
-// One thread per query, fp32, online softmax per TK-key tile staged in LDS (broadcast reads).
+// Block = 256 threads = 16 queries x 16 key lanes; K/V tiles of 64 keys staged in LDS (coalesced
+// along time), q in registers, online softmax per query with 16-lane shuffles, fp32 throughout.
 // Rows past len[b] are written as 0 (the reference's uniform-softmax junk there is multiplied by
 // x_mask before it can reach any valid position; see DESIGN.md "masked rows").
 // qkv: [B, 3H, T] (q rows [0,H), k rows [H,2H), v rows [2H,3H)), out [B,H,T].
-template <int DK, int TK>
-__global__ void __launch_bounds__(64) relpos_attention_kernel(const float* qkv, const float* ek, const float* ev,
-                                                               const int* len, float* out, int H, int T, int W) {
-  __shared__ float kt[DK * TK];
-  __shared__ float vt[DK * TK];
-  __shared__ float qe[9 * 64];  // [r][lane], W <= 4
-  const int lane = threadIdx.x, hd = blockIdx.y, b = blockIdx.z;
-  const int i = blockIdx.x * 64 + lane;
+#define ATT_TQ 16
+#define ATT_KL 16
+#define ATT_TK 64
+template <int DK>
+__global__ void __launch_bounds__(256) relpos_attention_kernel(const float* qkv, const float* ek, const float* ev,
+                                                                const int* len, float* out, int H, int T, int W) {
+  __shared__ float kt[DK * ATT_TK];
+  __shared__ float vt[DK * ATT_TK];
+  const int tid = threadIdx.x, kl = tid & (ATT_KL - 1), qi = tid >> 4;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * ATT_TQ + qi;
   const int L = len[b] < T ? len[b] : T;
-  const int NW = 2 * W + 1;
   const float* qb = qkv + ((long long)b * 3 * H + (long long)hd * DK) * T;
   const float* kb = qb + (long long)H * T;
   const float* vb = kb + (long long)H * T;
@@ -173,73 +217,83 @@ __global__ void __launch_bounds__(64) relpos_attention_kernel(const float* qkv, 
   float q[DK];
 #pragma unroll
   for (int d = 0; d < DK; ++d) q[d] = qb[(long long)d * T + ic] * scale;
-  for (int r = 0; r < NW; ++r) {
-    float e = 0.f;
+  // relative-key logits: lane kl < 2W+1 holds q~ . E_k[kl]
+  float qe = 0.f;
+  if (kl <= 2 * W) {
 #pragma unroll
-    for (int d = 0; d < DK; ++d) e += q[d] * ek[r * DK + d];
-    qe[r * 64 + lane] = e;
+    for (int d = 0; d < DK; ++d) qe += q[d] * ek[kl * DK + d];
   }
   float acc[DK];
 #pragma unroll
   for (int d = 0; d < DK; ++d) acc[d] = 0.f;
   float m = -3.0e38f, l = 0.f;
-  for (int j0 = 0; j0 < L; j0 += TK) {
+  for (int j0 = 0; j0 < L; j0 += ATT_TK) {
     __syncthreads();
-    for (int e = lane; e < DK * TK; e += 64) {
-      const int d = e / TK, jj = e % TK;
+    for (int e = tid; e < DK * ATT_TK; e += 256) {
+      const int d = e / ATT_TK, jj = e % ATT_TK;
       const int j = j0 + jj;
-      kt[e] = j < L ? kb[(long long)d * T + j] : 0.f;
-      vt[e] = j < L ? vb[(long long)d * T + j] : 0.f;
+      const bool ok = j < L;
+      kt[e] = ok ? kb[(long long)d * T + j] : 0.f;
+      vt[e] = ok ? vb[(long long)d * T + j] : 0.f;
     }
     __syncthreads();
-    float s[TK];
+    float s[ATT_TK / ATT_KL];
     float tmax = -3.0e38f;
 #pragma unroll
-    for (int jj = 0; jj < TK; ++jj) {
+    for (int mm = 0; mm < ATT_TK / ATT_KL; ++mm) {
+      const int jj = kl + ATT_KL * mm;
       float a = 0.f;
 #pragma unroll
-      for (int d = 0; d < DK; ++d) a += q[d] * kt[d * TK + jj];
+      for (int d = 0; d < DK; ++d) a += q[d] * kt[d * ATT_TK + jj];
       const int r = j0 + jj - i;
-      if (r >= -W && r <= W) a += qe[(r + W) * 64 + lane];
+      const int rc = r + W < 0 ? 0 : (r + W > 15 ? 15 : r + W);
+      const float bias = __shfl(qe, rc, ATT_KL);  // executed by all lanes
+      if (r >= -W && r <= W) a += bias;
       if (j0 + jj >= L) a = -3.0e38f;
-      s[jj] = a;
+      s[mm] = a;
       tmax = fmaxf(tmax, a);
     }
+#pragma unroll
+    for (int o = ATT_KL / 2; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, ATT_KL));
     const float mn = fmaxf(m, tmax);
     const float alpha = __expf(m - mn);
     l *= alpha;
 #pragma unroll
     for (int d = 0; d < DK; ++d) acc[d] *= alpha;
 #pragma unroll
-    for (int jj = 0; jj < TK; ++jj) {
-      const float p = (j0 + jj < L) ? __expf(s[jj] - mn) : 0.f;
+    for (int mm = 0; mm < ATT_TK / ATT_KL; ++mm) {
+      const int jj = kl + ATT_KL * mm;
+      const float p = (j0 + jj < L) ? __expf(s[mm] - mn) : 0.f;
       l += p;
 #pragma unroll
-      for (int d = 0; d < DK; ++d) acc[d] += p * vt[d * TK + jj];
+      for (int d = 0; d < DK; ++d) acc[d] += p * vt[d * ATT_TK + jj];
     }
     m = mn;
   }
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-#pragma unroll
-  for (int d = 0; d < DK; ++d) acc[d] *= inv;
-  // relative-value band: recompute the <= 2W+1 in-band probabilities (attentions.py:191-194)
-  if (active) {
-    for (int r = -W; r <= W; ++r) {
-      const int j = i + r;
-      if (j < 0 || j >= L) continue;
-      float a = 0.f;
+  // relative-value band (attentions.py:191-194): lane kl < 2W+1 owns offset r = kl - W; its probability
+  // is recomputed against the final max and folded into this lane's partial accumulator
+  if (active && kl <= 2 * W) {
+    const int j = i + kl - W;
+    if (j >= 0 && j < L) {
+      float a = qe;
 #pragma unroll
       for (int d = 0; d < DK; ++d) a += q[d] * kb[(long long)d * T + j];
-      a += qe[(r + W) * 64 + lane];
-      const float p = __expf(a - m) * inv;
+      const float p = __expf(a - m);
 #pragma unroll
-      for (int d = 0; d < DK; ++d) acc[d] += p * ev[(r + W) * DK + d];
+      for (int d = 0; d < DK; ++d) acc[d] += p * ev[kl * DK + d];
     }
   }
-  if (i < T) {
-    float* ob = out + ((long long)b * H + (long long)hd * DK) * T + i;
 #pragma unroll
-    for (int d = 0; d < DK; ++d) ob[(long long)d * T] = active ? acc[d] : 0.f;
+  for (int o = ATT_KL / 2; o > 0; o >>= 1) l += __shfl_xor(l, o, ATT_KL);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  // reduce the 16 partial accumulators of each query; lane kl writes channels d == kl (mod 16)
+  float* ob = out + ((long long)b * H + (long long)hd * DK) * T + i;
+#pragma unroll
+  for (int d = 0; d < DK; ++d) {
+    float a = acc[d];
+#pragma unroll
+    for (int o = ATT_KL / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, ATT_KL);
+    if ((d & (ATT_KL - 1)) == kl && i < T) ob[(long long)d * T] = active ? a * inv : 0.f;
   }
 }
 
