@@ -92,70 +92,170 @@ struct ConvParams {
   int last;           // EPI_RESSKIP: last layer (M == H, everything is skip; apply mask)
   int ntiles_m, ntiles_n;
   int row_len;        // LDS row = N_T + halo
+  long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
 };
+#define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ float conv_act_in(float v, float scale, float slope) {
   v *= scale;
   return v > 0.f ? v : v * slope;
 }
 
-// ---- shared epilogue: one accumulator element (row, col) of the output tile --------------------
-template <int EPI>
-__device__ __forceinline__ void conv_epilogue_elem(const ConvParams& P, const ConvGroup& G, int b, int lenb, int row, int col, float v) {
-  if (row >= P.Cout || col >= P.Tout) return;
+// ---- shared epilogue over one accumulator fragment ------------------------------------------------
+// NE elements of one output column `col` at rows row0 + (e&3) + 8*(e>>2) (e = e0 .. e0+NE-1 of the
+// 32x32 C/D layout).  Every load uses a clamped (always valid) address and every wave-uniform
+// condition is hoisted out of the element loops, so the loads of a fragment issue back to back and
+// are waited for once (a per-element `if (ptr) v += ptr[..]` makes hipcc serialise them).
+template <int EPI, int NE>
+__device__ __forceinline__ void conv_epilogue_frag(const ConvParams& P, const ConvGroup& G, int b, int lenb, int row0, int e0,
+                                                   int col, float (&v)[NE]) {
+  const bool colok = col < P.Tout;
+  const int colc = colok ? col : P.Tout - 1;
+  int row[NE];
+  bool ok[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = e0 + i;
+    const int r = row0 + (e & 3) + 8 * (e >> 2);
+    ok[i] = colok && r < P.Cout;
+    row[i] = r < P.Cout ? r : P.Cout - 1;
+  }
   if (EPI == EPI_STORE) {
     if (P.ups_u) {
-      const int phase = row / P.ups_cout, co = row - phase * P.ups_cout;
-      if (G.bias) v += G.bias[co];
-      G.y[(long long)b * P.y_bstride + (long long)co * P.Tout_stride + (long long)col * P.ups_u + phase] = v;
-    } else {
-      if (G.bias) v += G.bias[row];
-      if (P.bias_b) v += P.bias_b[(long long)b * P.bias_b_stride + P.bias_b_off + row];
-      if (P.relu) v = v > 0.f ? v : 0.f;
-      if (P.out_mask && col >= lenb) v = 0.f;
-      const long long o = (long long)b * P.y_bstride + (long long)row * P.Tout_stride + col;
-      if (G.res) v += G.res[o];
-      G.y[o] = v;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int phase = row[i] / P.ups_cout, co = row[i] - phase * P.ups_cout;
+        const float bv = G.bias ? G.bias[co] : 0.f;
+        if (ok[i]) G.y[(long long)b * P.y_bstride + (long long)co * P.Tout_stride + (long long)colc * P.ups_u + phase] = v[i] + bv;
+      }
+      return;
     }
+    long long o[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) o[i] = (long long)b * P.y_bstride + (long long)row[i] * P.Tout_stride + colc;
+    if (G.bias) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] += G.bias[row[i]];
+    }
+    if (P.bias_b) {
+      const float* bb = P.bias_b + (long long)b * P.bias_b_stride + P.bias_b_off;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] += bb[row[i]];
+    }
+    if (P.relu) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    }
+    if (P.out_mask && col >= lenb) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] = 0.f;
+    }
+    if (G.res) {
+      float r[NE];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) r[i] = G.res[o[i]];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] += r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+      if (ok[i]) G.y[o[i]] = v[i];
   } else if (EPI == EPI_RESSKIP) {
-    v += G.bias[row];
     const bool valid = col < lenb;
-    if (P.last || row >= P.H) {
-      const int sr = P.last ? row : row - P.H;
-      const long long o = (long long)b * P.y_bstride + (long long)sr * P.Tout_stride + col;
-      float s = P.first ? v : P.skip[o] + v;
-      if (P.last && !valid) s = 0.f;  // output * x_mask (modules.py:176)
-      P.skip[o] = s;
-    } else {
-      const long long o = (long long)b * P.y_bstride + (long long)row * P.Tout_stride + col;
-      P.io[o] = valid ? P.io[o] + v : 0.f;  // x = (x + res_acts) * x_mask (modules.py:171)
+    float bv[NE], old[NE];
+    long long o[NE];
+    bool to_skip[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      to_skip[i] = P.last || row[i] >= P.H;
+      const int sr = (P.last || row[i] < P.H) ? row[i] : row[i] - P.H;
+      o[i] = (long long)b * P.y_bstride + (long long)sr * P.Tout_stride + colc;
+      bv[i] = G.bias[row[i]];
+    }
+    // rows < H update x in place (modules.py:171); rows >= H (or every row of the last layer) feed the
+    // skip accumulator (modules.py:172-175).  First layer stores, later layers accumulate.
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const float* src = to_skip[i] ? P.skip : P.io;
+      old[i] = (to_skip[i] && P.first) ? 0.f : src[o[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      float r = old[i] + v[i] + bv[i];
+      if (to_skip[i]) {
+        if (P.last && !valid) r = 0.f;  // output * x_mask (modules.py:176)
+      } else if (!valid) {
+        r = 0.f;  // x = (x + res_acts) * x_mask
+      }
+      float* dst = to_skip[i] ? P.skip : P.io;
+      if (ok[i]) dst[o[i]] = r;
     }
   } else if (EPI == EPI_COUPLE) {
     // previous z = u (before the Flip that precedes this layer); this layer's logical input is
-    // flip(u): x0[c] = u[I-1-c], x1[c] = u[half-1-c].  new z = cat(x0, (x1 - m)*mask).
-    v += G.bias[row];
+    // flip(u): x0[c] = u[I-1-c], x1[c] = u[half-1-c].  new z = cat(x0, (x1 - m)*mask)  (models.py:390-392)
     const int half = P.H, I2 = 2 * P.H;
-    const long long bo = (long long)b * P.y_bstride + col;
-    const float x1 = P.u[bo + (long long)(half - 1 - row) * P.Tout_stride];
-    const float x0 = P.u[bo + (long long)(I2 - 1 - row) * P.Tout_stride];
-    P.io[bo + (long long)(half + row) * P.Tout_stride] = col < lenb ? (x1 - v) : 0.f;
-    P.io[bo + (long long)row * P.Tout_stride] = x0;
+    const long long bo = (long long)b * P.y_bstride + colc;
+    float x0[NE], x1[NE], bv[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      bv[i] = G.bias[row[i]];
+      x1[i] = P.u[bo + (long long)(half - 1 - row[i]) * P.Tout_stride];
+      x0[i] = P.u[bo + (long long)(I2 - 1 - row[i]) * P.Tout_stride];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      if (ok[i]) {
+        P.io[bo + (long long)(half + row[i]) * P.Tout_stride] = col < lenb ? (x1[i] - (v[i] + bv[i])) : 0.f;
+        P.io[bo + (long long)row[i] * P.Tout_stride] = x0[i];
+      }
+    }
   }
 }
-// WN gate (commons.py:100-107): channel ch of batch b at column col from the tanh / sigmoid pre-activations
-__device__ __forceinline__ void conv_epilogue_gate(const ConvParams& P, const ConvGroup& G, int b, int ch, int col, float at, float as) {
-  if (ch >= P.H || col >= P.Tout) return;
-  at += G.bias[ch];
-  as += G.bias[P.H + ch];
-  if (P.bias_b) {
-    const float* bb = P.bias_b + (long long)b * P.bias_b_stride + P.bias_b_off;
-    at += bb[ch];
-    as += bb[P.H + ch];
+// WN gate (commons.py:100-107): channels ch0 + (e&3) + 8*(e>>2) of batch b at column col from the
+// tanh / sigmoid pre-activation fragments
+template <int NE>
+__device__ __forceinline__ void conv_epilogue_gate(const ConvParams& P, const ConvGroup& G, int b, int ch0, int e0, int col,
+                                                   float (&at)[NE], float (&as)[NE]) {
+  const bool colok = col < P.Tout;
+  const int colc = colok ? col : P.Tout - 1;
+  const float* bb = P.bias_b ? P.bias_b + (long long)b * P.bias_b_stride + P.bias_b_off : G.bias;
+  const float bscale = P.bias_b ? 1.f : 0.f;
+  float b1[NE], b2[NE], c1[NE], c2[NE];
+  int ch[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = e0 + i;
+    const int c = ch0 + (e & 3) + 8 * (e >> 2);
+    ch[i] = c < P.H ? c : P.H - 1;
+    b1[i] = G.bias[ch[i]];
+    b2[i] = G.bias[P.H + ch[i]];
+    c1[i] = bb[ch[i]];
+    c2[i] = bb[P.H + ch[i]];
   }
-  const float tv = tanhf(at);
-  const float sv = 1.0f / (1.0f + __expf(-as));
-  G.y[(long long)b * P.y_bstride + (long long)ch * P.Tout_stride + col] = tv * sv;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = e0 + i;
+    const int c = ch0 + (e & 3) + 8 * (e >> 2);
+    const float tv = tanhf(at[i] + b1[i] + bscale * c1[i]);
+    const float sv = 1.0f / (1.0f + __expf(-(as[i] + b2[i] + bscale * c2[i])));
+    if (colok && c < P.H) G.y[(long long)b * P.y_bstride + (long long)ch[i] * P.Tout_stride + colc] = tv * sv;
+  }
 }
+
+// ---- branch-free staging -----------------------------------------------------------------------
+// Column geometry of a tile is the same for every channel chunk: per staging column j the clamped
+// input offset and a validity flag are computed once; chunk loads are then unconditional loads +
+// selects, with the number of summed inputs (1, or 3 for the MRF mean) hoisted out of the loop.
+#define CONV_STAGE_COLS(JT_)                                                                 \
+  int toff[JT_];                                                                             \
+  bool tok[JT_];                                                                             \
+  _Pragma("unroll") for (int j = 0; j < JT_; ++j) {                                          \
+    const int col = lane + 64 * j;                                                           \
+    int t = t_base + col;                                                                    \
+    if (P.reflect && t == -1) t = (P.Tin > 1) ? 1 : 0;                                       \
+    tok[j] = col < ROW && t >= 0 && t < t_lim;                                               \
+    toff[j] = t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t);                                      \
+  }
 
 template <int WM, int WN, int MI, int NI, int EPI>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
@@ -200,26 +300,29 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
   const float in_scale = P.in_scale, in_slope = P.in_slope;
   const int t_base = n0 - G.pad_l;
 
+  CONV_STAGE_COLS(JT)
   auto load_chunk = [&](int c) {
+    long long roff[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int ci = c * CONV_CI_T + wave + 4 * rr;
-      const long long roff = (long long)(P.x_ch_off + ci * P.x_ch_sign) * P.Tin_stride;
+    for (int rr = 0; rr < 4; ++rr) roff[rr] = (long long)(P.x_ch_off + (c * CONV_CI_T + wave + 4 * rr) * P.x_ch_sign) * P.Tin_stride;
+    if (xb2) {
 #pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        const int col = lane + 64 * j;
-        int t = t_base + col;
-        if (P.reflect && t == -1) t = (P.Tin > 1) ? 1 : 0;
-        float v = 0.f;
-        if (col < ROW && t >= 0 && t < t_lim) {
-          v = xb[roff + t];
-          if (xb2) v += xb2[roff + t];
-          if (xb3) v += xb3[roff + t];
-          v = conv_act_in(v, in_scale, in_slope);
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const long long o = roff[rr] + toff[j];
+          stg[rr][j] = xb[o] + xb2[o] + (xb3 ? xb3[o] : 0.f);
         }
-        stg[rr][j] = v;
-      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) stg[rr][j] = xb[roff[rr] + toff[j]];
     }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) stg[rr][j] = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;
   };
   auto store_chunk = [&](int buf) {
     float* dst = lds + buf * (CONV_CI_T * ROW);
@@ -269,12 +372,16 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
     const float* lb = lds + (c & 1) * (CONV_CI_T * ROW) + h * ROW + wn * (NI * 32) + l31 + tap_base;
 #pragma unroll 1
     for (int kk = 0; kk < K; ++kk) {
-      if (sg < n_sg) {
+      {
+        // unconditional (clamped) prefetch: a fixed number of loads per tap lets hipcc emit a counted
+        // s_waitcnt vmcnt(N) instead of draining the prefetch it has just issued
+        const int sgc = sg < n_sg ? sg : n_sg - 2;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          a_nxt[mi][0] = wp[mi][(size_t)sg * 64];
-          a_nxt[mi][1] = wp[mi][(size_t)(sg + 1) * 64];
+          a_nxt[mi][0] = wp[mi][(size_t)sgc * 64];
+          a_nxt[mi][1] = wp[mi][(size_t)(sgc + 1) * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of this tap's MFMAs
       }
       sg += 2;
       const float* lk = lb + kk * dil;
@@ -307,10 +414,10 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
     const int j = (m0 >> 6) + wm;  // channel block of 32
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int col = n0 + wn * (NI * 32) + ni * 32 + l31;
+      float at[16], as[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        conv_epilogue_gate(P, G, b, j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][ni][e], acc[MI - 1][ni][e]);
+      for (int e = 0; e < 16; ++e) { at[e] = acc[0][ni][e]; as[e] = acc[MI - 1][ni][e]; }
+      conv_epilogue_gate<16>(P, G, b, j * 32 + 4 * h, 0, n0 + wn * (NI * 32) + ni * 32 + l31, at, as);
     }
     return;
   }
@@ -318,32 +425,37 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int col = n0 + wn * (NI * 32) + ni * 32 + l31;
-      const int rbase = m0 + (wm * MI + mi) * 32 + 4 * h;
+      float v[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) conv_epilogue_elem<EPI>(P, G, b, lenb, rbase + (e & 3) + 8 * (e >> 2), col, acc[mi][ni][e]);
+      for (int e = 0; e < 16; ++e) v[e] = acc[mi][ni][e];
+      conv_epilogue_frag<EPI, 16>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, 0, n0 + wn * (NI * 32) + ni * 32 + l31, v);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Small-N variant ("K-split"): one workgroup owns a (MI*32) x (NI*32) output tile and its 4 waves
-// split the CONTRACTION (input-channel chunks c = wave, wave+4, ...).  Every wave stages its own
-// chunks into a wave-private LDS region and streams its own weight fragments with a 3-deep register
-// prefetch, so the main loop has no workgroup barrier and a single utterance (N = 50..2400 columns)
-// still spreads over hundreds of waves, each pulling a distinct weight slab from L2/HBM.  The four
-// partial accumulators are summed through LDS; wave w then finishes rows e in [4w, 4w+4) of every
-// 32x32 fragment through the shared epilogue.
+// split the CONTRACTION (input-channel chunks c = wave, wave+4, ...).  In this regime (one
+// utterance: N = 50..2400 columns) a tile is touched by one workgroup only, so LDS staging buys
+// no reuse and its instruction cost dwarfs the MFMAs (measured: ~3000 cycles of staging per
+// 512 cycles of MFMA for a 1-tap conv).  Instead every wave loads its B fragments STRAIGHT from
+// global/L1 — the 32x32x2 B layout (lane -> row k = lane>>5, column lane&31) is already coalesced
+// along time — double-buffered in registers one tap ahead, next to a 3-deep ring of weight
+// fragments.  No LDS and no barrier in the main loop; the four partial accumulators meet in LDS
+// once, then wave w finishes rows e in [4w, 4w+4) of every fragment through the shared epilogue.
 // ---------------------------------------------------------------------------------------------
-template <int MI, int NI, int EPI>
+struct ks_true { static constexpr bool value = true; };
+struct ks_false { static constexpr bool value = false; };
+template <int MI, int NI, int EPI, int NIN>
 __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   constexpr int M_T = MI * 32;
   constexpr int N_T = NI * 32;
-  constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
   extern __shared__ float lds[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps chunk/address math scalar
   const int h = lane >> 5, l31 = lane & 31;
+  CONV_DBG(0);
   int id;
   {
     const int nblk = gridDim.x, L = blockIdx.x;
@@ -356,7 +468,6 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   const int b = id / P.ntiles_n;
   const ConvGroup& G = P.g[grp];
 
-  const int ROW = P.row_len;
   const int n0 = nt * N_T, m0 = mt * M_T;
   const int K = G.K, dil = G.dil;
   int tap_base = 0;
@@ -364,47 +475,19 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   const int nchunks = P.Cin / CONV_CI_T;
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
-
-  float stg[CONV_CI_T][JT];
-  const float* xb = G.x + (long long)b * P.x_bstride;
-  const float* xb2 = G.x2 ? G.x2 + (long long)b * P.x_bstride : nullptr;
-  const float* xb3 = G.x3 ? G.x3 + (long long)b * P.x_bstride : nullptr;
   const float in_scale = P.in_scale, in_slope = P.in_slope;
-  const int t_base = n0 - G.pad_l;
-  float* wlds = lds + wave * (2 * CONV_CI_T * ROW);  // wave-private double buffer
 
-  auto load_chunk = [&](int c) {
+  // lane geometry.  Input addresses are  uniform_base(b, chunk, p)  +  lane_off(h, t)  with the
+  // lane part a non-negative 32-bit element offset, so the loads use the SGPR-base + VGPR-offset form.
+  int tcol[NI];
 #pragma unroll
-    for (int rr = 0; rr < CONV_CI_T; ++rr) {
-      const int ci = c * CONV_CI_T + rr;
-      const long long roff = (long long)(P.x_ch_off + ci * P.x_ch_sign) * P.Tin_stride;
-#pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        const int col = lane + 64 * j;
-        int t = t_base + col;
-        if (P.reflect && t == -1) t = (P.Tin > 1) ? 1 : 0;
-        float v = 0.f;
-        if (col < ROW && t >= 0 && t < t_lim) {
-          v = xb[roff + t];
-          if (xb2) v += xb2[roff + t];
-          if (xb3) v += xb3[roff + t];
-          v = conv_act_in(v, in_scale, in_slope);
-        }
-        stg[rr][j] = v;
-      }
-    }
-  };
-  auto store_chunk = [&](int buf) {
-    float* dst = wlds + buf * (CONV_CI_T * ROW);
-#pragma unroll
-    for (int rr = 0; rr < CONV_CI_T; ++rr) {
-#pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        const int col = lane + 64 * j;
-        if (col < ROW) dst[rr * ROW + col] = stg[rr][j];
-      }
-    }
-  };
+  for (int ni = 0; ni < NI; ++ni) tcol[ni] = n0 + ni * 32 + l31 - G.pad_l + tap_base;
+  const long long rs = (long long)P.x_ch_sign * P.Tin_stride;  // one input channel, in elements (may be < 0)
+  const long long ubase = (long long)b * P.x_bstride + (long long)P.x_ch_off * P.Tin_stride + (rs < 0 ? rs : 0);
+  const unsigned hoff = (unsigned)(h ? (rs < 0 ? 0 : rs) : (rs < 0 ? -rs : 0));  // row k = lane>>5
+  const float* xu = G.x + ubase;
+  const float* xu2 = G.x2 ? G.x2 + ubase : nullptr;
+  const float* xu3 = G.x3 ? G.x3 + ubase : nullptr;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -415,63 +498,106 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   const int n_mblocks = P.M >> 5;
-  const f32x4* wp[MI];
+  const f32x4* wp[MI];  // uniform per wave; + lane
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     int mb = (m0 >> 5) + mi;
     if (mb >= n_mblocks) mb = 0;
-    wp[mi] = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
+    wp[mi] = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64;
   }
-  // this wave's taps in order: (c, kk) for c = wave, wave+4, ... ; tap -> first step-group 2*(c*K+kk)
   const int my_chunks = wave < nchunks ? (nchunks - wave + 3) / 4 : 0;
   const int my_taps = my_chunks * K;
-  auto tap_sg = [&](int tp) { const int ci = tp / K, kk = tp - ci * K; return 2 * ((wave + 4 * ci) * K + kk); };
-  f32x4 a0[MI][2], a1[MI][2], a2[MI][2];  // taps tp, tp+1, tp+2
-  auto fetch = [&](f32x4 (&dst)[MI][2], int tp) {
-    if (tp < my_taps) {
-      const int sg = tap_sg(tp);
+  const int c_last = wave + 4 * (my_chunks > 0 ? my_chunks - 1 : 0);
+
+  // One "tap" = 8 MFMA k-steps of one (chunk, kk).  Taps are processed in super-steps of KS_U taps,
+  // double-buffered in registers: while super-step s computes, the A and B fragments of super-step
+  // s+1 (KS_U * 512 MFMA cycles ahead, > HBM latency) are in flight.  Every load is unconditional
+  // with clamped indices so hipcc can emit counted s_waitcnt.
+  constexpr int KS_U = 4;
+  struct TapBuf {
+    f32x4 a[KS_U][MI][2];
+    float bq[KS_U][8][NI];
+    unsigned ok[KS_U];
+  };
+  int lc = wave, lk = 0;  // load cursor (chunk, tap-in-chunk) of this wave's tap stream
+  const float* xq2 = NIN > 1 ? xu2 : xu;               // NIN == 3: MRF mean of three inputs (x3 may be absent)
+  const float* xq3 = NIN > 1 ? (xu3 ? xu3 : xu2) : xu;
+  const float s3 = (NIN > 1 && xu3) ? 1.f : 0.f;
+  const int refl_t = P.reflect ? ((P.Tin > 1) ? 1 : 0) : -1;
+
+  // Software pipeline inside ONE wave, pinned at source level: before every MFMA of the current
+  // super-step the wave issues one slice of the NEXT super-step's loads (weights at p == 0, one B
+  // fragment per k-step), and a sched_barrier after each pair keeps hipcc from regrouping them.  The
+  // load latency (L2 ~500, HBM ~900 cycles) is thereby covered by KS_U*8 = 32 MFMAs (2048 cycles), the
+  // address math runs in the MFMA shadow, and all loads are unconditional (clamped + select), which
+  // keeps the body one basic block with counted s_waitcnt.
+  auto pipe_step = [&](auto has_cur, const TapBuf& cur, TapBuf& nxt) {
+#pragma unroll
+    for (int u = 0; u < KS_U; ++u) {
+      const bool live = lc <= c_last;
+      const int cc = live ? lc : c_last;
+      const int sg = 2 * (cc * K + lk);
+      const long long coff = (long long)cc * CONV_CI_T * rs;
+      unsigned lo[NI];
+      unsigned okb = 0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int t = tcol[ni] + lk * dil;
+        t = (t == -1 && refl_t >= 0) ? refl_t : t;
+        okb |= ((t >= 0) & (t < t_lim) & live) ? (1u << ni) : 0u;
+        lo[ni] = hoff + (unsigned)(t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t));
+      }
+      nxt.ok[u] = okb;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        dst[mi][0] = wp[mi][(size_t)sg * 64];
-        dst[mi][1] = wp[mi][(size_t)(sg + 1) * 64];
+        nxt.a[u][mi][0] = wp[mi][(size_t)sg * 64 + lane];
+        nxt.a[u][mi][1] = wp[mi][(size_t)(sg + 1) * 64 + lane];
       }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const long long ro = coff + 2 * p * rs;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          float v = (xu + ro)[lo[ni]];
+          if (NIN > 1) v = (v + (xq2 + ro)[lo[ni]] + s3 * (xq3 + ro)[lo[ni]]) * in_scale;  // scale only on the MRF mean
+          nxt.bq[u][p][ni] = v;
+        }
+        if (decltype(has_cur)::value) {
+          float okf[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) okf[ni] = ((cur.ok[u] >> ni) & 1u) ? 1.f : 0.f;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            // leaky-relu for 0 <= slope <= 1 is max(v, slope*v); the edge/mask flag is a 0/1 multiplier:
+            // 3 VALU per MFMA instead of 5 (a single wave per SIMD is issue-bound, every slot counts)
+            const float x_ = cur.bq[u][p][ni];
+            const float bv = fmaxf(x_, x_ * in_slope) * okf[ni];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u][mi][p >> 2][p & 3], bv, acc[mi][ni], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bool wrap = (lk + 1 == K);
+      lk = wrap ? 0 : lk + 1;
+      lc = wrap ? lc + 4 : lc;
     }
   };
-  fetch(a0, 0);
-  fetch(a1, 1);
-  if (my_chunks > 0) { load_chunk(wave); store_chunk(0); }
-  int tp = 0;
-  for (int ci = 0; ci < my_chunks; ++ci) {
-    const int cn = wave + 4 * (ci + 1);
-    if (ci + 1 < my_chunks) load_chunk(cn);
-    const float* lb = wlds + (ci & 1) * (CONV_CI_T * ROW) + h * ROW + l31 + tap_base;
-#pragma unroll 1
-    for (int kk = 0; kk < K; ++kk, ++tp) {
-      fetch(a2, tp + 2);
-      const float* lk = lb + kk * dil;
-      float bv[8][NI];
-#pragma unroll
-      for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[p][ni] = lk[2 * p * ROW + ni * 32];
-#pragma unroll
-      for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi][p >> 2][p & 3], bv[p][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        a0[mi][0] = a1[mi][0]; a0[mi][1] = a1[mi][1];
-        a1[mi][0] = a2[mi][0]; a1[mi][1] = a2[mi][1];
-      }
-    }
-    if (ci + 1 < my_chunks) store_chunk((ci + 1) & 1);
-  }
 
-  // ---- cross-wave reduction through LDS (staging regions are dead after the barrier)
-  __syncthreads();
+  CONV_DBG(1);
+  if (my_taps > 0) {
+    TapBuf t0, t1;
+    pipe_step(ks_false{}, t1, t0);
+#pragma unroll 1
+    for (int tp = 0; tp < my_taps; tp += 2 * KS_U) {
+      pipe_step(ks_true{}, t0, t1);
+      if (tp + KS_U < my_taps) pipe_step(ks_true{}, t1, t0);
+    }
+  }
+  CONV_DBG(2);
+
+  // ---- cross-wave reduction through LDS
   float* red = lds;  // [wave][mi][ni][e][64]
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -480,6 +606,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) red[(((wave * MI + mi) * NI + ni) * 16 + e) * 64 + lane] = acc[mi][ni][e];
   __syncthreads();
+  CONV_DBG(3);
   const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
   float sum[MI][NI][4];
 #pragma unroll
@@ -494,21 +621,18 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
         for (int w = 0; w < 4; ++w) a += red[(((w * MI + mi) * NI + ni) * 16 + e) * 64 + lane];
         sum[mi][ni][ee] = a;
       }
+  CONV_DBG(4);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + ni * 32 + l31;
+    if (EPI == EPI_GATE) {
+      conv_epilogue_gate<4>(P, G, b, (m0 >> 6) * 32 + 4 * h, 4 * wave, col, sum[0][ni], sum[MI - 1][ni]);
+    } else {
 #pragma unroll
-    for (int ee = 0; ee < 4; ++ee) {
-      const int e = 4 * wave + ee;
-      const int rin = (e & 3) + 8 * (e >> 2) + 4 * h;  // row inside the 32-row fragment
-      if (EPI == EPI_GATE) {
-        conv_epilogue_gate(P, G, b, (m0 >> 6) * 32 + rin, col, sum[0][ni][ee], sum[MI - 1][ni][ee]);
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) conv_epilogue_elem<EPI>(P, G, b, lenb, m0 + mi * 32 + rin, col, sum[mi][ni][ee]);
-      }
+      for (int mi = 0; mi < MI; ++mi) conv_epilogue_frag<EPI, 4>(P, G, b, lenb, m0 + mi * 32 + 4 * h, 4 * wave, col, sum[mi][ni]);
     }
   }
+  CONV_DBG(5);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -592,14 +592,16 @@ static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
 template <int MI, int NI, int EPI>
 static void launch_ks(hipStream_t st, ConvParams& P, int halo) {
   constexpr int M_T = MI * 32, N_T = NI * 32;
+  (void)halo;  // no staging window: B fragments come straight from global memory
   P.ntiles_m = cdiv(P.M, M_T);
   P.ntiles_n = cdiv(P.Tout, N_T);
-  P.row_len = N_T + halo;
+  P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
-  size_t lds = (size_t)4 * 2 * CONV_CI_T * P.row_len * sizeof(float);
-  const size_t red = (size_t)4 * MI * NI * 16 * 64 * sizeof(float);
-  if (red > lds) lds = red;
-  hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI>), dim3(nblk), dim3(256), lds, st, P);
+  const size_t lds = (size_t)4 * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
+  if (EPI == EPI_STORE && P.g[0].x2)
+    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, (EPI == EPI_STORE ? 3 : 1)>), dim3(nblk), dim3(256), lds, st, P);
+  else
+    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, 1>), dim3(nblk), dim3(256), lds, st, P);
 }
 
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
@@ -616,7 +618,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
   hipStream_t st = s->stream;
   const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
-  const bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < 512);
+  bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < 512);
+  if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   if (epi == EPI_GATE) {
     if (small) launch_ks<2, 1, EPI_GATE>(st, P, halo); else launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo);
     return;
@@ -1373,10 +1376,30 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
     hipMemcpy(dx, x, sizeof(float) * (size_t)B * Cin * T, hipMemcpyHostToDevice);
     ConvParams P = conv_params(W, dx, dy, B, T, dil, (K - 1) * dil / 2);
     P.in_slope = slope;
-    launch_conv(&s, P, EPI_STORE, "op.conv1d");
+    const char* dbg_env = getenv("VITS_CONV_DBG");
+    long long* d_dbg = nullptr;
+    if (dbg_env) { hipMalloc((void**)&d_dbg, 32 * sizeof(long long)); hipMemset(d_dbg, 0, 32 * sizeof(long long)); P.dbg = d_dbg; }
+    const int reps = dbg_env ? atoi(dbg_env) : 1;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < reps; ++r) {
+      if (r == reps - 1) hipEventRecord(e0, 0);
+      launch_conv(&s, P, EPI_STORE, "op.conv1d");
+    }
+    hipEventRecord(e1, 0);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) rc = fail(VITS_ERR_DEVICE, "conv kernel failed: %s", hipGetErrorString(e));
     else hipMemcpy(y, dy, sizeof(float) * (size_t)B * Cout * T, hipMemcpyDeviceToHost);
+    if (dbg_env && rc == VITS_OK) {
+      long long h[32]; float ms = 0;
+      hipMemcpy(h, d_dbg, sizeof h, hipMemcpyDeviceToHost);
+      hipEventElapsedTime(&ms, e0, e1);
+      fprintf(stderr, "[conv dbg] B=%d Cin=%d Cout=%d T=%d K=%d dil=%d: last launch %.2f us (event); block 0 cycles since kernel start:\n", B, Cin, Cout, T, K, dil, ms * 1e3);
+      for (int w = 0; w < 4; ++w)
+        fprintf(stderr, "   wave %d: staged0 %lld  loop_done %lld  barrier %lld  reduced %lld  end %lld\n", w, h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8],
+                h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8]);
+    }
+    if (d_dbg) hipFree(d_dbg);
+    hipEventDestroy(e0); hipEventDestroy(e1);
   }
   if (dx) hipFree(dx);
   if (dy) hipFree(dy);
