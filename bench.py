@@ -14,7 +14,10 @@ MB-iSTFT-VITS2 architecture (the real checkpoint cannot be downloaded offline).
 Workloads (SURVEY.md §8 sizes; durations pinned to 3 frames/token so the work is fixed):
   c2  B=1,  T_x=50            -> T_y=150,  38 400 samples (1.74 s)      [default: BASELINE configs[1]]
   c3  B=32, T_x in [20,200]   -> padded to max, ragged masks             [configs[2], fp32 throughout]
+  c4  B=256 ragged, sharded over the ranks by vosk_tts_amd.batching.plan_shards (32 per GPU at 8)  [configs[3]]
   c5  B=1,  T_x=2000          -> T_y=6000, 69.7 s of audio               [configs[4]]
+The default run (c2) also measures c3 and reports it under "batch32" in the same JSON line, because
+BASELINE.json quotes the metric at "batch=1 and 32".
 """
 import argparse
 import json
@@ -31,7 +34,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 SAMPLE_RATE = 22050
 
 
-def make_workload(name, rng):
+def make_workload(name, rng, rank=0, world=1):
+    if name == "c4":
+        from vosk_tts_amd.batching import plan_shards
+
+        all_len = rng.integers(20, 201, size=256).astype(np.int64)
+        mine = plan_shards(all_len, world, max_batch=(256 + world - 1) // world)[rank]
+        lengths = all_len[mine]
+        B, Tx = len(lengths), int(lengths.max())
+        ids = rng.integers(1, 62, size=(B, Tx)).astype(np.int64)
+        dur = np.where(np.arange(Tx)[None] < lengths[:, None], 3, 0).astype(np.int32)
+        return ids, lengths, dur
     if name == "c2":
         lengths = np.array([50], np.int64)
     elif name == "c3":
@@ -53,7 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--no-batch32", action="store_true", help="skip the extra c3 (batch=32) measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget for the CPU-oracle baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -88,83 +102,105 @@ def main():
     lib = VitsLib()
     model = lib.create(blob, local_rank)
 
-    rng = np.random.default_rng(1234)
-    ids, lengths, dur = make_workload(args.workload, rng)
-    B, Tx = ids.shape
-    Ty = int(dur.sum(1).max())
-    S = Ty * hp.hop_length
-    valid_samples = int(dur.sum()) * hp.hop_length
-    scales = np.array([0.8, 1.0, 0.8], np.float32)  # runtime defaults (vosk_tts/synth.py:50-54)
-    dev = torch.device("cuda", local_rank)
-    d_ids = torch.from_numpy(ids).to(dev)
-    d_len = torch.from_numpy(lengths).to(dev)
-    d_sid = torch.full((B,), 2, dtype=torch.int64, device=dev)
-    d_dur = torch.from_numpy(dur).to(dev)
-    d_audio = torch.empty((B, S), dtype=torch.float32, device=dev)
-    sess = VitsDeviceSession(model, B, Tx, Ty)
-    sess.set_options(use_graph=not args.no_graph, profile=False)
+    def measure(wname, steps, warmup):
+        rng = np.random.default_rng(1234)
+        ids, lengths, dur = make_workload(wname, rng, rank, world)
+        B, Tx = ids.shape
+        Ty = int(dur.sum(1).max())
+        S = Ty * hp.hop_length
+        valid_samples = int(dur.sum()) * hp.hop_length
+        scales = np.array([0.8, 1.0, 0.8], np.float32)  # runtime defaults (vosk_tts/synth.py:50-54)
+        dev = torch.device("cuda", local_rank)
+        d_ids = torch.from_numpy(ids).to(dev)
+        d_len = torch.from_numpy(lengths).to(dev)
+        d_sid = torch.full((B,), 2, dtype=torch.int64, device=dev)
+        d_dur = torch.from_numpy(dur).to(dev)
+        d_audio = torch.empty((B, S), dtype=torch.float32, device=dev)
+        sess = VitsDeviceSession(model, B, Tx, Ty)
+        sess.set_options(use_graph=not args.no_graph, profile=False)
 
-    def step():
-        sess.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), B, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 7,
-                               d_audio.data_ptr(), S)
+        def step():
+            sess.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), B, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 7,
+                                   d_audio.data_ptr(), S)
 
-    def barrier():
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(warmup):
+            step()
+        sess.sync()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        sess.sync()  # surfaces any deferred device-side error
         if dist is not None:
-            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(d_audio).all().item(), "non-finite audio"
 
-    for _ in range(args.warmup):
-        step()
-    sess.sync()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    sess.sync()  # surfaces any deferred device-side error
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(d_audio).all().item(), "non-finite audio"
+        ms_per_step = elapsed / steps * 1e3
+        job_samples = valid_samples * world
+        if dist is not None:
+            tt = torch.tensor([float(valid_samples)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            job_samples = int(tt.item())
+        total_samples = job_samples * steps
+        value = total_samples / elapsed
+        audio_sec_per_step = job_samples / SAMPLE_RATE
+        rtf = (elapsed / steps) / audio_sec_per_step
 
-    ms_per_step = elapsed / args.steps * 1e3
-    total_samples = valid_samples * args.steps * world
-    value = total_samples / elapsed
-    audio_sec_per_step = valid_samples / SAMPLE_RATE
-    rtf = (elapsed / args.steps) / audio_sec_per_step
+        # ---- per-kernel device time with HIP events on the session stream (eager, profiled forwards)
+        flops_fwd = model.algorithmic_flops(B, Tx, Ty)
+        sess.set_options(use_graph=False, profile=True)
+        nprof = 3
+        for _ in range(nprof):
+            step()
+        rep = sess.profile_report()
+        sess.set_options(use_graph=not args.no_graph, profile=False)
+        conv = {k: v for k, v in rep.items() if v[2] > 0 and k != "attention"}
+        dom_name, dom = max(conv.items(), key=lambda kv: kv[1][1]) if conv else ("none", (1, 1.0, 0.0))
+        # the ResBlock convolutions (c1 + c2 launches run the same kernel instantiation) are one family
+        fam = [v for k, v in rep.items() if k.startswith("dec.res_")] if dom_name.startswith("dec.res_") else [dom]
+        fam_ms = sum(v[1] for v in fam)
+        fam_flops = sum(v[2] for v in fam)
+        fam_launches = sum(v[0] for v in fam)
+        achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        dev_ms_all = sum(v[1] for v in rep.values()) / nprof
+        roofline = {
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_mfma_kernel (" + ("dec.res_c1+dec.res_c2" if dom_name.startswith("dec.res_") else dom_name) + ")",
+            "avg_launch_us": round(fam_ms / max(fam_launches, 1) * 1e3, 2),
+            "algorithmic_flops_per_launch": fam_flops / max(fam_launches, 1),
+            "forward": {"algorithmic_gflop": round(flops_fwd / 1e9, 3),
+                        "achieved_tflops": round(flops_fwd / (elapsed / steps) / 1e12, 3),
+                        "frac": round(flops_fwd / (elapsed / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "sum_kernel_ms_eager": round(dev_ms_all, 4)},
+            "by_family_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])},
+        }
 
-    # ---- per-kernel device time with HIP events on the session stream (eager, profiled forwards)
-    flops_fwd = model.algorithmic_flops(B, Tx, Ty)
-    sess.set_options(use_graph=False, profile=True)
-    nprof = 3
-    for _ in range(nprof):
-        step()
-    rep = sess.profile_report()
-    sess.set_options(use_graph=not args.no_graph, profile=False)
-    conv = {k: v for k, v in rep.items() if v[2] > 0 and k != "attention"}
-    dom_name, dom = max(conv.items(), key=lambda kv: kv[1][1]) if conv else ("none", (1, 1.0, 0.0))
-    # the ResBlock convolutions (c1 + c2 launches run the same kernel instantiation) are one family
-    fam = [v for k, v in rep.items() if k.startswith("dec.res_")] if dom_name.startswith("dec.res_") else [dom]
-    fam_ms = sum(v[1] for v in fam)
-    fam_flops = sum(v[2] for v in fam)
-    fam_launches = sum(v[0] for v in fam)
-    achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
-    dev_ms_all = sum(v[1] for v in rep.values()) / nprof
-    roofline = {
-        "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-        "kernel": "conv_mfma_kernel (" + ("dec.res_c1+dec.res_c2" if dom_name.startswith("dec.res_") else dom_name) + ")",
-        "avg_launch_us": round(fam_ms / max(fam_launches, 1) * 1e3, 2),
-        "algorithmic_flops_per_launch": fam_flops / max(fam_launches, 1),
-        "forward": {"algorithmic_gflop": round(flops_fwd / 1e9, 3),
-                    "achieved_tflops": round(flops_fwd / (elapsed / args.steps) / 1e12, 3),
-                    "frac": round(flops_fwd / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "sum_kernel_ms_eager": round(dev_ms_all, 4)},
-        "by_family_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])},
-    }
+        sess.close()
+        return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
+                    ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales)
+
+    R = measure(args.workload, args.steps, args.warmup)
+    B, Tx, Ty, lengths, ids, dur = R["B"], R["Tx"], R["Ty"], R["lengths"], R["ids"], R["dur"]
+    valid_samples, ms_per_step, value, rtf, roofline, scales = R["valid_samples"], R["ms_per_step"], R["value"], R["rtf"], R["roofline"], R["scales"]
+    batch32 = None
+    if args.workload == "c2" and not args.no_batch32:
+        R3 = measure("c3", max(3, min(args.steps, 10)), 2)
+        batch32 = {"value": round(R3["value"], 1), "unit": "samples/s", "ms_per_step": round(R3["ms_per_step"], 4),
+                   "x_realtime": round(1.0 / R3["rtf"], 1), "batch": R3["B"], "T_x": R3["Tx"], "T_y": R3["Ty"],
+                   "samples_per_step_per_gpu": R3["valid_samples"],
+                   "workload": "c3: B=32 ragged 20..200 tokens padded, durations pinned 3/token, fp32",
+                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "forward")}}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,7 +239,7 @@ def main():
                                    f"-> T_y={Ty}, {valid_samples} valid samples/step/GPU, sid=2, scales=[0.8,1.0,0.8]",
                        "batch": B, "T_x": Tx, "T_y": Ty, "samples_per_step_per_gpu": valid_samples,
                        "parallelism": f"replicas x{world} (no collective)", "hipgraph": not args.no_graph},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "batch32": batch32,
         }
         print(json.dumps(line))
     if dist is not None:

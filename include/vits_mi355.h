@@ -221,6 +221,8 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
 /* Test hook: 0 = choose the conv kernel by problem size (default), 1 = always the big-tile kernel,
  * 2 = always the K-split small-N kernel.  Process-wide. */
 void vits_debug_force_tile(int mode);
+/* Test hook: 0 = fp32-MFMA flash attention (default), 1 = the scalar-VALU attention kernel. */
+void vits_debug_attention_impl(int impl);
 
 /* Algorithmic FLOPs of one forward (SURVEY.md §8a/§8d formula evaluated on the
  * model's own hparams): used by bench.py for the roofline line. */

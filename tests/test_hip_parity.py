@@ -112,6 +112,31 @@ def test_every_epilogue_on_both_conv_kernels(hip_lib, hip_default, hip_tiny, ora
         hip_lib.lib.vits_debug_force_tile(0)
 
 
+def test_both_attention_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny):
+    """Default = fp32-MFMA flash attention; the scalar-VALU kernel is an independent implementation of the same
+    banded relative-position math.  Both must match the oracle, incl. a flow long enough (T_y = 400) that
+    every wave of the MFMA kernel merges several key tiles and the band straddles tile borders."""
+    rng = np.random.default_rng(21)
+    B, Ty = 2, 400
+    z_p = rng.standard_normal((B, 192, Ty)).astype(np.float32)
+    ylen = np.array([400, 283], np.int64)
+    sid = np.array([3, 9], np.int64)
+    want = oracle_default.flow(z_p, ylen, sid)
+    mask = (np.arange(Ty)[None, :] < ylen[:, None])[:, None, :]
+    try:
+        for impl in (1, 0):
+            hip_lib.lib.vits_debug_attention_impl(impl)
+            got = hip_default.flow(z_p, ylen, sid)
+            assert_close(f"flow (attention impl {impl})", want * mask, got * mask, STAGE_TOL)
+            _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
+            for T in (1, 3, 4, 5, 9):
+                g = golden(f"enc_T{T}")
+                x, _, _ = hip_default.text_encoder(g["ids"], g["lengths"], g["sid"])
+                assert_close(f"enc T={T} impl {impl}", g["x"], x, STAGE_TOL)
+    finally:
+        hip_lib.lib.vits_debug_attention_impl(0)
+
+
 def test_free_running_infer_golden(hip_default):
     g = golden("free_c1")
     audio, olen = hip_default.synthesize(g["ids"], g["lengths"], g["scales"], g["sid"], noise_dp=g["noise_dp"],

@@ -577,6 +577,8 @@ struct ProfScope {
 
 // 0 = size heuristic, 1 = force the big-tile kernel, 2 = force the K-split kernel (tests only)
 static int g_force_tile = 0;
+// 0 = fp32-MFMA flash attention (default), 1 = the VALU kernel (kept as an independent cross-check in tests)
+static int g_attn_impl = 0;
 
 template <int WM, int WN, int MI, int NI, int EPI>
 static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
@@ -670,6 +672,15 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
   const vits_hparams& hp = s->m->hp;
   const int nh = hp.n_heads, dk = H / nh, W = hp.window_size;
   ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T);
+  if (g_attn_impl == 0) {  // fp32-MFMA flash kernel (default)
+    dim3 grid(cdiv(T, 32), nh, B);
+    const int wreg = dk * 33 + 10 * 32 + 9 * 32;
+    const size_t lds = (size_t)4 * wreg * sizeof(float);
+    if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), grid, dim3(256), lds, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+    else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), grid, dim3(256), lds, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+    else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), grid, dim3(256), lds, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+    return;
+  }
   dim3 grid(cdiv(T, ATT_TQ), nh, B);
   if (dk == 96) hipLaunchKernelGGL((relpos_attention_kernel<96>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
   else if (dk == 64) hipLaunchKernelGGL((relpos_attention_kernel<64>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
@@ -1318,6 +1329,7 @@ int vits_session_last_ms(vits_session* s, float* ms) {
 }
 
 void vits_debug_force_tile(int mode) { g_force_tile = mode; }
+void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
 
 int vits_session_sync(vits_session* s) {
   if (!s) return fail(VITS_ERR_ARG, "null session");

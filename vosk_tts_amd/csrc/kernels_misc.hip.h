@@ -297,6 +297,205 @@ __global__ void __launch_bounds__(256) relpos_attention_kernel(const float* qkv,
   }
 }
 
+// ----------------------------------------------------------------------------- attention (MFMA)
+// Same math as relpos_attention_kernel, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), flash style.
+// One workgroup = 32 queries of one (batch, head); its 4 waves split the KEY tiles (jt = wave, wave+4, ..)
+// and merge their (m, l, O) through LDS at the end, so a single short utterance still uses every wave
+// and long-form (T_y = 6000) has ~47 tiles per wave.
+//
+// "Swapped" formulation — everything is computed transposed so that a LANE owns a QUERY:
+//   S^T[key][q] = sum_d K[key][d] Q^T[d][q]        A = K fragment (coalesced from [d][T]), B = Q^T (registers)
+//   C/D layout: lane (h = lane>>5, l31 = lane&31) register e holds row kappa(e,h) = (e&3)+8(e>>2)+4h, column l31
+//   -> lane l31 holds 16 of the 32 scores of ITS query; row max / sum are in-register + one xor-32 exchange.
+//   O^T[d][q] += sum_key V[d][key] P^T[key][q]      the contraction order of an MFMA is free, so k-step s is
+//   DEFINED to cover keys kappa(s,0), kappa(s,1): then the B fragment of step s is exactly accumulator
+//   register s of S^T — P never moves.  A = V fragment read from a padded LDS tile.
+//   relative keys:   QE^T[r][q] = E_k[r] . q~  by one MFMA pass, kept in LDS [r][q]
+//   relative values: O^T[d][q] += sum_r E_v^T[d][r] Prel^T[r][q], Prel gathered through LDS on the <= 3 tiles
+//   that touch the diagonal band.
+template <int DK>
+__global__ void __launch_bounds__(256) relpos_attention_mfma_kernel(const float* qkv, const float* ek, const float* ev,
+                                                                     const int* len, float* out, int H, int T, int W) {
+  constexpr int NS = DK / 2, ND = DK / 32, VS = 33;
+  constexpr int WREG = DK * VS + 10 * 32 + 9 * 32;  // per-wave LDS: V tile | Prel | QE
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hd = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * 32;
+  const int L = len[b] < T ? len[b] : T;
+  const int i = i0 + l31;
+  float* ob = out + ((long long)b * H + (long long)hd * DK) * T;
+  if (i0 >= L) {  // whole query tile is padding: write zeros (see "masked rows" in DESIGN.md)
+    if (i < T)
+      for (int d = (threadIdx.x >> 5); d < DK; d += 8) ob[(long long)d * T + i] = 0.f;
+    return;
+  }
+  const bool active = i < L;
+  const int ic = active ? i : L - 1;
+  const float* qb = qkv + ((long long)b * 3 * H + (long long)hd * DK) * T;
+  const float* kb = qb + (long long)H * T;
+  const float* vb = kb + (long long)H * T;
+  float* vt = lds + wave * WREG;
+  float* prel = vt + DK * VS;
+  float* qes = prel + 10 * 32;
+  const float scale = 1.0f / sqrtf((float)DK);
+  const int NW = 2 * W + 1;
+
+  // B operand of every QK^T step: Q^T[d = 2s + h][query], pre-scaled
+  float qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qf[s] = qb[(long long)(2 * s + h) * T + ic] * scale;
+  // QE^T[r][q] (attentions.py:175-177): A = E_k[r = l31][d = 2s + h]
+  {
+    f32x16 qe;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) qe[e] = 0.f;
+    const int rr = l31 < NW ? l31 : 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float a = l31 < NW ? ek[rr * DK + 2 * s + h] : 0.f;
+      qe = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[s], qe, 0, 0, 0);
+    }
+    // rows r = kappa(e,h) < 9: h=0 -> e 0..3 (r 0..3) and e 4 (r 8); h=1 -> e 0..3 (r 4..7)
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (r < 9) qes[r * 32 + l31] = qe[e];
+    }
+  }
+
+  f32x16 O[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[dt][e] = 0.f;
+  float m = -3.0e38f, l = 0.f;
+
+  const int ntiles = (L + 31) >> 5;
+  for (int jt = wave; jt < ntiles; jt += 4) {
+    const int j0 = jt * 32;
+    // ---- V tile -> wave-private LDS [d][33] (keys beyond L read as 0)
+    {
+      const int j = j0 + l31;
+      const bool ok = j < L;
+      const int jc = ok ? j : L - 1;
+#pragma unroll 8
+      for (int d = h; d < DK; d += 2) {
+        const float v = vb[(long long)d * T + jc];
+        vt[d * VS + l31] = ok ? v : 0.f;
+      }
+    }
+    // ---- S^T = K Q^T
+    f32x16 S;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] = 0.f;
+    {
+      const int j = j0 + l31;
+      const int jc = j < L ? j : L - 1;
+      const float* kp = kb + (long long)h * T + jc;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float a = kp[(long long)(2 * s) * T];
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[s], S, 0, 0, 0);
+      }
+    }
+    // ---- relative-key bias on the diagonal band, key mask, tile max
+    const bool near = (j0 + 31 >= i0 - W) && (j0 <= i0 + 31 + W);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      float sv = S[e];
+      if (near) {
+        const int r = key - i + W;
+        const int rc = r < 0 ? 0 : (r > 8 ? 8 : r);
+        const float bias = qes[rc * 32 + l31];
+        sv += (r >= 0 && r < NW) ? bias : 0.f;
+      }
+      sv = key < L ? sv : -3.0e38f;
+      S[e] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float pe = key < L ? __expf(S[e] - mn) : 0.f;
+      S[e] = pe;  // S now holds P^T
+      psum += pe;
+    }
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) O[dt][e] *= alpha;
+    // ---- O^T += V P^T  (k-step s <-> keys kappa(s,0), kappa(s,1): B fragment == S[s])
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const float* vrow = vt + (dt * 32 + l31) * VS + 4 * h;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[(s & 3) + 8 * (s >> 2)], S[s], O[dt], 0, 0, 0);
+    }
+    // ---- relative values (attentions.py:191-194) on band tiles: Prel^T[r][q] through LDS, then 5 k-steps
+    if (near) {
+#pragma unroll
+      for (int r5 = 0; r5 < 5; ++r5) prel[(5 * h + r5) * 32 + l31] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int r = key - i + W;
+        if (r >= 0 && r < NW && key < L) prel[r * 32 + l31] = S[e];
+      }
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+          const int r = 2 * s5 + h;
+          const float a = r < NW ? ev[(r < NW ? r : 0) * DK + dt * 32 + l31] : 0.f;
+          O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, prel[r * 32 + l31], O[dt], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- merge the 4 waves' partial (m, l, O) through LDS; wave w finishes values idx == w (mod 4)
+  __syncthreads();
+  constexpr int NV = ND * 16 + 2;
+  float* comb = lds;  // [wave][NV][64]
+  {
+    float* c = comb + (wave * NV) * 64 + lane;
+    c[0] = m;
+    c[64] = l;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) c[(2 + dt * 16 + e) * 64] = O[dt][e];
+  }
+  __syncthreads();
+  float mw[4], sc[4];
+  float ms = -3.0e38f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { mw[w] = comb[(w * NV) * 64 + lane]; ms = fmaxf(ms, mw[w]); }
+  float lt = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { sc[w] = __expf(mw[w] - ms); lt += comb[(w * NV + 1) * 64 + lane] * sc[w]; }
+  lt += __shfl_xor(lt, 32, 64);
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+#pragma unroll
+  for (int k = 0; k < ND * 4; ++k) {
+    const int idx = 4 * k + wave;  // dt*16 + e
+    const int dt = idx >> 4, e = idx & 15;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) a += comb[(w * NV + 2 + idx) * 64 + lane] * sc[w];
+    const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (i < T) ob[(long long)d * T + i] = active ? a * inv : 0.f;
+  }
+}
+
 // ----------------------------------------------------------------------------- duration predictor
 // z[b,c,t] = noise * noise_scale_w  (models.py:96)
 __global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T) {
