@@ -94,7 +94,13 @@ struct ConvParams {
   int row_len;        // LDS row = N_T + halo
   long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
 };
+#ifdef CONV_TIMING
 #define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define CONV_DBG_DO(x) x
+#else
+#define CONV_DBG(k) do { } while (0)
+#define CONV_DBG_DO(x)
+#endif
 
 __device__ __forceinline__ float conv_act_in(float v, float scale, float slope) {
   v *= scale;
@@ -258,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue_gate(const ConvParams& P, const Co
   }
 
 template <int WM, int WN, int MI, int NI, int EPI>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
+__global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {  // 3 workgroups per CU
   static_assert(WM * WN == 4, "256-thread workgroups");
   constexpr int M_T = WM * MI * 32;
   constexpr int N_T = WN * NI * 32;
@@ -277,10 +283,21 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
     const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, within = L >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
-  const int mt = id % P.ntiles_m; id /= P.ntiles_m;
-  const int grp = id % P.n_groups; id /= P.n_groups;
-  const int nt = id % P.ntiles_n;
-  const int b = id / P.ntiles_n;
+  int mt, grp, nt, b;
+  if (P.n_groups > 1) {
+    // grouped launch (k = 11/7/3 ResBlocks, sorted heaviest first by the launcher): plain dispatch order
+    // with the group outermost, so the long blocks start first and the launch tail is made of short ones
+    id = blockIdx.x;
+    mt = id % P.ntiles_m; id /= P.ntiles_m;
+    nt = id % P.ntiles_n; id /= P.ntiles_n;
+    b = id % P.B;
+    grp = id / P.B;
+  } else {
+    mt = id % P.ntiles_m; id /= P.ntiles_m;
+    nt = id % P.ntiles_n;
+    b = id / P.ntiles_n;
+    grp = 0;
+  }
   const ConvGroup& G = P.g[grp];
 
   const int ROW = P.row_len;
@@ -319,10 +336,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) stg[rr][j] = xb[roff[rr] + toff[j]];
     }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-      for (int j = 0; j < JT; ++j) stg[rr][j] = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;
+    // NOTE: nothing here may CONSUME the loaded values — the raw registers ride through the whole tap
+    // loop and are activated only in store_chunk, otherwise every chunk starts with a memory-latency stall
   };
   auto store_chunk = [&](int buf) {
     float* dst = lds + buf * (CONV_CI_T * ROW);
@@ -331,7 +346,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
         const int col = lane + 64 * j;
-        if (col < ROW) dst[(wave + 4 * rr) * ROW + col] = stg[rr][j];
+        const float v = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;
+        if (col < ROW) dst[(wave + 4 * rr) * ROW + col] = v;
       }
     }
   };
@@ -355,9 +371,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
   }
   const int n_sg = G.n_sg;
 
+  CONV_DBG_DO(long long dbg_t0 = 0; long long dbg_tap = 0; long long dbg_sync = 0; long long dbg_x = 0; if (P.dbg) dbg_t0 = __builtin_readcyclecounter();)
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
+  CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;)
 
   f32x4 a_cur[MI][2], a_nxt[MI][2];
 #pragma unroll
@@ -368,6 +386,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
   int sg = 2;  // next step-group to fetch
 
   for (int c = 0; c < nchunks; ++c) {
+    CONV_DBG_DO(if (P.dbg) dbg_x = __builtin_readcyclecounter();)
     if (c + 1 < nchunks) load_chunk(c + 1);
     const float* lb = lds + (c & 1) * (CONV_CI_T * ROW) + h * ROW + wn * (NI * 32) + l31 + tap_base;
 #pragma unroll 1
@@ -390,6 +409,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
       for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bv[p][ni] = lk[2 * p * ROW + ni * 32];
+      __builtin_amdgcn_sched_barrier(0);  // all B-fragment reads of the tap in flight before its first MFMA
 #pragma unroll
       for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -403,34 +423,49 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams P) {
         a_cur[mi][1] = a_nxt[mi][1];
       }
     }
+    CONV_DBG_DO(if (P.dbg) { const long long t_ = __builtin_readcyclecounter(); dbg_tap += t_ - dbg_x; dbg_x = t_; })
     if (c + 1 < nchunks) store_chunk((c + 1) & 1);
     __syncthreads();
+    CONV_DBG_DO(if (P.dbg) dbg_sync += __builtin_readcyclecounter() - dbg_x;)
   }
+  CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) {
+    P.dbg[wave * 8 + 1] = dbg_tap;
+    P.dbg[wave * 8 + 2] = dbg_sync;
+    P.dbg[wave * 8 + 3] = __builtin_readcyclecounter() - dbg_t0;
+  })
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
+  // 4 accumulator elements at a time: a 16-wide epilogue needs >100 live registers (64-bit offsets, rows,
+  // residuals) and would set the whole kernel's allocation, i.e. its occupancy
   if (EPI == EPI_GATE) {
     // packed m-blocks alternate [tanh 32 rows | sigmoid 32 rows] of the same 32 channels
     const int j = (m0 >> 6) + wm;  // channel block of 32
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      float at[16], as[16];
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { at[e] = acc[0][ni][e]; as[e] = acc[MI - 1][ni][e]; }
-      conv_epilogue_gate<16>(P, G, b, j * 32 + 4 * h, 0, n0 + wn * (NI * 32) + ni * 32 + l31, at, as);
-    }
+      for (int e0 = 0; e0 < 16; e0 += 4) {
+        float at[4], as[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { at[i] = acc[0][ni][e0 + i]; as[i] = acc[MI - 1][ni][e0 + i]; }
+        conv_epilogue_gate<4>(P, G, b, j * 32 + 4 * h, e0, n0 + wn * (NI * 32) + ni * 32 + l31, at, as);
+      }
     return;
   }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      float v[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = acc[mi][ni][e];
-      conv_epilogue_frag<EPI, 16>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, 0, n0 + wn * (NI * 32) + ni * 32 + l31, v);
+      for (int e0 = 0; e0 < 16; e0 += 4) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][e0 + i];
+        conv_epilogue_frag<EPI, 4>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, e0, n0 + wn * (NI * 32) + ni * 32 + l31, v);
+      }
     }
   }
+  CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 4] = __builtin_readcyclecounter() - dbg_t0;)
 }
 
 // ---------------------------------------------------------------------------------------------

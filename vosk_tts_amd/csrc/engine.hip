@@ -619,6 +619,10 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
   hipStream_t st = s->stream;
+  // heaviest group first (longest-processing-time order; see the big-tile kernel's block decode)
+  for (int a = 0; a < P.n_groups; ++a)
+    for (int c = a + 1; c < P.n_groups; ++c)
+      if (P.g[c].K > P.g[a].K) { ConvGroup t = P.g[a]; P.g[a] = P.g[c]; P.g[c] = t; }
   const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < 512);
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
@@ -1406,6 +1410,21 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
       hipMemcpy(h, d_dbg, sizeof h, hipMemcpyDeviceToHost);
       hipEventElapsedTime(&ms, e0, e1);
       fprintf(stderr, "[conv dbg] B=%d Cin=%d Cout=%d T=%d K=%d dil=%d: last launch %.2f us (event); block 0 cycles since kernel start:\n", B, Cin, Cout, T, K, dil, ms * 1e3);
+      const long blocks64 = (long)cdiv(W.Mpad, 64) * cdiv(T, 64) * B;
+      {
+        int nb = -1, nb2 = -1, nb3 = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<2, 2, 2, 2, EPI_STORE>, 256, 2 * CONV_CI_T * (128 + 64) * 4);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, conv_mfma_kernel<2, 2, 1, 1, EPI_STORE>, 256, 2 * CONV_CI_T * (64 + 64) * 4);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, conv_mfma_ks_kernel<1, 1, EPI_STORE, 1>, 256, 16384);
+        hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)conv_mfma_kernel<2, 2, 2, 2, EPI_STORE>);
+        fprintf(stderr, "   occupancy API (blocks/CU): T128 %d  T64 %d  ks %d ; T128 numRegs %d sharedStatic %zu localMem %zu maxDynShared %d\n", nb, nb2, nb3, fa.numRegs,
+                fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes);
+      }
+      if (blocks64 >= 512) {
+        for (int w = 0; w < 4; ++w)
+          fprintf(stderr, "   [big-tile] wave %d: prologue %lld  taps %lld  store+barrier %lld  mainloop_end %lld  end %lld  (MFMA floor %lld)\n", w, h[w * 8], h[w * 8 + 1],
+                  h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], (long long)(Cin / 2) * K * 4 * 64);
+      } else
       for (int w = 0; w < 4; ++w)
         fprintf(stderr, "   wave %d: staged0 %lld  loop_done %lld  barrier %lld  reduced %lld  end %lld\n", w, h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8],
                 h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8]);
