@@ -153,8 +153,10 @@ typedef struct vits_synth_opts {
  *   scales   float [3] = [noise_scale, length_scale, noise_scale_w]
  *   sid      int64 [B] (ignored when n_speakers <= 1)
  * On success *out_audio points to a library-owned float [B, *out_samples] buffer
- * (row b valid for out_lengths[b] samples, rest is what the reference's padded
- * batch produces), to be released with vits_free_output.  Re-entrant: each call
+ * (row b is valid for out_lengths[b] samples — bit-identical to the reference's padded-batch
+ * result there; samples beyond out_lengths[b] + 32 frames are zeros: ragged items are not decoded
+ * past their own length plus a halo wider than the decoder's receptive field), to be released
+ * with vits_free_output.  Re-entrant: each call
  * uses its own workspace and HIP stream. */
 int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths,
                     int32_t B, int32_t T_x, const float* scales, const int64_t* sid,

@@ -16,6 +16,15 @@ STAGE_TOL = 1e-4
 E2E_TOL = 5e-4
 
 
+def _valid(audio, olen):
+    """Zero everything past each item's own length: the full-path entry points decode a ragged batch only up to
+    len + 32 frames per item (bit-identical below len, see DESIGN.md 'ragged batches')."""
+    a = np.array(audio, copy=True)
+    for b, n in enumerate(olen):
+        a[b, int(n):] = 0.0
+    return a
+
+
 # ----------------------------------------------------------------------------------- kernel level
 @pytest.mark.parametrize("B,Cin,Cout,T,K,dil,slope", [
     (1, 16, 32, 1, 1, 1, 1.0),
@@ -85,7 +94,7 @@ def _stages_vs(model, ref_model, g, tol):
     audio2, olen = model.synthesize(ids, lengths, scales, sid, noise_dp=g["noise_dp"], noise_prior=g["noise_prior"],
                                     forced_durations=g["forced_durations"])
     assert np.array_equal(olen, g["y_lengths"] * model.hp.hop_length)
-    assert_close("audio(e2e,golden)", g["audio"], audio2, E2E_TOL)
+    assert_close("audio(e2e,golden)", _valid(g["audio"], olen), _valid(audio2, olen), E2E_TOL)
 
 
 def test_stages_full_c1(hip_default, oracle_default):
@@ -202,7 +211,10 @@ def test_c3_shaped_ragged_batch_parity(hip_default, oracle_default):
     a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
     a_hip, l_hip = hip_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
     assert np.array_equal(l_ref, l_hip)
-    assert_close("waveform", a_ref, a_hip, E2E_TOL)
+    assert_close("waveform", _valid(a_ref, l_ref), _valid(a_hip, l_hip), E2E_TOL)
+    # ragged decode: nothing is computed past len + 32 frames, and what lies beyond is defined (zeros)
+    for b in range(B):
+        assert np.all(a_hip[b, int(l_hip[b]) + 33 * 256:] == 0.0)
 
 
 def test_philox_seeded_path_matches_oracle(hip_default, oracle_default):
@@ -213,9 +225,9 @@ def test_philox_seeded_path_matches_oracle(hip_default, oracle_default):
     lengths = np.array([17, 11], np.int64); sid = np.array([0, 199], np.int64)
     scales = np.array([0.667, 1.0, 0.8], np.float32)
     dur = rng.integers(1, 4, size=(2, 17)).astype(np.int32)
-    a_ref, _ = oracle_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=77)
+    a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=77)
     a_hip, _ = hip_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=77)
-    assert_close("waveform", a_ref, a_hip, E2E_TOL)
+    assert_close("waveform", _valid(a_ref, l_ref), _valid(a_hip, l_ref), E2E_TOL)
     a_hip2, _ = hip_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=78)
     assert np.abs(a_hip2 - a_hip).max() > 1e-3  # the seed matters
 

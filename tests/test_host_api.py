@@ -182,7 +182,7 @@ def test_session_is_reentrant_from_threads(hip_tiny, oracle_tiny):
     [t.start() for t in th]
     [t.join() for t in th]
     for k in range(len(jobs)):
-        assert_close(f"job {k}", want[k], got[k], 5e-4)
+        assert_close(f"job {k}", want[k], got[k], 5e-4)  # B = 1: no ragged skipping, whole buffer comparable
 
 
 @pytest.mark.gpu
@@ -215,5 +215,7 @@ def test_device_session_graph_replay_matches_host_path(hip_default):
                                 d_audio.data_ptr(), Ty * 256)
         s.sync()
         assert s.last_ms() > 0
-        assert_close("device session", want, d_audio.cpu().numpy(), 1e-6)
+        got = d_audio.cpu().numpy()
+        for b in range(B):  # identical on every valid sample; beyond len + halo both are zeros
+            assert_close(f"device session item {b}", want[b, :wl[b]], got[b, :wl[b]], 1e-6)
     s.close()

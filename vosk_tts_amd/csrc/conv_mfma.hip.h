@@ -93,6 +93,11 @@ struct ConvParams {
   int ntiles_m, ntiles_n;
   int row_len;        // LDS row = N_T + halo
   long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
+  // Ragged batches: item b only needs columns up to rag[b] frames (its length + a halo wider than the
+  // decoder's receptive field); input columns >= rag[b]*rag_in_mul + rag_in_add read as 0 and output tiles
+  // starting at or beyond rag[b]*rag_out_mul + rag_out_add are skipped.  null = dense (reference-padded).
+  const int* rag;
+  int rag_in_mul, rag_in_add, rag_out_mul, rag_out_add;
 };
 #ifdef CONV_TIMING
 #define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -308,6 +313,12 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   const int nchunks = P.Cin / CONV_CI_T;
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
+  if (P.rag) {
+    const int rl = P.rag[b];
+    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
+    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    t_lim = il < t_lim ? il : t_lim;
+  }
 
   // ---- staging: wave w owns chunk rows w, w+4, w+8, w+12; lanes stride over columns
   float stg[4][JT];
@@ -510,6 +521,12 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   const int nchunks = P.Cin / CONV_CI_T;
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
+  if (P.rag) {
+    const int rl = P.rag[b];
+    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
+    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    t_lim = il < t_lim ? il : t_lim;
+  }
   const float in_scale = P.in_scale, in_slope = P.in_slope;
 
   // lane geometry.  Input addresses are  uniform_base(b, chunk, p)  +  lane_off(h, t)  with the
@@ -598,15 +615,15 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
           nxt.bq[u][p][ni] = v;
         }
         if (decltype(has_cur)::value) {
-          float okf[NI];
+          bool okb_[NI];
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) okf[ni] = ((cur.ok[u] >> ni) & 1u) ? 1.f : 0.f;
+          for (int ni = 0; ni < NI; ++ni) okb_[ni] = (cur.ok[u] >> ni) & 1u;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
             // leaky-relu for 0 <= slope <= 1 is max(v, slope*v); the edge/mask flag is a 0/1 multiplier:
             // 3 VALU per MFMA instead of 5 (a single wave per SIMD is issue-bound, every slot counts)
             const float x_ = cur.bq[u][p][ni];
-            const float bv = fmaxf(x_, x_ * in_slope) * okf[ni];
+            const float bv = okb_[ni] ? fmaxf(x_, x_ * in_slope) : 0.f;  // select, not multiply: stale padding may hold NaN
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u][mi][p >> 2][p & 3], bv, acc[mi][ni], 0, 0, 0);

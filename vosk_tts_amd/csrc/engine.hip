@@ -430,7 +430,7 @@ struct vits_session {
 
   // named views (valid after plan())
   int B = 0, Tx = 0, Ty = 0;
-  int *len_x = nullptr, *len_y = nullptr, *dur = nullptr, *cum = nullptr;
+  int *len_x = nullptr, *len_y = nullptr, *len_rag = nullptr, *dur = nullptr, *cum = nullptr;
   int64_t* ylen64 = nullptr;
   float *x = nullptr, *qkv = nullptr, *att = nullptr, *y1 = nullptr, *ffh = nullptr, *stats = nullptr;
   float *condv = nullptr;
@@ -456,7 +456,7 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   const size_t Tm = (size_t)(Tx > Ty ? Tx : Ty);
   s->arena_used = 0;
   s->B = B; s->Tx = Tx; s->Ty = Ty;
-  s->len_x = bump<int>(s, B); s->len_y = bump<int>(s, B);
+  s->len_x = bump<int>(s, B); s->len_y = bump<int>(s, B); s->len_rag = bump<int>(s, B);
   s->ylen64 = bump<int64_t>(s, B);
   s->dur = bump<int>(s, (size_t)B * Tx); s->cum = bump<int>(s, (size_t)B * Tx);
   s->condv = bump<float>(s, (size_t)B * (s->m->cond_rows + 1));
@@ -864,14 +864,27 @@ static float* run_flow(vits_session* s, int B, int Ty) {
 
 // ---- a15-a20: decoder (models.py:1016-1054 / 872-891).  z [B,I,Ty] (masked at staging with len_y
 // when mask_in), audio -> d_audio [B, audio_bstride]
+// Frames of halo kept beyond each item's length in a ragged batch.  The decoder's receptive field is < 25
+// frames, so with 32 every sample below len*hop is bit-identical to the dense padded run.
+#define VITS_RAGGED_HALO 32
+static void set_rag(ConvParams& P, const int* rag, int in_mul, int in_add, int out_mul, int out_add) {
+  P.rag = rag; P.rag_in_mul = in_mul; P.rag_in_add = in_add; P.rag_out_mul = out_mul; P.rag_out_add = out_add;
+}
 static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, int Ty, float* d_audio, long long audio_bstride,
-                        float* d_mb) {
+                        float* d_mb, bool ragged = false) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   int C = hp.dec_initial_channel, T = Ty;
+  const int* rag = nullptr;
+  int rate = 1;  // columns per frame at the current stage
+  if (ragged && B > 1 && hp.dec_type == 0) {
+    hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, B, Ty, VITS_RAGGED_HALO);
+    rag = s->len_rag;
+  }
   float* cur = s->dec_bufs[0];
   ConvParams P = conv_params(m->conv_pre, z, cur, B, Ty, 1, 3);
   if (mask_in) { P.in_mask = 1; P.len = s->len_y; }  // (z * y_mask) models.py:1703
+  set_rag(P, rag, 1, 0, 1, 0);
   launch_conv(s, P, EPI_STORE, "dec.conv_pre");
   const float* in1 = cur; const float* in2 = nullptr; const float* in3 = nullptr;
   float in_scale = 1.f;
@@ -890,8 +903,9 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     P.in_slope = 0.1f; P.in_scale = in_scale;
     P.ups_u = U.u; P.ups_cout = Co;
     for (int r = 0; r < U.u; ++r) P.ups_shift[r] = U.shift[r];
+    set_rag(P, rag, rate, 0, rate, 0);  // polyphase: output "columns" are input positions q
     launch_conv(s, P, EPI_STORE, "dec.ups", U.halo);
-    C = Co; T = To;
+    C = Co; T = To; rate *= U.u;
     // MRF: 3 ResBlock1 chains in grouped launches (modules.py:210-223)
     const int nk = hp.n_resk;
     for (int d = 0; d < hp.n_resd; ++d) {
@@ -906,6 +920,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
       P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
       P.M = m->rb[(size_t)i * nk].c1[d].Mpad; P.Cout = C; P.Tout = T; P.Tout_stride = T; P.y_bstride = (long long)C * T;
       P.in_slope = 0.1f; P.in_scale = 1.f;
+      set_rag(P, rag, rate, 0, rate, 0);
       launch_conv(s, P, EPI_STORE, "dec.res_c1");
       for (int j = 0; j < nk; ++j) {  // x = c2(leaky_relu(xt)) + x
         const ResBlockW& R = m->rb[(size_t)i * nk + j];
@@ -931,16 +946,18 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
     P.M = m->conv_post.Mpad; P.Cout = Pc; P.Tout = Tp; P.Tout_stride = Tp; P.y_bstride = (long long)Pc * Tp;
     P.in_slope = 0.01f; P.in_scale = in_scale; P.reflect = 1;
+    set_rag(P, rag, rate, 0, rate, 1);
     launch_conv(s, P, EPI_STORE, "dec.conv_post");
     const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, Tm = T * hop;
     {
       ProfScope ps(s, "istft", 0);
-      hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm);
+      hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm,
+                         rag, rate * hop);
     }
     {
       ProfScope ps(s, "pqmf", 0);
       hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3(cdiv(Tm * S, 256), B), dim3(256), 0, s->stream, mb, m->pqmf, d_audio, S,
-                         hp.pqmf_taps, Tm, audio_bstride);
+                         hp.pqmf_taps, Tm, audio_bstride, rag, rate * hop * S);
     }
   } else {
     memset(&P, 0, sizeof P);
@@ -1001,7 +1018,7 @@ static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t*
   run_durations(s, d_forced, scales[1], B, Tx, Ty);
   run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
   float* z = run_flow(s, B, Ty);
-  run_decoder(s, z, true, B, Ty, d_audio, cap, nullptr);
+  run_decoder(s, z, true, B, Ty, d_audio, cap, nullptr, true);
 }
 
 
@@ -1263,7 +1280,7 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   const int64_t S = Ty * hp.hop_length;
   float* d_audio = hs.dev_alloc<float>((size_t)B * S);
   if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
-  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr);
+  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr, true);
   float* h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)B * S));
   if (!h_audio) return fail(VITS_ERR_NOMEM, "host alloc failed");
   hipError_t e = hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream);

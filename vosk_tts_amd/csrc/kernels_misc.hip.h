@@ -649,18 +649,27 @@ __global__ void expand_prior_kernel(const float* stats, const int* cum, const in
   }
 }
 
+// rag[b] = min(Ty, len_y[b] + halo): frames each item of a ragged batch needs in the (mask-free) decoder
+__global__ void ragged_len_kernel(const int* len_y, int* rag, int B, int Ty, int halo) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { const int v = len_y[b] + halo; rag[b] = v < Ty ? v : Ty; }
+}
+
 // ----------------------------------------------------------------------------- decoder tail
 // spec = exp(x[:, :, :cut]); phase = pi*sin(x[:, :, cut:]) (models.py:1043-1044);
 // OnnxSTFT.inverse (stft.py:246-262): conv_transpose1d with the windowed pinv-DFT basis, stride hop,
 // * n_fft/hop, trim n_fft/2 both sides.  One thread per sub-band output sample.
 // post: [B, S*(N+2), Tp]; mb: [B, S, Tm], Tm = (Tp-1)*hop.  basis: [N+2][N].
-__global__ void istft_kernel(const float* post, const float* basis, float* mb, int S, int N, int hop, int Tp, int Tm) {
+__global__ void istft_kernel(const float* post, const float* basis, float* mb, int S, int N, int hop, int Tp, int Tm,
+                             const int* rag, int rag_mul) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, b = blockIdx.z;
   if (n >= Tm) return;
+  if (rag && n >= rag[b] * rag_mul) return;  // ragged batch: beyond this item's length + halo
   const int cut = N / 2 + 1, C = S * (N + 2);
   const int np = n + N / 2;
   int t_hi = np / hop;
   if (t_hi > Tp - 1) t_hi = Tp - 1;
+  // (ragged: every post column this sample touches lies below rag*rag_mul/hop + N/hop, which conv_post computed)
   int t_lo = (np - N + hop) / hop;  // ceil((np-N+1)/hop)
   if (np - N + 1 <= 0) t_lo = 0;
   const float* pb = post + ((long long)b * C + (long long)s * (N + 2)) * Tp;
@@ -681,10 +690,11 @@ __global__ void istft_kernel(const float* post, const float* basis, float* mb, i
 // PQMF.synthesis (pqmf.py:105-116) in polyphase form: zero-stuffing by S with gain S, pad taps/2,
 // FIR [1,S,taps+1].  One thread per output sample: (taps+1)/S * S MACs instead of S*(taps+1).
 __global__ void pqmf_synthesis_kernel(const float* mb, const float* filt, float* audio, int S, int taps, int Tm,
-                                      long long audio_bstride) {
+                                      long long audio_bstride, const int* rag, int rag_mul) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   const int To = Tm * S, L = taps + 1, padl = taps / 2;
   if (t >= To) return;
+  if (rag && t >= rag[b] * rag_mul) { audio[(long long)b * audio_bstride + t] = 0.f; return; }  // padding: defined zeros
   const int j0 = ((padl - t) % S + S) % S;
   float a = 0.f;
   for (int s = 0; s < S; ++s) {
