@@ -167,29 +167,33 @@ def main():
         nprof = 3
         for _ in range(nprof):
             step()
-        rep = sess.profile_report()
-        rep = {k: (v[0], v[1], v[2] * (dec_exec_frac if k.startswith("dec.") else 1.0)) for k, v in rep.items()}
+        rep = sess.profile_report()  # {(op, kernel instantiation): (launches, ms, flops)}
+        rep = {k: (v[0], v[1], v[2] * (dec_exec_frac if k[0].startswith("dec.") else 1.0)) for k, v in rep.items()}
         sess.set_options(use_graph=not args.no_graph, profile=False)
-        conv = {k: v for k, v in rep.items() if v[2] > 0 and k != "attention"}
-        dom_name, dom = max(conv.items(), key=lambda kv: kv[1][1]) if conv else ("none", (1, 1.0, 0.0))
-        # the ResBlock convolutions (c1 + c2 launches run the same kernel instantiation) are one family
-        fam = [v for k, v in rep.items() if k.startswith("dec.res_")] if dom_name.startswith("dec.res_") else [dom]
-        fam_ms = sum(v[1] for v in fam)
-        fam_flops = sum(v[2] for v in fam)
-        fam_launches = sum(v[0] for v in fam)
+        by_op, by_kernel = {}, {}
+        for (op, kern), v in rep.items():
+            a = by_op.setdefault(op, [0, 0.0, 0.0]); a[0] += v[0]; a[1] += v[1]; a[2] += v[2]
+            a = by_kernel.setdefault(kern, [0, 0.0, 0.0]); a[0] += v[0]; a[1] += v[1]; a[2] += v[2]
+        # dominant kernel = the MFMA conv instantiation (the name rocprofv3 reports) with the most device time
+        convk = {k: v for k, v in by_kernel.items() if k.startswith("conv_mfma")}
+        dom_name, dom = max(convk.items(), key=lambda kv: kv[1][1]) if convk else ("none", [1, 1.0, 0.0])
+        fam_launches, fam_ms, fam_flops = dom
+        dom_ops = sorted({op for (op, kern) in rep if kern == dom_name})
         achieved = fam_flops / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         dev_ms_all = sum(v[1] for v in rep.values()) / nprof
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "conv_mfma_kernel (" + ("dec.res_c1+dec.res_c2" if dom_name.startswith("dec.res_") else dom_name) + ")",
+            "kernel": dom_name, "kernel_serves": dom_ops, "kernel_launches_per_forward": fam_launches // nprof,
+            "kernel_ms_per_forward": round(fam_ms / nprof, 4),
             "avg_launch_us": round(fam_ms / max(fam_launches, 1) * 1e3, 2),
             "algorithmic_flops_per_launch": fam_flops / max(fam_launches, 1),
             "forward": {"algorithmic_gflop": round(flops_fwd / 1e9, 3),
                         "achieved_tflops": round(flops_fwd / (elapsed / steps) / 1e12, 3),
                         "frac": round(flops_fwd / (elapsed / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                         "sum_kernel_ms_eager": round(dev_ms_all, 4)},
-            "by_family_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])},
+            "by_kernel_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])},
+            "by_op_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])},
         }
 
         sess.close()

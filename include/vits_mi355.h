@@ -187,7 +187,7 @@ int vits_session_sync(vits_session* s);
  * bracket every kernel launch with HIP events (for vits_session_profile_report). */
 int vits_session_set_options(vits_session* s, int use_graph, int profile);
 /* Per-kernel-family totals of the profiled forwards since the last report, one line per family:
- * "<name> <launches> <total_ms> <algorithmic_flops>". */
+ * "<op-name> <kernel-instantiation> <launches> <total_ms> <algorithmic_flops>". */
 int vits_session_profile_report(vits_session* s, char* buf, size_t cap);
 
 /* ---- stage-level entry points (parity tests; host buffers in/out) -------- */

@@ -308,11 +308,11 @@ class VitsDeviceSession:
         self.lib.check(self.lib._fn("session_set_options")(self._h, int(use_graph), int(profile)))
 
     def profile_report(self):
-        """-> {family: (launches, total_ms, flops)}"""
+        """-> {(op_name, kernel_instantiation): (launches, total_ms, flops)}"""
         buf = ctypes.create_string_buffer(1 << 16)
         self.lib.check(self.lib._fn("session_profile_report")(self._h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, n, ms, fl = line.split()
-            out[name] = (int(n), float(ms), float(fl))
+            name, kern, n, ms, fl = line.split()
+            out[(name, kern)] = (int(n), float(ms), float(fl))
         return out

@@ -410,7 +410,7 @@ static int load_model(vits_model* m) {
 // A session owns one HIP stream and a bump-allocated activation workspace sized for
 // (B, T_x, T_y).  vits_synthesize() borrows one from the model's pool, so concurrent calls from
 // the gRPC server's worker threads (server/tts_server.py:39-40,57) never share buffers.
-struct ProfRec { std::string name; hipEvent_t e0, e1; double flops; };
+struct ProfRec { std::string name; std::string kernel; hipEvent_t e0, e1; double flops; };
 
 struct vits_session {
   vits_model* m = nullptr;
@@ -565,13 +565,14 @@ static void pool_release(vits_model* m, vits_session* s) {
 // ------------------------------------------------------------------------------------ launch helpers
 struct ProfScope {
   vits_session* s; bool on;
-  ProfScope(vits_session* s_, const char* name, double flops) : s(s_), on(s_->profile) {
+  ProfScope(vits_session* s_, const char* name, double flops, const char* kernel = "-") : s(s_), on(s_->profile) {
     if (!on) return;
-    ProfRec r; r.name = name; r.flops = flops;
+    ProfRec r; r.name = name; r.kernel = kernel; r.flops = flops;
     hipEventCreate(&r.e0); hipEventCreate(&r.e1);
     hipEventRecord(r.e0, s->stream);
     s->prof.push_back(r);
   }
+  void set_kernel(const char* k) { if (on) s->prof.back().kernel = k; }
   ~ProfScope() { if (on) hipEventRecord(s->prof.back().e1, s->stream); }
 };
 
@@ -624,29 +625,36 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     for (int c = a + 1; c < P.n_groups; ++c)
       if (P.g[c].K > P.g[a].K) { ConvGroup t = P.g[a]; P.g[a] = P.g[c]; P.g[c] = t; }
   const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
-  bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < 512);
+  static const long ks_threshold = getenv("VITS_KS_THRESHOLD") ? atol(getenv("VITS_KS_THRESHOLD")) : 512;
+  bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   if (epi == EPI_GATE) {
-    if (small) launch_ks<2, 1, EPI_GATE>(st, P, halo); else launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo);
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(st, P, halo); }
+    else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo); }
     return;
   }
   if (epi == EPI_RESSKIP) {
-    if (small) launch_ks<1, 1, EPI_RESSKIP>(st, P, halo); else launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(st, P, halo);
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,RESSKIP,1>"); launch_ks<1, 1, EPI_RESSKIP>(st, P, halo); }
+    else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,RESSKIP>"); launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(st, P, halo); }
     return;
   }
   if (epi == EPI_COUPLE) {
-    if (small) launch_ks<1, 1, EPI_COUPLE>(st, P, halo); else launch_cfg<2, 2, 1, 1, EPI_COUPLE>(st, P, halo);
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(st, P, halo); }
+    else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(st, P, halo); }
     return;
   }
   if (small) {
     const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
-    if (blocks32 > 2048) launch_ks<1, 2, EPI_STORE>(st, P, halo); else launch_ks<1, 1, EPI_STORE>(st, P, halo);
+    const bool multi = P.g[0].x2 != nullptr;
+    if (blocks32 > 2048) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(st, P, halo); }
+    else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(st, P, halo); }
     return;
   }
-  if (P.ups_u && (P.ups_cout % 64)) { launch_cfg<1, 4, 1, 1, EPI_STORE>(st, P, halo); return; }
+  if (P.ups_u && (P.ups_cout % 64)) { ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(st, P, halo); return; }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
-  if (m_fits && big_blocks >= 512) { launch_cfg<2, 2, 2, 2, EPI_STORE>(st, P, halo); return; }
+  if (m_fits && big_blocks >= 512) { ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(st, P, halo); return; }
+  ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
   launch_cfg<2, 2, 1, 1, EPI_STORE>(st, P, halo);
 }
 
@@ -666,7 +674,7 @@ static ConvParams conv_params(const ConvW& W, const float* x, float* y, int B, i
 
 static void launch_ln(vits_session* s, const float* a, const float* b, const float* base, float* y, const float* gamma,
                       const float* beta, const int* len, int B, int C, int T, int gelu, int mask) {
-  ProfScope ps(s, "layernorm", 0);
+  ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
   LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask};
   hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, P);
 }
@@ -675,7 +683,7 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
                              int H, int T) {
   const vits_hparams& hp = s->m->hp;
   const int nh = hp.n_heads, dk = H / nh, W = hp.window_size;
-  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T);
+  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T, g_attn_impl == 0 ? "relpos_attention_mfma_kernel" : "relpos_attention_kernel");
   if (g_attn_impl == 0) {  // fp32-MFMA flash kernel (default)
     dim3 grid(cdiv(T, 32), nh, B);
     const int wreg = dk * 33 + 10 * 32 + 9 * 32;
@@ -950,12 +958,12 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     launch_conv(s, P, EPI_STORE, "dec.conv_post");
     const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, Tm = T * hop;
     {
-      ProfScope ps(s, "istft", 0);
+      ProfScope ps(s, "istft", 0, "istft_kernel");
       hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm,
                          rag, rate * hop);
     }
     {
-      ProfScope ps(s, "pqmf", 0);
+      ProfScope ps(s, "pqmf", 0, "pqmf_synthesis_kernel");
       hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3(cdiv(Tm * S, 256), B), dim3(256), 0, s->stream, mb, m->pqmf, d_audio, S,
                          hp.pqmf_taps, Tm, audio_bstride, rag, rate * hop * S);
     }
@@ -1373,7 +1381,7 @@ int vits_session_profile_report(vits_session* s, char* buf, size_t cap) {
   for (auto& r : s->prof) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.e0, r.e1);
-    auto& a = agg[r.name];
+    auto& a = agg[r.name + " " + r.kernel];
     std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += r.flops;
     hipEventDestroy(r.e0); hipEventDestroy(r.e1);
   }
