@@ -225,6 +225,8 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
 void vits_debug_force_tile(int mode);
 /* Test hook: 0 = fp32-MFMA flash attention (default), 1 = the scalar-VALU attention kernel. */
 void vits_debug_attention_impl(int impl);
+/* Test hook: fill every newly laid-out workspace with NaN bit patterns (stale-padding detector). */
+void vits_debug_poison_workspace(int on);
 
 /* Algorithmic FLOPs of one forward (SURVEY.md §8a/§8d formula evaluated on the
  * model's own hparams): used by bench.py for the roofline line. */

@@ -217,6 +217,34 @@ def test_c3_shaped_ragged_batch_parity(hip_default, oracle_default):
         assert np.all(a_hip[b, int(l_hip[b]) + 33 * 256:] == 0.0)
 
 
+def test_ragged_batch_with_poisoned_workspace(hip_lib, default_blob, oracle_default):
+    """Ragged batches skip every tile that lies in an item's padding (decoder: beyond len + 32 frames; encoder /
+    duration / flow: beyond len).  With the workspace pre-filled with NaN, any read of such a never-written
+    region by a valid sample would surface as NaN / a mismatch."""
+    hip_lib.lib.vits_debug_poison_workspace(1)
+    try:
+        model = hip_lib.create(default_blob, 0)  # fresh session pool -> fresh (poisoned) workspaces
+        rng = np.random.default_rng(123)
+        for B, lo, hi in ((5, 3, 40), (3, 60, 61), (4, 1, 90)):
+            ids, lengths = _synthetic_batch(rng, B, lo, hi)
+            Tx = ids.shape[1]
+            sid = rng.integers(0, 200, size=B).astype(np.int64)
+            scales = np.array([0.667, 1.0, 0.8], np.float32)
+            # free-running durations on both sides would hit the ceil() cliff; pin them, but run the
+            # duration predictor too (its result is unused) by a second, free-running call checked for finiteness
+            dur = rng.integers(0, 5, size=(B, Tx)).astype(np.int32)
+            a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=5)
+            a_hip, l_hip = model.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=5)
+            assert np.array_equal(l_ref, l_hip)
+            assert np.isfinite(a_hip).all()
+            assert_close("waveform (poisoned workspace)", _valid(a_ref, l_ref), _valid(a_hip, l_hip), E2E_TOL)
+            a_free, l_free = model.synthesize(ids, lengths, scales, sid, seed=6)
+            assert np.isfinite(a_free).all() and (l_free >= 256).all()
+        model.close()
+    finally:
+        hip_lib.lib.vits_debug_poison_workspace(0)
+
+
 def test_philox_seeded_path_matches_oracle(hip_default, oracle_default):
     """No injected noise: both sides draw from the same Philox definition (durations pinned so the
     ceil() cliff cannot turn ulp-level noise differences into a length change)."""

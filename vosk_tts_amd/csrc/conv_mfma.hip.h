@@ -98,7 +98,57 @@ struct ConvParams {
   // starting at or beyond rag[b]*rag_out_mul + rag_out_add are skipped.  null = dense (reference-padded).
   const int* rag;
   int rag_in_mul, rag_in_add, rag_out_mul, rag_out_add;
+  // Masked stages (encoder / duration predictor / flow) of a ragged batch: every consumer of this conv's
+  // output is either column-local or masks its input at len[b], so tiles that start at or beyond len[b]
+  // are not computed at all (their memory keeps whatever it held; see DESIGN.md "ragged batches").
+  int skip_len;
+  // Compact tile map of a ragged launch: tile_start[b] = number of column tiles of items < b (B+1 entries,
+  // built on the device by ragged_tiles_kernel for this launch's tile width).  Working tiles get the lowest
+  // block ids so they are dispatched first and spread over all CUs; ids >= tile_start[B] * ... exit at once.
+  const int* tile_start;
 };
+
+// block id -> (m tile, group, column tile, batch item); returns false when the block has no work
+__device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, int& grp, int& nt, int& b) {
+  if (P.tile_start) {
+    // plain dispatch order (no XCD-contiguous remap: working tiles must be spread over all XCDs)
+    int id = blockIdx.x;
+    mt = id % P.ntiles_m; id /= P.ntiles_m;
+    const int total = P.tile_start[P.B];
+    int q;
+    if (P.n_groups > 1) { q = id % (P.ntiles_n * P.B); grp = id / (P.ntiles_n * P.B); }  // heaviest group first
+    else { q = id; grp = 0; }
+    if (q >= total) return false;
+    int lo = 0, hi = P.B - 1;  // last b with tile_start[b] <= q
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P.tile_start[mid] <= q) lo = mid; else hi = mid - 1; }
+    b = lo;
+    nt = q - P.tile_start[b];
+    return true;
+  }
+  int id;
+  {
+    // bijective XCD remap: block L runs on XCD L%8; give each XCD a contiguous range of logical ids so
+    // tiles sharing an activation window share an L2
+    const int nblk = gridDim.x, L = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, within = L >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  if (P.n_groups > 1) {
+    // grouped launch (k = 11/7/3 ResBlocks, sorted heaviest first by the launcher): plain dispatch order
+    // with the group outermost, so the long blocks start first and the launch tail is made of short ones
+    id = blockIdx.x;
+    mt = id % P.ntiles_m; id /= P.ntiles_m;
+    nt = id % P.ntiles_n; id /= P.ntiles_n;
+    b = id % P.B;
+    grp = id / P.B;
+  } else {
+    mt = id % P.ntiles_m; id /= P.ntiles_m;
+    nt = id % P.ntiles_n;
+    b = id / P.ntiles_n;
+    grp = 0;
+  }
+  return true;
+}
 #ifdef CONV_TIMING
 #define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #define CONV_DBG_DO(x) x
@@ -280,29 +330,8 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l31 = lane & 31;
 
-  // ---- block decode (bijective XCD remap: block L runs on XCD L%8; give each XCD a contiguous
-  // range of logical ids so tiles sharing an activation window share an L2)
-  int id;
-  {
-    const int nblk = gridDim.x, L = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, within = L >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-  }
   int mt, grp, nt, b;
-  if (P.n_groups > 1) {
-    // grouped launch (k = 11/7/3 ResBlocks, sorted heaviest first by the launcher): plain dispatch order
-    // with the group outermost, so the long blocks start first and the launch tail is made of short ones
-    id = blockIdx.x;
-    mt = id % P.ntiles_m; id /= P.ntiles_m;
-    nt = id % P.ntiles_n; id /= P.ntiles_n;
-    b = id % P.B;
-    grp = id / P.B;
-  } else {
-    mt = id % P.ntiles_m; id /= P.ntiles_m;
-    nt = id % P.ntiles_n;
-    b = id / P.ntiles_n;
-    grp = 0;
-  }
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
   const ConvGroup& G = P.g[grp];
 
   const int ROW = P.row_len;
@@ -319,6 +348,7 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
     const int il = rl * P.rag_in_mul + P.rag_in_add;
     t_lim = il < t_lim ? il : t_lim;
   }
+  if (P.skip_len && n0 >= P.len[b]) return;  // masked stage: the whole tile lies in this item's padding
 
   // ---- staging: wave w owns chunk rows w, w+4, w+8, w+12; lanes stride over columns
   float stg[4][JT];
@@ -502,16 +532,8 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps chunk/address math scalar
   const int h = lane >> 5, l31 = lane & 31;
   CONV_DBG(0);
-  int id;
-  {
-    const int nblk = gridDim.x, L = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, within = L >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-  }
-  const int mt = id % P.ntiles_m; id /= P.ntiles_m;
-  const int grp = id % P.n_groups; id /= P.n_groups;
-  const int nt = id % P.ntiles_n;
-  const int b = id / P.ntiles_n;
+  int mt, grp, nt, b;
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
   const ConvGroup& G = P.g[grp];
 
   const int n0 = nt * N_T, m0 = mt * M_T;
@@ -527,6 +549,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
     const int il = rl * P.rag_in_mul + P.rag_in_add;
     t_lim = il < t_lim ? il : t_lim;
   }
+  if (P.skip_len && n0 >= P.len[b]) return;  // masked stage: the whole tile lies in this item's padding
   const float in_scale = P.in_scale, in_slope = P.in_slope;
 
   // lane geometry.  Input addresses are  uniform_base(b, chunk, p)  +  lane_off(h, t)  with the

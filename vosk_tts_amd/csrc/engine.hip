@@ -47,6 +47,14 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- test hooks (process-wide) -------------------------------------------------------------------
+// 0 = size heuristic, 1 = force the big-tile kernel, 2 = force the K-split kernel (tests only)
+static int g_force_tile = 0;
+// 0 = fp32-MFMA flash attention (default), 1 = the VALU kernel (kept as an independent cross-check in tests)
+static int g_attn_impl = 0;
+// tests: fill every freshly planned workspace with NaN so stale padding can never hide as zeros
+static int g_poison = 0;
+
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
   float* w = nullptr;     // packed, MFMA fragment order
@@ -427,10 +435,16 @@ struct vits_session {
   typedef std::tuple<const void*, const void*, const void*, const void*, void*, int, int, int, uint64_t, float, float, float> GKey;
   std::map<GKey, hipGraphExec_t> graphs;
   bool use_graph = true;
+  bool ragged = false;  // full-path calls with B > 1: skip padding tiles of masked stages (set per call)
 
   // named views (valid after plan())
   int B = 0, Tx = 0, Ty = 0;
   int *len_x = nullptr, *len_y = nullptr, *len_rag = nullptr, *dur = nullptr, *cum = nullptr;
+  // compact tile maps of the current forward (ragged batches): built on demand, reused by every launch with the
+  // same (length array, scale, cap, tile width); reset at the start of each forward
+  int* tile_tabs = nullptr;
+  int n_tile_tabs = 0;
+  std::vector<std::tuple<const int*, int, int, int, int>> tile_keys;
   int64_t* ylen64 = nullptr;
   float *x = nullptr, *qkv = nullptr, *att = nullptr, *y1 = nullptr, *ffh = nullptr, *stats = nullptr;
   float *condv = nullptr;
@@ -460,6 +474,7 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->ylen64 = bump<int64_t>(s, B);
   s->dur = bump<int>(s, (size_t)B * Tx); s->cum = bump<int>(s, (size_t)B * Tx);
   s->condv = bump<float>(s, (size_t)B * (s->m->cond_rows + 1));
+  s->tile_tabs = bump<int>(s, (size_t)32 * (B + 1));
   // encoder-shaped scratch is shared by the text encoder (T_x) and the flow pre-transformers (T_y)
   s->x = bump<float>(s, B * H * Tm);
   s->qkv = bump<float>(s, B * 3 * H * Tm);
@@ -520,6 +535,7 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     s->arena_bytes = want;
   }
   plan(s, B, Tx, Ty);
+  if (g_poison) hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);  // 0xFFFFFFFF = NaN
   return VITS_OK;
 }
 
@@ -576,14 +592,31 @@ struct ProfScope {
   ~ProfScope() { if (on) hipEventRecord(s->prof.back().e1, s->stream); }
 };
 
-// 0 = size heuristic, 1 = force the big-tile kernel, 2 = force the K-split kernel (tests only)
-static int g_force_tile = 0;
-// 0 = fp32-MFMA flash attention (default), 1 = the VALU kernel (kept as an independent cross-check in tests)
-static int g_attn_impl = 0;
+
+// compact tile map for a ragged launch (see conv_decode_block); nullptr when no table slot is left
+static const int* tile_table(vits_session* s, const int* len, int mul, int add, int cap, int tile) {
+  auto key = std::make_tuple(len, mul, add, cap, tile);
+  for (size_t i = 0; i < s->tile_keys.size(); ++i)
+    if (s->tile_keys[i] == key) return s->tile_tabs + i * (s->B + 1);
+  if (s->tile_keys.size() >= 32) return nullptr;
+  int* tab = s->tile_tabs + s->tile_keys.size() * (s->B + 1);
+  s->tile_keys.push_back(key);
+  hipLaunchKernelGGL(ragged_tiles_kernel, dim3(1), dim3(64), 0, s->stream, len, s->B, mul, add, cap, tile, tab);
+  return tab;
+}
+
+static void attach_tile_table(vits_session* s, ConvParams& P, int N_T) {
+  P.tile_start = nullptr;
+  if (!s || !s->arena) return;
+  if (P.rag) P.tile_start = tile_table(s, P.rag, P.rag_out_mul, P.rag_out_add, P.Tout, N_T);
+  else if (P.skip_len) P.tile_start = tile_table(s, P.len, 1, 0, P.Tout, N_T);
+}
 
 template <int WM, int WN, int MI, int NI, int EPI>
-static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
+static void launch_cfg(vits_session* s, ConvParams& P, int halo) {
+  hipStream_t st = s->stream;
   constexpr int M_T = WM * MI * 32, N_T = WN * NI * 32;
+  attach_tile_table(s, P, N_T);
   P.ntiles_m = cdiv(P.M, M_T);
   P.ntiles_n = cdiv(P.Tout, N_T);
   P.row_len = N_T + halo;
@@ -593,8 +626,10 @@ static void launch_cfg(hipStream_t st, ConvParams& P, int halo) {
 }
 
 template <int MI, int NI, int EPI>
-static void launch_ks(hipStream_t st, ConvParams& P, int halo) {
+static void launch_ks(vits_session* s, ConvParams& P, int halo) {
+  hipStream_t st = s->stream;
   constexpr int M_T = MI * 32, N_T = NI * 32;
+  attach_tile_table(s, P, N_T);
   (void)halo;  // no staging window: B fragments come straight from global memory
   P.ntiles_m = cdiv(P.M, M_T);
   P.ntiles_n = cdiv(P.Tout, N_T);
@@ -629,33 +664,33 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   if (epi == EPI_GATE) {
-    if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(st, P, halo); }
-    else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(st, P, halo); }
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo); }
+    else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
     return;
   }
   if (epi == EPI_RESSKIP) {
-    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,RESSKIP,1>"); launch_ks<1, 1, EPI_RESSKIP>(st, P, halo); }
-    else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,RESSKIP>"); launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(st, P, halo); }
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,RESSKIP,1>"); launch_ks<1, 1, EPI_RESSKIP>(s, P, halo); }
+    else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,RESSKIP>"); launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(s, P, halo); }
     return;
   }
   if (epi == EPI_COUPLE) {
-    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(st, P, halo); }
-    else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(st, P, halo); }
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(s, P, halo); }
+    else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(s, P, halo); }
     return;
   }
   if (small) {
     const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
     const bool multi = P.g[0].x2 != nullptr;
-    if (blocks32 > 2048) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(st, P, halo); }
-    else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(st, P, halo); }
+    if (blocks32 > 2048) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(s, P, halo); }
+    else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); }
     return;
   }
-  if (P.ups_u && (P.ups_cout % 64)) { ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(st, P, halo); return; }
+  if (P.ups_u && (P.ups_cout % 64)) { ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(s, P, halo); return; }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
-  if (m_fits && big_blocks >= 512) { ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(st, P, halo); return; }
+  if (m_fits && big_blocks >= 512) { ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return; }
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
-  launch_cfg<2, 2, 1, 1, EPI_STORE>(st, P, halo);
+  launch_cfg<2, 2, 1, 1, EPI_STORE>(s, P, halo);
 }
 
 // common-case parameter block: one group, same-length 'same'-padded Conv1d over [B,C,T]
@@ -672,10 +707,15 @@ static ConvParams conv_params(const ConvW& W, const float* x, float* y, int B, i
   return P;
 }
 
+// masked-stage conv of a ragged batch: tiles beyond len[b] are skipped (conv_mfma.hip.h, skip_len)
+static void mark_masked(vits_session* s, ConvParams& P, const int* len) {
+  if (s->ragged) { P.skip_len = 1; P.len = len; }
+}
+
 static void launch_ln(vits_session* s, const float* a, const float* b, const float* base, float* y, const float* gamma,
                       const float* beta, const int* len, int B, int C, int T, int gelu, int mask) {
   ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
-  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask};
+  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask, (s->ragged && len) ? 1 : 0};
   hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, P);
 }
 
@@ -712,18 +752,22 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
       hipLaunchKernelGGL(add_vec_mask_kernel, dim3(cdiv(T, 64), H, B), dim3(64), 0, s->stream, x, s->condv, m->cond_rows,
                          cond_off, len, H, T);
     ConvParams P = conv_params(L.qkv, x, s->qkv, B, T, 1, 0);
+    mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.qkv");
     launch_attention(s, s->qkv, L, len, s->att, B, H, T);
     P = conv_params(L.o, s->att, s->y1, B, T, 1, 0);  // y1 = x + conv_o(att)
     P.g[0].res = x;
+    mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.o");
     launch_ln(s, s->y1, nullptr, nullptr, x, L.g1, L.b1, len, B, H, T, 0, 0);
     // FFN (attentions.py:308-317): conv_1(pad(x*mask)) -> relu -> *mask -> conv_2(pad(.)) -> *mask
     P = conv_params(L.f1, x, s->ffh, B, T, 1, (K - 1) / 2);
     P.in_mask = 1; P.len = len; P.relu = 1; P.out_mask = 1;
+    mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.ffn1");
     P = conv_params(L.f2, s->ffh, s->y1, B, T, 1, (K - 1) / 2);
     P.in_mask = 1; P.len = len; P.out_mask = 1; P.g[0].res = x;  // y1 = x + ffn(x)
+    mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.ffn2");
     const bool lastl = i == n - 1;
     launch_ln(s, s->y1, nullptr, lastl ? final_base : nullptr, (lastl && final_out) ? final_out : x, L.g2, L.b2, len, B, H,
@@ -765,6 +809,7 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   run_encoder(s, m->enc_p, s->x, s->len_x, B, Tx, m->use_g ? hp.enc_cond_layer : -1, m->cond_enc_off, nullptr, nullptr);
   ConvParams P = conv_params(m->enc_proj, s->x, s->stats, B, Tx, 1, 0);
   P.out_mask = 1; P.len = s->len_x;
+  mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "enc.proj");
 }
 
@@ -774,9 +819,10 @@ static void run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
   const int D = hp.dp_filter_channels, K = hp.dp_kernel_size;
   int dil = 1;
   for (size_t i = 0; i < W.pw.size(); ++i) {
-    DwLnParams dp{h, s->dy, W.sw[i], W.sb[i], W.g1[i], W.b1[i], s->len_x, D, T, K, dil};
+    DwLnParams dp{h, s->dy, W.sw[i], W.sb[i], W.g1[i], W.b1[i], s->len_x, D, T, K, dil, s->ragged ? 1 : 0};
     hipLaunchKernelGGL(dwconv_ln_gelu_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, dp);
     ConvParams P = conv_params(W.pw[i], s->dy, s->dy2, B, T, 1, 0);
+    mark_masked(s, P, s->len_x);
     launch_conv(s, P, EPI_STORE, "dp.1x1");
     // x = x + gelu(LN2(y)) ; masked every layer (equivalent at valid positions)
     launch_ln(s, s->dy2, nullptr, h, h, W.g2[i], W.b2[i], s->len_x, B, D, T, 1, 1);
@@ -791,10 +837,12 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   const int D = hp.dp_filter_channels;
   ConvParams P = conv_params(m->dp_pre, x, s->dh, B, Tx, 1, 0);
   if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dp_off; }
+  mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.pre");
   run_dds(s, m->dp_dds, s->dh, B, Tx);
   P = conv_params(m->dp_proj, s->dh, s->dc, B, Tx, 1, 0);
   P.out_mask = 1; P.len = s->len_x;
+  mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.proj");
   hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx);
   int swap = 0;
@@ -808,6 +856,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
     run_dds(s, c.dds, s->dfh, B, Tx);
     P = conv_params(c.proj, s->dfh, s->dpr, B, Tx, 1, 0);
     P.out_mask = 1; P.len = s->len_x;
+    mark_masked(s, P, s->len_x);
     launch_conv(s, P, EPI_STORE, "dp.cfproj");
     hipLaunchKernelGGL(spline_inverse_kernel, dim3(cdiv(Tx, 64), B), dim3(64), 0, s->stream, s->dz, swap, s->dpr, c.proj.M,
                        s->len_x, Tx, hp.dp_num_bins, hp.dp_tail_bound, 1.0f / sqrtf((float)D));
@@ -846,6 +895,7 @@ static float* run_flow(vits_session* s, int B, int Ty) {
     ConvParams P = conv_params(C.pre, u, s->fh, B, Ty, 1, 0);
     P.x_ch_off = I - 1; P.x_ch_sign = -1; P.x_bstride = (long long)I * Ty;
     P.out_mask = 1; P.len = s->len_y;
+    mark_masked(s, P, s->len_y);
     launch_conv(s, P, EPI_STORE, "flow.pre");
     // h = h + pre_transformer(h * mask)  (models.py:377)
     hipMemcpyAsync(s->x, s->fh, sizeof(float) * (size_t)B * H * Ty, hipMemcpyDeviceToDevice, s->stream);
@@ -855,15 +905,21 @@ static float* run_flow(vits_session* s, int B, int Ty) {
       P = conv_params(C.in_layers[i], s->fx, s->facts, B, Ty, 1, (K5 - 1) / 2);
       P.Cout = H; P.H = H; P.y_bstride = (long long)H * Ty;
       if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = C.cond_off + i * 2 * H; }
+      // x is masked in the reference (modules.py:171); reading it through the mask makes the K=5 window
+      // independent of whatever a skipped padding tile left behind
+      P.in_mask = 1; P.len = s->len_y;
+      mark_masked(s, P, s->len_y);
       launch_conv(s, P, EPI_GATE, "flow.wn_in");
       P = conv_params(C.rs_layers[i], s->facts, nullptr, B, Ty, 1, 0);
       P.io = s->fx; P.skip = s->fskip; P.H = H; P.first = i == 0; P.last = i == L - 1; P.len = s->len_y;
       P.y_bstride = (long long)H * Ty;
+      mark_masked(s, P, s->len_y);
       launch_conv(s, P, EPI_RESSKIP, "flow.wn_rs");
     }
     // m = post(h) * mask ; x1 = (x1 - m) * mask ; cat (models.py:379-392)
     P = conv_params(C.post, s->fskip, nullptr, B, Ty, 1, 0);
     P.u = u; P.io = v; P.H = half; P.len = s->len_y; P.y_bstride = (long long)I * Ty;
+    mark_masked(s, P, s->len_y);
     launch_conv(s, P, EPI_COUPLE, "flow.post");
     float* t = u; u = v; v = t;
   }
@@ -885,7 +941,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
   int C = hp.dec_initial_channel, T = Ty;
   const int* rag = nullptr;
   int rate = 1;  // columns per frame at the current stage
-  if (ragged && B > 1 && hp.dec_type == 0) {
+  if (ragged && B > 1 && hp.dec_type == 0 && !getenv("VITS_NO_RAGGED")) {
     hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, B, Ty, VITS_RAGGED_HALO);
     rag = s->len_rag;
   }
@@ -1019,6 +1075,9 @@ static void set_lengths(vits_session* s, const int64_t* d_len64, int* d_len32, i
 
 static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t* d_len, int B, int Tx, const float* scales,
                            const int64_t* d_sid, const int32_t* d_forced, int Ty, uint64_t seed, float* d_audio, int64_t cap) {
+  static const bool no_ragged = getenv("VITS_NO_RAGGED") != nullptr;  // A/B switch for tools/
+  s->ragged = B > 1 && !no_ragged;
+  s->tile_keys.clear();
   set_lengths(s, d_len, s->len_x, B, Tx);
   run_cond(s, d_sid, B);
   run_text_encoder(s, d_ids, B, Tx);
@@ -1027,6 +1086,7 @@ static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t*
   run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
   float* z = run_flow(s, B, Ty);
   run_decoder(s, z, true, B, Ty, d_audio, cap, nullptr, true);
+  s->ragged = false;
 }
 
 
@@ -1239,6 +1299,9 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   int64_t* d_len = hs.to_dev(lengths, B);
   int64_t* d_sid = hs.to_dev(sid, B);
   if (!d_ids || !d_len) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  s->ragged = B > 1;
+  s->tile_keys.clear();
+  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; } } ragged_off{s};
   set_lengths(s, d_len, s->len_x, B, Tx);
   run_cond(s, d_sid, B);
   run_text_encoder(s, d_ids, B, Tx);
@@ -1267,6 +1330,7 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   HIP_TRY(hipMemcpyAsync(keep_cum, s->cum, sizeof(int) * (size_t)B * Tx, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   TRY(session_reserve(s, B, Tx, (int)Ty));
+  s->tile_keys.clear();  // the tile tables live in the (re-planned) workspace
   HIP_TRY(hipMemcpyAsync(s->stats, keep_stats, sizeof(float) * (size_t)B * 2 * I * Tx, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->cum, keep_cum, sizeof(int) * (size_t)B * Tx, hipMemcpyDeviceToDevice, s->stream));
   std::vector<int> ylen32(B);
@@ -1359,6 +1423,7 @@ int vits_session_last_ms(vits_session* s, float* ms) {
 
 void vits_debug_force_tile(int mode) { g_force_tile = mode; }
 void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
+void vits_debug_poison_workspace(int on) { g_poison = on; }
 
 int vits_session_sync(vits_session* s) {
   if (!s) return fail(VITS_ERR_ARG, "null session");

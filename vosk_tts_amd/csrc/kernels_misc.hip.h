@@ -90,6 +90,7 @@ struct LNParams {
   const float* a; const float* b; const float* base; float* y;
   const float* gamma; const float* beta; const int* len;
   int C, T; int gelu; int mask;
+  int skip_len;  // ragged batch: blocks that start at or beyond len[b] do nothing
 };
 __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
   red[cg * LN_TL + tl] = v;
@@ -103,6 +104,7 @@ __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int c
 __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   __shared__ float red[LN_CG * LN_TL];
   const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
+  if (P.skip_len && (int)(blockIdx.x * LN_TL) >= P.len[b]) return;  // block-uniform
   const int t = blockIdx.x * LN_TL + tl;
   const bool in = t < P.T;
   const long long o0 = (long long)b * P.C * P.T + (in ? t : 0);
@@ -146,10 +148,12 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
 struct DwLnParams {
   const float* x; float* y; const float* w; const float* bias; const float* gamma; const float* beta; const int* len;
   int C, T, K, dil;
+  int skip_len;
 };
 __global__ void __launch_bounds__(256) dwconv_ln_gelu_kernel(const DwLnParams P) {
   __shared__ float red[LN_CG * LN_TL];
   const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
+  if (P.skip_len && (int)(blockIdx.x * LN_TL) >= P.len[b]) return;  // block-uniform
   const int t = blockIdx.x * LN_TL + tl;
   const bool in = t < P.T;
   const int L = P.len[b] < P.T ? P.len[b] : P.T, pad = (P.K * P.dil - P.dil) / 2;
@@ -649,6 +653,21 @@ __global__ void expand_prior_kernel(const float* stats, const int* cum, const in
   }
 }
 
+// tile_start[b] = sum_{b' < b} ceil(min(cap, len[b']*mul + add) / tile)  (B+1 entries): the compact tile map of
+// one ragged conv launch (conv_decode_block).  One thread; B <= a few hundred.
+__global__ void ragged_tiles_kernel(const int* len, int B, int mul, int add, int cap, int tile, int* tile_start) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int run = 0;
+  for (int b = 0; b < B; ++b) {
+    tile_start[b] = run;
+    int cols = len[b] * mul + add;
+    cols = cols < cap ? cols : cap;
+    cols = cols < 0 ? 0 : cols;
+    run += (cols + tile - 1) / tile;
+  }
+  tile_start[B] = run;
+}
+
 // rag[b] = min(Ty, len_y[b] + halo): frames each item of a ragged batch needs in the (mask-free) decoder
 __global__ void ragged_len_kernel(const int* len_y, int* rag, int B, int Ty, int halo) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,7 +688,10 @@ __global__ void istft_kernel(const float* post, const float* basis, float* mb, i
   const int np = n + N / 2;
   int t_hi = np / hop;
   if (t_hi > Tp - 1) t_hi = Tp - 1;
-  // (ragged: every post column this sample touches lies below rag*rag_mul/hop + N/hop, which conv_post computed)
+  if (rag) {  // conv_post computed columns [0, rag*rag_mul/hop]; later ones were never written
+    const int lim = rag[b] * rag_mul / hop;
+    if (t_hi > lim) t_hi = lim;
+  }
   int t_lo = (np - N + hop) / hop;  // ceil((np-N+1)/hop)
   if (np - N + 1 <= 0) t_lo = 0;
   const float* pb = post + ((long long)b * C + (long long)s * (N + 2)) * Tp;
@@ -696,12 +718,13 @@ __global__ void pqmf_synthesis_kernel(const float* mb, const float* filt, float*
   if (t >= To) return;
   if (rag && t >= rag[b] * rag_mul) { audio[(long long)b * audio_bstride + t] = 0.f; return; }  // padding: defined zeros
   const int j0 = ((padl - t) % S + S) % S;
+  const int u_lim = rag ? (rag[b] * rag_mul < To ? rag[b] * rag_mul : To) : To;  // sub-band samples that exist
   float a = 0.f;
   for (int s = 0; s < S; ++s) {
     const float* xb = mb + ((long long)b * S + s) * Tm;
     for (int j = j0; j < L; j += S) {
       const int u = t + j - padl;
-      if (u >= 0 && u < To) a += filt[s * L + j] * (xb[u / S] * (float)S);
+      if (u >= 0 && u < u_lim) a += filt[s * L + j] * (xb[u / S] * (float)S);
     }
   }
   audio[(long long)b * audio_bstride + t] = a;
