@@ -125,7 +125,7 @@ def main():
 
         def barrier():
             if dist is not None:
-                dist.barrier()
+                dist.barrier(device_ids=[local_rank])
 
         for _ in range(warmup):
             step()
@@ -242,7 +242,7 @@ def main():
         line = {
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.workload == "c4" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rtf": round(rtf, 6), "x_realtime": round(1.0 / rtf, 1),
             "config": {"workload": f"{args.workload}: MB-iSTFT-VITS2 (ru-0.9-multi-shaped, seeded synthetic weights), "
                                    f"B={B} T_x={Tx} (lengths {int(lengths.min())}..{int(lengths.max())}), durations pinned 3/token "

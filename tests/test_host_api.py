@@ -94,6 +94,22 @@ def test_synth_audio_feed_defaults_and_int16(tmp_path):
     assert m.onnx.feeds[-1][1]["sid"].tolist() == [3]
 
 
+def test_cli_flag_surface_and_missing_input():
+    """same flags as the reference console script (vosk_tts/cli.py:12-43); no --input -> exit status 1 (cli.py:59-61)"""
+    from vosk_tts_amd import cli
+
+    ap = cli.build_parser()
+    o = ap.parse_args(["-m", "/x", "-n", "nm", "-l", "ru", "-i", "т+екст", "-s", "3", "-r", "1.5", "-o", "a.wav", "--log-level", "debug"])
+    assert (o.model, o.model_name, o.lang, o.input, o.speaker, o.speech_rate, o.output, o.log_level) == \
+        ("/x", "nm", "ru", "т+екст", 3, 1.5, "a.wav", "debug")
+    d = ap.parse_args([])
+    assert d.lang == "en-us" and d.speech_rate == 1.0 and d.output == "out.wav" and d.speaker is None
+    assert not d.list_models and not d.list_languages
+    with pytest.raises(SystemExit) as e:
+        cli.main([])
+    assert e.value.code == 1
+
+
 def test_toy_model_directory_layout(tmp_path):
     from vosk_tts_amd import weights as W
     from vosk_tts_amd.toymodel import PHONEMES, write_toy_model

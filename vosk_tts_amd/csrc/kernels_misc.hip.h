@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) relpos_attention_kernel(const float* qkv,
 //   relative values: O^T[d][q] += sum_r E_v^T[d][r] Prel^T[r][q], Prel gathered through LDS on the <= 3 tiles
 //   that touch the diagonal band.
 template <int DK>
-__global__ void __launch_bounds__(256) relpos_attention_mfma_kernel(const float* qkv, const float* ek, const float* ev,
+__global__ void __launch_bounds__(256, 2) relpos_attention_mfma_kernel(const float* qkv, const float* ek, const float* ev,
                                                                      const int* len, float* out, int H, int T, int W) {
   constexpr int NS = DK / 2, ND = DK / 32, VS = 33;
   constexpr int WREG = DK * VS + 10 * 32 + 9 * 32;  // per-wave LDS: V tile | Prel | QE
@@ -376,33 +376,40 @@ __global__ void __launch_bounds__(256) relpos_attention_mfma_kernel(const float*
   float m = -3.0e38f, l = 0.f;
 
   const int ntiles = (L + 31) >> 5;
+  // K fragments of the current tile live in registers and are prefetched one tile ahead (issued before the
+  // PV MFMAs of the previous tile); the V tile's loads are issued at the top of the tile and fly under the
+  // 48 QK^T MFMAs before they are written to LDS.
+  float kf[NS];
+  auto load_k = [&](int jt_) {
+    const int j = jt_ * 32 + l31;
+    const int jc = j < L ? j : L - 1;
+    const float* kp = kb + (long long)h * T + jc;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kf[s] = kp[(long long)(2 * s) * T];
+  };
+  if (wave < ntiles) load_k(wave);
   for (int jt = wave; jt < ntiles; jt += 4) {
     const int j0 = jt * 32;
-    // ---- V tile -> wave-private LDS [d][33] (keys beyond L read as 0)
+    // ---- V tile: issue the loads now (keys beyond L read as 0) ...
+    float vst[NS];
+    const bool vok = j0 + l31 < L;
     {
-      const int j = j0 + l31;
-      const bool ok = j < L;
-      const int jc = ok ? j : L - 1;
-#pragma unroll 8
-      for (int d = h; d < DK; d += 2) {
-        const float v = vb[(long long)d * T + jc];
-        vt[d * VS + l31] = ok ? v : 0.f;
-      }
+      const int jc = vok ? j0 + l31 : L - 1;
+      const float* vp = vb + (long long)h * T + jc;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vst[s] = vp[(long long)(2 * s) * T];
     }
-    // ---- S^T = K Q^T
+    // ---- S^T = K Q^T on the prefetched K fragments
     f32x16 S;
 #pragma unroll
     for (int e = 0; e < 16; ++e) S[e] = 0.f;
-    {
-      const int j = j0 + l31;
-      const int jc = j < L ? j : L - 1;
-      const float* kp = kb + (long long)h * T + jc;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float a = kp[(long long)(2 * s) * T];
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[s], S, 0, 0, 0);
-      }
-    }
+    for (int s = 0; s < NS; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], S, 0, 0, 0);
+    // ... and park V in the wave-private LDS tile [d][33] once QK^T has been issued
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vt[(2 * s + h) * VS + l31] = vok ? vst[s] : 0.f;
+    // next tile's K fragments fly under the softmax and the PV MFMAs
+    if (jt + 4 < ntiles) load_k(jt + 4);
     // ---- relative-key bias on the diagonal band, key mask, tile max
     const bool near = (j0 + 31 >= i0 - W) && (j0 <= i0 + 31 + W);
     float mx = -3.0e38f;
