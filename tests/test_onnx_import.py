@@ -1,0 +1,77 @@
+"""reading the weights out of a shipped model.onnx.  No real vosk model is available
+offline, so the wire parser and the name/shape -> hparams mapping are exercised on a synthetic ONNX file
+written by an independent minimal protobuf writer (initializers under the reference's state_dict names)."""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_roundtrip_synthetic_onnx(tmp_path):
+    from vosk_tts_amd import onnx_import as oi
+    from vosk_tts_amd import weights as W
+
+    hp = W.tiny_hparams()
+    tens = W.make_synthetic_weights(hp, 99)
+    extra = dict(tens)
+    extra["dec.stft.inverse_basis"] = np.zeros((18, 1, 16), np.float32)  # buffers the exporter also writes
+    extra["onnx::Conv_1234"] = np.ones((3, 3), np.float32)             # anonymous constants are ignored
+    path = oi.write_minimal_onnx(str(tmp_path / "model.onnx"), extra, use_float_data={"enc_p.proj.bias", "dp.flows.0.m"})
+    got_hp, got = oi.import_onnx(path)
+    for f, _ in W.HParams._fields_:
+        if f in ("reserved", "up_rates", "up_kernels", "res_kernels", "res_dilations"):
+            continue
+        assert getattr(got_hp, f) == pytest.approx(getattr(hp, f)), f
+    assert list(got_hp.up_kernels)[:2] == [16, 16] and list(got_hp.res_kernels)[:3] == [3, 7, 11]
+    assert set(got) == set(tens)
+    assert all(np.array_equal(got[k], tens[k]) for k in tens)
+    # and the produced blob is what the engine/oracle parse
+    blob_path = str(tmp_path / "model.vitsw")
+    oi.convert(path, blob_path, {"upsample_rates": [4, 4], "resblock_dilation_sizes": [[1, 3, 5]] * 3})
+    hp2, t2 = W.unpack_blob(open(blob_path, "rb").read())
+    assert hp2.hidden_channels == hp.hidden_channels and np.array_equal(t2["emb_g.weight"], tens["emb_g.weight"])
+
+
+def test_imported_blob_runs_in_the_oracle(tmp_path, oracle_lib, oracle_tiny):
+    from vosk_tts_amd import onnx_import as oi
+    from vosk_tts_amd import weights as W
+
+    hp = W.tiny_hparams()
+    tens = W.make_synthetic_weights(hp, 1234)
+    path = oi.write_minimal_onnx(str(tmp_path / "m.onnx"), tens)
+    oi.convert(path, str(tmp_path / "m.vitsw"))
+    m = oracle_lib.create(open(tmp_path / "m.vitsw", "rb").read())
+    ids = np.array([[1, 5, 0, 7, 3]], np.int64)
+    a, _ = m.synthesize(ids, [5], [0.0, 1.0, 0.0], [1], forced_durations=np.full((1, 5), 2, np.int32))
+    b, _ = oracle_tiny.synthesize(ids, [5], [0.0, 1.0, 0.0], [1], forced_durations=np.full((1, 5), 2, np.int32))
+    assert np.array_equal(a, b)
+
+
+def test_foreign_graphs_are_rejected_loudly(tmp_path):
+    from vosk_tts_amd import onnx_import as oi
+    from vosk_tts_amd import weights as W
+
+    tens = W.make_synthetic_weights(W.tiny_hparams(), 1)
+    missing = {k: v for k, v in tens.items() if not k.startswith("dp.")}
+    with pytest.raises(NotImplementedError, match="dp.pre.weight"):
+        oi.import_onnx(oi.write_minimal_onnx(str(tmp_path / "a.onnx"), missing))
+    bert = dict(tens, **{"bert_proj.weight": np.zeros((4, 4), np.float32)})
+    with pytest.raises(NotImplementedError, match="BERT"):
+        oi.import_onnx(oi.write_minimal_onnx(str(tmp_path / "b.onnx"), bert))
+    bad = dict(tens)
+    bad["dec.conv_pre.bias"] = np.zeros(7, np.float32)
+    with pytest.raises(NotImplementedError, match="unexpected shapes"):
+        oi.import_onnx(oi.write_minimal_onnx(str(tmp_path / "c.onnx"), bad))
+    with pytest.raises(ValueError):
+        oi.read_initializers(b"\x3a\xff\xff\xff\xff\x0f")  # length-delimited field running past the buffer
+
+
+def test_varint_and_negative_int64_fields():
+    from vosk_tts_amd import onnx_import as oi
+
+    # TensorProto{dims:[2], data_type: INT64(7), int64_data packed [-1, 300], name "x"}
+    neg1 = oi._enc_varint((1 << 64) - 1)
+    tp = oi._enc_field(1, 0, 2) + oi._enc_field(2, 0, 7) + oi._enc_field(7, 2, neg1 + oi._enc_varint(300)) + oi._enc_field(8, 2, b"x")
+    model = oi._enc_field(7, 2, oi._enc_field(5, 2, tp))
+    t = oi.read_initializers(model)
+    assert t["x"].tolist() == [-1, 300]

@@ -2,7 +2,8 @@
 replaced by the MI355X-native engine.
 
 A model directory holds (reference layout, model.py:46-63):
-    model.vitsw   weight blob for the HIP engine (replaces model.onnx; see vosk_tts_amd/weights.py)
+    model.vitsw   weight blob for the HIP engine (see vosk_tts_amd/weights.py) — or the reference's model.onnx,
+                  whose initializers are imported on load (vosk_tts_amd/onnx_import.py)
     dictionary    word prob phonemes... ; the highest-probability pronunciation wins (model.py:48-55)
     config.json   inference defaults, phoneme_id_map, model_type, no_blank (synth.py:50-56,64,88,177)
 Attributes kept: .onnx (object with .run(None, feed)), .dic, .config, .tokenizer.
@@ -54,12 +55,24 @@ class Model:
             device = int(os.getenv("VOSK_TTS_DEVICE", os.getenv("LOCAL_RANK", "0")))
         logging.info(f"Loading model from {model_path}")
         blob_path = model_path / "model.vitsw"
-        if not blob_path.exists():
-            raise FileNotFoundError(
-                f"{blob_path} not found: this engine loads VITSW001 weight blobs (see vosk_tts_amd/weights.py); "
-                "an ONNX importer is listed as next work in SURVEY.md §8f")
-        with open(blob_path, "rb") as f:
-            self.onnx = VitsSession(f.read(), device=device)
+        if blob_path.exists():
+            with open(blob_path, "rb") as f:
+                blob = f.read()
+        elif (model_path / "model.onnx").exists():
+            # a reference model directory (model.py:46): pull the initializers out of the exported graph
+            from . import weights as W
+            from .onnx_import import import_onnx
+
+            cfg = {}
+            if (model_path / "config.json").exists():
+                with open(model_path / "config.json") as f:
+                    raw = json.load(f)
+                cfg = dict(raw.get("model", {}), **raw.get("data", {})) if isinstance(raw, dict) else {}
+            hp, tensors = import_onnx(str(model_path / "model.onnx"), cfg)
+            blob = W.pack_blob(hp, tensors)
+        else:
+            raise FileNotFoundError(f"neither {blob_path} nor model.onnx found in {model_path}")
+        self.onnx = VitsSession(blob, device=device)
 
         self.dic = {}
         probs = {}

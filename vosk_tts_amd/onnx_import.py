@@ -1,0 +1,297 @@
+"""Import the weights of a shipped `model.onnx`.
+
+The reference runtime loads `model.onnx` with onnxruntime (vosk_tts/model.py:46); the graph was
+written by `torch.onnx.export` from `SynthesizerTrn` with weight-norm removed from `dec` and `flow`
+(training/vits2/onnx_export.py:47-104), so its *initializers* carry the parameter names of the
+PyTorch module ("dec.conv_pre.weight", "enc_p.encoder.attn_layers.0.conv_q.bias", ...).  This
+module reads those initializers with a minimal protobuf wire-format parser (no `onnx` package is
+needed), infers the hyper-parameters from the tensor shapes and produces the engine's VITSW001 blob.
+
+Limits (stated, not hidden): only graphs of the in-repo VITS2 family are recognised; tensors that
+the exporter constant-folded under anonymous names ("onnx::Conv_123") cannot be matched and are
+reported as missing; BERT-conditioned / multistream flavours (vosk_tts/synth.py:64-99) are rejected.
+This path could not be validated against a real vosk model here (none is available offline); the
+wire parser and the name/shape mapping are covered by tests/test_onnx_import.py with a synthetic file.
+
+ONNX protobuf fields used (onnx.proto3): ModelProto.graph = 7; GraphProto.node = 1, .initializer = 5;
+NodeProto.output = 2, .op_type = 4, .attribute = 5; AttributeProto.name = 1, .t = 5;
+TensorProto.dims = 1, .data_type = 2, .float_data = 4, .int64_data = 7, .name = 8, .raw_data = 9,
+.double_data = 10, .data_location = 14.
+"""
+import struct
+
+import numpy as np
+
+from . import weights as W
+
+# ---------------------------------------------------------------------------------------------------
+# protobuf wire format
+# ---------------------------------------------------------------------------------------------------
+
+
+def _varint(buf, pos):
+    out = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+        if shift > 70:
+            raise ValueError("malformed varint")
+
+
+def _fields(buf):
+    """yield (field_number, wire_type, value) for one message; value is int (varint / fixed) or memoryview (bytes)"""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        fno, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = bytes(buf[pos:pos + 8]); pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]; pos += ln
+        elif wt == 5:
+            v = bytes(buf[pos:pos + 4]); pos += 4
+        else:
+            raise ValueError(f"unsupported protobuf wire type {wt}")
+        if pos > n:
+            raise ValueError("truncated protobuf message")
+        yield fno, wt, v
+
+
+_DTYPES = {1: np.float32, 7: np.int64, 11: np.float64, 6: np.int32, 10: np.float16}
+
+
+def _packed_varints(v):
+    out, pos = [], 0
+    while pos < len(v):
+        x, pos = _varint(v, pos)
+        out.append(x)
+    return out
+
+
+def _tensor(buf):
+    """TensorProto -> (name, ndarray or None)"""
+    dims, dtype, name, raw, floats, int64s, doubles, external = [], 1, "", None, [], [], [], False
+    for fno, wt, v in _fields(buf):
+        if fno == 1:
+            dims.extend(_packed_varints(v) if wt == 2 else [v])
+        elif fno == 2:
+            dtype = v
+        elif fno == 4:
+            floats.append(np.frombuffer(bytes(v), "<f4") if wt == 2 else np.frombuffer(v, "<f4"))
+        elif fno == 7:
+            int64s.extend(_packed_varints(v) if wt == 2 else [v])
+        elif fno == 8:
+            name = bytes(v).decode("utf-8", "replace")
+        elif fno == 9:
+            raw = bytes(v)
+        elif fno == 10:
+            doubles.append(np.frombuffer(bytes(v), "<f8") if wt == 2 else np.frombuffer(v, "<f8"))
+        elif fno == 14 and v == 1:
+            external = True
+    if external:
+        return name, None
+    np_dt = _DTYPES.get(dtype)
+    if np_dt is None:
+        return name, None
+    if raw is not None:
+        arr = np.frombuffer(raw, dtype=np.dtype(np_dt).newbyteorder("<"))
+    elif floats:
+        arr = np.concatenate(floats)
+    elif doubles:
+        arr = np.concatenate(doubles)
+    elif int64s:
+        arr = np.array([x - (1 << 64) if x >= (1 << 63) else x for x in int64s], dtype=np.int64)
+    else:
+        arr = np.zeros(0, np_dt)
+    shape = tuple(int(d) for d in dims)
+    if int(np.prod(shape, dtype=np.int64)) != arr.size:
+        return name, None
+    return name, arr.reshape(shape)
+
+
+def read_initializers(path_or_bytes):
+    """name -> ndarray for every initializer (and Constant node output) of an ONNX model file."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
+    buf = memoryview(data)
+    out = {}
+    for fno, wt, v in _fields(buf):
+        if fno != 7 or wt != 2:  # ModelProto.graph
+            continue
+        for gno, gwt, gv in _fields(v):
+            if gno == 5 and gwt == 2:  # initializer
+                name, arr = _tensor(gv)
+                if arr is not None:
+                    out[name] = arr
+            elif gno == 1 and gwt == 2:  # node: pick up Constant tensors by output name
+                outputs, op, tens = [], "", None
+                for nno, nwt, nv in _fields(gv):
+                    if nno == 2:
+                        outputs.append(bytes(nv).decode("utf-8", "replace"))
+                    elif nno == 4:
+                        op = bytes(nv).decode("utf-8", "replace")
+                    elif nno == 5 and nwt == 2:
+                        for ano, awt, av in _fields(nv):
+                            if ano == 5 and awt == 2:
+                                tens = _tensor(av)[1]
+                if op == "Constant" and tens is not None and outputs:
+                    out.setdefault(outputs[0], tens)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# graph family recognition
+# ---------------------------------------------------------------------------------------------------
+
+
+def infer_hparams(t):
+    """Hyper-parameters from tensor shapes (training/vits2/models.py:1503-1630 constructor wiring)."""
+    def need(name):
+        if name not in t:
+            raise KeyError(name)
+        return t[name]
+
+    try:
+        emb = need("enc_p.emb.weight")
+        hp = W.default_hparams(n_vocab=emb.shape[0])
+        hp.hidden_channels = emb.shape[1]
+        f1 = need("enc_p.encoder.ffn_layers.0.conv_1.weight")
+        hp.filter_channels, hp.kernel_size = f1.shape[0], f1.shape[2]
+        hp.n_layers = sum(1 for k in t if k.startswith("enc_p.encoder.attn_layers.") and k.endswith(".conv_q.weight"))
+        rel = need("enc_p.encoder.attn_layers.0.emb_rel_k")
+        hp.window_size = (rel.shape[1] - 1) // 2
+        hp.n_heads = hp.hidden_channels // rel.shape[2]
+        hp.inter_channels = need("enc_p.proj.weight").shape[0] // 2
+        if "emb_g.weight" in t:
+            hp.n_speakers, hp.gin_channels = t["emb_g.weight"].shape
+        else:
+            hp.n_speakers, hp.gin_channels = 0, 0
+        hp.enc_cond_layer = 2 if "enc_p.encoder.spk_emb_linear.weight" in t else -1
+        hp.dp_filter_channels = need("dp.pre.weight").shape[0]
+        hp.dp_kernel_size = need("dp.convs.convs_sep.0.weight").shape[2]
+        hp.dp_dds_layers = sum(1 for k in t if k.startswith("dp.convs.convs_sep.") and k.endswith(".weight"))
+        cf = sorted({int(k.split(".")[2]) for k in t if k.startswith("dp.flows.") and k.endswith(".proj.weight")})
+        hp.dp_n_flows = (max(cf) + 1) // 2 if cf else 4
+        hp.dp_num_bins = (need(f"dp.flows.{max(cf)}.proj.weight").shape[0] + 1) // 3
+        fl = sorted({int(k.split(".")[2]) for k in t if k.startswith("flow.flows.") and k.endswith(".pre.weight")})
+        hp.flow_n_flows = len(fl)
+        hp.flow_wn_layers = sum(1 for k in t if k.startswith("flow.flows.0.enc.in_layers.") and k.endswith(".weight"))
+        hp.flow_kernel_size = need("flow.flows.0.enc.in_layers.0.weight").shape[2]
+        hp.dec_initial_channel = need("dec.conv_pre.weight").shape[0]
+        ups = sorted({int(k.split(".")[2]) for k in t if k.startswith("dec.ups.") and k.endswith(".weight")})
+        hp.n_ups = len(ups)
+        for i in ups:
+            hp.up_kernels[i] = t[f"dec.ups.{i}.weight"].shape[2]
+        n_rb = len({int(k.split(".")[2]) for k in t if k.startswith("dec.resblocks.")})
+        hp.n_resk = n_rb // max(hp.n_ups, 1)
+        for j in range(hp.n_resk):
+            hp.res_kernels[j] = t[f"dec.resblocks.{j}.convs1.0.weight"].shape[2]
+        hp.n_resd = sum(1 for k in t if k.startswith("dec.resblocks.0.convs1.") and k.endswith(".weight"))
+        if "dec.subband_conv_post.weight" in t:
+            hp.dec_type = 0
+            post = t["dec.subband_conv_post.weight"].shape[0]
+            hp.istft_n_fft = post // hp.subbands - 2
+        elif "dec.conv_post.weight" in t:
+            hp.dec_type = 1
+        else:
+            raise KeyError("dec.subband_conv_post.weight / dec.conv_post.weight")
+    except KeyError as e:
+        raise NotImplementedError(
+            f"not an in-repo VITS2 graph: initializer {e.args[0]!r} not found (BERT / multistream flavours and graphs whose "
+            "parameters were constant-folded under anonymous names are outside this importer, SURVEY.md §8f)") from None
+    return hp
+
+
+def import_onnx(path_or_bytes, config=None):
+    """-> (HParams, {name: float32 ndarray}) restricted to the tensors the engine needs.
+
+    `config`: optional dict with the values that shapes cannot reveal — "upsample_rates",
+    "resblock_dilation_sizes", "gen_istft_hop_size", "subbands", "sampling_rate", "hop_length"
+    (keys of training/vits2/configs/*.json "model"/"data")."""
+    t = read_initializers(path_or_bytes)
+    if any(k.startswith(("bert", "enc_p.bert")) for k in t):
+        raise NotImplementedError("BERT-conditioned flavour: not part of the VITS2 hot path (SURVEY.md §8f rank 2)")
+    hp = infer_hparams(t)
+    config = config or {}
+    for i, r in enumerate(config.get("upsample_rates", [])):
+        hp.up_rates[i] = int(r)
+    for j, dl in enumerate(config.get("resblock_dilation_sizes", [])):
+        for d, v in enumerate(dl):
+            hp.res_dilations[j][d] = int(v)
+    for key, field in (("gen_istft_hop_size", "istft_hop"), ("subbands", "subbands"), ("sampling_rate", "sampling_rate"),
+                       ("hop_length", "hop_length")):
+        if key in config:
+            setattr(hp, field, int(config[key]))
+    tensors, missing, bad = {}, [], []
+    for name, shape, _kind, _fan, _gain in W.tensor_specs(hp):
+        if name not in t:
+            missing.append(name)
+            continue
+        a = np.asarray(t[name], dtype=np.float32)
+        if tuple(a.shape) != tuple(shape):
+            bad.append(f"{name}: {tuple(a.shape)} != {tuple(shape)}")
+            continue
+        tensors[name] = np.ascontiguousarray(a)
+    if missing or bad:
+        raise NotImplementedError("model.onnx does not match the VITS2 tensor inventory: "
+                                  f"{len(missing)} missing (e.g. {missing[:3]}), {len(bad)} with unexpected shapes (e.g. {bad[:2]})")
+    return hp, tensors
+
+
+def convert(onnx_path, blob_path, config=None):
+    hp, tensors = import_onnx(onnx_path, config)
+    W.save_blob(blob_path, hp, tensors)
+    return hp
+
+
+# tiny writer used by the tests (and handy for fixtures): the inverse of read_initializers for float32 tensors
+
+
+def _enc_varint(x):
+    out = bytearray()
+    while True:
+        b = x & 0x7F
+        x >>= 7
+        out.append(b | (0x80 if x else 0))
+        if not x:
+            return bytes(out)
+
+
+def _enc_field(fno, wt, payload):
+    if wt == 0:
+        return _enc_varint(fno << 3) + _enc_varint(payload)
+    return _enc_varint(fno << 3 | 2) + _enc_varint(len(payload)) + payload
+
+
+def write_minimal_onnx(path, tensors, use_float_data=()):
+    """ModelProto{ir_version, graph{initializer...}} with raw_data (or float_data for names in use_float_data)."""
+    graph = bytearray()
+    for name, a in tensors.items():
+        a = np.ascontiguousarray(a, dtype="<f4")
+        tp = b"".join(_enc_field(1, 0, int(d)) for d in a.shape) + _enc_field(2, 0, 1) + _enc_field(8, 2, name.encode())
+        if name in use_float_data:
+            tp += _enc_field(4, 2, a.tobytes())
+        else:
+            tp += _enc_field(9, 2, a.tobytes())
+        graph += _enc_field(5, 2, tp)
+    model = _enc_field(1, 0, 8) + _enc_field(7, 2, bytes(graph))
+    with open(path, "wb") as f:
+        f.write(model)
+    return path
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+
+    cfg = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
+    if cfg and "model" in cfg:
+        cfg = dict(cfg["model"], **cfg.get("data", {}))
+    h = convert(sys.argv[1], sys.argv[2], cfg)
+    print(f"wrote {sys.argv[2]}: hidden {h.hidden_channels}, {h.n_layers} layers, {h.n_speakers} speakers")
