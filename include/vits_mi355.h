@@ -210,9 +210,10 @@ int vits_stage_regulate(vits_model* m, const float* logw, const int32_t* forced_
  * z_p, z: [B,inter,T_y] contiguous */
 int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, int32_t B, int32_t T_y,
                     const int64_t* sid, float* z);
-/* a15-a20: dec((z*y_mask)) (models.py:1016-1054, :1703).  z [B,inter,T_y] already masked.
- * audio [B, T_y*hop_length]; audio_mb [B,subbands,T_y*hop/subbands] may be NULL. */
-int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t T_y, float* audio, float* audio_mb);
+/* a15-a21: dec((z*y_mask), g) (models.py:1016-1054 / 872-891, :1703).  z [B,inter,T_y] already masked.
+ * audio [B, T_y*hop_length]; audio_mb [B,subbands,T_y*hop/subbands] may be NULL.  sid is used only by the
+ * plain Generator variant (dec_type 1: x = conv_pre(x) + cond(g), models.py:873-875) and may be NULL. */
+int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t T_y, const int64_t* sid, float* audio, float* audio_mb);
 
 /* Single generic op for kernel-level parity: y = conv1d(act(x)) with the library's
  * main MFMA conv kernel.  x [B,C_in,T], w [C_out,C_in,K] (PyTorch layout), bias may be NULL.

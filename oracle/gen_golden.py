@@ -19,6 +19,8 @@ Cases
   enc_T{1,3,4,5,9}  text encoder at the relative-attention edge lengths (window 4)
   tiny_b3      scaled-down config (hidden 64, 3 layers, 5 speakers), B=3 ragged
   consts       OnnxSTFT.inverse_basis and PQMF.synthesis_filter buffers
+  plain_b2     the plain HiFi-GAN `Generator` decoder variant (models.py:845-898) with speaker conditioning,
+               ups [8,8,2,2]: reference Generator module alone, B=2
   g2p          known answers of vosk_tts/g2p.py:convert (examples at g2p.py:5-11 + extra words)
 """
 import importlib.util
@@ -146,6 +148,26 @@ def main():
     ids = rng.integers(1, thp.n_vocab, size=(3, 20))
     dur = rng.integers(0, 4, size=(3, 20))
     full_case(tnet, thp, "tiny_b3", ids, np.array([20, 7, 13]), np.array([0, 4, 2]), [0.5, 0.9, 0.7], dur, rng)
+    # ---- plain Generator variant: the reference module alone
+    print("plain Generator:")
+    php = W.plain_hparams()
+    ptens = W.make_synthetic_weights(php, SEED)
+    models = refimport.ref_modules()["models"]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        gen = models.Generator(php.inter_channels, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 2, 2], php.dec_initial_channel,
+                               [16, 16, 4, 4], gin_channels=php.gin_channels).eval()
+        gen.remove_weight_norm()
+    sd = gen.state_dict()
+    with torch.no_grad():
+        for k in sd:
+            sd[k].copy_(torch.from_numpy(ptens["dec." + k]))
+    z = rng.standard_normal((2, php.inter_channels, 12)).astype(np.float32)
+    sid = np.array([1, 3], np.int64)
+    with torch.no_grad():
+        g = torch.from_numpy(ptens["emb_g.weight"][sid]).unsqueeze(-1)
+        audio = gen(torch.from_numpy(z), g=g)
+    save("plain_b2", z=z, sid=sid, audio=audio.numpy()[:, 0])
     # ---- g2p known answers (vosk_tts/g2p.py; imported by file path: the package itself needs onnxruntime)
     spec = importlib.util.spec_from_file_location("ref_g2p", os.path.join(refimport.REF_ROOT, "vosk_tts", "g2p.py"))
     g2p = importlib.util.module_from_spec(spec)

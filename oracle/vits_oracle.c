@@ -811,7 +811,7 @@ static void resblock1(vits_model* m, int idx, float* x, int B, int C, int T, int
 }
 
 /* Multiband_iSTFT_Generator.forward (models.py:1016-1054) / Generator.forward (models.py:872-891) */
-int API(stage_decoder)(vits_model* m, const float* z, int32_t B, int32_t T, float* audio, float* audio_mb) {
+int API(stage_decoder)(vits_model* m, const float* z, int32_t B, int32_t T, const int64_t* sid, float* audio, float* audio_mb) {
   if (!m || !z || !audio || B <= 0 || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
   const vits_hparams* hp = &m->hp;
   int I = hp->inter_channels, C = hp->dec_initial_channel;
@@ -821,6 +821,22 @@ int API(stage_decoder)(vits_model* m, const float* z, int32_t B, int32_t T, floa
   if (m->missing) return VITS_ERR_BLOB;
   float* x = falloc((size_t)B * C * T);
   conv1d(z, B, I, T, w, bi, C, 7, 1, 3, T, x);
+  if (hp->dec_type == 1 && hp->gin_channels > 0 && hp->n_speakers > 1) { /* x = x + cond(g) (models.py:873-875) */
+    int G = hp->gin_channels;
+    const float* cw = tget(m, 3, C, G, 1, "dec.cond.weight");
+    const float* cb = tget(m, 1, C, -1, -1, "dec.cond.bias");
+    float* g = falloc((size_t)B * G);
+    int rc = m->missing ? VITS_ERR_BLOB : speaker_g(m, sid, B, g);
+    if (rc) { free(g); free(x); return rc; }
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c) {
+        float a = cb[c];
+        for (int j = 0; j < G; ++j) a += cw[(size_t)c * G + j] * g[(size_t)b * G + j];
+        float* p = x + ((size_t)b * C + c) * T;
+        for (int t = 0; t < T; ++t) p[t] += a;
+      }
+    free(g);
+  }
   int Tc = T;
   for (int i = 0; i < hp->n_ups && !m->missing; ++i) {
     int u = hp->up_rates[i], k = hp->up_kernels[i], Co = C / 2;
@@ -1043,7 +1059,7 @@ int API(synthesize)(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   mul_mask(z, B, I, (int)Ty, ylen); /* (z * y_mask) models.py:1703 */
   int64_t up = hp->hop_length;
   audio = (float*)malloc(sizeof(float) * (size_t)B * Ty * up);
-  rc = API(stage_decoder)(m, z, B, (int32_t)Ty, audio, NULL);
+  rc = API(stage_decoder)(m, z, B, (int32_t)Ty, sid, audio, NULL);
   if (rc) { free(audio); audio = NULL; goto done; }
   *out_audio = audio;
   *out_samples = Ty * up;

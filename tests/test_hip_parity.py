@@ -146,6 +146,27 @@ def test_both_attention_kernels(hip_lib, hip_default, hip_tiny, oracle_default, 
         hip_lib.lib.vits_debug_attention_impl(0)
 
 
+def test_plain_generator_variant(hip_lib, oracle_lib):
+    """SURVEY.md 8a row a21 on the GPU: plain HiFi-GAN Generator tail (conv_post -> tanh), speaker conditioning
+    after conv_pre, polyphase upsampling with u = 8 and u = 2; stage level vs golden and end to end vs the oracle."""
+    from vosk_tts_amd import weights as W
+
+    blob = W.synthetic_blob(W.plain_hparams(), 1234)
+    g = golden("plain_b2")
+    hip, ref = hip_lib.create(blob, 0), oracle_lib.create(blob)
+    audio, _ = hip.decoder(g["z"], sid=g["sid"])
+    assert_close("audio(golden)", g["audio"], audio, STAGE_TOL)
+    rng = np.random.default_rng(4)
+    ids = rng.integers(1, 20, size=(2, 9)).astype(np.int64)
+    lens = np.array([9, 6], np.int64); sid = np.array([0, 4], np.int64)
+    dur = rng.integers(1, 4, size=(2, 9)).astype(np.int32)
+    a_ref, l_ref = ref.synthesize(ids, lens, [0.667, 1.0, 0.8], sid, forced_durations=dur, seed=3)
+    a_hip, l_hip = hip.synthesize(ids, lens, [0.667, 1.0, 0.8], sid, forced_durations=dur, seed=3)
+    assert np.array_equal(l_ref, l_hip)
+    assert_close("waveform", a_ref, a_hip, E2E_TOL)  # dec_type 1 is decoded densely (no ragged skipping)
+    hip.close()
+
+
 def test_free_running_infer_golden(hip_default):
     g = golden("free_c1")
     audio, olen = hip_default.synthesize(g["ids"], g["lengths"], g["scales"], g["sid"], noise_dp=g["noise_dp"],

@@ -74,6 +74,17 @@ def test_encoder_relative_window_edges(oracle_default, T):
     assert_close("m_p", g["m_p_tok"], m_p, TOL)
 
 
+def test_plain_generator_variant(oracle_lib):
+    """Generator (models.py:845-898) incl. x = conv_pre(x) + cond(g), tanh tail, ups [8,8,2,2]."""
+    from vosk_tts_amd import weights as W
+
+    g = golden("plain_b2")
+    m = oracle_lib.create(W.synthetic_blob(W.plain_hparams(), 1234))
+    audio, mb = m.decoder(g["z"], sid=g["sid"])
+    assert mb is None and audio.shape == g["audio"].shape
+    assert_close("audio", g["audio"], audio, TOL)
+
+
 def test_constants(oracle_lib, oracle_default):
     import ctypes
 

@@ -95,7 +95,7 @@ class VitsLib:
                                         ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_float, ctypes.c_int32, c_i32p,
                                         c_i64p, c_f32p]
         f("stage_flow").argtypes = [ctypes.c_void_p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p]
-        f("stage_decoder").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p]
+        f("stage_decoder").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p, c_f32p]
         f("op_conv1d").argtypes = [ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p]
         f("algorithmic_flops").argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
@@ -234,15 +234,16 @@ class VitsModel:
                                                   _p(z, c_f32p)))
         return z
 
-    def decoder(self, z, want_mb=True):
+    def decoder(self, z, want_mb=True, sid=None):
         z = _f32(z)
         B, _, T = z.shape
+        sid = _i64(sid) if sid is not None else None
         hop = self.hp.hop_length
         audio = np.empty((B, T * hop), np.float32)
         mb = None
         if want_mb and self.hp.dec_type == 0:
             mb = np.empty((B, self.hp.subbands, T * hop // self.hp.subbands), np.float32)
-        self.lib.check(self.lib._fn("stage_decoder")(self._h, _p(z, c_f32p), B, T, _p(audio, c_f32p), _p(mb, c_f32p)))
+        self.lib.check(self.lib._fn("stage_decoder")(self._h, _p(z, c_f32p), B, T, _p(sid, c_i64p), _p(audio, c_f32p), _p(mb, c_f32p)))
         return audio, mb
 
     def algorithmic_flops(self, B, Tx, Ty):

@@ -109,7 +109,7 @@ struct vits_model {
 
   float *emb = nullptr, *emb_g = nullptr;
   float *cond_W = nullptr, *cond_b = nullptr;  // all cond(g)/Linear(g) matrices row-concatenated
-  int cond_rows = 0, cond_enc_off = -1, cond_dp_off = -1;
+  int cond_rows = 0, cond_enc_off = -1, cond_dp_off = -1, cond_dec_off = -1;
   EncoderW enc_p;
   ConvW enc_proj;
   ConvW dp_pre, dp_proj;
@@ -329,6 +329,9 @@ static int load_model(vits_model* m) {
     snprintf(nm, sizeof nm, "flow.flows.%d.post", 2 * f);
     c.post = conv_from(m, nm, I / 2, H, 1, true);
   }
+  if (m->use_g && hp.dec_type == 1)  // Generator.cond (models.py:869-870, 873-875)
+    m->cond_dec_off = add_cond(tget(m, 3, hp.dec_initial_channel, G, 1, "dec.cond.weight"),
+                               tget(m, 1, hp.dec_initial_channel, -1, -1, "dec.cond.bias"), hp.dec_initial_channel);
   if (m->missing) return VITS_ERR_BLOB;
   m->cond_rows = (int)cB.size();
   if (m->cond_rows) { m->cond_W = upload(m, cW.data(), cW.size()); m->cond_b = upload(m, cB.data(), cB.size()); }
@@ -655,6 +658,32 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
   hipStream_t st = s->stream;
+#ifdef CONV_TIMING
+  // timing build only: VITS_DBG_LAUNCH=<i> attaches the phase-stamp buffer to the i-th conv launch of the process
+  // and prints the stamps (cycles since kernel start, block 0) right after it
+  static long dbg_counter = 0;
+  static const long dbg_want = getenv("VITS_DBG_LAUNCH") ? atol(getenv("VITS_DBG_LAUNCH")) : -1;
+  static long long* dbg_buf = nullptr;
+  const bool dbg_this = (dbg_counter++ == dbg_want);
+  if (dbg_this) {
+    if (!dbg_buf) hipMalloc((void**)&dbg_buf, 64 * sizeof(long long));
+    hipMemsetAsync(dbg_buf, 0, 64 * sizeof(long long), st);
+    P.dbg = dbg_buf;
+  }
+  struct DbgPrint {
+    bool on; hipStream_t st; long long* buf; const char* name; int M, Cin, K, T, B;
+    ~DbgPrint() {
+      if (!on) return;
+      long long h[64];
+      hipStreamSynchronize(st);
+      hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[in-forward conv dbg] %s M=%d Cin=%d K=%d T=%d B=%d\n", name, M, Cin, K, T, B);
+      for (int w = 0; w < 4; ++w)
+        fprintf(stderr, "   wave %d: +%lld first-loads-issued  +%lld loop_done  +%lld barrier  +%lld reduced  +%lld end\n", w, h[w * 8 + 1] - h[w * 8],
+                h[w * 8 + 2] - h[w * 8], h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8]);
+    }
+  } dbg_print{dbg_this, st, dbg_buf, name, P.Cout, P.Cin, P.g[0].K, P.Tout, P.B};
+#endif
   // heaviest group first (longest-processing-time order; see the big-tile kernel's block decode)
   for (int a = 0; a < P.n_groups; ++a)
     for (int c = a + 1; c < P.n_groups; ++c)
@@ -948,6 +977,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
   float* cur = s->dec_bufs[0];
   ConvParams P = conv_params(m->conv_pre, z, cur, B, Ty, 1, 3);
   if (mask_in) { P.in_mask = 1; P.len = s->len_y; }  // (z * y_mask) models.py:1703
+  if (m->cond_dec_off >= 0) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dec_off; }  // + cond(g)
   set_rag(P, rag, 1, 0, 1, 0);
   launch_conv(s, P, EPI_STORE, "dec.conv_pre");
   const float* in1 = cur; const float* in2 = nullptr; const float* in3 = nullptr;
@@ -1265,7 +1295,7 @@ int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, i
   return check_err(s);
 }
 
-int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, float* audio, float* audio_mb) {
+int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, const int64_t* sid, float* audio, float* audio_mb) {
   if (!m || !z || !audio || B <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
   HostStage hs(m);
   TRY(begin_stage(hs, B, 1, Ty));
@@ -1274,6 +1304,7 @@ int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, flo
   const int I = hp.inter_channels;
   const long long S = (long long)Ty * hp.hop_length;
   HIP_TRY(hipMemcpyAsync(s->zA, z, sizeof(float) * (size_t)B * I * Ty, hipMemcpyHostToDevice, s->stream));
+  if (m->cond_dec_off >= 0) { int64_t* d_sid = hs.to_dev(sid, B); run_cond(s, d_sid, B); }
   float* d_audio = hs.dev_alloc<float>((size_t)B * S);
   if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
   run_decoder(s, s->zA, false, B, Ty, d_audio, S, nullptr);

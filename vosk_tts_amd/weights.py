@@ -154,6 +154,18 @@ def tiny_hparams(n_vocab=20):
     return hp
 
 
+def plain_hparams(n_vocab=20):
+    """Tiny graph with the plain HiFi-GAN `Generator` decoder (models.py:845-898) and the classic V1
+    upsampling [8,8,2,2] / kernels [16,16,4,4] — SURVEY.md §8a row a21."""
+    hp = tiny_hparams(n_vocab)
+    hp.dec_type = 1
+    hp.dec_initial_channel = 512
+    hp.n_ups = 4
+    for i, (u, k) in enumerate(((8, 16), (8, 16), (2, 4), (2, 4))):
+        hp.up_rates[i], hp.up_kernels[i] = u, k
+    return hp
+
+
 # --------------------------------------------------------------------------- #
 # tensor inventory
 # --------------------------------------------------------------------------- #
@@ -231,6 +243,8 @@ def tensor_specs(hp):
         conv("dec.subband_conv_post", hp.subbands * (hp.istft_n_fft + 2), ch, 7, bias=False, gain=0.5)
     else:
         conv("dec.conv_post", 1, ch, 7, bias=False, gain=0.5)
+        if G > 0 and hp.n_speakers > 1:
+            conv("dec.cond", C0, G, 1)  # Generator.cond (models.py:869-870)
 
     # flow (models.py:329-396, 630-762); only even indices carry weights
     for f in range(hp.flow_n_flows):
