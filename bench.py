@@ -196,6 +196,24 @@ def main():
             "by_op_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])},
         }
 
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected
+        # by tools/pmc_passes.sh (separate rocprofv3 --pmc passes of THIS command, FETCH_SIZE/WRITE_SIZE calibrated with
+        # tools/pmc_calib as MI355X_MICROARCH.md prescribes) and committed as profiles/r1_pmc_<workload>.json.
+        pmc_path = os.path.join(ROOT, "profiles", f"r1_pmc_{wname}.json")
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as f:
+                    pk = json.load(f)["kernels"].get(dom_name)
+                if pk and "hbm_bytes_per_launch" in pk:
+                    roofline["traffic"] = round(pk["hbm_bytes_per_launch"])
+                    roofline["traffic_unit"] = "HBM bytes per launch (PMC, committed measurement)"
+                    roofline["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+                    roofline["hbm_gbps_at_avg_launch"] = round(pk["hbm_bytes_per_launch"] / (fam_ms / max(fam_launches, 1) * 1e-3) / 1e9, 1)
+                    if "mfma_flops_per_launch" in pk:
+                        roofline["mfma_flops_executed_per_launch_pmc"] = pk["mfma_flops_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
+
         sess.close()
         return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
                     ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales)
@@ -210,7 +228,7 @@ def main():
                    "x_realtime": round(1.0 / R3["rtf"], 1), "batch": R3["B"], "T_x": R3["Tx"], "T_y": R3["Ty"],
                    "samples_per_step_per_gpu": R3["valid_samples"],
                    "workload": "c3: B=32 ragged 20..200 tokens padded, durations pinned 3/token, fp32",
-                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "forward")}}
+                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_gbps_at_avg_launch", "kernel", "avg_launch_us", "forward") if k in R3["roofline"]}}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
