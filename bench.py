@@ -230,6 +230,31 @@ def main():
                    "workload": "c3: B=32 ragged 20..200 tokens padded, durations pinned 3/token, fp32",
                    "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_gbps_at_avg_launch", "kernel", "avg_launch_us", "forward") if k in R3["roofline"]}}
 
+    streaming = None
+    if args.workload == "c5" and rank == 0:
+        # configs[4]: chunked streaming through the host API (vits_stream_*): time to first audio on the host and
+        # total time for all chunks, next to the one-shot host call (both include H2D of ids and D2H of audio).
+        chunk = 128
+        sc = np.array([0.8, 1.0, 0.8], np.float32)
+        ttfa, total, oneshot = [], [], []
+        for it in range(6):
+            t0 = time.perf_counter()
+            g = model.stream(ids[:1], sc, 2, chunk_frames=chunk, forced_durations=dur[:1], seed=7)
+            first = next(g)
+            t1 = time.perf_counter()
+            n = len(first) + sum(len(c) for c in g)
+            t2 = time.perf_counter()
+            c0 = time.perf_counter()
+            a, _ = model.synthesize(ids[:1], lengths[:1], sc, [2], forced_durations=dur[:1], seed=7)
+            c1 = time.perf_counter()
+            assert n == a.shape[1]
+            if it:  # first iteration warms the graph capture and the workspace
+                ttfa.append((t1 - t0) * 1e3); total.append((t2 - t0) * 1e3); oneshot.append((c1 - c0) * 1e3)
+        streaming = {"chunk_frames": chunk, "chunk_sec": round(chunk * 256 / SAMPLE_RATE, 3), "chunks": -(-Ty // chunk),
+                     "time_to_first_audio_ms": round(float(np.median(ttfa)), 3), "all_chunks_ms": round(float(np.median(total)), 3),
+                     "one_shot_host_call_ms": round(float(np.median(oneshot)), 3),
+                     "note": "host API incl. H2D/D2H; acoustic half once over the utterance, decoder hipGraph replayed per chunk"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # TEST-INFRASTRUCTURE leg: the CPU oracle (plain C restatement of the reference arithmetic)
@@ -267,7 +292,7 @@ def main():
                                    f"-> T_y={Ty}, {valid_samples} valid samples/step/GPU, sid=2, scales=[0.8,1.0,0.8]",
                        "batch": B, "T_x": Tx, "T_y": Ty, "samples_per_step_per_gpu": valid_samples,
                        "parallelism": f"replicas x{world} (no collective)", "hipgraph": not args.no_graph},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "batch32": batch32,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "batch32": batch32, "streaming": streaming,
         }
         print(json.dumps(line))
     if dist is not None:

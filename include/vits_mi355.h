@@ -164,6 +164,21 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths,
                     float** out_audio, int64_t* out_samples, int64_t* out_lengths);
 void vits_free_output(float* p);
 
+/* ---- streaming synthesis of one utterance --------------------------------------------------
+ * BASELINE.json configs[4] ("long-form streaming synthesis, chunked flow+vocoder") and the transport the reference
+ * already declares: `rpc ... returns (stream AudioChunk)` (server/tts_service.proto:46-54,91-95; tts_server.py:54
+ * currently sends the whole utterance as one chunk).  vits_stream_open runs SynthesizerTrn.infer up to the flow
+ * (models.py:1680-1701) over the whole utterance -- the flow's attention is global -- and returns the total sample
+ * count; each vits_stream_next returns the next chunk_frames*hop_length samples (fewer for the last chunk, 0 at the
+ * end), decoded by replaying one captured hipGraph of the decoder over a frame window with a 32-frame halo, while the
+ * following chunk is already decoding.  The concatenated chunks equal the one-shot vits_synthesize output (decoder
+ * receptive field < 25 frames).  B = 1; opts as for vits_synthesize. */
+typedef struct vits_stream vits_stream;
+int vits_stream_open(vits_model* m, const int64_t* ids, int32_t T_x, const float* scales, int64_t sid,
+                     const vits_synth_opts* opts, int32_t chunk_frames, vits_stream** out, int64_t* total_samples);
+int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n_samples);
+void vits_stream_close(vits_stream* st);
+
 /* Device-resident variant used by bench.py: ids/lengths/sid already in HBM
  * (int64 device pointers), audio written to a caller-provided device buffer
  * [B, audio_capacity].  Durations must be forced (device int32 [B,T_x]) or

@@ -309,3 +309,43 @@ def test_decoder_linearity_free_property_large(hip_default):
     a = full[:, lo * 256:hi * 256]
     b = part[:, halo * 256:(halo + hi - lo) * 256]
     assert_close("chunked decode", a, b, 1e-4)
+
+
+@pytest.mark.parametrize("chunk", [16, 37, 200])
+def test_streaming_chunks_equal_one_shot(hip_default, oracle_default, chunk):
+    """vits_stream_* (BASELINE configs[4]): decoding fixed-width frame windows with a 32-frame halo and emitting only
+    the interior reproduces the one-shot waveform (decoder receptive field < 25 frames); chunk sizes
+    smaller than, not dividing, and larger than T_y; checked against the one-shot HIP result and the oracle."""
+    rng = np.random.default_rng(11)
+    Tx = 40
+    ids = rng.integers(1, 62, size=(1, Tx)).astype(np.int64)
+    dur = rng.integers(1, 6, size=(1, Tx)).astype(np.int32)
+    Ty = int(dur.sum())
+    scales = [0.667, 1.0, 0.8]
+    one, olen = hip_default.synthesize(ids, [Tx], scales, [2], forced_durations=dur, seed=5)
+    chunks = list(hip_default.stream(ids, scales, 2, chunk_frames=chunk, forced_durations=dur, seed=5))
+    assert all(len(c) == chunk * 256 for c in chunks[:-1]) and 0 < len(chunks[-1]) <= chunk * 256
+    assert len(chunks) == -(-Ty // chunk)
+    got = np.concatenate(chunks)[None]
+    assert got.shape == one.shape == (1, Ty * 256)
+    assert_close("stream vs one-shot", one, got, 2e-5)
+    ref, _ = oracle_default.synthesize(ids, [Tx], scales, [2], forced_durations=dur, seed=5)
+    assert_close("stream vs oracle", ref, got, E2E_TOL)
+
+
+def test_streaming_free_running_and_errors(hip_default):
+    """free-running durations (device Philox) size the stream; bad ids surface at open; early close is clean"""
+    from vosk_tts_amd.capi import VitsError
+
+    rng = np.random.default_rng(12)
+    ids = rng.integers(1, 62, size=(1, 30)).astype(np.int64)
+    one, _ = hip_default.synthesize(ids, [30], [0.8, 1.0, 0.8], [3], seed=9)
+    got = np.concatenate(list(hip_default.stream(ids, [0.8, 1.0, 0.8], 3, chunk_frames=24, seed=9)))[None]
+    assert got.shape == one.shape
+    assert_close("free-running stream", one, got, 2e-5)
+    with pytest.raises(VitsError, match="token id"):
+        next(hip_default.stream(np.array([[999]]), [0.8, 1.0, 0.8], 0))
+    g = hip_default.stream(ids, [0.8, 1.0, 0.8], 3, chunk_frames=8, seed=9)
+    first = next(g)
+    g.close()  # generator finalizer -> vits_stream_close with chunks still pending
+    assert_close("first chunk", one[0, :2048], first, 2e-5)

@@ -235,3 +235,26 @@ def test_device_session_graph_replay_matches_host_path(hip_default):
         for b in range(B):  # identical on every valid sample; beyond len + halo both are zeros
             assert_close(f"device session item {b}", want[b, :wl[b]], got[b, :wl[b]], 1e-6)
     s.close()
+
+
+@pytest.mark.gpu
+def test_synth_stream_matches_synth_audio(tmp_path):
+    """Synth.synth_stream: int16 chunks whose concatenation is synth_audio's PCM for the same seed."""
+    import itertools
+
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), W.tiny_hparams(n_vocab=len(PHONEMES)))
+    model = Model(model_path=d, device=0)
+    synth = Synth(model)
+    text = "прив+ет, м+ир! сег+одня хор+ошая пог+ода."
+    model.onnx._seed = itertools.count(5)
+    whole = synth.synth_audio(text, speaker_id=1, scale=0.9)
+    model.onnx._seed = itertools.count(5)
+    chunks = list(synth.synth_stream(text, speaker_id=1, scale=0.9, chunk_frames=8))
+    assert len(chunks) > 1 and all(c.dtype == np.int16 for c in chunks)
+    got = np.concatenate(chunks)
+    assert got.shape == whole.shape
+    assert np.max(np.abs(got.astype(np.int32) - whole.astype(np.int32))) <= 1  # float tolerance -> at most 1 LSB

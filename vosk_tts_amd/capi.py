@@ -111,6 +111,11 @@ class VitsLib:
                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64,
                 ctypes.c_void_p]
             f("session_last_ms").argtypes = [ctypes.c_void_p, c_f32p]
+            f("stream_open").argtypes = [ctypes.c_void_p, c_i64p, ctypes.c_int32, c_f32p, ctypes.c_int64,
+                                         ctypes.POINTER(SynthOpts), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), c_i64p]
+            f("stream_next").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int64, c_i64p]
+            f("stream_close").argtypes = [ctypes.c_void_p]
+            f("stream_close").restype = None
 
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -149,17 +154,7 @@ class VitsModel:
         except Exception:
             pass
 
-    # ---- the hot path -----------------------------------------------------
-    def synthesize(self, ids, lengths, scales, sid, noise_dp=None, noise_prior=None, forced_durations=None, seed=0,
-                   max_frames=0):
-        """One .run(): returns (audio float32 [B,S], out_lengths int64 [B])."""
-        ids = _i64(ids)
-        B, Tx = ids.shape
-        lengths = _i64(lengths)
-        sid = _i64(sid)
-        scales = _f32(scales)
-        if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
-            raise ValueError("bad feed shapes")
+    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames):
         opts = SynthOpts()
         keep = []
         if noise_dp is not None:
@@ -180,6 +175,20 @@ class VitsModel:
             opts.forced_durations = _p(a, c_i32p)
         opts.seed = seed
         opts.max_frames = max_frames
+        return opts, keep
+
+    # ---- the hot path -----------------------------------------------------
+    def synthesize(self, ids, lengths, scales, sid, noise_dp=None, noise_prior=None, forced_durations=None, seed=0,
+                   max_frames=0):
+        """One .run(): returns (audio float32 [B,S], out_lengths int64 [B])."""
+        ids = _i64(ids)
+        B, Tx = ids.shape
+        lengths = _i64(lengths)
+        sid = _i64(sid)
+        scales = _f32(scales)
+        if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
+            raise ValueError("bad feed shapes")
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames)
         out = c_f32p()
         ns = ctypes.c_int64()
         olen = np.zeros(B, dtype=np.int64)
@@ -191,6 +200,32 @@ class VitsModel:
         finally:
             self.lib._fn("free_output")(out)
         return audio, olen
+
+    def stream(self, ids, scales, sid, chunk_frames=64, noise_dp=None, noise_prior=None, forced_durations=None, seed=0):
+        """Streaming synthesis of ONE utterance (vits_stream_*): a generator of float32 chunks of
+        chunk_frames*hop_length samples (the last one shorter); their concatenation equals synthesize()."""
+        if not self.lib.has("stream_open"):
+            raise VitsError(-1, "this backend has no streaming entry points")
+        ids = _i64(ids).reshape(1, -1)
+        Tx = ids.shape[1]
+        scales = _f32(scales)
+        opts, keep = self._opts(1, Tx, noise_dp, noise_prior, forced_durations, seed, 0)
+        L = self.lib
+        st = ctypes.c_void_p()
+        total = ctypes.c_int64()
+        L.check(L._fn("stream_open")(self._h, _p(ids, c_i64p), Tx, _p(scales, c_f32p), int(sid), ctypes.byref(opts),
+                                     int(chunk_frames), ctypes.byref(st), ctypes.byref(total)))
+        cap = int(chunk_frames) * self.hp.hop_length
+        n = ctypes.c_int64()
+        try:
+            while True:
+                buf = np.empty(cap, np.float32)
+                L.check(L._fn("stream_next")(st, _p(buf, c_f32p), cap, ctypes.byref(n)))
+                if n.value == 0:
+                    break
+                yield buf[:n.value]
+        finally:
+            L._fn("stream_close")(st)
 
     # ---- stage-level entry points (parity tests) ---------------------------
     def text_encoder(self, ids, lengths, sid):

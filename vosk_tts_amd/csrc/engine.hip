@@ -1315,15 +1315,15 @@ int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, con
 }
 
 // ---- the hot path, host buffers (SynthesizerTrn.infer, models.py:1679-1704)
-int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
-                    const int64_t* sid, const vits_synth_opts* opts, float** out_audio, int64_t* out_samples, int64_t* out_lengths) {
-  if (!m || !ids || !lengths || !scales || !out_audio || !out_samples || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
-  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+// Everything up to and including the flow (models.py:1680-1701) for host inputs: leaves z [B,inter,T_y] in the
+// session workspace (masked by the decoder's first staging), the per-item frame counts in ylen.
+static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                         const int64_t* sid, const vits_synth_opts* opts, std::vector<int64_t>& ylen, int64_t& Ty_out, float*& z_out) {
+  vits_model* m = hs.m;
   const vits_hparams& hp = m->hp;
   const int I = hp.inter_channels;
   const float noise_scale = scales[0], length_scale = scales[1], noise_scale_w = scales[2];
   const uint64_t seed = opts ? opts->seed : 0;
-  HostStage hs(m);
   TRY(begin_stage(hs, B, Tx, 1));
   vits_session* s = hs.s;
   int64_t* d_ids = hs.to_dev(ids, (size_t)B * Tx);
@@ -1345,7 +1345,7 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   }
   run_durations(s, d_forced, length_scale, B, Tx, 0);
   // the one host round trip of the free-running path: T_y sizes everything downstream
-  std::vector<int64_t> ylen(B);
+  ylen.assign(B, 0);
   HIP_TRY(hipMemcpyAsync(ylen.data(), s->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s->stream));
   TRY(check_err(s));
   int64_t Ty = 1;
@@ -1379,7 +1379,24 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
     if (!d_npr) return fail(VITS_ERR_NOMEM, "device alloc failed");
   }
   run_expand(s, d_npr, nstride, noise_scale, seed, s->zA, B, Tx, (int)Ty);
-  float* z = run_flow(s, B, (int)Ty);
+  z_out = run_flow(s, B, (int)Ty);
+  Ty_out = Ty;
+  return VITS_OK;
+}
+
+int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                    const int64_t* sid, const vits_synth_opts* opts, float** out_audio, int64_t* out_samples, int64_t* out_lengths) {
+  if (!m || !ids || !lengths || !scales || !out_audio || !out_samples || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+  const vits_hparams& hp = m->hp;
+  HostStage hs(m);
+  std::vector<int64_t> ylen;
+  int64_t Ty = 0;
+  float* z = nullptr;
+  TRY(acoustic_host(hs, ids, lengths, B, Tx, scales, sid, opts, ylen, Ty, z));
+  vits_session* s = hs.s;
+  s->ragged = B > 1;
+  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; } } ragged_off{s};
   const int64_t S = Ty * hp.hop_length;
   float* d_audio = hs.dev_alloc<float>((size_t)B * S);
   if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
@@ -1396,6 +1413,114 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
 }
 
 void vits_free_output(float* p) { free(p); }
+
+// ---- streaming synthesis (BASELINE configs[4]; the server's `stream AudioChunk`, tts_service.proto:46-54)
+// The flow has global attention, so the acoustic half runs once over the whole utterance; the decoder is purely
+// convolutional with a receptive field < 25 frames, so it is run on fixed-width frame windows
+// [lo - halo, hi + halo) and only the samples of [lo, hi) are emitted -- identical to the one-shot decode.  Every
+// window has the same width W = chunk + 2*halo (clamped to the utterance at both ends, where the true zero padding
+// applies), so ONE captured hipGraph of the decoder is replayed per chunk; the next chunk is decoded while the
+// caller consumes the current one.
+struct vits_stream {
+  vits_model* m = nullptr;
+  HostStage* hs = nullptr;          // acoustic session + temporaries; z lives in its workspace
+  const float* z = nullptr;
+  int Ty = 0, chunk = 0, W = 0, halo = VITS_RAGGED_HALO;
+  int pos = 0;                      // first frame not yet handed to the caller
+  int win_start = -1;               // frame window currently decoded (or in flight) in d_aud
+  float *d_win = nullptr, *d_aud = nullptr, *h_pin = nullptr;
+  hipGraphExec_t graph = nullptr;
+  hipEvent_t ev = nullptr;
+};
+
+static int stream_window_start(const vits_stream* st, int lo) {
+  int start = lo - st->halo;
+  if (start > st->Ty - st->W) start = st->Ty - st->W;
+  return start < 0 ? 0 : start;
+}
+
+// enqueues the decode of the window that covers chunk [lo, ...) unless d_aud already holds it
+static int stream_launch(vits_stream* st, int lo) {
+  vits_session* s = st->hs->s;
+  const int start = stream_window_start(st, lo);
+  if (start == st->win_start) return VITS_OK;
+  const int I = st->m->hp.inter_channels;
+  hipLaunchKernelGGL(window_copy_kernel, dim3(cdiv(st->W, 256), I), dim3(256), 0, s->stream, st->z, (long long)st->Ty, start, st->W, st->d_win);
+  if (!st->graph) {
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    run_decoder(s, st->d_win, false, 1, st->W, st->d_aud, (long long)st->W * st->m->hp.hop_length, nullptr);
+    HIP_TRY(hipStreamEndCapture(s->stream, &g));
+    HIP_TRY(hipGraphInstantiate(&st->graph, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+  }
+  HIP_TRY(hipGraphLaunch(st->graph, s->stream));
+  st->win_start = start;
+  return VITS_OK;
+}
+
+void vits_stream_close(vits_stream* st) {
+  if (!st) return;
+  hipSetDevice(st->m->device);
+  if (st->hs && st->hs->s) hipStreamSynchronize(st->hs->s->stream);
+  if (st->graph) hipGraphExecDestroy(st->graph);
+  if (st->ev) hipEventDestroy(st->ev);
+  if (st->h_pin) hipHostFree(st->h_pin);
+  delete st->hs;  // frees d_win/d_aud and returns the session to the pool
+  delete st;
+}
+
+int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const vits_synth_opts* opts,
+                     int32_t chunk_frames, vits_stream** out, int64_t* total_samples) {
+  if (!m || !ids || !scales || !out || Tx <= 0 || chunk_frames <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  vits_stream* st = new vits_stream();
+  st->m = m;
+  st->hs = new HostStage(m);
+  std::vector<int64_t> ylen;
+  int64_t Ty = 0, len = Tx;
+  float* z = nullptr;
+  int rc = acoustic_host(*st->hs, ids, &len, 1, Tx, scales, &sid, opts, ylen, Ty, z);
+  if (rc != VITS_OK) { vits_stream_close(st); return rc; }
+  const vits_hparams& hp = m->hp;
+  st->z = z;
+  st->Ty = (int)Ty;
+  st->chunk = chunk_frames;
+  st->W = chunk_frames + 2 * st->halo;
+  if (st->W > st->Ty) st->W = st->Ty;
+  st->d_win = st->hs->dev_alloc<float>((size_t)hp.inter_channels * st->W);
+  st->d_aud = st->hs->dev_alloc<float>((size_t)st->W * hp.hop_length);
+  if (!st->d_win || !st->d_aud || hipHostMalloc((void**)&st->h_pin, sizeof(float) * (size_t)chunk_frames * hp.hop_length) != hipSuccess ||
+      hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) {
+    vits_stream_close(st);
+    return fail(VITS_ERR_NOMEM, "stream buffers");
+  }
+  rc = stream_launch(st, 0);  // first chunk is already decoding when the caller asks for it
+  if (rc != VITS_OK) { vits_stream_close(st); return rc; }
+  if (total_samples) *total_samples = Ty * hp.hop_length;
+  *out = st;
+  return VITS_OK;
+}
+
+int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n_samples) {
+  if (!st || !audio || !n_samples) return fail(VITS_ERR_ARG, "bad argument");
+  *n_samples = 0;
+  if (st->pos >= st->Ty) return VITS_OK;  // end of stream
+  HIP_TRY(hipSetDevice(st->m->device));
+  vits_session* s = st->hs->s;
+  const int hop = st->m->hp.hop_length;
+  const int lo = st->pos, hi = lo + st->chunk < st->Ty ? lo + st->chunk : st->Ty;
+  const int64_t n = (int64_t)(hi - lo) * hop;
+  if (capacity < n) return fail(VITS_ERR_ARG, "chunk capacity %lld < %lld samples", (long long)capacity, (long long)n);
+  TRY(stream_launch(st, lo));  // no-op when decode-ahead already covered it
+  HIP_TRY(hipMemcpyAsync(st->h_pin, st->d_aud + (size_t)(lo - st->win_start) * hop, sizeof(float) * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipEventRecord(st->ev, s->stream));
+  st->pos = hi;
+  if (hi < st->Ty) TRY(stream_launch(st, hi));  // decode ahead; stream order keeps it behind the copy above
+  HIP_TRY(hipEventSynchronize(st->ev));
+  memcpy(audio, st->h_pin, sizeof(float) * n);
+  *n_samples = n;
+  return VITS_OK;
+}
 
 // ---- device-resident sessions (bench / serving loop)
 int vits_session_create(vits_model* m, int32_t max_B, int32_t max_Tx, int32_t max_Ty, vits_session** out) {

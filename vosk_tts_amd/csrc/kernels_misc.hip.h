@@ -742,3 +742,9 @@ __global__ void tanh_copy_kernel(const float* x, float* y, int T, long long x_bs
   const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (t < T) y[(long long)b * y_bstride + t] = tanhf(x[(long long)b * x_bstride + t]);
 }
+
+// Streaming decode: copies the frame window [start, start+W) of z [C, T] (row stride T) into a dense [C, W] buffer.
+__global__ void window_copy_kernel(const float* __restrict__ z, long long zstride, int start, int W, float* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t < W) dst[(size_t)c * W + t] = z[(size_t)c * zstride + start + t];
+}

@@ -50,7 +50,7 @@ class VitsSession:
     def get_providers(self):
         return ["MI355XExecutionProvider"]
 
-    def run(self, output_names, input_feed, run_options=None):
+    def _validated(self, output_names, input_feed):
         if output_names is not None and list(output_names) != ["output"]:
             raise ValueError(f"unknown output names {output_names}")
         feed = {k: v for k, v in input_feed.items() if v is not None}  # ORT ignores None feeds
@@ -75,12 +75,31 @@ class VitsSession:
         if seed is None:
             with self._seed_lock:
                 seed = next(self._seed)
+        return feed, ids, sid, int(seed)
+
+    def run(self, output_names, input_feed, run_options=None):
+        feed, ids, sid, seed = self._validated(output_names, input_feed)
         audio, lengths = self._model.synthesize(
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
             forced_durations=feed.get("vits.forced_durations"), seed=int(seed))
         self.last_lengths = lengths
         return [audio[:, None, None, :]]
+
+    def run_stream(self, output_names, input_feed, chunk_frames=64):
+        """Streaming form of run() for ONE utterance (extension; the reference's transport is already
+        `stream AudioChunk`, server/tts_service.proto:46-54): yields float32 [n] chunks of chunk_frames*256
+        samples whose concatenation equals run(...)[0].squeeze() for the same feed (same "vits.seed")."""
+        feed, ids, sid, seed = self._validated(output_names, input_feed)
+        if ids.shape[0] != 1:
+            raise ValueError("run_stream takes one utterance")
+        n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
+        fd = feed.get("vits.forced_durations")
+        nd = feed.get("vits.noise_dp")
+        return self._model.stream(
+            ids[:, :n], np.asarray(feed["scales"], np.float32).reshape(-1), int(sid[0]), chunk_frames=chunk_frames,
+            noise_dp=None if nd is None else np.asarray(nd)[:, :, :n], noise_prior=feed.get("vits.noise_prior"),
+            forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed)
 
     def close(self):
         self._model.close()

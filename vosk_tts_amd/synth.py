@@ -23,7 +23,8 @@ class Synth:
         audio_norm = np.clip(audio * max_wav_value, -max_wav_value, max_wav_value)
         return audio_norm.astype("int16")
 
-    def synth_audio(self, text, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None):
+    def _feed(self, text, speaker_id, noise_level, speech_rate, duration_noise_level, scale):
+        """Runtime defaults and the six-key feed of synth.py:50-56,100-120."""
         inf = self.model.config.get("inference", {})
         if noise_level is None:
             noise_level = inf.get("noise_level", 0.8)
@@ -48,6 +49,10 @@ class Synth:
         sid = np.array([speaker_id], dtype=np.int64)
         args = {"input": ids, "input_lengths": lengths, "scales": scales, "sid": sid, "bert": None,
                 "phone_duration_extra": None}
+        return args, scale
+
+    def synth_audio(self, text, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None):
+        args, scale = self._feed(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
 
         start_time = time.perf_counter()
         audio = self.model.onnx.run(None, args)[0]
@@ -61,6 +66,15 @@ class Synth:
         real_time_factor = infer_sec / audio_duration_sec if audio_duration_sec > 0 else 0.0
         logging.info("Real-time factor: %0.2f (infer=%0.2f sec, audio=%0.2f sec)" % (real_time_factor, infer_sec, audio_duration_sec))
         return audio
+
+    def synth_stream(self, text, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None,
+                     chunk_frames=64):
+        """Generator of int16 PCM chunks (chunk_frames*256 samples each, ~0.74 s at the default): what a streaming
+        `SynthesizeStream` handler would put into successive AudioChunk messages (tts_service.proto:46-54) instead
+        of the single whole-utterance chunk of tts_server.py:54.  Same conversion as synth_audio per chunk."""
+        args, scale = self._feed(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
+        for chunk in self.model.onnx.run_stream(None, args, chunk_frames=chunk_frames):
+            yield self.audio_float_to_int16(chunk * scale)
 
     def synth(self, text, oname, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None):
         audio = self.synth_audio(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
