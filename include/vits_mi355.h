@@ -179,6 +179,17 @@ int vits_stream_open(vits_model* m, const int64_t* ids, int32_t T_x, const float
 int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n_samples);
 void vits_stream_close(vits_stream* st);
 
+/* ---- monotonic alignment search (training-side reuse) ------------------
+ * monotonic_align.maximum_path (training/vits2/monotonic_align/__init__.py:6-20 -> core.pyx:7-42):
+ * for each item, the monotonic path through value[t_y, t_x] (rows = frames, columns = tokens) that maximises the
+ * summed score: Q[y,x] = value[y,x] + max(Q[y-1,x-1], Q[y-1,x]) inside the band
+ * max(0, t_x+y-t_y) <= x < min(t_x, y+1), then backtracking from (t_y-1, t_x-1) with the reference's strict `<` tie
+ * rule.  values [B,T_y,T_x] float32 (NOT modified, unlike the Cython routine which accumulates in place),
+ * t_ys/t_xs int32 [B] valid extents, paths int32 [B,T_y,T_x] (0/1, zero outside the valid extents).
+ * Host buffers; bit-exact with the reference (one fp32 add per cell, same operands). */
+int vits_mas_maximum_path(int device, const float* values, const int32_t* t_ys, const int32_t* t_xs,
+                          int32_t B, int32_t T_y, int32_t T_x, int32_t* paths);
+
 /* Device-resident variant used by bench.py: ids/lengths/sid already in HBM
  * (int64 device pointers), audio written to a caller-provided device buffer
  * [B, audio_capacity].  Durations must be forced (device int32 [B,T_x]) or

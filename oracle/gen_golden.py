@@ -21,6 +21,8 @@ Cases
   consts       OnnxSTFT.inverse_basis and PQMF.synthesis_filter buffers
   plain_b2     the plain HiFi-GAN `Generator` decoder variant (models.py:845-898) with speaker conditioning,
                ups [8,8,2,2]: reference Generator module alone, B=2
+  mas          monotonic_align.maximum_path_c (the reference's Cython core, compiled here from its own .pyx):
+               ragged batch incl. t_x == t_y, t_x == 1, ties, noise-scaled scores
   g2p          known answers of vosk_tts/g2p.py:convert (examples at g2p.py:5-11 + extra words)
 """
 import importlib.util
@@ -168,6 +170,16 @@ def main():
         g = torch.from_numpy(ptens["emb_g.weight"][sid]).unsqueeze(-1)
         audio = gen(torch.from_numpy(z), g=g)
     save("plain_b2", z=z, sid=sid, audio=audio.numpy()[:, 0])
+    # ---- monotonic alignment search: the reference's compiled Cython core
+    mas = refimport.build_reference_mas()
+    B, Ty, Tx = 7, 96, 40
+    values = (rng.standard_normal((B, Ty, Tx)) * 3.0).astype(np.float32)
+    values[5] = np.round(values[5])          # many exact ties -> exercises the strict `<` rule
+    t_ys = np.array([96, 50, 40, 7, 96, 64, 1], np.int32)
+    t_xs = np.array([40, 23, 40, 1, 17, 33, 1], np.int32)   # item 2: t_x == t_y, item 3: one token, item 6: 1x1
+    paths = np.zeros((B, Ty, Tx), np.int32)
+    mas.maximum_path_c(paths, values.copy(), t_ys, t_xs)     # the routine accumulates into its `values` argument
+    save("mas", values=values, t_ys=t_ys, t_xs=t_xs, paths=paths.astype(np.int8))
     # ---- g2p known answers (vosk_tts/g2p.py; imported by file path: the package itself needs onnxruntime)
     spec = importlib.util.spec_from_file_location("ref_g2p", os.path.join(refimport.REF_ROOT, "vosk_tts", "g2p.py"))
     g2p = importlib.util.module_from_spec(spec)

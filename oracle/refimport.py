@@ -214,3 +214,27 @@ def run_reference_stages(net, ids, lengths, sid, scales, noise_dp, noise_prior_f
         out["audio"], out["audio_mb"] = o.numpy(), o_mb.numpy()
         out["y_mask"] = y_mask.numpy()
     return out
+
+
+def build_reference_mas():
+    """Compiles the reference's own Cython MAS core (training/vits2/monotonic_align/core.pyx) from where it lies
+    under /root/reference into oracle/_ref/mas/ (git-ignored) with the installed Cython + gcc, and returns the
+    module (exposes maximum_path_c).  Container-only, used by gen_golden.py."""
+    import importlib.util
+    import subprocess
+    import sysconfig
+
+    if not have_reference():
+        raise RuntimeError("/root/reference is not present")
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "mas")
+    os.makedirs(out, exist_ok=True)
+    pyx = os.path.join(REF_VITS2, "monotonic_align", "core.pyx")
+    c_file = os.path.join(out, "core.c")
+    so = os.path.join(out, "core" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not os.path.exists(so):
+        subprocess.check_call([sys.executable, "-m", "cython", "-3", pyx, "-o", c_file])
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fopenmp", "-I" + sysconfig.get_paths()["include"], c_file, "-o", so])
+    spec = importlib.util.spec_from_file_location("core", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

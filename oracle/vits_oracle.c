@@ -1121,3 +1121,39 @@ double API(algorithmic_flops)(const vits_model* m, int32_t B, int32_t Tx, int32_
   frame += dec;
   return (double)B * ((double)Tx * (tok + tok_quad * Tx) + (double)Ty * (frame + frame_quad * Ty));
 }
+
+/* ---- monotonic alignment search: monotonic_align/core.pyx:7-42 (maximum_path_each + the prange over items).
+ * The Cython routine accumulates into `value` in place; this restatement works on a copy so the caller's
+ * scores are preserved (paths are identical). */
+int API(mas_maximum_path)(int device, const float* values, const int32_t* t_ys, const int32_t* t_xs, int32_t B, int32_t Ty,
+                          int32_t Tx, int32_t* paths) {
+  (void)device;
+  if (!values || !t_ys || !t_xs || !paths || B <= 0 || Ty <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  const float max_neg_val = -1e9f; /* core.pyx:7 */
+  for (int b = 0; b < B; ++b)
+    if (t_ys[b] < 0 || t_ys[b] > Ty || t_xs[b] < 0 || t_xs[b] > Tx) return fail(VITS_ERR_ARG, "extent out of range");
+  memset(paths, 0, sizeof(int32_t) * (size_t)B * Ty * Tx);
+  for (int b = 0; b < B; ++b) {
+    const int t_y = t_ys[b], t_x = t_xs[b];
+    if (t_y == 0 || t_x == 0) continue;
+    float* v = (float*)malloc(sizeof(float) * (size_t)Ty * Tx);
+    if (!v) return fail(VITS_ERR_NOMEM, "host alloc failed");
+    memcpy(v, values + (size_t)b * Ty * Tx, sizeof(float) * (size_t)Ty * Tx);
+    int32_t* path = paths + (size_t)b * Ty * Tx;
+    for (int y = 0; y < t_y; ++y) { /* core.pyx:15-27 */
+      const int x0 = t_x + y - t_y > 0 ? t_x + y - t_y : 0, x1 = t_x < y + 1 ? t_x : y + 1;
+      for (int x = x0; x < x1; ++x) {
+        const float v_cur = x == y ? max_neg_val : v[(size_t)(y - 1) * Tx + x];
+        const float v_prev = x == 0 ? (y == 0 ? 0.f : max_neg_val) : v[(size_t)(y - 1) * Tx + x - 1];
+        v[(size_t)y * Tx + x] += v_prev > v_cur ? v_prev : v_cur;
+      }
+    }
+    int index = t_x - 1; /* core.pyx:29-32 */
+    for (int y = t_y - 1; y >= 0; --y) {
+      path[(size_t)y * Tx + index] = 1;
+      if (index != 0 && (index == y || v[(size_t)(y - 1) * Tx + index] < v[(size_t)(y - 1) * Tx + index - 1])) index -= 1;
+    }
+    free(v);
+  }
+  return VITS_OK;
+}

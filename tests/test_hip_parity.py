@@ -349,3 +349,30 @@ def test_streaming_free_running_and_errors(hip_default):
     first = next(g)
     g.close()  # generator finalizer -> vits_stream_close with chunks still pending
     assert_close("first chunk", one[0, :2048], first, 2e-5)
+
+
+def test_monotonic_alignment_search(hip_lib, oracle_lib):
+    """vits_mas_maximum_path (core.pyx:7-42 as a HIP kernel): integer result, bit-exact against the golden paths of the
+    reference's compiled Cython core, against the oracle on a larger training-sized batch, and through the
+    monotonic_align.maximum_path mirror (mask -> extents)."""
+    g = golden("mas")
+    paths = hip_lib.mas_maximum_path(g["values"], g["t_ys"], g["t_xs"])
+    assert np.array_equal(paths, g["paths"].astype(np.int32))
+    rng = np.random.default_rng(21)
+    B, Ty, Tx = 16, 700, 180  # a training batch: frames x tokens
+    values = (rng.standard_normal((B, Ty, Tx)) * 4.0).astype(np.float32)
+    t_xs = rng.integers(1, Tx + 1, size=B).astype(np.int32)
+    t_ys = np.array([rng.integers(tx, Ty + 1) for tx in t_xs], np.int32)
+    t_ys[0], t_xs[0] = Ty, Tx
+    want = oracle_lib.mas_maximum_path(values, t_ys, t_xs)
+    got = hip_lib.mas_maximum_path(values, t_ys, t_xs)
+    assert np.array_equal(want, got)
+    from vosk_tts_amd import mas
+
+    mask = (np.arange(Ty)[None, :, None] < t_ys[:, None, None]) & (np.arange(Tx)[None, None, :] < t_xs[:, None, None])
+    p2 = mas.maximum_path(values, mask.astype(np.float32), lib=hip_lib)
+    assert p2.dtype == np.float32 and np.array_equal(p2.astype(np.int32), want)
+    from vosk_tts_amd.capi import VitsError
+
+    with pytest.raises(VitsError):
+        hip_lib.mas_maximum_path(values, t_ys + 5000, t_xs)

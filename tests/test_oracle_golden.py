@@ -85,6 +85,26 @@ def test_plain_generator_variant(oracle_lib):
     assert_close("audio", g["audio"], audio, TOL)
 
 
+def test_monotonic_alignment_search(oracle_lib):
+    """the C restatement of core.pyx:7-42 reproduces the compiled Cython core bit for bit
+    (ragged extents, t_x == t_y, single token, exact ties); the caller's scores are left untouched."""
+    g = golden("mas")
+    v = g["values"].copy()
+    paths = oracle_lib.mas_maximum_path(v, g["t_ys"], g["t_xs"])
+    assert np.array_equal(v, g["values"])
+    assert np.array_equal(paths, g["paths"].astype(np.int32))
+    # structure: one token per frame inside the extents, monotone, starts at token 0 and ends at t_x-1
+    for b in range(len(g["t_ys"])):
+        ty, tx = int(g["t_ys"][b]), int(g["t_xs"][b])
+        assert paths[b, :ty].sum(1).tolist() == [1] * ty and paths[b, ty:].sum() == 0 and paths[b, :, tx:].sum() == 0
+        idx = paths[b, :ty].argmax(1)
+        assert idx[0] == 0 and idx[-1] == tx - 1 and np.all((np.diff(idx) == 0) | (np.diff(idx) == 1))
+    from vosk_tts_amd.capi import VitsError
+
+    with pytest.raises(VitsError):
+        oracle_lib.mas_maximum_path(v, g["t_ys"] + 1000, g["t_xs"])
+
+
 def test_constants(oracle_lib, oracle_default):
     import ctypes
 

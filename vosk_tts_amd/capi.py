@@ -100,6 +100,8 @@ class VitsLib:
                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p]
         f("algorithmic_flops").argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         f("algorithmic_flops").restype = ctypes.c_double
+        f("mas_maximum_path").argtypes = [ctypes.c_int, c_f32p, c_i32p, c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          c_i32p]
         self.is_device = bool(f("is_device_backend")())
         if self.is_device:
             f("session_create").argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -129,6 +131,20 @@ class VitsLib:
 
     def create(self, blob, device=0):
         return VitsModel(self, blob, device)
+
+    def mas_maximum_path(self, values, t_ys, t_xs, device=0):
+        """monotonic_align.maximum_path_c (core.pyx:35-42): values float32 [B,T_y,T_x] -> paths int32 [B,T_y,T_x]."""
+        values = _f32(values)
+        if values.ndim != 3:
+            raise ValueError("values must be [B,T_y,T_x]")
+        B, Ty, Tx = values.shape
+        t_ys = _i32(t_ys).reshape(-1); t_xs = _i32(t_xs).reshape(-1)
+        if t_ys.shape != (B,) or t_xs.shape != (B,):
+            raise ValueError("t_ys/t_xs must be [B]")
+        paths = np.empty((B, Ty, Tx), np.int32)
+        self.check(self._fn("mas_maximum_path")(device, _p(values, c_f32p), _p(t_ys, c_i32p), _p(t_xs, c_i32p), B, Ty, Tx,
+                                                _p(paths, c_i32p)))
+        return paths
 
 
 class VitsModel:

@@ -1522,6 +1522,33 @@ int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n
   return VITS_OK;
 }
 
+// ---- monotonic alignment search (monotonic_align/core.pyx:7-42), host buffers
+int vits_mas_maximum_path(int device, const float* values, const int32_t* t_ys, const int32_t* t_xs, int32_t B, int32_t Ty,
+                          int32_t Tx, int32_t* paths) {
+  if (!values || !t_ys || !t_xs || !paths || B <= 0 || Ty <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  for (int b = 0; b < B; ++b)
+    if (t_ys[b] < 0 || t_ys[b] > Ty || t_xs[b] < 0 || t_xs[b] > Tx) return fail(VITS_ERR_ARG, "extent out of range");
+  if ((size_t)2 * Tx * sizeof(float) > 160 * 1024) return fail(VITS_ERR_ARG, "T_x %d too large for the LDS row buffers", Tx);
+  HIP_TRY(hipSetDevice(device));
+  const size_t n = (size_t)B * Ty * Tx;
+  float* d_v = nullptr; int *d_ty = nullptr, *d_tx = nullptr, *d_p = nullptr; unsigned char* d_d = nullptr;
+  struct Free { std::vector<void*> p; ~Free() { for (void* q : p) hipFree(q); } } fr;
+  auto alloc = [&](void** q, size_t bytes) { if (hipMalloc(q, bytes) != hipSuccess) return false; fr.p.push_back(*q); return true; };
+  if (!alloc((void**)&d_v, n * 4) || !alloc((void**)&d_p, n * 4) || !alloc((void**)&d_d, n) || !alloc((void**)&d_ty, B * 4) ||
+      !alloc((void**)&d_tx, B * 4))
+    return fail(VITS_ERR_NOMEM, "device alloc failed");
+  HIP_TRY(hipMemcpy(d_v, values, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ty, t_ys, B * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_tx, t_xs, B * 4, hipMemcpyHostToDevice));
+  const size_t lds = (size_t)2 * Tx * sizeof(float);
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)mas_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mas_kernel, dim3(B), dim3(256), lds, 0, d_v, d_ty, d_tx, Ty, Tx, d_d, d_p);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(VITS_ERR_DEVICE, "launch failed: %s", hipGetErrorString(le));
+  HIP_TRY(hipMemcpy(paths, d_p, n * 4, hipMemcpyDeviceToHost));
+  return VITS_OK;
+}
+
 // ---- device-resident sessions (bench / serving loop)
 int vits_session_create(vits_model* m, int32_t max_B, int32_t max_Tx, int32_t max_Ty, vits_session** out) {
   if (!m || !out || max_B <= 0 || max_Tx <= 0 || max_Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");

@@ -748,3 +748,44 @@ __global__ void window_copy_kernel(const float* __restrict__ z, long long zstrid
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
   if (t < W) dst[(size_t)c * W + t] = z[(size_t)c * zstride + start + t];
 }
+
+// Monotonic alignment search (monotonic_align/core.pyx:7-42), one workgroup per item.
+// Forward: rows are dependent, columns of one row are not -> threads own columns, the previous row's running
+// scores live in a double-buffered LDS row, one barrier per frame row.  Instead of keeping the whole Q matrix for
+// the backtrack, each cell records the one bit the reference's backtrack reads: Q[y-1,x] < Q[y-1,x-1] (strict).
+// Backtrack: a single lane walks t_y steps over the byte map (dependent loads served from L2).
+// The band  max(0, t_x+y-t_y) <= x < min(t_x, y+1)  is the reference's; cells outside it are never read.
+__global__ void __launch_bounds__(256) mas_kernel(const float* __restrict__ values, const int* __restrict__ t_ys,
+                                                  const int* __restrict__ t_xs, int Ty, int Tx, unsigned char* __restrict__ diag,
+                                                  int* __restrict__ paths) {
+  extern __shared__ float rows[];  // [2][Tx]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int t_y = t_ys[b], t_x = t_xs[b];
+  const float* v = values + (size_t)b * Ty * Tx;
+  unsigned char* dg = diag + (size_t)b * Ty * Tx;
+  int* path = paths + (size_t)b * Ty * Tx;
+  for (size_t i = tid; i < (size_t)Ty * Tx; i += nt) path[i] = 0;
+  if (t_y <= 0 || t_x <= 0) return;
+  const float max_neg_val = -1e9f;
+  for (int y = 0; y < t_y; ++y) {
+    const float* prev = rows + ((y + 1) & 1) * Tx;
+    float* cur = rows + (y & 1) * Tx;
+    const int x0 = t_x + y - t_y > 0 ? t_x + y - t_y : 0, x1 = t_x < y + 1 ? t_x : y + 1;
+    for (int x = x0 + tid; x < x1; x += nt) {
+      const float v_cur = x == y ? max_neg_val : prev[x];
+      const float v_prev = x == 0 ? (y == 0 ? 0.f : max_neg_val) : prev[x - 1];
+      cur[x] = v[(size_t)y * Tx + x] + (v_prev > v_cur ? v_prev : v_cur);
+      // what the backtrack at row y asks about row y-1 (core.pyx:31); only read where both cells are in the band
+      dg[(size_t)y * Tx + x] = (x != 0 && x != y && v_cur < v_prev) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  __threadfence_block();
+  if (tid == 0) {
+    int index = t_x - 1;
+    for (int y = t_y - 1; y >= 0; --y) {
+      path[(size_t)y * Tx + index] = 1;
+      if (index != 0 && (index == y || dg[(size_t)y * Tx + index])) index -= 1;
+    }
+  }
+}
