@@ -520,6 +520,10 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
 // fragments.  No LDS and no barrier in the main loop; the four partial accumulators meet in LDS
 // once, then wave w finishes rows e in [4w, 4w+4) of every fragment through the shared epilogue.
 // ---------------------------------------------------------------------------------------------
+// uniform base pointer + per-lane 32-bit byte offset -> global_load_dword v, v_off, s[base:base+1]
+__device__ __forceinline__ float ks_ld(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 struct ks_true { static constexpr bool value = true; };
 struct ks_false { static constexpr bool value = false; };
 template <int MI, int NI, int EPI, int NIN>
@@ -595,6 +599,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
     unsigned ok[KS_U];
   };
   int lc = wave, lk = 0;  // load cursor (chunk, tap-in-chunk) of this wave's tap stream
+  const unsigned lane16 = (unsigned)lane * 16u;
   const float* xq2 = NIN > 1 ? xu2 : xu;               // NIN == 3: MRF mean of three inputs (x3 may be absent)
   const float* xq3 = NIN > 1 ? (xu3 ? xu3 : xu2) : xu;
   const float s3 = (NIN > 1 && xu3) ? 1.f : 0.f;
@@ -606,7 +611,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   // load latency (L2 ~500, HBM ~900 cycles) is thereby covered by KS_U*8 = 32 MFMAs (2048 cycles), the
   // address math runs in the MFMA shadow, and all loads are unconditional (clamped + select), which
   // keeps the body one basic block with counted s_waitcnt.
-  auto pipe_step = [&](auto has_cur, const TapBuf& cur, TapBuf& nxt) {
+  auto pipe_step = [&](auto has_cur, auto act, const TapBuf& cur, TapBuf& nxt) {
 #pragma unroll
     for (int u = 0; u < KS_U; ++u) {
       const bool live = lc <= c_last;
@@ -620,21 +625,21 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
         int t = tcol[ni] + lk * dil;
         t = (t == -1 && refl_t >= 0) ? refl_t : t;
         okb |= ((t >= 0) & (t < t_lim) & live) ? (1u << ni) : 0u;
-        lo[ni] = hoff + (unsigned)(t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t));
+        lo[ni] = (hoff + (unsigned)(t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t))) * 4u;  // BYTE offset: keeps the saddr + 32-bit voffset form
       }
       nxt.ok[u] = okb;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        nxt.a[u][mi][0] = wp[mi][(size_t)sg * 64 + lane];
-        nxt.a[u][mi][1] = wp[mi][(size_t)(sg + 1) * 64 + lane];
+        nxt.a[u][mi][0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wp[mi] + (size_t)sg * 64) + lane16);
+        nxt.a[u][mi][1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wp[mi] + (size_t)(sg + 1) * 64) + lane16);
       }
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const long long ro = coff + 2 * p * rs;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          float v = (xu + ro)[lo[ni]];
-          if (NIN > 1) v = (v + (xq2 + ro)[lo[ni]] + s3 * (xq3 + ro)[lo[ni]]) * in_scale;  // scale only on the MRF mean
+          float v = ks_ld(xu + ro, lo[ni]);
+          if (NIN > 1) v = (v + ks_ld(xq2 + ro, lo[ni]) + s3 * ks_ld(xq3 + ro, lo[ni])) * in_scale;  // scale only on the MRF mean
           nxt.bq[u][p][ni] = v;
         }
         if (decltype(has_cur)::value) {
@@ -646,7 +651,9 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
             // leaky-relu for 0 <= slope <= 1 is max(v, slope*v); the edge/mask flag is a 0/1 multiplier:
             // 3 VALU per MFMA instead of 5 (a single wave per SIMD is issue-bound, every slot counts)
             const float x_ = cur.bq[u][p][ni];
-            const float bv = okb_[ni] ? fmaxf(x_, x_ * in_slope) : 0.f;  // select, not multiply: stale padding may hold NaN
+            // select, not multiply: stale padding may hold NaN.  in_slope == 1 (every encoder / flow conv) skips the
+            // activation: a lone wave per SIMD pays ~7 cycles per VALU op next to each 64-cycle MFMA (tools/mfmaprobe)
+            const float bv = okb_[ni] ? (decltype(act)::value ? fmaxf(x_, x_ * in_slope) : x_) : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u][mi][p >> 2][p & 3], bv, acc[mi][ni], 0, 0, 0);
@@ -661,14 +668,18 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   };
 
   CONV_DBG(1);
-  if (my_taps > 0) {
+  auto run_pipe = [&](auto act) {
     TapBuf t0, t1;
-    pipe_step(ks_false{}, t1, t0);
+    pipe_step(ks_false{}, act, t1, t0);
 #pragma unroll 1
     for (int tp = 0; tp < my_taps; tp += 2 * KS_U) {
-      pipe_step(ks_true{}, t0, t1);
-      if (tp + KS_U < my_taps) pipe_step(ks_true{}, t1, t0);
+      pipe_step(ks_true{}, act, t0, t1);
+      if (tp + KS_U < my_taps) pipe_step(ks_true{}, act, t1, t0);
     }
+  };
+  if (my_taps > 0) {
+    if (in_slope == 1.f) run_pipe(ks_false{});
+    else run_pipe(ks_true{});
   }
   CONV_DBG(2);
 
