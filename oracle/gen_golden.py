@@ -19,6 +19,8 @@ Cases
   enc_T{1,3,4,5,9}  text encoder at the relative-attention edge lengths (window 4)
   tiny_b3      scaled-down config (hidden 64, 3 layers, 5 speakers), B=3 ragged
   consts       OnnxSTFT.inverse_basis and PQMF.synthesis_filter buffers
+  edge_b3      default config, B=3 with lengths (6, 0, 1): an empty item (y_length clamps to 1 frame, models.py:1691), a
+               one-token item, and zero durations at both ends of the first item
   plain_b2     the plain HiFi-GAN `Generator` decoder variant (models.py:845-898) with speaker conditioning,
                ups [8,8,2,2]: reference Generator module alone, B=2
   mas          monotonic_align.maximum_path_c (the reference's Cython core, compiled here from its own .pyx):
@@ -150,6 +152,13 @@ def main():
     ids = rng.integers(1, thp.n_vocab, size=(3, 20))
     dur = rng.integers(0, 4, size=(3, 20))
     full_case(tnet, thp, "tiny_b3", ids, np.array([20, 7, 13]), np.array([0, 4, 2]), [0.5, 0.9, 0.7], dur, rng)
+    # ---- edge cases: empty item, single token, zero durations at the boundaries (separate rng: keeps the older fixtures stable)
+    erng = np.random.default_rng(77)
+    ids = erng.integers(1, hp.n_vocab, size=(3, 6))
+    dur = erng.integers(1, 4, size=(3, 6))
+    dur[0, 0] = 0
+    dur[0, 5] = 0
+    full_case(net, hp, "edge_b3", ids, np.array([6, 0, 1]), np.array([1, 2, 3]), [0.667, 1.0, 0.8], dur, erng)
     # ---- plain Generator variant: the reference module alone
     print("plain Generator:")
     php = W.plain_hparams()

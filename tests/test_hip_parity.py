@@ -109,6 +109,11 @@ def test_stages_tiny_b3_ragged(hip_tiny, oracle_tiny):
     _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
 
 
+def test_stages_edge_empty_item_single_token(hip_default, oracle_default):
+    """lengths (6, 0, 1) with zero durations at the ends of item 0: empty item -> one frame, models.py:1691"""
+    _stages_vs(hip_default, oracle_default, golden("edge_b3"), STAGE_TOL)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_every_epilogue_on_both_conv_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny, mode):
     """The size heuristic picks the K-split kernel for these small fixtures; force each kernel in turn so
@@ -376,3 +381,21 @@ def test_monotonic_alignment_search(hip_lib, oracle_lib):
 
     with pytest.raises(VitsError):
         hip_lib.mas_maximum_path(values, t_ys + 5000, t_xs)
+
+
+def test_long_form_properties_at_c5_size(hip_default):
+    """BASELINE configs[4] size (2000 tokens -> 6000 frames, 69.7 s) without an oracle run: (1) the streamed chunks
+    equal the one-shot waveform, (2) the first 1000 tokens' audio is NOT what a 1000-token call gives (global
+    attention in the flow: the acoustic half cannot be chunked), but (3) decoding is local: the one-shot decode of z
+    windows agrees away from the edges (covered by the stream equality), and (4) output length = 256 * sum(durations)."""
+    rng = np.random.default_rng(5)
+    Tx = 2000
+    ids = rng.integers(1, 62, size=(1, Tx)).astype(np.int64)
+    dur = np.full((1, Tx), 3, np.int32)
+    sc = [0.667, 1.0, 0.8]
+    one, olen = hip_default.synthesize(ids, [Tx], sc, [2], forced_durations=dur, seed=3)
+    assert one.shape == (1, 6000 * 256) and olen[0] == 6000 * 256 and np.isfinite(one).all()
+    got = np.concatenate(list(hip_default.stream(ids, sc, 2, chunk_frames=512, forced_durations=dur, seed=3)))[None]
+    assert_close("c5 stream vs one-shot", one, got, 2e-5)
+    half, _ = hip_default.synthesize(ids[:, :1000], [1000], sc, [2], forced_durations=dur[:, :1000], seed=3)
+    assert float(np.max(np.abs(half[0, :100000] - one[0, :100000]))) > 1e-3

@@ -50,6 +50,13 @@ def test_tiny_b3_ragged(oracle_tiny):
     _full(oracle_tiny, golden("tiny_b3"))
 
 
+def test_edge_empty_item_single_token_zero_durations(oracle_default):
+    """lengths (6, 0, 1): an empty item (T_y clamps to 1, models.py:1691), a one-token item, zero durations at both ends"""
+    g = golden("edge_b3")
+    assert g["y_lengths"].tolist() == [12, 1, 2]
+    _full(oracle_default, g)
+
+
 def test_free_running_infer(oracle_default):
     """The real SynthesizerTrn.infer() call (free-running durations through ceil)."""
     g = golden("free_c1")
