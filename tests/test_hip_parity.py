@@ -399,3 +399,20 @@ def test_long_form_properties_at_c5_size(hip_default):
     assert_close("c5 stream vs one-shot", one, got, 2e-5)
     half, _ = hip_default.synthesize(ids[:, :1000], [1000], sc, [2], forced_durations=dur[:, :1000], seed=3)
     assert float(np.max(np.abs(half[0, :100000] - one[0, :100000]))) > 1e-3
+
+
+@pytest.mark.parametrize("B,T", [(2, 37), (16, 160)])
+def test_duration_predictor_both_dds_paths(hip_default, oracle_default, B, T):
+    """StochasticDurationPredictor reverse (models.py:56-63,93-101) at a single-utterance size (fused one-launch-per-
+    DDSConv-layer kernel) and at a batch size beyond its B*T <= 2048 gate (depthwise+LN, MFMA 1x1, LN launches)."""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((B, 192, T)).astype(np.float32)
+    lens = rng.integers(T // 2, T + 1, size=B).astype(np.int64)
+    lens[0] = T
+    x *= (np.arange(T)[None, None, :] < lens[:, None, None])
+    sid = rng.integers(0, 10, size=B).astype(np.int64)
+    noise = rng.standard_normal((B, 2, T)).astype(np.float32)
+    want = oracle_default.duration(x, lens, sid, noise, 0.8)
+    got = hip_default.duration(x, lens, sid, noise, 0.8)
+    m = np.arange(T)[None, :] < lens[:, None]
+    assert_close("logw", want * m, got * m, STAGE_TOL)

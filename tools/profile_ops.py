@@ -11,10 +11,11 @@ from vosk_tts_amd import weights as W  # noqa: E402
 from vosk_tts_amd.capi import VitsLib, VitsDeviceSession  # noqa: E402
 
 w = sys.argv[1] if len(sys.argv) > 1 else "c2"
+free = len(sys.argv) > 2 and sys.argv[2] == "free"  # free-running durations: the duration predictor runs too
 hp = W.default_hparams()
 model = VitsLib().create(W.synthetic_blob(hp, 1234), 0)
 ids, lengths, dur = bench.make_workload(w, np.random.default_rng(1234), 0, 1)
-B, Tx = ids.shape; Ty = int(dur.sum(1).max()); S = Ty * hp.hop_length
+B, Tx = ids.shape; Ty = int(dur.sum(1).max()) * int(os.environ.get("PROFILE_TY_MULT", "1")); S = Ty * hp.hop_length
 dev = torch.device("cuda", 0)
 d = [torch.from_numpy(a).to(dev) for a in (ids, lengths, dur)]
 sid = torch.full((B,), 2, dtype=torch.int64, device=dev)
@@ -22,7 +23,7 @@ audio = torch.empty((B, S), dtype=torch.float32, device=dev)
 sess = VitsDeviceSession(model, B, Tx, Ty)
 scales = np.array([0.8, 1.0, 0.8], np.float32)
 def step():
-    sess.synthesize_device(d[0].data_ptr(), d[1].data_ptr(), B, Tx, scales, sid.data_ptr(), d[2].data_ptr(), Ty, 7, audio.data_ptr(), S)
+    sess.synthesize_device(d[0].data_ptr(), d[1].data_ptr(), B, Tx, scales, sid.data_ptr(), 0 if free else d[2].data_ptr(), Ty, 7, audio.data_ptr(), S)
 for _ in range(3): step()
 sess.sync()
 import time

@@ -71,6 +71,7 @@ struct EncoderW {
 };
 struct DDSW {
   std::vector<float*> sw, sb, g1, b1, g2, b2;
+  std::vector<float*> wt;  // 1x1 weights transposed [ci][co] for the fused layer kernel
   std::vector<ConvW> pw;
 };
 struct ConvFlowW {
@@ -228,6 +229,13 @@ static void load_dds(vits_model* m, DDSW& D, const char* pfx, int C, int K, int 
     D.sb.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.convs_sep.%d.bias", pfx, i), C));
     snprintf(nm, sizeof nm, "%s.convs_1x1.%d", pfx, i);
     D.pw.push_back(conv_from(m, nm, C, C, 1, true));
+    {
+      const float* w = tget(m, 3, C, C, 1, "%s.weight", nm);
+      std::vector<float> t((size_t)C * C);
+      // wt4[ci/4][co][ci%4] (dds_layer_kernel: one dwordx4 per thread per 4 input channels)
+      if (w && C % 4 == 0) for (int co = 0; co < C; ++co) for (int ci = 0; ci < C; ++ci) t[((size_t)(ci / 4) * C + co) * 4 + (ci & 3)] = w[(size_t)co * C + ci];
+      D.wt.push_back(upload(m, t.data(), t.size()));
+    }
     D.g1.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_1.%d.gamma", pfx, i), C));
     D.b1.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_1.%d.beta", pfx, i), C));
     D.g2.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.norms_2.%d.gamma", pfx, i), C));
@@ -454,6 +462,10 @@ struct vits_session {
   float *dh = nullptr, *dy = nullptr, *dy2 = nullptr, *dc = nullptr, *dz = nullptr, *dpr = nullptr, *logw = nullptr, *dfh = nullptr;
   float *zA = nullptr, *zB = nullptr, *fh = nullptr, *fx = nullptr, *facts = nullptr, *fskip = nullptr;
   std::vector<float*> dec_bufs;
+  // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
+  // session, so a steady stream of vits_synthesize calls does no hipMalloc / hipFree (both synchronise the device)
+  char* stage = nullptr;
+  size_t stage_bytes = 0, stage_used = 0;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -562,6 +574,7 @@ static void session_free(vits_session* s) {
   drop_graphs(s);
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
+  if (s->stage) hipFree(s->stage);
   if (s->d_err) hipFree(s->d_err);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -845,11 +858,28 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   launch_conv(s, P, EPI_STORE, "enc.proj");
 }
 
-// DDSConv.forward (modules.py:96-108) on h [B,D,T] in place (h already includes +g)
-static void run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
+// DDSConv.forward (modules.py:96-108) on h [B,D,T] (h already includes +g); returns the buffer holding the result
+// (h itself, or s->dy after an odd number of fused layers)
+static float* run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
   const vits_hparams& hp = s->m->hp;
   const int D = hp.dp_filter_channels, K = hp.dp_kernel_size;
   int dil = 1;
+  static const bool no_fuse = getenv("VITS_NO_DDS_FUSION") != nullptr;  // A/B switch for tools/ and tests
+  // Single utterances / small batches only: there the three launches per layer are pure latency.  Every workgroup
+  // of the fused kernel streams the whole D x D matrix and does its mat-vec on the VALU, so beyond ~one workgroup
+  // per CU (B*T/8 > 256) the MFMA conv path below wins.
+  if (D <= 256 && D % 64 == 0 && (long)B * T <= 2048 && !no_fuse) {  // dds_layer_kernel, ping-pong between h and s->dy
+    float* src = h; float* dst = s->dy;
+    for (size_t i = 0; i < W.pw.size(); ++i) {
+      ProfScope ps(s, "dp.dds_layer", 2.0 * B * T * ((double)D * D + (double)D * K), "dds_layer_kernel");
+      DdsParams dp{src, dst, W.sw[i], W.sb[i], W.g1[i], W.b1[i], W.wt[i], W.pw[i].bias, W.g2[i], W.b2[i], s->len_x, D, T, K, dil,
+                   s->ragged ? 1 : 0};
+      hipLaunchKernelGGL(dds_layer_kernel, dim3(cdiv(T, DDS_TL), B), dim3(256), 0, s->stream, dp);
+      float* t = src; src = dst; dst = t;
+      dil *= K;
+    }
+    return src;
+  }
   for (size_t i = 0; i < W.pw.size(); ++i) {
     DwLnParams dp{h, s->dy, W.sw[i], W.sb[i], W.g1[i], W.b1[i], s->len_x, D, T, K, dil, s->ragged ? 1 : 0};
     hipLaunchKernelGGL(dwconv_ln_gelu_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, dp);
@@ -860,6 +890,7 @@ static void run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
     launch_ln(s, s->dy2, nullptr, h, h, W.g2[i], W.b2[i], s->len_x, B, D, T, 1, 1);
     dil *= K;
   }
+  return h;
 }
 
 // ---- a6: StochasticDurationPredictor.forward(reverse=True) (models.py:56-63,93-101) -> s->logw
@@ -871,8 +902,8 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dp_off; }
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.pre");
-  run_dds(s, m->dp_dds, s->dh, B, Tx);
-  P = conv_params(m->dp_proj, s->dh, s->dc, B, Tx, 1, 0);
+  const float* hd = run_dds(s, m->dp_dds, s->dh, B, Tx);
+  P = conv_params(m->dp_proj, hd, s->dc, B, Tx, 1, 0);
   P.out_mask = 1; P.len = s->len_x;
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.proj");
@@ -885,8 +916,8 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
     const ConvFlowW& c = m->cf[k];
     hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(Tx, 64), D, B), dim3(64), 0, s->stream, s->dz, swap, c.pre_w, c.pre_b,
                        s->dc, s->dfh, D, Tx);
-    run_dds(s, c.dds, s->dfh, B, Tx);
-    P = conv_params(c.proj, s->dfh, s->dpr, B, Tx, 1, 0);
+    const float* hf = run_dds(s, c.dds, s->dfh, B, Tx);
+    P = conv_params(c.proj, hf, s->dpr, B, Tx, 1, 0);
     P.out_mask = 1; P.len = s->len_x;
     mark_masked(s, P, s->len_x);
     launch_conv(s, P, EPI_STORE, "dp.cfproj");
@@ -1074,23 +1105,39 @@ struct HostStage {
   vits_model* m; vits_session* s = nullptr; std::vector<void*> tmp;
   explicit HostStage(vits_model* m_) : m(m_) {}
   ~HostStage() {
-    if (s) { hipStreamSynchronize(s->stream); pool_release(m, s); }
+    if (s) {
+      hipStreamSynchronize(s->stream);
+      if (!tmp.empty()) {  // the staging area overflowed during this call: grow it once, for the next one
+        size_t want = s->stage_used + (s->stage_used >> 2) + (1 << 20);
+        if (s->stage) hipFree(s->stage);
+        s->stage = nullptr; s->stage_bytes = 0;
+        void* p = nullptr;
+        if (hipMalloc(&p, want) == hipSuccess) { s->stage = static_cast<char*>(p); s->stage_bytes = want; }
+      }
+      s->stage_used = 0;
+      pool_release(m, s);
+    }
     for (void* p : tmp) hipFree(p);
+  }
+  // bump allocation from the session's staging area; falls back to hipMalloc (freed at the end of the call) when full
+  void* raw_alloc(size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, 256);
+    const size_t off = s->stage_used;
+    s->stage_used += bytes;  // also counts overflow, so the destructor knows how much this call needed
+    if (off + bytes <= s->stage_bytes) return s->stage + off;
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    tmp.push_back(d);
+    return d;
   }
   template <typename T> T* to_dev(const T* h, size_t n) {
     if (!h) return nullptr;
-    void* d = nullptr;
-    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-    tmp.push_back(d);
+    void* d = raw_alloc(n * sizeof(T));
+    if (!d) return nullptr;
     hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s->stream);
     return static_cast<T*>(d);
   }
-  template <typename T> T* dev_alloc(size_t n) {
-    void* d = nullptr;
-    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-    tmp.push_back(d);
-    return static_cast<T*>(d);
-  }
+  template <typename T> T* dev_alloc(size_t n) { return static_cast<T*>(raw_alloc(n * sizeof(T))); }
 };
 
 static int begin_stage(HostStage& hs, int B, int Tx, int Ty) {

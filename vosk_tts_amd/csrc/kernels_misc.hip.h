@@ -190,6 +190,138 @@ __global__ void __launch_bounds__(256) dwconv_ln_gelu_kernel(const DwLnParams P)
   }
 }
 
+// One whole DDSConv layer (modules.py:96-108) per launch for D <= 256 channels:
+//   y = conv_sep(x * mask) (depthwise, K taps, dilation K^i) -> LN1 -> GELU -> conv_1x1 -> LN2 -> GELU ; x = (x + y) * mask
+// A workgroup owns DDS_TL columns and ALL channels (thread = channel), so both channel LayerNorms are block
+// reductions and the 1x1 conv is a [D x D] mat-vec per column on the VALU: thread co walks the TRANSPOSED weight
+// matrix wt[ci][co] (coalesced) against the activations broadcast from LDS.  At these sizes (T_x tokens, D = 256:
+// 3.3 MFLOP per layer) the three launches this replaces were pure launch latency.  Input and output buffers differ
+// (the depthwise taps read neighbouring columns owned by other workgroups).
+#define DDS_TL 8
+struct DdsParams {
+  const float* x; float* y;
+  const float* sw; const float* sb; const float* g1; const float* b1;
+  const float* wt; const float* pb; const float* g2; const float* b2;
+  const int* len;
+  int D, T, K, dil, skip_len;
+};
+__device__ __forceinline__ void dds_block_sum(float (&v)[DDS_TL], float* red, int lane, int wave) {
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[j] += __shfl_xor(v[j], off);
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < DDS_TL; ++j) red[wave * DDS_TL + j] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) v[j] = red[j] + red[DDS_TL + j] + red[2 * DDS_TL + j] + red[3 * DDS_TL + j];
+  __syncthreads();
+}
+__device__ __forceinline__ void dds_ln_gelu(float (&v)[DDS_TL], bool live, float gamma, float beta, float invD, float* red, int lane, int wave) {
+  float s[DDS_TL];
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) s[j] = live ? v[j] : 0.f;
+  dds_block_sum(s, red, lane, wave);
+  float q[DDS_TL];
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) { s[j] *= invD; const float d = v[j] - s[j]; q[j] = live ? d * d : 0.f; }
+  dds_block_sum(q, red, lane, wave);
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) v[j] = gelu_erf((v[j] - s[j]) * (1.0f / sqrtf(q[j] * invD + 1e-5f)) * gamma + beta);
+}
+// weights of the 1x1 conv arrive as wt4[ci/4][co] = float4{W[co][ci..ci+3]}: one dwordx4 per thread per 4 input
+// channels.  The whole matrix (D*D*4 bytes, 256 KB at D = 256) is streamed by EVERY workgroup and comes from HBM / MALL
+// on first touch, so the stream is software-pipelined in two register batches of 16 float4 (64 input channels): batch 0
+// is issued before the depthwise/LayerNorm phase, batch k+1 while batch k is consumed.
+#define DDS_WB 16
+__device__ __forceinline__ void dds_load_batch(float4 (&w)[DDS_WB], const float4* wt4, int D, int k, int co) {
+#pragma unroll
+  for (int i = 0; i < DDS_WB; ++i) w[i] = wt4[(size_t)(k * DDS_WB + i) * D + co];
+}
+__device__ __forceinline__ void dds_use_batch(const float4 (&w)[DDS_WB], const float* act, int k, float (&acc)[DDS_TL]) {
+#pragma unroll
+  for (int i = 0; i < DDS_WB; ++i) {
+    const float wv[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* ap = act + ((k * DDS_WB + i) * 4 + q) * DDS_TL;
+      const float4 a0 = *reinterpret_cast<const float4*>(ap);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+      acc[0] += wv[q] * a0.x; acc[1] += wv[q] * a0.y; acc[2] += wv[q] * a0.z; acc[3] += wv[q] * a0.w;
+      acc[4] += wv[q] * a1.x; acc[5] += wv[q] * a1.y; acc[6] += wv[q] * a1.z; acc[7] += wv[q] * a1.w;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) dds_layer_kernel(const DdsParams P) {
+  __shared__ __attribute__((aligned(16))) float act[256 * DDS_TL];
+  __shared__ float red[4 * DDS_TL];
+  const int c = threadIdx.x, lane = c & 63, wave = c >> 6, b = blockIdx.y, t0 = blockIdx.x * DDS_TL;
+  const int L = P.len[b] < P.T ? P.len[b] : P.T;
+  if (P.skip_len && t0 >= L) return;  // block-uniform: the whole tile is padding of a masked stage
+  const int D = P.D, T = P.T, pad = (P.K * P.dil - P.dil) / 2;
+  const bool live = c < D;
+  const int cc = live ? c : 0;
+  const float invD = 1.0f / (float)D;
+  const int nb = D / (4 * DDS_WB);  // weight batches of 64 input channels (D is a multiple of 64, <= 256)
+  const float4* wt4 = reinterpret_cast<const float4*>(P.wt);
+  float4 wa[DDS_WB], wb[DDS_WB];
+  dds_load_batch(wa, wt4, D, 0, cc);
+  const float* xr = P.x + ((long long)b * D + cc) * T;
+  float v[DDS_TL];
+  {
+    // every load unconditional with a clamped index, validity applied as a select: a per-element `if` around the load
+    // would serialise the K * DDS_TL row reads behind s_waitcnt vmcnt(0)
+    const float bias = P.sb[cc];
+#pragma unroll
+    for (int j = 0; j < DDS_TL; ++j) v[j] = bias;
+    const int Lc = L > 0 ? L - 1 : 0;
+    for (int k = 0; k < P.K; ++k) {
+      const float wk = P.sw[cc * P.K + k];
+      float xv[DDS_TL];
+#pragma unroll
+      for (int j = 0; j < DDS_TL; ++j) {
+        const int s = t0 + j + k * P.dil - pad;
+        xv[j] = xr[s < 0 ? 0 : (s > Lc ? Lc : s)];
+      }
+#pragma unroll
+      for (int j = 0; j < DDS_TL; ++j) {
+        const int s = t0 + j + k * P.dil - pad;
+        v[j] += (s >= 0 && s < L) ? wk * xv[j] : 0.f;
+      }
+    }
+  }
+  const float g2c = P.g2[cc], b2c = P.b2[cc];
+  float xres[DDS_TL];  // residual input, fetched early
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) { const int t = t0 + j; xres[j] = xr[t < T ? t : T - 1]; }
+  dds_ln_gelu(v, live, P.g1[cc], P.b1[cc], invD, red, lane, wave);
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) act[c * DDS_TL + j] = live ? v[j] : 0.f;
+  __syncthreads();
+  float acc[DDS_TL];
+  {
+    const float pb = P.pb[cc];
+#pragma unroll
+    for (int j = 0; j < DDS_TL; ++j) acc[j] = pb;
+  }
+  if (nb > 1) dds_load_batch(wb, wt4, D, 1, cc);
+  dds_use_batch(wa, act, 0, acc);
+  if (nb > 2) dds_load_batch(wa, wt4, D, 2, cc);
+  if (nb > 1) dds_use_batch(wb, act, 1, acc);
+  if (nb > 3) dds_load_batch(wb, wt4, D, 3, cc);
+  if (nb > 2) dds_use_batch(wa, act, 2, acc);
+  if (nb > 3) dds_use_batch(wb, act, 3, acc);
+  dds_ln_gelu(acc, live, g2c, b2c, invD, red, lane, wave);
+  if (!live) return;
+  float* yr = P.y + ((long long)b * D + c) * T;
+#pragma unroll
+  for (int j = 0; j < DDS_TL; ++j) {
+    const int t = t0 + j;
+    if (t < T) yr[t] = t < L ? xres[j] + acc[j] : 0.f;
+  }
+}
+
 // ----------------------------------------------------------------------------- attention
 // MultiHeadAttention.attention (attentions.py:165-196) with the relative-position key/value terms
 // (attentions.py:198-260) in exact banded form: O(T) memory, no [T,2T-1] skew.
