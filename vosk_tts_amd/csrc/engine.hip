@@ -1627,6 +1627,7 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
     vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed, scales[0], scales[1], scales[2]);
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
+      if (s->graphs.size() >= 64) drop_graphs(s);  // bound the cache: a caller that varies shapes/pointers forever must not leak
       hipGraph_t g = nullptr;
       HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
       forward_device(s, d_ids, d_lengths, B, Tx, scales, d_sid, d_forced, Ty, seed, d_audio, cap);
