@@ -168,7 +168,26 @@ def main():
         for _ in range(nprof):
             step()
         rep = sess.profile_report()  # {(op, kernel instantiation): (launches, ms, flops)}
-        rep = {k: (v[0], v[1], v[2] * (dec_exec_frac if k[0].startswith("dec.") else 1.0)) for k, v in rep.items()}
+        # masked stages of a ragged batch run on valid columns only: scale their dense tallies by the valid fraction
+        enc_frac = float(lengths.sum()) / float(B * Tx)
+        flow_frac = float(ylens.sum()) / float(B * Ty)
+
+        def exec_frac(op):
+            if op.startswith("dec."):
+                return dec_exec_frac
+            if op.startswith("flow."):
+                return flow_frac
+            if op == "attention":  # QK^T + PV over valid (query, key) pairs only
+                num = n_enc_layers * float((lengths.astype(np.float64) ** 2).sum()) + n_flow_layers * float((ylens.astype(np.float64) ** 2).sum())
+                return num / (n_enc_layers * B * float(Tx) ** 2 + n_flow_layers * B * float(Ty) ** 2)
+            if op.startswith("enc."):  # the flow's pre-transformer FFN/attention launches share the enc.* labels
+                return None
+            return 1.0
+
+        n_flow_layers, n_enc_layers = hp.flow_n_flows, hp.n_layers
+        mix = (n_enc_layers * Tx * enc_frac + n_flow_layers * Ty * flow_frac) / max(n_enc_layers * Tx + n_flow_layers * Ty, 1)
+        rep = {k: (v[0], v[1], v[2] * (exec_frac(k[0]) if exec_frac(k[0]) is not None else (enc_frac if k[0] == "enc.proj" else mix)))
+               for k, v in rep.items()}
         sess.set_options(use_graph=not args.no_graph, profile=False)
         by_op, by_kernel = {}, {}
         for (op, kern), v in rep.items():
@@ -194,6 +213,8 @@ def main():
                         "sum_kernel_ms_eager": round(dev_ms_all, 4)},
             "by_kernel_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])},
             "by_op_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])},
+            "by_op_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])
+                             if v[2] > 0 and v[1] > 0},
         }
 
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected

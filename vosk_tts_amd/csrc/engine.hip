@@ -667,7 +667,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   for (int g = 0; g < P.n_groups; ++g) {
     const int hg = halo_override >= 0 ? halo_override : (P.g[g].K - 1) * P.g[g].dil;
     if (hg > halo) halo = hg;
-    macs += (double)P.Cout * P.Cin * P.g[g].K;
+    // rows the conv actually computes: the gate kernel stores H channels but contracts 2H rows (tanh | sigmoid)
+    macs += (double)(epi == EPI_GATE ? 2 * P.H : P.Cout) * P.Cin * P.g[g].K;
   }
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
   hipStream_t st = s->stream;
