@@ -23,6 +23,8 @@ Cases
                one-token item, and zero durations at both ends of the first item
   plain_b2     the plain HiFi-GAN `Generator` decoder variant (models.py:845-898) with speaker conditioning,
                ups [8,8,2,2]: reference Generator module alone, B=2
+  hifigan_v1   the HiFi-GAN V1 generator bundled with StableTTS (training/stabletts/matcha/hifigan/models.py:148-199,
+               config.py v1; the `vocoder.decode(mel)` of matcha/onnx/export.py:28-32): 80-channel mel -> waveform, B=2
   mas          monotonic_align.maximum_path_c (the reference's Cython core, compiled here from its own .pyx):
                ragged batch incl. t_x == t_y, t_x == 1, ties, noise-scaled scores
   g2p          known answers of vosk_tts/g2p.py:convert (examples at g2p.py:5-11 + extra words)
@@ -179,6 +181,27 @@ def main():
         g = torch.from_numpy(ptens["emb_g.weight"][sid]).unsqueeze(-1)
         audio = gen(torch.from_numpy(z), g=g)
     save("plain_b2", z=z, sid=sid, audio=audio.numpy()[:, 0])
+    # ---- StableTTS' bundled HiFi-GAN V1 vocoder (vocoder stage only)
+    sys.path.insert(0, os.path.join(refimport.REF_ROOT, "training", "stabletts"))
+    from matcha.hifigan.config import v1 as hifigan_v1_cfg  # noqa: E402
+    from matcha.hifigan.env import AttrDict  # noqa: E402
+    from matcha.hifigan.models import Generator as HifiGenerator  # noqa: E402
+
+    vhp = W.hifigan_v1_vocoder_hparams()
+    vtens = W.make_synthetic_weights(vhp, SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        hg = HifiGenerator(AttrDict(hifigan_v1_cfg)).eval()
+        hg.remove_weight_norm()
+    sd = hg.state_dict()
+    assert set("dec." + k for k in sd) == set(vtens), sorted(set("dec." + k for k in sd) ^ set(vtens))[:5]
+    with torch.no_grad():
+        for k in sd:
+            sd[k].copy_(torch.from_numpy(vtens["dec." + k]))
+    vrng = np.random.default_rng(91)
+    mel = vrng.standard_normal((2, 80, 10)).astype(np.float32)
+    with torch.no_grad():
+        wav = hg(torch.from_numpy(mel))
+    save("hifigan_v1", mel=mel, audio=wav.numpy()[:, 0])
     # ---- monotonic alignment search: the reference's compiled Cython core
     mas = refimport.build_reference_mas()
     B, Ty, Tx = 7, 96, 40

@@ -76,6 +76,13 @@ static const float* tget(vits_model* m, int ndim, int d0, int d1, int d2, const 
   return NULL;
 }
 
+/* optional tensors (e.g. the conv_post bias of the StableTTS HiFi-GAN): presence test without raising `missing` */
+static int thas(const vits_model* m, const char* name) {
+  for (uint32_t i = 0; i < m->n_entries; ++i)
+    if (strncmp(m->entries[i].name, name, sizeof m->entries[i].name) == 0) return 1;
+  return 0;
+}
+
 static float* falloc(size_t n) {
   float* p = (float*)calloc(n ? n : 1, sizeof(float));
   if (!p) { fprintf(stderr, "vits_oracle: out of memory\n"); abort(); }
@@ -864,9 +871,12 @@ int API(stage_decoder)(vits_model* m, const float* z, int32_t B, int32_t T, cons
   size_t n = (size_t)B * C * Tc;
   if (hp->dec_type == 1) { /* plain HiFi-GAN tail: leaky_relu -> conv_post -> tanh (models.py:887-889) */
     const float* pw = tget(m, 3, 1, C, 7, "dec.conv_post.weight");
+    /* VITS' Generator has no conv_post bias (models.py:866); the HiFi-GAN bundled with StableTTS does
+     * (training/stabletts/matcha/hifigan/models.py:176) */
+    const float* pb = thas(m, "dec.conv_post.bias") ? tget(m, 1, 1, -1, -1, "dec.conv_post.bias") : NULL;
     if (!pw) { free(x); return VITS_ERR_BLOB; }
     lrelu_inplace(x, n, 0.01f);
-    conv1d(x, B, C, Tc, pw, NULL, 1, 7, 1, 3, Tc, audio);
+    conv1d(x, B, C, Tc, pw, pb, 1, 7, 1, 3, Tc, audio);
     for (size_t e = 0; e < (size_t)B * Tc; ++e) audio[e] = tanhf(audio[e]);
     free(x);
     return VITS_OK;

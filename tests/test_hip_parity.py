@@ -416,3 +416,25 @@ def test_duration_predictor_both_dds_paths(hip_default, oracle_default, B, T):
     got = hip_default.duration(x, lens, sid, noise, 0.8)
     m = np.arange(T)[None, :] < lens[:, None]
     assert_close("logw", want * m, got * m, STAGE_TOL)
+
+
+def test_stabletts_hifigan_v1_vocoder(hip_lib, oracle_lib):
+    """Vocoder-only blob (n_vocab = 0): StableTTS' bundled HiFi-GAN V1 on the decoder kernels -- golden from the
+    reference module, a longer mel against the oracle, and the acoustic entry points refuse such a model."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.capi import VitsError
+
+    blob = W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234)
+    g = golden("hifigan_v1")
+    hip, ref = hip_lib.create(blob, 0), oracle_lib.create(blob)
+    audio, _ = hip.decoder(g["mel"])
+    assert_close("audio(golden)", g["audio"], audio, STAGE_TOL)
+    mel = np.random.default_rng(8).standard_normal((1, 80, 75)).astype(np.float32)
+    want, _ = ref.decoder(mel)
+    got, _ = hip.decoder(mel)
+    assert_close("audio(oracle)", want, got, STAGE_TOL)
+    with pytest.raises(VitsError, match="vocoder-only"):
+        hip.synthesize(np.array([[1, 2]]), [2], [0.6, 1.0, 0.8], [0])
+    with pytest.raises(VitsError, match="vocoder-only"):
+        hip.text_encoder(np.array([[1, 2]]), [2], [0])
+    hip.close()

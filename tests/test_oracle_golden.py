@@ -92,6 +92,18 @@ def test_plain_generator_variant(oracle_lib):
     assert_close("audio", g["audio"], audio, TOL)
 
 
+def test_stabletts_hifigan_v1_vocoder(oracle_lib):
+    """SURVEY.md 8f rank 3, vocoder stage: the HiFi-GAN V1 generator bundled with StableTTS (matcha/hifigan/models.py:
+    148-199: 80 mels, conv_post with bias, no conditioning) as a vocoder-only blob (n_vocab = 0)."""
+    from vosk_tts_amd import weights as W
+
+    g = golden("hifigan_v1")
+    m = oracle_lib.create(W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234))
+    audio, mb = m.decoder(g["mel"])
+    assert mb is None and audio.shape == g["audio"].shape == (2, 10 * 256)
+    assert_close("audio", g["audio"], audio, TOL)
+
+
 def test_monotonic_alignment_search(oracle_lib):
     """the C restatement of core.pyx:7-42 reproduces the compiled Cython core bit for bit
     (ragged extents, t_x == t_y, single token, exact ties); the caller's scores are left untouched."""

@@ -99,6 +99,7 @@ struct UpW {
 struct vits_session;
 
 struct vits_model {
+  bool acoustic = true;  // false: vocoder-only blob (n_vocab == 0)
   vits_hparams hp;
   int device = 0;
   std::vector<void*> allocs;
@@ -152,6 +153,12 @@ static const float* tget(vits_model* m, int ndim, int d0, int d1, int d2, const 
   m->missing = true;
   fail(VITS_ERR_BLOB, "tensor %s missing from blob", name);
   return nullptr;
+}
+
+static bool thas(const vits_model* m, const char* name) {  // optional tensors
+  for (uint32_t i = 0; i < m->n_entries; ++i)
+    if (strncmp(m->entries[i].name, name, sizeof m->entries[i].name) == 0) return true;
+  return false;
 }
 
 static float* upload(vits_model* m, const float* host, size_t n) {
@@ -249,10 +256,104 @@ static double bessel_i0(double x) {
   return s;
 }
 
+// ---- decoder weights (Multiband_iSTFT_Generator models.py:975-1054 / Generator :845-898)
+static int load_decoder(vits_model* m) {
+  const vits_hparams& hp = m->hp;
+  const int I = hp.inter_channels;
+  char nm[200];
+  int C = hp.dec_initial_channel;
+  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true);
+  m->ups.resize(hp.n_ups);
+  m->rb.resize((size_t)hp.n_ups * hp.n_resk);
+  for (int i = 0; i < hp.n_ups && !m->missing; ++i) {
+    UpW& U = m->ups[i];
+    const int u = hp.up_rates[i], Ku = hp.up_kernels[i], Co = C / 2, p = (Ku - u) / 2;
+    if (u > 8 || Ku % u || (Ku - u) % 2 || C % 64) return fail(VITS_ERR_UNSUPPORTED, "upsample rate/kernel unsupported");
+    const float* w = tget(m, 3, C, Co, Ku, "dec.ups.%d.weight", i);  // [Cin, Cout, K]
+    const float* b = tget(m, 1, Co, -1, -1, "dec.ups.%d.bias", i);
+    if (m->missing) break;
+    U.u = u; U.Ku = Ku; U.cout = Co; U.taps = Ku / u;
+    // out[u*q + r] = sum_{delta} x[q + delta] * W[.., r + p - u*delta]; delta in [dmin(r), dmin(r)+taps-1]
+    int dmin[8], dmin_all = 1 << 30, dmax_all = -(1 << 30);
+    for (int r = 0; r < u; ++r) {
+      const int dmax = (r + p) / u;  // floor, r+p >= 0
+      dmin[r] = dmax - U.taps + 1;
+      if (dmin[r] < dmin_all) dmin_all = dmin[r];
+      if (dmax > dmax_all) dmax_all = dmax;
+    }
+    U.pad_l = -dmin_all;
+    U.halo = dmax_all - dmin_all;
+    for (int r = 0; r < u; ++r) U.shift[r] = dmin[r] + U.pad_l;
+    const int Cin = C;
+    U.w = make_conv(m, u * Co, Cin, U.taps, nullptr, [&](int row, int ci, int j) {
+      const int r = row / Co, co = row % Co;
+      const int k = r + p - u * (dmin[r] + j);
+      return (k >= 0 && k < Ku) ? w[((size_t)ci * Co + co) * Ku + k] : 0.f;
+    });
+    U.w.bias = upload(m, b, Co);
+    C = Co;
+    for (int j = 0; j < hp.n_resk && !m->missing; ++j) {
+      ResBlockW& R = m->rb[(size_t)i * hp.n_resk + j];
+      R.K = hp.res_kernels[j];
+      for (int d = 0; d < hp.n_resd; ++d) {
+        R.dil[d] = hp.res_dilations[j][d];
+        if ((R.K - 1) * R.dil[d] > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "resblock receptive field too wide");
+        snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", i * hp.n_resk + j, d);
+        R.c1[d] = conv_from(m, nm, C, C, R.K, true);
+        snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", i * hp.n_resk + j, d);
+        R.c2[d] = conv_from(m, nm, C, C, R.K, true);
+      }
+    }
+  }
+  if (m->missing) return VITS_ERR_BLOB;
+  if (hp.dec_type == 0) {
+    const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, cut = N / 2 + 1;
+    m->conv_post = conv_from(m, "dec.subband_conv_post", S * (N + 2), C, 7, false);
+    // OnnxSTFT inverse basis (stft.py:191-214): pinv(scale*[Re F;Im F]).T * hann == irfft synthesis rows / scale
+    std::vector<float> basis((size_t)2 * cut * N);
+    const double PI_D = 3.14159265358979323846, scale = (double)N / hop;
+    for (int n = 0; n < N; ++n) {
+      const double win = 0.5 - 0.5 * cos(2.0 * PI_D * n / N);
+      for (int k = 0; k < cut; ++k) {
+        const double wk = (k == 0 || k == N / 2) ? 1.0 : 2.0, th = 2.0 * PI_D * k * n / N;
+        basis[(size_t)k * N + n] = (float)(wk * cos(th) / N / scale) * (float)win;
+        basis[(size_t)(cut + k) * N + n] = (float)(-wk * sin(th) / N / scale) * (float)win;
+      }
+    }
+    m->istft_basis = upload(m, basis.data(), basis.size());
+    // PQMF synthesis filter (pqmf.py:15-43,64-75)
+    const int taps = hp.pqmf_taps, Lf = taps + 1;
+    std::vector<double> hpz(Lf);
+    for (int n = 0; n < Lf; ++n) {
+      const double xx = n - 0.5 * taps;
+      const double hi = (n == taps / 2) ? (double)hp.pqmf_cutoff : sin(PI_D * hp.pqmf_cutoff * xx) / (PI_D * xx);
+      const double r = (n - (Lf - 1) / 2.0) / ((Lf - 1) / 2.0), arg = 1.0 - r * r;
+      hpz[n] = hi * bessel_i0(hp.pqmf_beta * sqrt(arg < 0 ? 0 : arg)) / bessel_i0(hp.pqmf_beta);
+    }
+    std::vector<float> filt((size_t)S * Lf);
+    for (int k = 0; k < S; ++k)
+      for (int n = 0; n < Lf; ++n)
+        filt[(size_t)k * Lf + n] = (float)(2.0 * hpz[n] * cos((2 * k + 1) * (PI_D / (2.0 * S)) * (n - ((taps - 1) / 2.0)) - ((k % 2 == 0) ? 1.0 : -1.0) * PI_D / 4.0));
+    m->pqmf = upload(m, filt.data(), filt.size());
+  } else {
+    // VITS' Generator has no conv_post bias (models.py:866); the HiFi-GAN bundled with StableTTS has one
+    m->conv_post = conv_from(m, "dec.conv_post", 1, C, 7, thas(m, "dec.conv_post.bias"));
+  }
+  return m->missing ? VITS_ERR_BLOB : VITS_OK;
+}
+
 static int load_model(vits_model* m) {
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels, I = hp.inter_channels, F = hp.filter_channels, G = hp.gin_channels;
   const int D = hp.dp_filter_channels;
+  // n_vocab == 0: a vocoder-only blob (e.g. the HiFi-GAN bundled with StableTTS, matcha/hifigan/models.py:148-199):
+  // only the decoder tensors exist and only vits_stage_decoder / vits_stream-less decoding is available
+  m->acoustic = hp.n_vocab > 0;
+  if (!m->acoustic) {
+    if (I % CONV_CI_T) return fail(VITS_ERR_UNSUPPORTED, "decoder input channels must be a multiple of %d", CONV_CI_T);
+    if (hp.n_ups > VITS_MAX_UPS || hp.n_resk > 3 || hp.n_resd > VITS_MAX_RESD || hp.n_ups < 1) return fail(VITS_ERR_UNSUPPORTED, "hparams out of range");
+    return load_decoder(m);
+  }
   if (hp.n_heads <= 0 || H % hp.n_heads) return fail(VITS_ERR_UNSUPPORTED, "hidden %% n_heads != 0");
   const int dk = H / hp.n_heads;
   if (dk != 32 && dk != 64 && dk != 96) return fail(VITS_ERR_UNSUPPORTED, "head dim %d not in {32,64,96}", dk);
@@ -344,85 +445,7 @@ static int load_model(vits_model* m) {
   m->cond_rows = (int)cB.size();
   if (m->cond_rows) { m->cond_W = upload(m, cW.data(), cW.size()); m->cond_b = upload(m, cB.data(), cB.size()); }
 
-  // ---- decoder
-  int C = hp.dec_initial_channel;
-  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true);
-  m->ups.resize(hp.n_ups);
-  m->rb.resize((size_t)hp.n_ups * hp.n_resk);
-  for (int i = 0; i < hp.n_ups && !m->missing; ++i) {
-    UpW& U = m->ups[i];
-    const int u = hp.up_rates[i], Ku = hp.up_kernels[i], Co = C / 2, p = (Ku - u) / 2;
-    if (u > 8 || Ku % u || (Ku - u) % 2 || C % 64) return fail(VITS_ERR_UNSUPPORTED, "upsample rate/kernel unsupported");
-    const float* w = tget(m, 3, C, Co, Ku, "dec.ups.%d.weight", i);  // [Cin, Cout, K]
-    const float* b = tget(m, 1, Co, -1, -1, "dec.ups.%d.bias", i);
-    if (m->missing) break;
-    U.u = u; U.Ku = Ku; U.cout = Co; U.taps = Ku / u;
-    // out[u*q + r] = sum_{delta} x[q + delta] * W[.., r + p - u*delta]; delta in [dmin(r), dmin(r)+taps-1]
-    int dmin[8], dmin_all = 1 << 30, dmax_all = -(1 << 30);
-    for (int r = 0; r < u; ++r) {
-      const int dmax = (r + p) / u;  // floor, r+p >= 0
-      dmin[r] = dmax - U.taps + 1;
-      if (dmin[r] < dmin_all) dmin_all = dmin[r];
-      if (dmax > dmax_all) dmax_all = dmax;
-    }
-    U.pad_l = -dmin_all;
-    U.halo = dmax_all - dmin_all;
-    for (int r = 0; r < u; ++r) U.shift[r] = dmin[r] + U.pad_l;
-    const int Cin = C;
-    U.w = make_conv(m, u * Co, Cin, U.taps, nullptr, [&](int row, int ci, int j) {
-      const int r = row / Co, co = row % Co;
-      const int k = r + p - u * (dmin[r] + j);
-      return (k >= 0 && k < Ku) ? w[((size_t)ci * Co + co) * Ku + k] : 0.f;
-    });
-    U.w.bias = upload(m, b, Co);
-    C = Co;
-    for (int j = 0; j < hp.n_resk && !m->missing; ++j) {
-      ResBlockW& R = m->rb[(size_t)i * hp.n_resk + j];
-      R.K = hp.res_kernels[j];
-      for (int d = 0; d < hp.n_resd; ++d) {
-        R.dil[d] = hp.res_dilations[j][d];
-        if ((R.K - 1) * R.dil[d] > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "resblock receptive field too wide");
-        snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", i * hp.n_resk + j, d);
-        R.c1[d] = conv_from(m, nm, C, C, R.K, true);
-        snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", i * hp.n_resk + j, d);
-        R.c2[d] = conv_from(m, nm, C, C, R.K, true);
-      }
-    }
-  }
-  if (m->missing) return VITS_ERR_BLOB;
-  if (hp.dec_type == 0) {
-    const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, cut = N / 2 + 1;
-    m->conv_post = conv_from(m, "dec.subband_conv_post", S * (N + 2), C, 7, false);
-    // OnnxSTFT inverse basis (stft.py:191-214): pinv(scale*[Re F;Im F]).T * hann == irfft synthesis rows / scale
-    std::vector<float> basis((size_t)2 * cut * N);
-    const double PI_D = 3.14159265358979323846, scale = (double)N / hop;
-    for (int n = 0; n < N; ++n) {
-      const double win = 0.5 - 0.5 * cos(2.0 * PI_D * n / N);
-      for (int k = 0; k < cut; ++k) {
-        const double wk = (k == 0 || k == N / 2) ? 1.0 : 2.0, th = 2.0 * PI_D * k * n / N;
-        basis[(size_t)k * N + n] = (float)(wk * cos(th) / N / scale) * (float)win;
-        basis[(size_t)(cut + k) * N + n] = (float)(-wk * sin(th) / N / scale) * (float)win;
-      }
-    }
-    m->istft_basis = upload(m, basis.data(), basis.size());
-    // PQMF synthesis filter (pqmf.py:15-43,64-75)
-    const int taps = hp.pqmf_taps, Lf = taps + 1;
-    std::vector<double> hpz(Lf);
-    for (int n = 0; n < Lf; ++n) {
-      const double xx = n - 0.5 * taps;
-      const double hi = (n == taps / 2) ? (double)hp.pqmf_cutoff : sin(PI_D * hp.pqmf_cutoff * xx) / (PI_D * xx);
-      const double r = (n - (Lf - 1) / 2.0) / ((Lf - 1) / 2.0), arg = 1.0 - r * r;
-      hpz[n] = hi * bessel_i0(hp.pqmf_beta * sqrt(arg < 0 ? 0 : arg)) / bessel_i0(hp.pqmf_beta);
-    }
-    std::vector<float> filt((size_t)S * Lf);
-    for (int k = 0; k < S; ++k)
-      for (int n = 0; n < Lf; ++n)
-        filt[(size_t)k * Lf + n] = (float)(2.0 * hpz[n] * cos((2 * k + 1) * (PI_D / (2.0 * S)) * (n - ((taps - 1) / 2.0)) - ((k % 2 == 0) ? 1.0 : -1.0) * PI_D / 4.0));
-    m->pqmf = upload(m, filt.data(), filt.size());
-  } else {
-    m->conv_post = conv_from(m, "dec.conv_post", 1, C, 7, false);
-  }
-  return m->missing ? VITS_ERR_BLOB : VITS_OK;
+  return load_decoder(m);
 }
 
 // ------------------------------------------------------------------------------------ sessions
@@ -1091,7 +1114,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
   } else {
     memset(&P, 0, sizeof P);
     P.n_groups = 1;
-    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = m->conv_post.w; P.g[0].y = post;
+    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = m->conv_post.w; P.g[0].bias = m->conv_post.bias; P.g[0].y = post;
     P.g[0].K = 7; P.g[0].dil = 1; P.g[0].pad_l = 3; P.g[0].n_sg = m->conv_post.n_sg;
     P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
     P.M = m->conv_post.Mpad; P.Cout = 1; P.Tout = T; P.Tout_stride = T; P.y_bstride = T;
@@ -1255,6 +1278,7 @@ double vits_algorithmic_flops(const vits_model* m, int32_t B, int32_t Tx, int32_
 
 int vits_stage_text_encoder(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const int64_t* sid,
                             float* x, float* m_p, float* logs_p) {
+  if (m && !m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!m || !ids || !lengths || !x || !m_p || !logs_p || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
   for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
   HostStage hs(m);
@@ -1278,6 +1302,7 @@ int vits_stage_text_encoder(vits_model* m, const int64_t* ids, const int64_t* le
 
 int vits_stage_duration(vits_model* m, const float* x, const int64_t* lengths, int32_t B, int32_t Tx, const int64_t* sid,
                         const float* noise, float noise_scale_w, float* logw) {
+  if (m && !m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!m || !x || !lengths || !noise || !logw || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
   HostStage hs(m);
   TRY(begin_stage(hs, B, Tx, 1));
@@ -1298,6 +1323,7 @@ int vits_stage_duration(vits_model* m, const float* x, const int64_t* lengths, i
 int vits_stage_regulate(vits_model* m, const float* logw, const int32_t* forced, const int64_t* lengths, int32_t B, int32_t Tx,
                         float length_scale, const float* m_p, const float* logs_p, const float* noise, float noise_scale,
                         int32_t Tcap, int32_t* durations, int64_t* y_lengths, float* z_p) {
+  if (m && !m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!m || !lengths || !durations || !y_lengths || (!logw && !forced) || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
   if (z_p && (!m_p || !logs_p || Tcap <= 0)) return fail(VITS_ERR_ARG, "m_p/logs_p/T_cap required");
   HostStage hs(m);
@@ -1331,6 +1357,7 @@ int vits_stage_regulate(vits_model* m, const float* logw, const int32_t* forced,
 }
 
 int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, int32_t B, int32_t Ty, const int64_t* sid, float* z) {
+  if (m && !m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!m || !z_p || !y_lengths || !z || B <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
   HostStage hs(m);
   TRY(begin_stage(hs, B, 1, Ty));
@@ -1370,6 +1397,7 @@ int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, con
 // session workspace (masked by the decoder's first staging), the per-item frame counts in ylen.
 static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
                          const int64_t* sid, const vits_synth_opts* opts, std::vector<int64_t>& ylen, int64_t& Ty_out, float*& z_out) {
+  if (!hs.m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   vits_model* m = hs.m;
   const vits_hparams& hp = m->hp;
   const int I = hp.inter_channels;
@@ -1617,6 +1645,7 @@ void vits_session_destroy(vits_session* s) { session_free(s); }
 int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const int64_t* d_lengths, int32_t B, int32_t Tx,
                                    const float* scales, const int64_t* d_sid, const int32_t* d_forced, int32_t Ty, uint64_t seed,
                                    float* d_audio, int64_t cap, void* stream) {
+  if (s && !s->m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!s || !d_ids || !d_lengths || !scales || !d_audio || B <= 0 || Tx <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
   vits_model* m = s->m;
   if (cap < (int64_t)Ty * m->hp.hop_length) return fail(VITS_ERR_ARG, "audio capacity %lld < T_y*hop", (long long)cap);

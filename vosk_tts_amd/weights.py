@@ -166,6 +166,24 @@ def plain_hparams(n_vocab=20):
     return hp
 
 
+def hifigan_v1_vocoder_hparams():
+    """Vocoder-only blob (n_vocab = 0): the HiFi-GAN V1 generator bundled with StableTTS
+    (training/stabletts/matcha/hifigan/models.py:148-199, config.py v1) that the multistream export wraps as
+    `vocoder.decode(mel)` (matcha/onnx/export.py:28-32): 80 mel channels in, ups [8,8,2,2], conv_post WITH bias,
+    no speaker conditioning.  Only the decoder stage is available on such a model."""
+    hp = default_hparams(0)
+    hp.n_vocab = 0
+    hp.n_speakers = 0
+    hp.gin_channels = 0
+    hp.inter_channels = 80
+    hp.dec_type = 1
+    hp.dec_initial_channel = 512
+    hp.n_ups = 4
+    for i, (u, k) in enumerate(((8, 16), (8, 16), (2, 4), (2, 4))):
+        hp.up_rates[i], hp.up_kernels[i] = u, k
+    return hp
+
+
 # --------------------------------------------------------------------------- #
 # tensor inventory
 # --------------------------------------------------------------------------- #
@@ -215,13 +233,15 @@ def tensor_specs(hp):
         for i in range(n):
             ln(f"{prefix}.norms_2.{i}", c)
 
-    # text encoder (models.py:283-326)
-    specs.append(("enc_p.emb.weight", (hp.n_vocab, H), "emb", H, 1.0))
-    encoder("enc_p.encoder", hp.n_layers, F, hp.kernel_size)
-    if hp.enc_cond_layer >= 0 and G > 0:
-        specs.append(("enc_p.encoder.spk_emb_linear.weight", (H, G), "w", G, 1.0))
-        specs.append(("enc_p.encoder.spk_emb_linear.bias", (H,), "b", 0, 1.0))
-    conv("enc_p.proj", 2 * I, H, 1, gain=0.5)
+    acoustic = hp.n_vocab > 0  # n_vocab == 0: vocoder-only blob, decoder tensors only
+    if acoustic:
+        # text encoder (models.py:283-326)
+        specs.append(("enc_p.emb.weight", (hp.n_vocab, H), "emb", H, 1.0))
+        encoder("enc_p.encoder", hp.n_layers, F, hp.kernel_size)
+        if hp.enc_cond_layer >= 0 and G > 0:
+            specs.append(("enc_p.encoder.spk_emb_linear.weight", (H, G), "w", G, 1.0))
+            specs.append(("enc_p.encoder.spk_emb_linear.bias", (H,), "b", 0, 1.0))
+        conv("enc_p.proj", 2 * I, H, 1, gain=0.5)
 
     # decoder (models.py:974-1014 / 845-871)
     C0 = hp.dec_initial_channel
@@ -242,9 +262,12 @@ def tensor_specs(hp):
     if hp.dec_type == 0:
         conv("dec.subband_conv_post", hp.subbands * (hp.istft_n_fft + 2), ch, 7, bias=False, gain=0.5)
     else:
-        conv("dec.conv_post", 1, ch, 7, bias=False, gain=0.5)
+        # VITS' Generator: no conv_post bias (models.py:866); StableTTS' HiFi-GAN: bias (hifigan/models.py:176)
+        conv("dec.conv_post", 1, ch, 7, bias=not acoustic, gain=0.5)
         if G > 0 and hp.n_speakers > 1:
             conv("dec.cond", C0, G, 1)  # Generator.cond (models.py:869-870)
+    if not acoustic:
+        return specs
 
     # flow (models.py:329-396, 630-762); only even indices carry weights
     for f in range(hp.flow_n_flows):
