@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/stts_*.npz by running the REFERENCE's own StableTTS / Matcha modules
+(training/stabletts/matcha, imported through oracle/refimport_stts.py) on build-owned synthetic weights.
+TEST INFRASTRUCTURE, container-only.   python oracle/gen_golden_stts.py
+
+  stts_b1   B=1, T_x=14, 5-stream ids, random bert, phone_duration_extra with two forced pauses,
+            MatchaTTS.synthesise (n_timesteps=5, Euler, guidance 0.5) with the noise draw captured; stage tensors:
+            encoder concat x, mu_dp, durations, y_lengths, mu_y, one estimator call (real and CFG branch), decoder
+            output before/after the pause fill, denormalised mel, and the waveform of the bundled HiFi-GAN V1.
+  stts_nobert  the `multistream_v2` without tokenizer case of vosk_tts/synth.py:77-81: bert = zeros, no
+            phone_duration_extra (None -> zeros inside synthesise).
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refimport_stts as R  # noqa: E402
+from vosk_tts_amd import weights as W  # noqa: E402
+from vosk_tts_amd import weights_stts as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+N_VOCAB, N_SPKS = 40, 7
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def build():
+    hp = S.default_hparams(N_VOCAB, N_SPKS)
+    tens = S.make_synthetic_weights(hp, SEED)
+    net = R.build_reference_model(N_VOCAB, N_SPKS)
+    sd = net.state_dict()
+    mine = set(tens)
+    theirs = {k for k in sd if not k.startswith("encoder.encoder.") and k not in ("mel_mean", "mel_std")}
+    assert mine == theirs, sorted(mine ^ theirs)[:8]
+    with torch.no_grad():
+        for k, v in tens.items():
+            assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(torch.from_numpy(v))
+    assert abs(float(net.mel_mean) - hp.mel_mean) < 1e-6 and abs(float(net.mel_std) - hp.mel_std) < 1e-6
+    # vocoder: the bundled HiFi-GAN V1 with the synthetic vocoder-only blob's tensors
+    M = R.modules()
+    vhp = W.hifigan_v1_vocoder_hparams()
+    vt = W.make_synthetic_weights(vhp, SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        voc = M["hifigan"].Generator(M["AttrDict"](M["hifigan_cfg"])).eval()
+        voc.remove_weight_norm()
+    vsd = voc.state_dict()
+    with torch.no_grad():
+        for k in vsd:
+            vsd[k].copy_(torch.from_numpy(vt["dec." + k]))
+    return hp, net, voc
+
+
+def case(name, net, voc, hp, rng, Tx, bert_zero, pde_mode, sid, scales):
+    ids = rng.integers(1, N_VOCAB, size=(1, 5, Tx)).astype(np.int64)
+    lens = np.array([Tx], np.int64)
+    bert = np.zeros((1, 768, Tx), np.float32) if bert_zero else rng.standard_normal((1, 768, Tx)).astype(np.float32)
+    pde = None
+    if pde_mode:
+        pde = np.zeros((1, Tx), np.float32)
+        pde[0, 3] = 7.0   # forced 7-frame pause tokens (synth.py g2p_multistream_scales)
+        pde[0, Tx - 2] = 4.0
+    temperature, length_scale, dp_temperature = scales  # scales = [noise_level, 1/speech_rate, duration_noise]
+    x_t, l_t, s_t, b_t = torch.from_numpy(ids), torch.from_numpy(lens), torch.tensor([sid]), torch.from_numpy(bert)
+    p_t = None if pde is None else torch.from_numpy(pde)
+    out = {}
+    with torch.no_grad():
+        spk = net.spk_emb(s_t)
+        dspk = net.dur_spk_emb(s_t)
+        x, x_mel, mu_mel, x_dp, mu_dp, x_mask = net.encoder(x_t, l_t, spk, dspk, b_t)
+        out["enc_x"], out["mu_dp"] = x.numpy(), mu_dp.numpy()
+    captured = {}
+    orig_randn = torch.randn
+
+    def fake_randn(*size, **kw):
+        shape = size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+        z = torch.from_numpy(rng.standard_normal(tuple(int(v) for v in shape)).astype(np.float32))
+        captured["z"] = z.numpy().copy()
+        return z
+
+    # record every estimator call of the Euler loop
+    calls = []
+    est = net.decoder.estimator
+    orig_forward = est.forward
+
+    def rec_forward(xx, mask, mu, t, c):
+        r = orig_forward(xx, mask, mu, t, c)
+        calls.append((xx.numpy().copy(), mu.numpy().copy(), float(t), c.numpy().copy(), r.numpy().copy()))
+        return r
+
+    est.forward = rec_forward
+    torch.randn = fake_randn
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = net.synthesise(x_t, l_t, n_timesteps=hp.n_timesteps, temperature=temperature, dp_temperature=dp_temperature,
+                                 spks=s_t, bert=b_t, length_scale=length_scale, phone_duration_extra=p_t)
+    finally:
+        torch.randn = orig_randn
+        est.forward = orig_forward
+    assert len(calls) == 2 * hp.n_timesteps
+    y_len = int(res["mel_lengths"][0])
+    with torch.no_grad():
+        wav = voc(res["mel"]).clamp(-1, 1)
+    out.update(
+        ids=ids, lengths=lens, sid=np.array([sid], np.int64), bert=bert, scales=np.asarray(scales, np.float32),
+        phone_duration_extra=np.zeros((1, Tx), np.float32) if pde is None else pde, has_pde=np.int32(pde is not None),
+        noise=captured["z"], y_lengths=np.array([y_len], np.int64),
+        durations=res["attn"][0, 0].sum(-1).numpy().astype(np.int32)[None],
+        est_x=calls[0][0], est_mu=calls[0][1], est_t=np.float32(calls[0][2]), est_c=calls[0][3], est_out=calls[0][4],
+        est_fake_mu=calls[1][1], est_fake_c=calls[1][3], est_fake_out=calls[1][4],
+        est_last_t=np.float32(calls[-2][2]), decoder_outputs=res["decoder_outputs"].numpy(), mel=res["mel"].numpy(),
+        audio=wav.numpy()[:, 0])
+    save(name, **out)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    hp, net, voc = build()
+    rng = np.random.default_rng(4321)
+    case("stts_b1", net, voc, hp, rng, 14, False, True, 3, [0.8, 1.1, 0.8])
+    case("stts_nobert", net, voc, hp, rng, 9, True, False, 1, [0.667, 1.0, 0.8])
+
+
+if __name__ == "__main__":
+    main()

@@ -310,8 +310,12 @@ def _rng(name, seed):
 
 def make_synthetic_weights(hp, seed=1234):
     """name -> float32 ndarray.  Fan-in scaled uniform so activations stay O(1)."""
+    return synthetic_from_specs(tensor_specs(hp), seed)
+
+
+def synthetic_from_specs(specs, seed=1234):
     out = {}
-    for name, shape, kind, fan_in, gain in tensor_specs(hp):
+    for name, shape, kind, fan_in, gain in specs:
         r = _rng(name, seed)
         u = r.random(size=shape, dtype=np.float64) * 2.0 - 1.0  # U(-1,1)
         if kind == "w":
@@ -343,10 +347,10 @@ def make_synthetic_weights(hp, seed=1234):
 # blob I/O
 # --------------------------------------------------------------------------- #
 
-def pack_blob(hp, tensors):
+def pack_blob(hp, tensors, magic=MAGIC):
     names = list(tensors.keys())
     n = len(names)
-    head = MAGIC + struct.pack("<I", ctypes.sizeof(HParams)) + bytes(hp) + struct.pack("<I", n)
+    head = magic + struct.pack("<I", ctypes.sizeof(type(hp))) + bytes(hp) + struct.pack("<I", n)
     table_bytes = n * ctypes.sizeof(BlobEntry)
     off = len(head) + table_bytes
     off = (off + 63) // 64 * 64
