@@ -1,0 +1,96 @@
+"""GPU parity tests of the StableTTS / Matcha ("multistream") path through the C ABI of include/stts_mi355.h:
+HIP vs the reference goldens (tests/golden/stts_*.npz) and vs the CPU oracle on other seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+STAGE_TOL = 1e-4
+E2E_TOL = 5e-4  # north_star budget: 1e-3
+
+
+def golden(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def stts_pair(hip_lib, oracle_lib):
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.capi_stts import SttsModel
+
+    vblob = W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234)
+    blob = S.synthetic_blob(S.default_hparams(40, 7), 1234)
+    hip = SttsModel(hip_lib, blob, hip_lib.create(vblob, 0))
+    ref = SttsModel(oracle_lib, blob, oracle_lib.create(vblob))
+    yield hip, ref
+    hip.close()
+
+
+@pytest.mark.parametrize("name", ["stts_b1", "stts_nobert"])
+def test_stts_stages_vs_golden(stts_pair, name):
+    hip, _ = stts_pair
+    g = golden(name)
+    x, mu = hip.encoder(g["ids"], g["lengths"], g["sid"], g["bert"])
+    assert_close("enc_x", g["enc_x"], x, STAGE_TOL)
+    assert_close("mu_dp", g["mu_dp"], mu, STAGE_TOL)
+    pde = g["phone_duration_extra"] if int(g["has_pde"]) else None
+    d, yl = hip.durations(g["mu_dp"], float(g["scales"][1]), pde)
+    assert np.array_equal(d, g["durations"]) and yl.tolist() == g["y_lengths"].tolist()
+    ylen = [int(g["y_lengths"][0])]
+    assert_close("estimator", g["est_out"], hip.estimator(g["est_x"], g["est_mu"], ylen, float(g["est_t"]), g["est_c"]), STAGE_TOL)
+    assert_close("estimator(cfg)", g["est_fake_out"],
+                 hip.estimator(g["est_x"], g["est_fake_mu"], ylen, float(g["est_t"]), g["est_fake_c"]), STAGE_TOL)
+
+
+@pytest.mark.parametrize("name", ["stts_b1", "stts_nobert"])
+def test_stts_synthesise_vs_golden(stts_pair, name):
+    hip, _ = stts_pair
+    g = golden(name)
+    pde = g["phone_duration_extra"][0] if int(g["has_pde"]) else None
+    audio, mel = hip.synthesize(g["ids"][0], g["scales"], int(g["sid"][0]), g["bert"][0], pde, noise=g["noise"][0])
+    assert mel.shape == g["mel"][0].shape and audio.shape == g["audio"][0].shape
+    assert_close("mel", g["mel"][0], mel, E2E_TOL)
+    assert_close("audio", g["audio"][0], audio, E2E_TOL)
+
+
+def test_stts_batched_estimator_and_cfm_vs_oracle(stts_pair):
+    """estimator with B=3 ragged lengths, and the whole Euler/CFG loop (stage_cfm) on another size, against the oracle"""
+    hip, ref = stts_pair
+    rng = np.random.default_rng(17)
+    B, T = 3, 44
+    x = rng.standard_normal((B, 80, T)).astype(np.float32)
+    mu = rng.standard_normal((B, 256, T)).astype(np.float32)
+    c = rng.standard_normal((B, 128)).astype(np.float32)
+    yl = np.array([44, 30, 17], np.int64)
+    assert_close("estimator B=3", ref.estimator(x, mu, yl, 0.37, c), hip.estimator(x, mu, yl, 0.37, c), STAGE_TOL)
+    T = 52
+    mu_y = rng.standard_normal((256, T)).astype(np.float32)
+    mu_y[:, 50:] = 0
+    noise = rng.standard_normal((80, T)).astype(np.float32)
+    want = ref.cfm(mu_y, 50, 2, noise, 0.8, 3)
+    got = hip.cfm(mu_y, 50, 2, noise, 0.8, 3)
+    assert_close("cfm", want[:, :50], got[:, :50], E2E_TOL)
+
+
+def test_stts_seeded_noise_and_errors(stts_pair):
+    """library Philox noise is the same stream in HIP and oracle; bad ids / speaker are refused; mel-only call works"""
+    from vosk_tts_amd.capi import VitsError
+
+    hip, ref = stts_pair
+    g = golden("stts_nobert")
+    a_ref, m_ref = ref.synthesize(g["ids"][0], g["scales"], 2, None, None, seed=11, n_timesteps=2)
+    a_hip, m_hip = hip.synthesize(g["ids"][0], g["scales"], 2, None, None, seed=11, n_timesteps=2)
+    assert_close("mel(seeded)", m_ref, m_hip, E2E_TOL)
+    assert_close("audio(seeded)", a_ref, a_hip, E2E_TOL)
+    a, m = hip.synthesize(g["ids"][0], g["scales"], 2, seed=11, n_timesteps=2, want_audio=False)
+    assert a is None and np.array_equal(m, m_hip)
+    bad = g["ids"][0].copy(); bad[0, 0] = 12345
+    with pytest.raises(VitsError, match="token id"):
+        hip.synthesize(bad, g["scales"], 0)
+    with pytest.raises(VitsError, match="speaker id"):
+        hip.synthesize(g["ids"][0], g["scales"], 77)

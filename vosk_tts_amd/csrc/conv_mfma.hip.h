@@ -76,7 +76,10 @@ struct ConvParams {
   int in_mask;        // zero input where t >= len[b]
   int reflect;        // ReflectionPad1d((1,0)) folded into staging: index -1 reads index 1
   const int* len;     // [B] lengths for masks
-  int relu;
+  int relu;           // 1: ReLU, 2: SiLU (stabletts FFN / cond_proj) on acc + bias
+  const float* scale_b;  // per-batch per-row gate [B][scale_b_stride] applied after the mask, before the residual
+  int scale_b_stride;    // (adaLN-Zero gates: x + gate * f(x) * mask, diffusion_transformer.py:112-113)
+  int scale_b_off;
   int out_mask;
   const float* bias_b;  // per-batch bias [B][bias_b_stride] or null (cond(g) terms)
   int bias_b_stride;
@@ -203,13 +206,21 @@ __device__ __forceinline__ void conv_epilogue_frag(const ConvParams& P, const Co
 #pragma unroll
       for (int i = 0; i < NE; ++i) v[i] += bb[row[i]];
     }
-    if (P.relu) {
+    if (P.relu == 1) {
 #pragma unroll
       for (int i = 0; i < NE; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    } else if (P.relu == 2) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
     }
     if (P.out_mask && col >= lenb) {
 #pragma unroll
       for (int i = 0; i < NE; ++i) v[i] = 0.f;
+    }
+    if (P.scale_b) {
+      const float* sb = P.scale_b + (long long)b * P.scale_b_stride + P.scale_b_off;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] *= sb[row[i]];
     }
     if (G.res) {
       float r[NE];

@@ -784,7 +784,7 @@ static void mark_masked(vits_session* s, ConvParams& P, const int* len) {
 static void launch_ln(vits_session* s, const float* a, const float* b, const float* base, float* y, const float* gamma,
                       const float* beta, const int* len, int B, int C, int T, int gelu, int mask) {
   ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
-  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask, (s->ragged && len) ? 1 : 0};
+  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask, (s->ragged && len) ? 1 : 0, 0};
   hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, P);
 }
 
@@ -1793,3 +1793,5 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
 }
 
 }  // extern "C"
+
+#include "stts.hip.h"

@@ -91,6 +91,9 @@ struct LNParams {
   const float* gamma; const float* beta; const int* len;
   int C, T; int gelu; int mask;
   int skip_len;  // ragged batch: blocks that start at or beyond len[b] do nothing
+  // adaLN (DiT blocks, stabletts diffusion_transformer.py:111,120-122): when > 0 the affine part is per batch item,
+  // y = LN(x) * (1 + gamma[b*mod_stride + c]) + beta[b*mod_stride + c]   (LayerNorm without elementwise affine + modulate)
+  int mod_stride;
 };
 __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
   red[cg * LN_TL + tl] = v;
@@ -135,7 +138,9 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = cg + i * LN_CG;
     if (c < P.C) {
-      float x = (v[i] - mean) * rstd * P.gamma[c] + P.beta[c];
+      const float ga = P.mod_stride ? 1.0f + P.gamma[(long long)b * P.mod_stride + c] : P.gamma[c];
+      const float be = P.mod_stride ? P.beta[(long long)b * P.mod_stride + c] : P.beta[c];
+      float x = (v[i] - mean) * rstd * ga + be;
       if (P.gelu) x = gelu_erf(x);
       if (P.base) x += P.base[o0 + (long long)c * P.T];
       P.y[o0 + (long long)c * P.T] = zero ? 0.f : x;
@@ -920,4 +925,106 @@ __global__ void __launch_bounds__(256) mas_kernel(const float* __restrict__ valu
       if (index != 0 && (index == y || dg[(size_t)y * Tx + index])) index -= 1;
     }
   }
+}
+
+// ============================================================================ StableTTS / Matcha (stts.hip.h)
+// Small, launch-latency-bound pieces of MatchaTTS.synthesise; the contractions run on the shared MFMA conv kernels.
+
+// TextEncoder.forward streams (text_encoder.py:113-127): x[b][0:E] = emb[ids[b,0,t]]*sqrt(E), four auxiliary streams
+// x[b][E + (s-1)*Pd + c] = punc_emb[ids[b,s,t]]*sqrt(Pd); the bert_proj rows are written by a 1x1 conv launch.
+__global__ void stts_embed_kernel(const int64_t* ids, const float* emb, const float* pemb, float* x, int H, int E, int Pd, int T,
+                                  int n_vocab, float es, float ps, int* err) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const int s = c < E ? 0 : 1 + (c - E) / Pd;
+  long long id = ids[((long long)b * 5 + s) * T + t];
+  if (id < 0 || id >= n_vocab) { atomicOr(err, 1); id = 0; }
+  x[((long long)b * H + c) * T + t] = c < E ? emb[id * E + c] * es : pemb[id * Pd + (c - E) % Pd] * ps;
+}
+__global__ void mask_rows_kernel(float* x, const int* len, int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t < T && t >= len[b]) x[((long long)b * C + c) * T + t] = 0.f;
+}
+// RotaryPositionalEmbeddings (diffusion_transformer.py:124-198) on the q and k rows of a fused [B,3H,T] qkv buffer:
+// d = dk/2 rotated features per head, pairs (j, j + d/2), theta_j = 10000^(-2j/d), position = column index.
+__global__ void rope_kernel(float* qkv, int H, int T, int heads, int dk) {
+  const int d = dk / 2, d2 = d / 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, hj = blockIdx.y, b = blockIdx.z >> 1, which = blockIdx.z & 1;
+  if (t >= T) return;
+  const int h = hj / d2, j = hj % d2;
+  const float theta = 1.0f / powf(10000.0f, (float)(2 * j) / (float)d);
+  const float ang = (float)t * theta, cs = cosf(ang), sn = sinf(ang);
+  float* r0 = qkv + (((long long)b * 3 + which) * H + h * dk + j) * T + t;
+  float* r1 = r0 + (long long)d2 * T;
+  const float x0 = *r0, x1 = *r1;
+  *r0 = x0 * cs - x1 * sn;
+  *r1 = x1 * cs + x0 * sn;
+}
+// DitWrapper.time_fusion (components/decoder.py:15-16,31-33): h = (gamma[c] * h + beta[c]) * mask, film = [gamma | beta]
+__global__ void film_mask_kernel(float* h, const float* film, const int* len, int H, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const long long o = ((long long)b * H + c) * T + t;
+  h[o] = t < len[b] ? film[c] * h[o] + film[H + c] : 0.f;
+}
+// y[n][r] = act(bias[r] + sum_j W[r][j] * x[n][j]); one wave per (row, n).  act: 0 none, 1 SiLU
+__global__ void gemv_rows_kernel(const float* W, const float* bias, const float* x, int x_stride, float* y, int y_stride, int rows,
+                                 int cols, int act) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n = blockIdx.y;
+  if (row >= rows) return;
+  float a = 0.f;
+  for (int j = lane; j < cols; j += 64) a += W[(long long)row * cols + j] * x[(long long)n * x_stride + j];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if (lane == 0) {
+    a += bias ? bias[row] : 0.f;
+    y[(long long)n * y_stride + row] = act == 1 ? a / (1.0f + __expf(-a)) : a;
+  }
+}
+__global__ void copy_rows_kernel(const float* src, long long sb, float* dst, long long db, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+  if (t < T) dst[(long long)b * db + (long long)r * T + t] = src[(long long)b * sb + (long long)r * T + t];
+}
+// z = randn * temperature (flow_matching.py:52) into the state rows of both CFG batch items
+__global__ void cfm_init_kernel(float* cat, long long cat_b, const float* noise, long long nstride, float temperature, uint64_t seed,
+                                int NF, int T, int nb) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t >= T) return;
+  const float v = (noise ? noise[(long long)c * nstride + t] : philox_normal(seed, 3u, (uint32_t)c, (uint32_t)t)) * temperature;
+  for (int b = 0; b < nb; ++b) cat[(long long)b * cat_b + (long long)c * T + t] = v;
+}
+// solve_euler step with classifier-free guidance (flow_matching.py:84-93,177-189):
+// x <- x + dt * (d0 + g * (d0 - d1)); the state lives in rows [0,NF) of every batch item of the in_proj input
+__global__ void cfm_euler_kernel(float* cat, long long cat_b, const float* d, float dt, float g, int NF, int T, int nb) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t >= T) return;
+  const long long o = (long long)c * T + t;
+  float d0 = d[o];
+  if (nb > 1) d0 = d0 + g * (d0 - d[(long long)NF * T + o]);
+  const float x = cat[o] + dt * d0;
+  for (int b = 0; b < nb; ++b) cat[(long long)b * cat_b + o] = x;
+}
+// generate_path + matmul as a gather (matcha_tts.py:163-174): frame t belongs to the token j with cum[j-1] <= t < cum[j]
+__global__ void stts_expand_kernel(const float* x, const int* cum, int Tx, float* mu_y, int CC, int T, const float* pde, float* pau) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t >= T) return;
+  int lo = 0, hi = Tx;  // first j with cum[j] > t
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] > t) hi = mid; else lo = mid + 1; }
+  const bool valid = lo < Tx;
+  mu_y[(long long)c * T + t] = valid ? x[(long long)c * Tx + lo] : 0.f;
+  if (c == 0) pau[t] = (valid && pde) ? pde[lo] : 0.f;
+}
+// decoder_outputs[:, :, :y_len] with the frames of forced pauses replaced by frame 0 (matcha_tts.py:180-192), denormalised
+__global__ void stts_mel_kernel(const float* cat, int T, const float* pau, float* mel, int ylen, float mel_std, float mel_mean) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t >= ylen) return;
+  const float v = pau[t] > 0.f ? cat[(long long)c * T] : cat[(long long)c * T + t];
+  mel[(long long)c * ylen + t] = v * mel_std + mel_mean;
+}
+__global__ void fill_rows_kernel(float* dst, const float* vec, int T) {  // dst[c][t] = vec[c]  (fake_content.repeat, flow_matching.py:184)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t < T) dst[(long long)c * T + t] = vec[c];
+}
+__global__ void clamp_kernel(float* a, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = fminf(1.f, fmaxf(-1.f, a[i]));
 }

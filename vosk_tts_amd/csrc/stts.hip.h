@@ -1,0 +1,597 @@
+// stts.hip.h — StableTTS / Matcha ("multistream") inference on the MI355X, C ABI of include/stts_mi355.h.
+// Included at the end of engine.hip: the contractions (1x1 / k=3 convs, fused qkv, cond_proj, long-skip convs) run on
+// the shared fp32-MFMA conv kernels, attention on relpos_attention_mfma_kernel with an all-zero relative table (RoPE is
+// applied to q/k beforehand), the adaLN / FiLM / Euler glue on the small kernels at the end of kernels_misc.hip.h.
+// Reference citations are relative to /root/reference/training/stabletts/matcha/.
+#include "../../include/stts_mi355.h"
+
+struct DitW {  // DiTConVBlock (models/components/diffusion_transformer.py:82-118)
+  ConvW qkv, o, c1, c2;
+  float *a0w = nullptr, *a0b = nullptr, *a2w = nullptr, *a2b = nullptr;  // adaLN_modulation Linear(G,H), Linear(H,6H)
+};
+
+struct stts_model {
+  vits_model base;  // blob table, device allocations and the session pool (tget / upload / make_conv / pool_acquire)
+  stts_hparams hp;
+  vits_model* vocoder = nullptr;
+  float *emb = nullptr, *pemb = nullptr, *spk_emb = nullptr, *dur_spk_emb = nullptr, *fake_speaker = nullptr, *fake_content = nullptr;
+  float *zero_vec = nullptr;  // zeros: speaker vector when n_spks <= 1, relative-position tables of the attention kernel
+  ConvW bert_proj, enc_proj, in_proj, final_proj, cp0, cp2, cp4;
+  std::vector<DitW> enc, dec;
+  std::vector<ConvW> lsc;
+  float *t0w = nullptr, *t0b = nullptr, *t2w = nullptr, *t2b = nullptr;
+  std::vector<float*> film_w, film_b;
+};
+
+static DitW load_dit(vits_model* b, const char* p, int H, int F, int K, int G) {
+  DitW d;
+  char nm[200];
+  const float* wq = tget(b, 3, H, H, 1, "%s.attn.conv_q.weight", p);
+  const float* wk = tget(b, 3, H, H, 1, "%s.attn.conv_k.weight", p);
+  const float* wv = tget(b, 3, H, H, 1, "%s.attn.conv_v.weight", p);
+  const float* bq = tget(b, 1, H, -1, -1, "%s.attn.conv_q.bias", p);
+  const float* bk = tget(b, 1, H, -1, -1, "%s.attn.conv_k.bias", p);
+  const float* bv = tget(b, 1, H, -1, -1, "%s.attn.conv_v.bias", p);
+  if (b->missing) return d;
+  std::vector<float> bias((size_t)3 * H);
+  memcpy(bias.data(), bq, sizeof(float) * H); memcpy(bias.data() + H, bk, sizeof(float) * H); memcpy(bias.data() + 2 * H, bv, sizeof(float) * H);
+  d.qkv = make_conv(b, 3 * H, H, 1, bias.data(), [&](int r, int ci, int) { return (r < H ? wq : (r < 2 * H ? wk : wv))[(size_t)(r % H) * H + ci]; });
+  snprintf(nm, sizeof nm, "%s.attn.conv_o", p); d.o = conv_from(b, nm, H, H, 1, true);
+  snprintf(nm, sizeof nm, "%s.mlp.conv_1", p); d.c1 = conv_from(b, nm, F, H, K, true);
+  snprintf(nm, sizeof nm, "%s.mlp.conv_2", p); d.c2 = conv_from(b, nm, H, F, K, true);
+  d.a0w = upload(b, tget(b, 2, H, G, -1, "%s.adaLN_modulation.0.weight", p), (size_t)H * G);
+  d.a0b = upload(b, tget(b, 1, H, -1, -1, "%s.adaLN_modulation.0.bias", p), H);
+  d.a2w = upload(b, tget(b, 2, 6 * H, H, -1, "%s.adaLN_modulation.2.weight", p), (size_t)6 * H * H);
+  d.a2b = upload(b, tget(b, 1, 6 * H, -1, -1, "%s.adaLN_modulation.2.bias", p), (size_t)6 * H);
+  return d;
+}
+
+static int stts_load(stts_model* m) {
+  vits_model* b = &m->base;
+  const stts_hparams& hp = m->hp;
+  const int H = hp.enc_hidden, Hd = hp.dec_hidden, Fd = hp.dec_filter, G = hp.spk_emb_dim, NF = hp.n_feats;
+  if (hp.emb_dim + 4 * hp.punc_dim + hp.bert_proj_dim != H) return fail(VITS_ERR_UNSUPPORTED, "stream widths do not add up to enc_hidden");
+  if (H % 32 || Hd % 32 || NF % CONV_CI_T || hp.bert_dim % CONV_CI_T || hp.bert_proj_dim % 32)
+    return fail(VITS_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (mel/bert: 16)");
+  if (H > LN_MAXV * LN_CG || Hd > LN_MAXV * LN_CG) return fail(VITS_ERR_UNSUPPORTED, "LayerNorm width > %d", LN_MAXV * LN_CG);
+  const int dke = H / hp.enc_heads, dkd = Hd / hp.dec_heads;
+  if ((dke != 32 && dke != 64 && dke != 96) || (dkd != 32 && dkd != 64 && dkd != 96)) return fail(VITS_ERR_UNSUPPORTED, "head dim not in {32,64,96}");
+  if (hp.dec_layers % 2) return fail(VITS_ERR_UNSUPPORTED, "long skip connections need an even number of decoder layers");
+  char nm[200];
+  m->emb = upload(b, tget(b, 2, hp.n_vocab, hp.emb_dim, -1, "encoder.emb.weight"), (size_t)hp.n_vocab * hp.emb_dim);
+  m->pemb = upload(b, tget(b, 2, hp.n_vocab, hp.punc_dim, -1, "encoder.punc_emb.weight"), (size_t)hp.n_vocab * hp.punc_dim);
+  {  // bert_proj: Dropout + Linear(768, 32) applied per column == a 1x1 conv (text_encoder.py:108,129)
+    const float* w = tget(b, 2, hp.bert_proj_dim, hp.bert_dim, -1, "encoder.bert_proj.1.weight");
+    const float* bb = tget(b, 1, hp.bert_proj_dim, -1, -1, "encoder.bert_proj.1.bias");
+    if (!b->missing) m->bert_proj = make_conv(b, hp.bert_proj_dim, hp.bert_dim, 1, bb, [&](int r, int ci, int) { return w[(size_t)r * hp.bert_dim + ci]; });
+  }
+  if (hp.n_spks > 1) {
+    m->spk_emb = upload(b, tget(b, 2, hp.n_spks, G, -1, "spk_emb.weight"), (size_t)hp.n_spks * G);
+    m->dur_spk_emb = upload(b, tget(b, 2, hp.n_spks, G, -1, "dur_spk_emb.weight"), (size_t)hp.n_spks * G);
+  }
+  m->fake_speaker = upload(b, tget(b, 2, 1, G, -1, "fake_speaker"), G);
+  m->fake_content = upload(b, tget(b, 3, 1, H, 1, "fake_content"), H);
+  {
+    std::vector<float> z((size_t)(G > 9 * 96 ? G : 9 * 96), 0.f);
+    m->zero_vec = upload(b, z.data(), z.size());
+  }
+  for (int i = 0; i < hp.enc_layers && !b->missing; ++i) {
+    snprintf(nm, sizeof nm, "encoder.dp_encoder.encoder.%d", i);
+    m->enc.push_back(load_dit(b, nm, H, hp.enc_filter, hp.enc_kernel, G));
+  }
+  m->enc_proj = conv_from(b, "encoder.dp_encoder.proj", hp.dp_out, H, 1, true);
+  const char* e = "decoder.estimator";
+  m->t0w = upload(b, tget(b, 2, Fd, Hd, -1, "%s.time_mlp.layer.0.weight", e), (size_t)Fd * Hd);
+  m->t0b = upload(b, tget(b, 1, Fd, -1, -1, "%s.time_mlp.layer.0.bias", e), Fd);
+  m->t2w = upload(b, tget(b, 2, Hd, Fd, -1, "%s.time_mlp.layer.2.weight", e), (size_t)Hd * Fd);
+  m->t2b = upload(b, tget(b, 1, Hd, -1, -1, "%s.time_mlp.layer.2.bias", e), Hd);
+  snprintf(nm, sizeof nm, "%s.in_proj", e); m->in_proj = conv_from(b, nm, Hd, NF + Hd, 1, true);
+  snprintf(nm, sizeof nm, "%s.final_proj", e); m->final_proj = conv_from(b, nm, NF, Hd, 1, true);
+  snprintf(nm, sizeof nm, "%s.cond_proj.0", e); m->cp0 = conv_from(b, nm, Fd, H, hp.dec_kernel, true);
+  snprintf(nm, sizeof nm, "%s.cond_proj.2", e); m->cp2 = conv_from(b, nm, Fd, Fd, hp.dec_kernel, true);
+  snprintf(nm, sizeof nm, "%s.cond_proj.4", e); m->cp4 = conv_from(b, nm, Hd, Fd, hp.dec_kernel, true);
+  for (int i = 0; i < hp.dec_layers && !b->missing; ++i) {
+    m->film_w.push_back(upload(b, tget(b, 3, 2 * Hd, Hd, 1, "%s.blocks.%d.time_fusion.film.weight", e, i), (size_t)2 * Hd * Hd));
+    m->film_b.push_back(upload(b, tget(b, 1, 2 * Hd, -1, -1, "%s.blocks.%d.time_fusion.film.bias", e, i), (size_t)2 * Hd));
+    snprintf(nm, sizeof nm, "%s.blocks.%d.block", e, i);
+    m->dec.push_back(load_dit(b, nm, Hd, Fd, hp.dec_kernel, G));
+  }
+  for (int j = 0; j < hp.dec_layers / 2 && !b->missing; ++j) {
+    snprintf(nm, sizeof nm, "%s.lsc_layers.%d", e, j);
+    m->lsc.push_back(conv_from(b, nm, Hd, 2 * Hd, hp.dec_kernel, true));
+  }
+  return b->missing ? VITS_ERR_BLOB : VITS_OK;
+}
+
+// ---- workspace: a bump arena on a pooled session of &m->base (stream + error word + events)
+static int stts_arena(vits_session* s, size_t bytes) {
+  s->arena_used = 0;
+  if (bytes <= s->arena_bytes) return VITS_OK;
+  if (s->arena) { hipStreamSynchronize(s->stream); hipFree(s->arena); s->arena = nullptr; s->arena_bytes = 0; }
+  void* p = nullptr;
+  const size_t want = bytes + bytes / 4 + 4096;
+  if (hipMalloc(&p, want) != hipSuccess) return fail(VITS_ERR_NOMEM, "workspace hipMalloc of %zu bytes failed", want);
+  s->arena = static_cast<char*>(p);
+  s->arena_bytes = want;
+  return VITS_OK;
+}
+
+static void stts_attention(vits_session* s, const stts_model* m, const float* qkv, const int* len, float* out, int B, int H, int T, int nh) {
+  const int dk = H / nh;
+  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(T, 64), nh * (dk / 4), B * 2), dim3(64), 0, s->stream, const_cast<float*>(qkv), H, T, nh, dk);
+  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T, "relpos_attention_mfma_kernel");
+  dim3 grid(cdiv(T, 32), nh, B);
+  const size_t lds = (size_t)4 * (dk * 33 + 10 * 32 + 9 * 32) * sizeof(float);
+  // window 4 with all-zero relative key/value tables: the banded terms add exactly 0 (F.scaled_dot_product_attention has none)
+  if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), grid, dim3(256), lds, s->stream, qkv, m->zero_vec, m->zero_vec, len, out, H, T, 4);
+  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), grid, dim3(256), lds, s->stream, qkv, m->zero_vec, m->zero_vec, len, out, H, T, 4);
+  else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), grid, dim3(256), lds, s->stream, qkv, m->zero_vec, m->zero_vec, len, out, H, T, 4);
+}
+
+struct DitScratch { float *hn, *qkv, *att, *ffh; };
+
+static void stts_ln_mod(vits_session* s, const float* x, float* y, const float* shift, const float* scale, int mod_stride, int B, int H, int T) {
+  ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
+  LNParams P{x, nullptr, nullptr, y, scale, shift, nullptr, H, T, 0, 0, 0, mod_stride};
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, P);
+}
+
+// DiTConVBlock.forward (diffusion_transformer.py:99-118) on h [B,H,T] in place; h must already be masked.
+// mod [B][6H]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+static void stts_dit_block(vits_session* s, const stts_model* m, const DitW& W, float* h, const float* mod, const int* len, int B,
+                           int H, int F, int nh, int K, int T, const DitScratch& sc, const char* tag) {
+  char nm[64];
+  stts_ln_mod(s, h, sc.hn, mod, mod + H, 6 * H, B, H, T);
+  ConvParams P = conv_params(W.qkv, sc.hn, sc.qkv, B, T, 1, 0);
+  snprintf(nm, sizeof nm, "%s.qkv", tag); launch_conv(s, P, EPI_STORE, nm);
+  stts_attention(s, m, sc.qkv, len, sc.att, B, H, T, nh);
+  P = conv_params(W.o, sc.att, h, B, T, 1, 0);  // x = x + gate_msa * attn(...) * x_mask
+  P.out_mask = 1; P.len = len; P.scale_b = mod; P.scale_b_stride = 6 * H; P.scale_b_off = 2 * H; P.g[0].res = h;
+  snprintf(nm, sizeof nm, "%s.o", tag); launch_conv(s, P, EPI_STORE, nm);
+  stts_ln_mod(s, h, sc.hn, mod + 3 * H, mod + 4 * H, 6 * H, B, H, T);
+  P = conv_params(W.c1, sc.hn, sc.ffh, B, T, 1, K / 2);  // FFN: conv_1(x * mask) -> SiLU (diffusion_transformer.py:25-27)
+  P.in_mask = 1; P.len = len; P.relu = 2;
+  snprintf(nm, sizeof nm, "%s.ffn1", tag); launch_conv(s, P, EPI_STORE, nm);
+  P = conv_params(W.c2, sc.ffh, h, B, T, 1, K / 2);  // conv_2(. * mask) * mask ; x = x + gate_mlp * mlp
+  P.in_mask = 1; P.out_mask = 1; P.len = len; P.scale_b = mod; P.scale_b_stride = 6 * H; P.scale_b_off = 5 * H; P.g[0].res = h;
+  snprintf(nm, sizeof nm, "%s.ffn2", tag); launch_conv(s, P, EPI_STORE, nm);
+}
+
+static void stts_gemv(vits_session* s, const float* W, const float* bias, const float* x, int x_stride, float* y, int y_stride, int rows,
+                      int cols, int n, int act) {
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(cdiv(rows, 4), n), dim3(256), 0, s->stream, W, bias, x, x_stride, y, y_stride, rows, cols, act);
+}
+
+// adaLN_modulation(c) for a stack of blocks: mods[i][n][6H], c [n][G] (diffusion_transformer.py:93-97,110)
+static void stts_modulations(vits_session* s, const std::vector<DitW>& blocks, const float* c, int n, int H, int G, float* tmp, float* mods) {
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    stts_gemv(s, blocks[i].a0w, blocks[i].a0b, c, G, tmp, H, H, G, n, 1);
+    stts_gemv(s, blocks[i].a2w, blocks[i].a2b, tmp, H, mods + i * (size_t)n * 6 * H, 6 * H, 6 * H, H, n, 0);
+  }
+}
+
+// ---- TextEncoder.forward (text_encoder.py:111-139) on device: d_x [B,H,T] (unmasked concat), d_mu [B,dp_out,T]
+struct SttsEncBufs { float *h, *cvec, *tmp, *mods; DitScratch sc; int* len; };
+static size_t stts_enc_bytes(const stts_hparams& hp, int B, int T) {
+  const size_t H = hp.enc_hidden, F = hp.enc_filter;
+  return ((size_t)B * T * (H * 2 + 3 * H + H + F) + (size_t)B * (hp.spk_emb_dim + H + hp.enc_layers * 6 * H)) * sizeof(float) + 64 * 1024;
+}
+static void stts_run_encoder(vits_session* s, const stts_model* m, const int64_t* d_ids, const int* d_len, const int64_t* sid_host, int B,
+                             int T, const float* d_bert, float* d_x, float* d_mu) {
+  const stts_hparams& hp = m->hp;
+  const int H = hp.enc_hidden, F = hp.enc_filter, G = hp.spk_emb_dim, E = hp.emb_dim, Pd = hp.punc_dim, NE = E + 4 * Pd;
+  SttsEncBufs w;
+  w.h = bump<float>(s, (size_t)B * H * T); w.sc.hn = bump<float>(s, (size_t)B * H * T); w.sc.qkv = bump<float>(s, (size_t)B * 3 * H * T);
+  w.sc.att = bump<float>(s, (size_t)B * H * T); w.sc.ffh = bump<float>(s, (size_t)B * F * T);
+  w.cvec = bump<float>(s, (size_t)B * G); w.tmp = bump<float>(s, (size_t)B * H); w.mods = bump<float>(s, (size_t)hp.enc_layers * B * 6 * H);
+  hipLaunchKernelGGL(stts_embed_kernel, dim3(cdiv(T, 64), NE, B), dim3(64), 0, s->stream, d_ids, m->emb, m->pemb, d_x, H, E, Pd, T, hp.n_vocab,
+                     sqrtf((float)E), sqrtf((float)Pd), s->d_err);
+  ConvParams P = conv_params(m->bert_proj, d_bert, d_x + (size_t)NE * T, B, T, 1, 0);
+  P.y_bstride = (long long)H * T;  // rows [NE, H) of the concatenated x
+  launch_conv(s, P, EPI_STORE, "enc.bert_proj");
+  hipMemcpyAsync(w.h, d_x, sizeof(float) * (size_t)B * H * T, hipMemcpyDeviceToDevice, s->stream);
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(T, 64), H, B), dim3(64), 0, s->stream, w.h, d_len, H, T);
+  for (int b = 0; b < B; ++b)  // dur_spks = dur_spk_emb(sid) (matcha_tts.py:139)
+    hipMemcpyAsync(w.cvec + (size_t)b * G, hp.n_spks > 1 ? m->dur_spk_emb + (size_t)sid_host[b] * G : m->zero_vec, sizeof(float) * G,
+                   hipMemcpyDeviceToDevice, s->stream);
+  stts_modulations(s, m->enc, w.cvec, B, H, G, w.tmp, w.mods);
+  for (int i = 0; i < hp.enc_layers; ++i)
+    stts_dit_block(s, m, m->enc[i], w.h, w.mods + (size_t)i * B * 6 * H, d_len, B, H, F, hp.enc_heads, hp.enc_kernel, T, w.sc, "enc");
+  P = conv_params(m->enc_proj, w.h, d_mu, B, T, 1, 0);  // mu_x = proj(x) * x_mask (text_encoder.py:45)
+  P.out_mask = 1; P.len = d_len;
+  launch_conv(s, P, EPI_STORE, "enc.proj");
+}
+
+// ---- estimator state for one synthesis: everything that does not depend on the Euler step is computed once
+struct SttsEst {
+  int nb, T, n_steps;
+  float *cat, *h, *dphi, *film, *mods, *lsc[3 + 8], *a1, *a2;
+  DitScratch sc;
+  int* len;
+};
+static size_t stts_est_bytes(const stts_hparams& hp, int nb, int T, int n_steps) {
+  const size_t H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers;
+  size_t fl = (size_t)nb * T * ((NF + H) + H + NF + H + 3 * H + H + F + (NL / 2) * 2 * H + 2 * F + hp.enc_hidden);
+  fl += (size_t)n_steps * (H + F + H + NL * 2 * H) + (size_t)nb * (hp.spk_emb_dim + H + NL * 6 * H);
+  return fl * sizeof(float) + 256 * 1024;
+}
+// c [nb][G] device, mu [nb][enc_hidden][T] device (item 1 = fake content when nb == 2), tvals host [n_steps]
+static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu, const int* d_len, const float* tvals) {
+  const stts_hparams& hp = m->hp;
+  const int H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers, G = hp.spk_emb_dim, K = hp.dec_kernel;
+  const int nb = E.nb, T = E.T, n = E.n_steps;
+  E.len = const_cast<int*>(d_len);
+  E.cat = bump<float>(s, (size_t)nb * (NF + H) * T); E.h = bump<float>(s, (size_t)nb * H * T); E.dphi = bump<float>(s, (size_t)nb * NF * T);
+  E.sc.hn = bump<float>(s, (size_t)nb * H * T); E.sc.qkv = bump<float>(s, (size_t)nb * 3 * H * T); E.sc.att = bump<float>(s, (size_t)nb * H * T);
+  E.sc.ffh = bump<float>(s, (size_t)nb * F * T);
+  for (int j = 0; j < NL / 2; ++j) E.lsc[j] = bump<float>(s, (size_t)nb * 2 * H * T);
+  E.a1 = bump<float>(s, (size_t)nb * F * T); E.a2 = bump<float>(s, (size_t)nb * F * T);
+  // time embeddings of every step: SinusoidalPosEmb(H)(t, scale=1000) on the host (n_steps * H values), TimestepEmbedding
+  // and the FiLM projections of all blocks as GEMVs over the n_steps columns (components/decoder.py:35-62,15-33)
+  float* sinus = bump<float>(s, (size_t)n * H); float* t1 = bump<float>(s, (size_t)n * F); float* temb = bump<float>(s, (size_t)n * H);
+  E.film = bump<float>(s, (size_t)NL * n * 2 * H);
+  {
+    std::vector<float> hs((size_t)n * H);
+    const int half = H / 2;
+    const float lg = logf(10000.0f) / (float)(half - 1);
+    for (int k = 0; k < n; ++k)
+      for (int j = 0; j < half; ++j) {
+        const float a = 1000.0f * tvals[k] * expf((float)j * -lg);
+        hs[(size_t)k * H + j] = sinf(a); hs[(size_t)k * H + half + j] = cosf(a);
+      }
+    hipMemcpyAsync(sinus, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, s->stream);
+    hipStreamSynchronize(s->stream);  // hs is a stack-lifetime buffer
+  }
+  stts_gemv(s, m->t0w, m->t0b, sinus, H, t1, F, F, H, n, 1);
+  stts_gemv(s, m->t2w, m->t2b, t1, F, temb, H, H, F, n, 0);
+  for (int i = 0; i < NL; ++i) stts_gemv(s, m->film_w[i], m->film_b[i], temb, H, E.film + (size_t)i * n * 2 * H, 2 * H, 2 * H, H, n, 0);
+  float* tmp = bump<float>(s, (size_t)nb * H);
+  E.mods = bump<float>(s, (size_t)NL * nb * 6 * H);
+  stts_modulations(s, m->dec, d_c, nb, H, G, tmp, E.mods);
+  // mu = cond_proj(mu): conv -> SiLU -> conv -> SiLU -> conv, no masks (decoder.py:82-88,121); lands in rows [NF, NF+H) of cat
+  ConvParams P = conv_params(m->cp0, d_mu, E.a1, nb, T, 1, K / 2); P.relu = 2; launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
+  P = conv_params(m->cp2, E.a1, E.a2, nb, T, 1, K / 2); P.relu = 2; launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
+  P = conv_params(m->cp4, E.a2, E.cat + (size_t)NF * T, nb, T, 1, K / 2); P.y_bstride = (long long)(NF + H) * T; launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
+}
+// one Decoder.forward (decoder.py:105-138) over the nb batch items; state x = rows [0,NF) of E.cat; result in E.dphi
+static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int step) {
+  const stts_hparams& hp = m->hp;
+  const int H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers, K = hp.dec_kernel;
+  const int nb = E.nb, T = E.T, n = E.n_steps;
+  ConvParams P = conv_params(m->in_proj, E.cat, E.h, nb, T, 1, 0);
+  launch_conv(s, P, EPI_STORE, "cfm.in_proj");
+  const dim3 cg(cdiv(T, 256), H, nb);
+  for (int idx = 0; idx < NL; ++idx) {
+    if (idx < NL / 2) {  // lsc_outputs.append(x): popped by layer NL-1-idx -> upper half of that layer's concat buffer
+      hipLaunchKernelGGL(copy_rows_kernel, cg, dim3(256), 0, s->stream, E.h, (long long)H * T, E.lsc[NL / 2 - 1 - idx] + (size_t)H * T, (long long)2 * H * T, T);
+    } else {  // x = lsc_layers[idx - NL/2](cat((x, lsc_outputs.pop()), dim=1))
+      float* cb = E.lsc[idx - NL / 2];
+      hipLaunchKernelGGL(copy_rows_kernel, cg, dim3(256), 0, s->stream, E.h, (long long)H * T, cb, (long long)2 * H * T, T);
+      P = conv_params(m->lsc[idx - NL / 2], cb, E.h, nb, T, 1, K / 2);
+      launch_conv(s, P, EPI_STORE, "cfm.lsc");
+    }
+    hipLaunchKernelGGL(film_mask_kernel, dim3(cdiv(T, 64), H, nb), dim3(64), 0, s->stream, E.h, E.film + ((size_t)idx * n + step) * 2 * H, E.len, H, T);
+    stts_dit_block(s, m, m->dec[idx], E.h, E.mods + (size_t)idx * nb * 6 * H, E.len, nb, H, F, hp.dec_heads, K, T, E.sc, "cfm");
+  }
+  P = conv_params(m->final_proj, E.h, E.dphi, nb, T, 1, 0);  // final_proj(x * mask) * mask
+  P.in_mask = 1; P.out_mask = 1; P.len = E.len;
+  launch_conv(s, P, EPI_STORE, "cfm.final_proj");
+}
+
+// t_span of BASECFM.forward (flow_matching.py:53-54) and the (t, dt) sequence of solve_euler (:84-106), in fp32 like torch
+static void stts_time_grid(int n, std::vector<float>& tv, std::vector<float>& dtv) {
+  std::vector<float> ts(n + 1);
+  for (int i = 0; i <= n; ++i) {
+    const float step = 1.0f / (float)n;
+    const float lin = i < (n + 1) / 2 ? step * (float)i : 1.0f - step * (float)(n - i);  // torch.linspace
+    ts[i] = 1.0f - cosf(lin * 0.5f * 3.14159265358979323846f);
+  }
+  tv.resize(n); dtv.resize(n);
+  float t = ts[0], dt = ts[1] - ts[0];
+  for (int k = 1; k <= n; ++k) {
+    tv[k - 1] = t; dtv[k - 1] = dt;
+    t = t + dt;
+    if (k < n) dt = ts[k + 1] - t;
+  }
+}
+
+struct SttsCall {  // pooled session + temporaries of one entry-point call
+  stts_model* m; vits_session* s = nullptr; std::vector<void*> tmp;
+  explicit SttsCall(stts_model* m_) : m(m_) {}
+  ~SttsCall() {
+    if (s) { hipStreamSynchronize(s->stream); pool_release(&m->base, s); }
+    for (void* p : tmp) hipFree(p);
+  }
+  int begin(size_t arena_bytes) {
+    hipError_t e = hipSetDevice(m->base.device);
+    if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
+    TRY(pool_acquire(&m->base, &s));
+    return stts_arena(s, arena_bytes);
+  }
+  template <typename T> T* dev(size_t n) {
+    void* d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    tmp.push_back(d);
+    return static_cast<T*>(d);
+  }
+  template <typename T> T* up(const T* h, size_t n) {
+    if (!h) return nullptr;
+    T* d = dev<T>(n);
+    if (d) hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s->stream);
+    return d;
+  }
+};
+
+static int stts_check_sid(const stts_model* m, const int64_t* sid, int B) {
+  if (m->hp.n_spks <= 1) return VITS_OK;
+  if (!sid) return fail(VITS_ERR_ARG, "sid required");
+  for (int b = 0; b < B; ++b) if (sid[b] < 0 || sid[b] >= m->hp.n_spks) return fail(VITS_ERR_ARG, "speaker id out of range");
+  return VITS_OK;
+}
+
+// matcha_tts.py:144-158 on the host (T_x * dp_out values; the host round trip is needed for T_y anyway)
+static void stts_durations_host(const stts_hparams& hp, const float* mu_dp, int B, int T, float length_scale, const float* pde, int32_t* dur, int64_t* ylen) {
+  const int K = hp.dp_out;
+  for (int b = 0; b < B; ++b) {
+    int64_t tot = 0;
+    for (int t = 0; t < T; ++t) {
+      float lw = 0.f;
+      for (int k = 0; k < K; ++k) lw += 1.0f / (1.0f + expf(-mu_dp[((size_t)b * K + k) * T + t]));
+      if (pde && pde[(size_t)b * T + t] != 0.f) lw = pde[(size_t)b * T + t];
+      float w = rintf(lw * length_scale);  // torch.round: half to even
+      if (w < 1.f) w = 1.f;
+      dur[(size_t)b * T + t] = (int32_t)w;
+      tot += (int64_t)w;
+    }
+    ylen[b] = tot;
+  }
+}
+
+// BASECFM.forward + solve_euler with guidance (flow_matching.py:36-108,177-189) for one utterance, all on device.
+// d_mu2 [nb][enc_hidden][T] (item 1 pre-filled with fake_content), result: state rows of E.cat item 0
+static void stts_run_cfm(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu2, const int* d_len, const float* d_noise,
+                         long long nstride, float temperature, uint64_t seed) {
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats, H = hp.dec_hidden, T = E.T;
+  std::vector<float> tv, dtv;
+  stts_time_grid(E.n_steps, tv, dtv);
+  stts_est_setup(s, m, E, d_c, d_mu2, d_len, tv.data());
+  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, E.nb);
+  for (int k = 0; k < E.n_steps; ++k) {
+    stts_est_step(s, m, E, k);
+    hipLaunchKernelGGL(cfm_euler_kernel, dim3(cdiv(T, 64), NF), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, E.dphi, dtv[k], hp.guidance_scale, NF, T, E.nb);
+  }
+}
+
+extern "C" {
+
+const char* stts_last_error(void) { return g_err; }
+
+int stts_create(const void* blob, size_t bytes, vits_model* vocoder, int device, stts_model** out) {
+  if (!blob || !out || bytes < 16 + sizeof(stts_hparams)) return fail(VITS_ERR_ARG, "bad blob argument");
+  const unsigned char* p = static_cast<const unsigned char*>(blob);
+  if (memcmp(p, "STTSW001", 8) != 0) return fail(VITS_ERR_BLOB, "bad magic");
+  uint32_t hb;
+  memcpy(&hb, p + 8, 4);
+  if (hb != sizeof(stts_hparams)) return fail(VITS_ERR_BLOB, "hparams size %u != %zu", hb, sizeof(stts_hparams));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VITS_ERR_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(VITS_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+  if (vocoder && (vocoder->device != device || vocoder->acoustic || vocoder->hp.inter_channels != reinterpret_cast<const stts_hparams*>(p + 12)->n_feats))
+    return fail(VITS_ERR_ARG, "vocoder must be a vocoder-only model with n_feats input channels on the same device");
+  HIP_TRY(hipSetDevice(device));
+  stts_model* m = new stts_model();
+  memcpy(&m->hp, p + 12, sizeof(stts_hparams));
+  if (m->hp.abi_version != STTS_ABI_VERSION) { delete m; return fail(VITS_ERR_BLOB, "abi version mismatch"); }
+  vits_model* b = &m->base;
+  b->device = device; b->acoustic = false;
+  b->blob = p; b->blob_bytes = bytes;
+  memcpy(&b->n_entries, p + 12 + hb, 4);
+  b->entries = reinterpret_cast<const vits_blob_entry*>(p + 16 + hb);
+  int rc = VITS_OK;
+  if (16 + hb + (size_t)b->n_entries * sizeof(vits_blob_entry) > bytes) rc = fail(VITS_ERR_BLOB, "truncated table");
+  for (uint32_t i = 0; rc == VITS_OK && i < b->n_entries; ++i)
+    if (b->entries[i].offset + b->entries[i].nelem * 4 > bytes) rc = fail(VITS_ERR_BLOB, "truncated data");
+  if (rc == VITS_OK) rc = stts_load(m);
+  b->blob = nullptr; b->entries = nullptr;
+  if (rc != VITS_OK) { for (void* a : b->allocs) hipFree(a); delete m; return rc; }
+  m->vocoder = vocoder;
+  hipDeviceSynchronize();
+  *out = m;
+  return VITS_OK;
+}
+
+void stts_destroy(stts_model* m) {
+  if (!m) return;
+  hipSetDevice(m->base.device);
+  for (vits_session* s : m->base.pool) session_free(s);
+  for (void* a : m->base.allocs) hipFree(a);
+  delete m;
+}
+
+int stts_get_hparams(const stts_model* m, stts_hparams* out) {
+  if (!m || !out) return fail(VITS_ERR_ARG, "null argument");
+  *out = m->hp;
+  return VITS_OK;
+}
+
+int stts_stage_encoder(stts_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t T, const int64_t* sid, const float* bert,
+                       float* x, float* mu_dp) {
+  if (!m || !ids || !lengths || !x || !mu_dp || B <= 0 || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > T) return fail(VITS_ERR_ARG, "length out of range");
+  TRY(stts_check_sid(m, sid, B));
+  const stts_hparams& hp = m->hp;
+  SttsCall c(m);
+  TRY(c.begin(stts_enc_bytes(hp, B, T)));
+  vits_session* s = c.s;
+  int64_t* d_ids = c.up(ids, (size_t)B * 5 * T);
+  std::vector<int> l32(B);
+  for (int b = 0; b < B; ++b) l32[b] = (int)lengths[b];
+  int* d_len = c.up(l32.data(), B);
+  float* d_bert = bert ? c.up(bert, (size_t)B * hp.bert_dim * T) : c.dev<float>((size_t)B * hp.bert_dim * T);
+  float* d_x = c.dev<float>((size_t)B * hp.enc_hidden * T);
+  float* d_mu = c.dev<float>((size_t)B * hp.dp_out * T);
+  if (!d_ids || !d_len || !d_bert || !d_x || !d_mu) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  if (!bert) HIP_TRY(hipMemsetAsync(d_bert, 0, sizeof(float) * (size_t)B * hp.bert_dim * T, s->stream));
+  stts_run_encoder(s, m, d_ids, d_len, sid, B, T, d_bert, d_x, d_mu);
+  HIP_TRY(hipMemcpyAsync(x, d_x, sizeof(float) * (size_t)B * hp.enc_hidden * T, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(mu_dp, d_mu, sizeof(float) * (size_t)B * hp.dp_out * T, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
+}
+
+int stts_stage_durations(stts_model* m, const float* mu_dp, int32_t B, int32_t T, float length_scale, const float* pde, int32_t* durations,
+                         int64_t* y_lengths) {
+  if (!m || !mu_dp || !durations || !y_lengths || B <= 0 || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  stts_durations_host(m->hp, mu_dp, B, T, length_scale, pde, durations, y_lengths);
+  return VITS_OK;
+}
+
+int stts_stage_estimator(stts_model* m, const float* x, const float* mu, const int64_t* y_lengths, int32_t B, int32_t T, float t, const float* c,
+                         float* out) {
+  if (!m || !x || !mu || !y_lengths || !c || !out || B <= 0 || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats, H = hp.dec_hidden;
+  SttsCall call(m);
+  TRY(call.begin(stts_est_bytes(hp, B, T, 1)));
+  vits_session* s = call.s;
+  std::vector<int> l32(B);
+  for (int b = 0; b < B; ++b) l32[b] = (int)y_lengths[b];
+  int* d_len = call.up(l32.data(), B);
+  float* d_c = call.up(c, (size_t)B * hp.spk_emb_dim);
+  float* d_mu = call.up(mu, (size_t)B * hp.enc_hidden * T);
+  float* d_x = call.up(x, (size_t)B * NF * T);
+  if (!d_len || !d_c || !d_mu || !d_x) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  SttsEst E; E.nb = B; E.T = T; E.n_steps = 1;
+  stts_est_setup(s, m, E, d_c, d_mu, d_len, &t);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(T, 256), NF, B), dim3(256), 0, s->stream, d_x, (long long)NF * T, E.cat, (long long)(NF + H) * T, T);
+  stts_est_step(s, m, E, 0);
+  HIP_TRY(hipMemcpyAsync(out, E.dphi, sizeof(float) * (size_t)B * NF * T, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
+}
+
+int stts_stage_cfm(stts_model* m, const float* mu_y, int64_t y_length, int32_t T, int64_t sid, const float* noise, float temperature,
+                   int32_t n_timesteps, float* out) {
+  if (!m || !mu_y || !noise || !out || T <= 0 || y_length < 0 || y_length > T) return fail(VITS_ERR_ARG, "bad argument");
+  TRY(stts_check_sid(m, &sid, 1));
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats, CC = hp.enc_hidden, G = hp.spk_emb_dim, H = hp.dec_hidden;
+  const int n = n_timesteps > 0 ? n_timesteps : hp.n_timesteps, nb = hp.guidance_scale > 0.f ? 2 : 1;
+  SttsCall call(m);
+  TRY(call.begin(stts_est_bytes(hp, nb, T, n)));
+  vits_session* s = call.s;
+  const int l2[2] = {(int)y_length, (int)y_length};
+  int* d_len = call.up(l2, 2);
+  float* d_noise = call.up(noise, (size_t)NF * T);
+  float* d_mu2 = call.dev<float>((size_t)nb * CC * T);
+  float* d_c = call.dev<float>((size_t)nb * G);
+  if (!d_len || !d_noise || !d_mu2 || !d_c) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  HIP_TRY(hipMemcpyAsync(d_mu2, mu_y, sizeof(float) * (size_t)CC * T, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_c, hp.n_spks > 1 ? m->spk_emb + (size_t)sid * G : m->zero_vec, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
+  if (nb == 2) {  // fake_content.repeat(1, 1, T), fake_speaker (flow_matching.py:183-185)
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_mu2 + (size_t)CC * T, m->fake_content, T);
+    HIP_TRY(hipMemcpyAsync(d_c + G, m->fake_speaker, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
+  }
+  SttsEst E; E.nb = nb; E.T = T; E.n_steps = n;
+  stts_run_cfm(s, m, E, d_c, d_mu2, d_len, d_noise, T, temperature, 0);
+  HIP_TRY(hipMemcpyAsync(out, E.cat, sizeof(float) * (size_t)NF * T, hipMemcpyDeviceToHost, s->stream));  // state rows of item 0
+  (void)H;
+  return check_err(s);
+}
+
+int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const float* bert, const float* pde,
+                    const stts_synth_opts* opts, float** out_audio, int64_t* out_samples, float** out_mel, int64_t* out_frames) {
+  if (!m || !ids || !scales || Tx <= 0 || (out_audio && !out_samples) || (out_mel && !out_frames)) return fail(VITS_ERR_ARG, "bad argument");
+  if (out_audio && !m->vocoder) return fail(VITS_ERR_ARG, "no vocoder attached");
+  TRY(stts_check_sid(m, &sid, 1));
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats, CC = hp.enc_hidden, G = hp.spk_emb_dim, H = hp.dec_hidden;
+  const float temperature = scales[0], length_scale = scales[1];
+  const int n = (opts && opts->n_timesteps > 0) ? opts->n_timesteps : hp.n_timesteps, nb = hp.guidance_scale > 0.f ? 2 : 1;
+  SttsCall call(m);
+  TRY(call.begin(stts_enc_bytes(hp, 1, Tx)));
+  vits_session* s = call.s;
+  // ---- text encoder + durations
+  int64_t* d_ids = call.up(ids, (size_t)5 * Tx);
+  const int lx = Tx;
+  int* d_lenx = call.up(&lx, 1);
+  float* d_bert = bert ? call.up(bert, (size_t)hp.bert_dim * Tx) : call.dev<float>((size_t)hp.bert_dim * Tx);
+  float* d_x = call.dev<float>((size_t)CC * Tx);
+  float* d_mu = call.dev<float>((size_t)hp.dp_out * Tx);
+  if (!d_ids || !d_lenx || !d_bert || !d_x || !d_mu) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  if (!bert) HIP_TRY(hipMemsetAsync(d_bert, 0, sizeof(float) * (size_t)hp.bert_dim * Tx, s->stream));
+  stts_run_encoder(s, m, d_ids, d_lenx, &sid, 1, Tx, d_bert, d_x, d_mu);
+  std::vector<float> mu_dp((size_t)hp.dp_out * Tx);
+  HIP_TRY(hipMemcpyAsync(mu_dp.data(), d_mu, sizeof(float) * mu_dp.size(), hipMemcpyDeviceToHost, s->stream));
+  TRY(check_err(s));  // also surfaces bad token ids
+  std::vector<int32_t> dur(Tx);
+  int64_t ylen = 0;
+  stts_durations_host(hp, mu_dp.data(), 1, Tx, length_scale, pde, dur.data(), &ylen);
+  if (ylen > (1 << 22)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  const int T = (int)((ylen + 3) / 4 * 4);  // fix_len_compatibility (utils/model.py:14-20)
+  std::vector<int> cum(Tx);
+  for (int j = 0, a = 0; j < Tx; ++j) { a += dur[j]; cum[j] = a; }
+  // ---- flow-matching decoder
+  TRY(stts_arena(s, stts_est_bytes(hp, nb, T, n)));
+  int* d_cum = call.up(cum.data(), Tx);
+  float* d_pde = pde ? call.up(pde, Tx) : nullptr;
+  const int l2[2] = {(int)ylen, (int)ylen};
+  int* d_len = call.up(l2, 2);
+  float* d_mu2 = call.dev<float>((size_t)nb * CC * T);
+  float* d_pau = call.dev<float>(T);
+  float* d_c = call.dev<float>((size_t)nb * G);
+  float* d_mel = call.dev<float>((size_t)NF * (ylen ? ylen : 1));
+  if (!d_cum || !d_len || !d_mu2 || !d_pau || !d_c || !d_mel) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  hipLaunchKernelGGL(stts_expand_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_x, d_cum, Tx, d_mu2, CC, T, d_pde, d_pau);
+  HIP_TRY(hipMemcpyAsync(d_c, hp.n_spks > 1 ? m->spk_emb + (size_t)sid * G : m->zero_vec, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
+  if (nb == 2) {
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_mu2 + (size_t)CC * T, m->fake_content, T);
+    HIP_TRY(hipMemcpyAsync(d_c + G, m->fake_speaker, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
+  }
+  float* d_noise = nullptr;
+  long long nstride = T;
+  if (opts && opts->noise) {
+    if (opts->noise_stride < T) return fail(VITS_ERR_ARG, "noise stride %lld < %d", (long long)opts->noise_stride, T);
+    nstride = opts->noise_stride;
+    d_noise = call.up(opts->noise, (size_t)NF * nstride);
+    if (!d_noise) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  }
+  SttsEst E; E.nb = nb; E.T = T; E.n_steps = n;
+  stts_run_cfm(s, m, E, d_c, d_mu2, d_len, d_noise, nstride, temperature, opts ? opts->seed : 0);
+  hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv((int)ylen, 64), NF), dim3(64), 0, s->stream, E.cat, T, d_pau, d_mel, (int)ylen, hp.mel_std, hp.mel_mean);
+  float* h_mel = nullptr;
+  if (out_mel) {
+    h_mel = static_cast<float*>(malloc(sizeof(float) * (size_t)NF * ylen));
+    if (!h_mel) return fail(VITS_ERR_NOMEM, "host alloc failed");
+    hipMemcpyAsync(h_mel, d_mel, sizeof(float) * (size_t)NF * ylen, hipMemcpyDeviceToHost, s->stream);
+  }
+  float* h_audio = nullptr;
+  int64_t S = 0;
+  int rc = VITS_OK;
+  if (out_audio) {  // vocoder.decode(mel).clamp(-1, 1) (onnx/export.py:28-31): the vocoder-only model's decoder stage
+    vits_model* v = m->vocoder;
+    S = ylen * v->hp.hop_length;
+    float* d_audio = call.dev<float>((size_t)S);
+    h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)(S ? S : 1)));
+    vits_session* sv = nullptr;
+    if (!d_audio || !h_audio) rc = fail(VITS_ERR_NOMEM, "alloc failed");
+    if (rc == VITS_OK) rc = check_err(s);  // the mel must be complete before the vocoder's own stream reads it
+    if (rc == VITS_OK) rc = pool_acquire(v, &sv);
+    if (rc == VITS_OK) rc = session_reserve(sv, 1, 1, (int)ylen);
+    if (rc == VITS_OK) {
+      run_decoder(sv, d_mel, false, 1, (int)ylen, d_audio, S, nullptr);
+      hipLaunchKernelGGL(clamp_kernel, dim3(cdiv((int)S, 256)), dim3(256), 0, sv->stream, d_audio, (long long)S);
+      hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, sv->stream);
+      rc = check_err(sv);
+    }
+    if (sv) pool_release(v, sv);
+  } else {
+    rc = check_err(s);
+  }
+  if (rc != VITS_OK) { free(h_mel); free(h_audio); return rc; }
+  if (out_audio) { *out_audio = h_audio; *out_samples = S; }
+  if (out_mel) { *out_mel = h_mel; *out_frames = ylen; }
+  (void)H;
+  return VITS_OK;
+}
+
+}  // extern "C"
