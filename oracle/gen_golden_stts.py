@@ -127,7 +127,43 @@ def case(name, net, voc, hp, rng, Tx, bert_zero, pde_mode, sid, scales):
     save(name, **out)
 
 
+def frontend_golden():
+    """vosk_tts.Synth.g2p_multistream (vosk_tts/synth.py:273-347) on fixed sentences, with the toy dictionary and id map
+    of vosk_tts_amd.toymodel as the model data.  synth.py is loaded by file path with onnxruntime stubbed out."""
+    import importlib.util
+    import types
+
+    from vosk_tts_amd.toymodel import multistream_phoneme_id_map
+
+    sys.modules.setdefault("onnxruntime", types.ModuleType("onnxruntime"))
+    pkg = types.ModuleType("vosk_tts_ref")
+    pkg.__path__ = [os.path.join(R.REF_ROOT, "vosk_tts")]
+    sys.modules["vosk_tts_ref"] = pkg
+    for name in ("g2p", "synth"):
+        spec = importlib.util.spec_from_file_location(f"vosk_tts_ref.{name}", os.path.join(R.REF_ROOT, "vosk_tts", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"vosk_tts_ref.{name}"] = mod
+        spec.loader.exec_module(mod)
+    Synth = sys.modules["vosk_tts_ref.synth"].Synth
+    model = types.SimpleNamespace(dic={"привет": "p rj i0 vj e1 t", "мир": "mj i1 r"},
+                                  config={"phoneme_id_map": multistream_phoneme_id_map()}, tokenizer=None)
+    synth = Synth(model)
+    sentences = ['Прив+ет, "м+ир" - да... Нет!', "м+ир", "Да? Нет. (Мож+ет б+ыть): хорош+о; ладно - пок+а!", '"Прив+ет" сказ+ал +он, и уш+ёл...',
+                 "од+ин -  дв+а -тр+и", "чт+о... чт+о?! д+а."]
+    flat, offs = [], [0]
+    for sent in sentences:
+        for wp in (False, True):
+            with contextlib.redirect_stdout(io.StringIO()):
+                ids, _ = synth.g2p_multistream(sent, None, word_pos=wp) if wp else synth.g2p_multistream(sent, None)
+            flat.extend(ids)
+            offs.append(len(flat))
+    np.savez_compressed(os.path.join(OUT, "stts_frontend.npz"), sentences=np.array(sentences), ids=np.array(flat, np.int64),
+                        offsets=np.array(offs, np.int64))
+    print("  stts_frontend.npz")
+
+
 def main():
+    frontend_golden()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     hp, net, voc = build()

@@ -258,3 +258,63 @@ def test_synth_stream_matches_synth_audio(tmp_path):
     got = np.concatenate(chunks)
     assert got.shape == whole.shape
     assert np.max(np.abs(got.astype(np.int32) - whole.astype(np.int32))) <= 1  # float tolerance -> at most 1 LSB
+
+
+def test_multistream_frontend_matches_reference_function():
+    """g2p_multistream (five id streams; vosk_tts/synth.py:273-347) against outputs of the reference's own function on
+    fixed sentences (tests/golden/stts_frontend.npz, oracle/gen_golden_stts.py), with and without word positions."""
+    from vosk_tts_amd.multistream import g2p_multistream, word_positions
+    from vosk_tts_amd.toymodel import multistream_phoneme_id_map
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stts_frontend.npz"))
+    dic = {"привет": "p rj i0 vj e1 t", "мир": "mj i1 r"}
+    idmap = multistream_phoneme_id_map()
+    k = 0
+    for sent in g["sentences"]:
+        for wp in (False, True):
+            want = g["ids"][g["offsets"][k]:g["offsets"][k + 1]]
+            got, bert = g2p_multistream(str(sent), dic, idmap, None, word_pos=wp)
+            assert bert == [] and np.array_equal(np.array(got, np.int64), want), (sent, wp)
+            k += 1
+    assert word_positions(["a"]) == ["a_S"] and word_positions(["a", "b", "c"]) == ["a_B", "b_I", "c_E"]
+    # per-word BERT vectors fan out to the symbols of each word; index 0 belongs to '^'
+    ids, bert = g2p_multistream("м+ир да", dic, idmap, ["w0", "w1", "w2", "w3"], word_pos=True)
+    assert bert[0] == "w0" and bert[1:4] == ["w1"] * 3 and bert[-1] == "w3" and len(bert) == len(ids)
+
+
+@pytest.mark.gpu
+def test_multistream_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
+    """A `multistream_v2` voice without a tokenizer (vosk_tts/synth.py:77-81): Model picks the StableTTS engine, Synth
+    builds the [1,5,T] feed with zero BERT vectors, run() returns [wav [1,S], wav_lengths]; checked against the oracle."""
+    import itertools
+
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.capi_stts import SttsModel
+    from vosk_tts_amd.multistream import g2p_multistream
+    from vosk_tts_amd.toymodel import write_toy_multistream_model
+
+    d = write_toy_multistream_model(str(tmp_path / "ms"))
+    model = Model(model_path=d, device=0)
+    assert model.config["model_type"] == "multistream_v2" and model.tokenizer is None
+    synth = Synth(model)
+    out = tmp_path / "o.wav"
+    synth.synth('Прив+ет, "м+ир"!', str(out), speaker_id=2)
+    with wave.open(str(out)) as f:
+        n = f.getnframes()
+        assert f.getframerate() == 22050 and n > 0 and n % 256 == 0
+    ids, _ = g2p_multistream("м+ир - да.", model.dic, model.config["phoneme_id_map"], None, word_pos=True)
+    ids = np.transpose(np.array(ids, np.int64))[None]
+    feed = {"input": ids, "input_lengths": np.array([ids.shape[2]], np.int64), "scales": np.array([0.7, 1.0, 0.8], np.float32),
+            "sid": np.array([1], np.int64), "bert": np.zeros((1, 768, ids.shape[2]), np.float32), "phone_duration_extra": None,
+            "vits.seed": 5}
+    wav, wav_len = model.onnx.run(None, feed)
+    assert wav.ndim == 2 and wav.shape[0] == 1 and wav_len.tolist() == [wav.shape[1]] and np.abs(wav).max() <= 1.0
+    vref = oracle_lib.create(open(os.path.join(d, "vocoder.vitsw"), "rb").read())
+    ref = SttsModel(oracle_lib, open(os.path.join(d, "model.sttsw"), "rb").read(), vref)
+    want, _ = ref.synthesize(ids[0], feed["scales"], 1, None, None, seed=5)
+    assert_close("run() vs oracle", want, wav[0], 5e-4)
+    with pytest.raises(ValueError):
+        model.onnx.run(None, dict(feed, input=ids[:, :3]))
+    with pytest.raises(ValueError):
+        model.onnx.run(None, dict(feed, bogus=np.zeros(1)))

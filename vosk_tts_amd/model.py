@@ -55,7 +55,16 @@ class Model:
             device = int(os.getenv("VOSK_TTS_DEVICE", os.getenv("LOCAL_RANK", "0")))
         logging.info(f"Loading model from {model_path}")
         blob_path = model_path / "model.vitsw"
-        if blob_path.exists():
+        if (model_path / "model.sttsw").exists():
+            # a `multistream_v*` (StableTTS / Matcha) voice: acoustic blob + vocoder-only blob (vosk_tts_amd/weights_stts.py)
+            from .session_stts import SttsSession
+
+            with open(model_path / "model.sttsw", "rb") as f:
+                blob = f.read()
+            with open(model_path / "vocoder.vitsw", "rb") as f:
+                vblob = f.read()
+            self.onnx = SttsSession(blob, vblob, device=device)
+        elif blob_path.exists():
             with open(blob_path, "rb") as f:
                 blob = f.read()
         elif (model_path / "model.onnx").exists():
@@ -72,7 +81,8 @@ class Model:
             blob = W.pack_blob(hp, tensors)
         else:
             raise FileNotFoundError(f"neither {blob_path} nor model.onnx found in {model_path}")
-        self.onnx = VitsSession(blob, device=device)
+        if not hasattr(self, "onnx"):
+            self.onnx = VitsSession(blob, device=device)
 
         self.dic = {}
         probs = {}

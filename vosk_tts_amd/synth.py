@@ -36,18 +36,31 @@ class Synth:
             scale = inf.get("scale", 1.0)
 
         text = re.sub("—", "-", text.strip())
-        model_type = self.model.config.get("model_type")
-        if self.model.tokenizer is not None or (model_type or "").startswith("multistream"):
-            raise NotImplementedError("BERT / multistream flavours (synth.py:64-99) are outside the VITS2 hot path; "
-                                      "see SURVEY.md §8f")
-        phoneme_ids = self.g2p_noembed(text)
-        ids = np.expand_dims(np.array(phoneme_ids, dtype=np.int64), 0)
-        lengths = np.array([ids.shape[1]], dtype=np.int64)
+        model_type = self.model.config.get("model_type") or ""
+        bert_embs = None
+        if self.model.tokenizer is not None:
+            raise NotImplementedError("BERT-conditioned flavours (synth.py:64-76,82-99) need the rubert encoder; see SURVEY.md §8f rank 2")
+        if model_type == "multistream_v2":
+            # the tokenizer-less multistream_v2 branch (synth.py:77-81): five id streams, zero BERT embeddings
+            from .multistream import g2p_multistream
+
+            stream_ids, _ = g2p_multistream(text, self.model.dic, self.model.config["phoneme_id_map"], None, word_pos=True)
+            ids = np.expand_dims(np.transpose(np.array(stream_ids, dtype=np.int64)), 0)  # [1, 5, T]
+            bert_embs = np.zeros((1, 768, ids.shape[2]), dtype=np.float32)
+            lengths = np.array([ids.shape[2]], dtype=np.int64)
+        elif model_type.startswith("multistream"):
+            # without a tokenizer the reference falls through to g2p_noembed for v1/v3 (synth.py:100-103), which a 5-stream
+            # graph cannot take; only v2 is drivable without BERT
+            raise NotImplementedError(f"{model_type} needs the BERT front-end (synth.py:64-70,82-87)")
+        else:
+            phoneme_ids = self.g2p_noembed(text)
+            ids = np.expand_dims(np.array(phoneme_ids, dtype=np.int64), 0)
+            lengths = np.array([ids.shape[1]], dtype=np.int64)
         scales = np.array([noise_level, 1.0 / speech_rate, duration_noise_level], dtype=np.float32)
         if speaker_id is None:
             speaker_id = 0
         sid = np.array([speaker_id], dtype=np.int64)
-        args = {"input": ids, "input_lengths": lengths, "scales": scales, "sid": sid, "bert": None,
+        args = {"input": ids, "input_lengths": lengths, "scales": scales, "sid": sid, "bert": bert_embs,
                 "phone_duration_extra": None}
         return args, scale
 

@@ -32,3 +32,34 @@ def write_toy_model(path, hp=None, seed=1234, dictionary=None, inference=None):
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, ensure_ascii=False)
     return path
+
+
+# ---- multistream (StableTTS / Matcha) toy voice ------------------------------------------------------------------
+_MS_PUNCT = ["_", " ", "^", "$", ",", ".", "...", "?", "!", ";", ":", "(", ")", "-"]
+_MS_BASE = [p for p in PHONEMES if p not in _MS_PUNCT and p != '"']
+
+
+def multistream_phoneme_id_map():
+    """ids 0/1 stay free for the in-quote stream, which the graph consumes as a raw id (synth.py:343)"""
+    syms = _MS_PUNCT + [b + suf for b in _MS_BASE for suf in ("", "_B", "_I", "_E", "_S")]  # "" = multistream_v1 (no word positions)
+    return {p: i + 2 for i, p in enumerate(syms)}
+
+
+def write_toy_multistream_model(path, seed=1234, n_spks=5, inference=None):
+    """model.sttsw + vocoder.vitsw + dictionary + config.json (model_type multistream_v2, no bert/ directory)"""
+    from . import weights_stts as S
+
+    os.makedirs(path, exist_ok=True)
+    idmap = multistream_phoneme_id_map()
+    hp = S.default_hparams(n_vocab=max(idmap.values()) + 1, n_spks=n_spks)
+    with open(os.path.join(path, "model.sttsw"), "wb") as f:
+        f.write(S.synthetic_blob(hp, seed))
+    W.save_blob(os.path.join(path, "vocoder.vitsw"), W.hifigan_v1_vocoder_hparams(), W.make_synthetic_weights(W.hifigan_v1_vocoder_hparams(), seed))
+    with open(os.path.join(path, "dictionary"), "w", encoding="utf-8") as f:
+        f.write("привет 1.0 p rj i0 vj e1 t\nмир 0.9 mj i1 r\n")
+    cfg = {"audio": {"sample_rate": hp.sampling_rate},
+           "inference": inference or {"noise_level": 0.8, "speech_rate": 1.0, "duration_noise_level": 0.8, "scale": 1.0},
+           "phoneme_id_map": idmap, "num_speakers": n_spks, "model_type": "multistream_v2"}
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, ensure_ascii=False)
+    return path
