@@ -61,12 +61,110 @@ def make_workload(name, rng, rank=0, world=1):
     return ids, lengths, dur
 
 
+def stts_algorithmic_flops(hp, voc_model, Tx, Ty, n_steps):
+    """MatchaTTS.synthesise + vocoder, multiply-adds x 2: dp_encoder per symbol; per frame the estimator
+    (in_proj, 6 DiT blocks, 3 long-skip convs, final_proj) x (1 + CFG) x n_steps plus cond_proj once per CFG branch."""
+    He, Fe, Hd, Fd, NF, K = hp.enc_hidden, hp.enc_filter, hp.dec_hidden, hp.dec_filter, hp.n_feats, hp.dec_kernel
+    tok = 2 * hp.bert_dim * hp.bert_proj_dim + hp.enc_layers * (2 * 4 * He * He + 2 * 2 * He * Fe * hp.enc_kernel) + 2 * He * hp.dp_out
+    tok_quad = hp.enc_layers * 4 * He
+    blk = 2 * 4 * Hd * Hd + 2 * 2 * Hd * Fd * K
+    est = 2 * (NF + Hd) * Hd + hp.dec_layers * blk + (hp.dec_layers // 2) * 2 * (2 * Hd) * Hd * K + 2 * Hd * NF
+    est_quad = hp.dec_layers * 4 * Hd
+    cond = 2 * K * (hp.enc_hidden * Fd + Fd * Fd + Fd * Hd)
+    nb = 2 if hp.guidance_scale > 0 else 1
+    frame = nb * (n_steps * est + cond)
+    return Tx * (tok + tok_quad * Tx) + Ty * (frame + nb * n_steps * est_quad * Ty) + voc_model.algorithmic_flops(1, 0, Ty)
+
+
+def bench_multistream(args, torch, rank, world, local_rank, dist):
+    """configs[1]-shaped single utterance on the StableTTS / Matcha family: 50 symbols, 3 frames per
+    symbol pinned through phone_duration_extra, 5 Euler steps with guidance, bundled HiFi-GAN V1 vocoder; host entry point
+    (ids in, PCM-ready float waveform out), so the few KB of H2D and the 150 KB D2H are inside the timed region."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.capi import VitsLib
+    from vosk_tts_amd.capi_stts import SttsModel
+
+    lib = VitsLib()
+    vblob = W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234)
+    hp = S.default_hparams(62, 5)
+    blob = S.synthetic_blob(hp, 1234)
+    voc = lib.create(vblob, local_rank)
+    model = SttsModel(lib, blob, voc, local_rank)
+    rng = np.random.default_rng(1234 + rank)
+    Tx = 50
+    ids = rng.integers(1, 62, size=(5, Tx)).astype(np.int64)
+    pde = np.full(Tx, 3.0, np.float32)
+    scales = np.array([0.8, 1.0, 0.8], np.float32)
+
+    def step(i):
+        return model.synthesize(ids, scales, 2, None, pde, seed=7 + i, want_mel=False)[0]
+
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        audio = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    S_ = int(audio.shape[0])
+    Ty = S_ // hp.hop_length
+    assert np.isfinite(audio).all() and Ty == 3 * Tx
+    flops = stts_algorithmic_flops(hp, voc, Tx, Ty, hp.n_timesteps)
+    value = S_ * world * args.steps / elapsed
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        so = os.path.join(ROOT, "oracle", "libvits_oracle.so")
+        if os.path.exists(so):
+            import ctypes
+
+            olib = VitsLib(so, "vitsref_")
+            ref = SttsModel(olib, blob, olib.create(vblob))
+            olib.lib.vitsref_num_threads.restype = ctypes.c_int
+            n, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds and n < 20:
+                c0 = time.perf_counter()
+                ref.synthesize(ids, scales, 2, None, pde, seed=7, want_mel=False)
+                t_cpu += time.perf_counter() - c0
+                n += 1
+            cpu_baseline = {"value": round(S_ * n / t_cpu, 1), "unit": "samples/s", "cores": int(olib.lib.vitsref_num_threads()), "kind": "port",
+                            "sample": f"{n} forward(s) of the same utterance through oracle/libvits_oracle.so (sttsref_synthesize, OpenMP), {t_cpu:.1f} s",
+                            "x_realtime": round(S_ * n / t_cpu / SAMPLE_RATE, 2)}
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
+            "config": {"workload": f"m2: StableTTS/Matcha multistream graph (seeded synthetic weights) + bundled HiFi-GAN V1, B=1, {Tx} symbols x 5 streams, "
+                                   f"zero BERT vectors, durations pinned 3/symbol -> T_y={Ty}, {hp.n_timesteps} Euler steps with guidance {hp.guidance_scale:g}, "
+                                   f"{S_} samples/step/GPU, host entry point stts_synthesize", "batch": 1, "T_x": Tx, "T_y": Ty,
+                       "samples_per_step_per_gpu": S_, "parallelism": f"replicas x{world} (no collective)", "hipgraph": False},
+            "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole forward (per-kernel breakdown: rocprofv3 --kernel-trace of this command)",
+                         "forward": {"algorithmic_gflop": round(flops / 1e9, 3)}},
+            "cpu_baseline": cpu_baseline}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "m2"],
+                    help="c1..c5: BASELINE configs on the VITS2 graph; m2: the configs[1] shape on the StableTTS (multistream) family")
     ap.add_argument("--no-batch32", action="store_true", help="skip the extra c3 (batch=32) measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget for the CPU-oracle baseline leg")
@@ -96,6 +194,9 @@ def main():
 
     from vosk_tts_amd import weights as W
     from vosk_tts_amd.capi import VitsDeviceSession, VitsLib
+
+    if args.workload == "m2":
+        return bench_multistream(args, torch, rank, world, local_rank, dist)
 
     hp = W.default_hparams()
     blob = W.synthetic_blob(hp, 1234)
