@@ -113,16 +113,26 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   const long long o0 = (long long)b * P.C * P.T + (in ? t : 0);
   float v[LN_MAXV];
   float sum = 0.f;
+  // every load unconditional with a clamped channel index (validity is a select afterwards): a per-element `if` around
+  // the load makes hipcc wait for each one in turn -- 12..24 dependent L2 round trips instead of one
+  if (P.b) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+      v[i] = P.a[o0 + (long long)cc * P.T] + P.b[o0 + (long long)cc * P.T];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+      v[i] = P.a[o0 + (long long)cc * P.T];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = cg + i * LN_CG;
-    float x = 0.f;
-    if (in && c < P.C) {
-      x = P.a[o0 + (long long)c * P.T];
-      if (P.b) x += P.b[o0 + (long long)c * P.T];
-    }
-    v[i] = x;
-    sum += x;
+    v[i] = (in && c < P.C) ? v[i] : 0.f;
+    sum += v[i];
   }
   const float mean = ln_group_sum(sum, red, tl, cg) / (float)P.C;
   float sq = 0.f;
@@ -134,17 +144,23 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   const float rstd = 1.0f / sqrtf(ln_group_sum(sq, red, tl, cg) / (float)P.C + 1e-5f);
   if (!in) return;
   const bool zero = P.mask && t >= P.len[b];
+  const float* gp = P.gamma + (P.mod_stride ? (long long)b * P.mod_stride : 0);
+  const float* bp = P.beta + (P.mod_stride ? (long long)b * P.mod_stride : 0);
+  const float g1 = P.mod_stride ? 1.0f : 0.0f;  // adaLN: 1 + scale
+  float ga[LN_MAXV], be[LN_MAXV], ba[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+    ga[i] = gp[cc]; be[i] = bp[cc];
+    ba[i] = P.base ? P.base[o0 + (long long)cc * P.T] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = cg + i * LN_CG;
-    if (c < P.C) {
-      const float ga = P.mod_stride ? 1.0f + P.gamma[(long long)b * P.mod_stride + c] : P.gamma[c];
-      const float be = P.mod_stride ? P.beta[(long long)b * P.mod_stride + c] : P.beta[c];
-      float x = (v[i] - mean) * rstd * ga + be;
-      if (P.gelu) x = gelu_erf(x);
-      if (P.base) x += P.base[o0 + (long long)c * P.T];
-      P.y[o0 + (long long)c * P.T] = zero ? 0.f : x;
-    }
+    float x = (v[i] - mean) * rstd * (g1 + ga[i]) + be[i];
+    if (P.gelu) x = gelu_erf(x);
+    x += ba[i];
+    if (c < P.C) P.y[o0 + (long long)c * P.T] = zero ? 0.f : x;
   }
 }
 
