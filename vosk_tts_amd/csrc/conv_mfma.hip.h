@@ -73,6 +73,8 @@ struct ConvParams {
   long long y_bstride;
   float in_slope;     // leaky-relu slope applied at staging (1 = identity)
   float in_scale;     // multiplies the (summed) input at staging
+  int x_split;        // K-split kernel, NIN == 2: input channels >= x_split come from g.x2 (channel ci - x_split):
+                      // a conv over cat((x, x2), dim=1) without materialising the concatenation; multiple of 16
   int in_mask;        // zero input where t >= len[b]
   int reflect;        // ReflectionPad1d((1,0)) folded into staging: index -1 reads index 1
   const int* len;     // [B] lengths for masks
@@ -611,9 +613,10 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   };
   int lc = wave, lk = 0;  // load cursor (chunk, tap-in-chunk) of this wave's tap stream
   const unsigned lane16 = (unsigned)lane * 16u;
-  const float* xq2 = NIN > 1 ? xu2 : xu;               // NIN == 3: MRF mean of three inputs (x3 may be absent)
-  const float* xq3 = NIN > 1 ? (xu3 ? xu3 : xu2) : xu;
-  const float s3 = (NIN > 1 && xu3) ? 1.f : 0.f;
+  const float* xq2 = NIN > 2 ? xu2 : xu;               // NIN == 3: MRF mean of three inputs (x3 may be absent)
+  const float* xq3 = NIN > 2 ? (xu3 ? xu3 : xu2) : xu;
+  const float s3 = (NIN > 2 && xu3) ? 1.f : 0.f;
+  const int split_chunk = NIN == 2 ? P.x_split / CONV_CI_T : 0x7fffffff;  // NIN == 2: channel-concatenated second input
   const int refl_t = P.reflect ? ((P.Tin > 1) ? 1 : 0) : -1;
 
   // Software pipeline inside ONE wave, pinned at source level: before every MFMA of the current
@@ -628,7 +631,9 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
       const bool live = lc <= c_last;
       const int cc = live ? lc : c_last;
       const int sg = 2 * (cc * K + lk);
-      const long long coff = (long long)cc * CONV_CI_T * rs;
+      const bool second = NIN == 2 && cc >= split_chunk;  // wave-uniform
+      const float* xsrc = second ? xu2 : xu;
+      const long long coff = (long long)(second ? cc - split_chunk : cc) * CONV_CI_T * rs;
       unsigned lo[NI];
       unsigned okb = 0;
 #pragma unroll
@@ -649,8 +654,8 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
         const long long ro = coff + 2 * p * rs;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          float v = ks_ld(xu + ro, lo[ni]);
-          if (NIN > 1) v = (v + ks_ld(xq2 + ro, lo[ni]) + s3 * ks_ld(xq3 + ro, lo[ni])) * in_scale;  // scale only on the MRF mean
+          float v = ks_ld(xsrc + ro, lo[ni]);
+          if (NIN > 2) v = (v + ks_ld(xq2 + ro, lo[ni]) + s3 * ks_ld(xq3 + ro, lo[ni])) * in_scale;  // scale only on the MRF mean
           nxt.bq[u][p][ni] = v;
         }
         if (decltype(has_cur)::value) {

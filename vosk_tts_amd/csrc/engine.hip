@@ -675,7 +675,9 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo) {
   P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
   const size_t lds = (size_t)4 * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
-  if (EPI == EPI_STORE && P.g[0].x2)
+  if (EPI == EPI_STORE && MI * NI == 1 && P.x_split)
+    hipLaunchKernelGGL((conv_mfma_ks_kernel<1, 1, EPI_STORE, 2>), dim3(nblk), dim3(256), lds, st, P);
+  else if (EPI == EPI_STORE && P.g[0].x2)
     hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, (EPI == EPI_STORE ? 3 : 1)>), dim3(nblk), dim3(256), lds, st, P);
   else
     hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, 1>), dim3(nblk), dim3(256), lds, st, P);
@@ -728,6 +730,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
   static const long ks_threshold = getenv("VITS_KS_THRESHOLD") ? atol(getenv("VITS_KS_THRESHOLD")) : 512;
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
+  if (P.x_split) small = true;  // channel-concatenated inputs exist in the K-split kernel only
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   if (epi == EPI_GATE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo); }
@@ -750,6 +753,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     static const int ks_shape = getenv("VITS_KS_SHAPE") ? atoi(getenv("VITS_KS_SHAPE")) : 0;  // tools/: force MI,NI (e.g. 21)
     if (ks_shape == 22 && !multi) { ps.set_kernel("conv_mfma_ks_kernel<2,2,STORE,1>"); launch_ks<2, 2, EPI_STORE>(s, P, halo); return; }
     if (ks_shape == 21 && !multi) { ps.set_kernel("conv_mfma_ks_kernel<2,1,STORE,1>"); launch_ks<2, 1, EPI_STORE>(s, P, halo); return; }
+    if (P.x_split) { ps.set_kernel("conv_mfma_ks_kernel<1,1,STORE,2>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); return; }
     if (ks_shape == 12 || (ks_shape == 0 && blocks32 > 2048)) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(s, P, halo); }
     else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); }
     return;

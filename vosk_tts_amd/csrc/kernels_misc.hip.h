@@ -977,11 +977,11 @@ __global__ void rope_kernel(float* qkv, int H, int T, int heads, int dk) {
   *r1 = x1 * cs + x0 * sn;
 }
 // DitWrapper.time_fusion (components/decoder.py:15-16,31-33): h = (gamma[c] * h + beta[c]) * mask, film = [gamma | beta]
-__global__ void film_mask_kernel(float* h, const float* film, const int* len, int H, int T) {
+__global__ void film_mask_kernel(const float* h, float* out, const float* film, const int* len, int H, int T) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   const long long o = ((long long)b * H + c) * T + t;
-  h[o] = t < len[b] ? film[c] * h[o] + film[H + c] : 0.f;
+  out[o] = t < len[b] ? film[c] * h[o] + film[H + c] : 0.f;
 }
 // y[n][r] = act(bias[r] + sum_j W[r][j] * x[n][j]); one wave per (row, n).  act: 0 none, 1 SiLU
 __global__ void gemv_rows_kernel(const float* W, const float* bias, const float* x, int x_stride, float* y, int y_stride, int rows,

@@ -205,7 +205,7 @@ static void stts_run_encoder(vits_session* s, const stts_model* m, const int64_t
 // ---- estimator state for one synthesis: everything that does not depend on the Euler step is computed once
 struct SttsEst {
   int nb, T, n_steps;
-  float *cat, *h, *dphi, *film, *mods, *lsc[3 + 8], *a1, *a2;
+  float *cat, *h, *h2, *dphi, *film, *mods, *lsc[3 + 8], *a1, *a2;
   DitScratch sc;
   int* len;
 };
@@ -224,7 +224,8 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
   E.cat = bump<float>(s, (size_t)nb * (NF + H) * T); E.h = bump<float>(s, (size_t)nb * H * T); E.dphi = bump<float>(s, (size_t)nb * NF * T);
   E.sc.hn = bump<float>(s, (size_t)nb * H * T); E.sc.qkv = bump<float>(s, (size_t)nb * 3 * H * T); E.sc.att = bump<float>(s, (size_t)nb * H * T);
   E.sc.ffh = bump<float>(s, (size_t)nb * F * T);
-  for (int j = 0; j < NL / 2; ++j) E.lsc[j] = bump<float>(s, (size_t)nb * 2 * H * T);
+  for (int j = 0; j < NL / 2; ++j) E.lsc[j] = bump<float>(s, (size_t)nb * H * T);
+  E.h2 = bump<float>(s, (size_t)nb * H * T);
   E.a1 = bump<float>(s, (size_t)nb * F * T); E.a2 = bump<float>(s, (size_t)nb * F * T);
   // time embeddings of every step: SinusoidalPosEmb(H)(t, scale=1000) on the host (n_steps * H values), TimestepEmbedding
   // and the FiLM projections of all blocks as GEMVs over the n_steps columns (components/decoder.py:35-62,15-33)
@@ -260,20 +261,33 @@ static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int 
   const int nb = E.nb, T = E.T, n = E.n_steps;
   ConvParams P = conv_params(m->in_proj, E.cat, E.h, nb, T, 1, 0);
   launch_conv(s, P, EPI_STORE, "cfm.in_proj");
-  const dim3 cg(cdiv(T, 256), H, nb);
+  // Buffer choreography without copies: FiLM runs out of place, so for the first NL/2 blocks the tensor it READ is left
+  // untouched and IS the long-skip output (lsc_outputs.append(x)); the second half consumes them in reverse through the
+  // channel-split conv (cat((x, skip), dim=1) never exists).
+  float* cur = E.h;                 // in_proj output
+  float* skips[8];
+  int sp = 0, nfree = 0;
+  float* freeb[12];
+  for (int j = 0; j < NL / 2; ++j) freeb[nfree++] = E.lsc[j];
+  freeb[nfree++] = E.h2;
   for (int idx = 0; idx < NL; ++idx) {
-    if (idx < NL / 2) {  // lsc_outputs.append(x): popped by layer NL-1-idx -> upper half of that layer's concat buffer
-      hipLaunchKernelGGL(copy_rows_kernel, cg, dim3(256), 0, s->stream, E.h, (long long)H * T, E.lsc[NL / 2 - 1 - idx] + (size_t)H * T, (long long)2 * H * T, T);
-    } else {  // x = lsc_layers[idx - NL/2](cat((x, lsc_outputs.pop()), dim=1))
-      float* cb = E.lsc[idx - NL / 2];
-      hipLaunchKernelGGL(copy_rows_kernel, cg, dim3(256), 0, s->stream, E.h, (long long)H * T, cb, (long long)2 * H * T, T);
-      P = conv_params(m->lsc[idx - NL / 2], cb, E.h, nb, T, 1, K / 2);
+    if (idx >= NL / 2) {  // x = lsc_layers[idx - NL/2](cat((x, lsc_outputs.pop()), dim=1)): channels [0,H) from x, [H,2H) from the skip
+      float* skip = skips[--sp];
+      float* out = freeb[--nfree];
+      P = conv_params(m->lsc[idx - NL / 2], cur, out, nb, T, 1, K / 2);
+      P.x_bstride = (long long)H * T;  // each of the two inputs is a dense [nb, H, T] tensor
+      P.g[0].x2 = skip; P.x_split = H;
       launch_conv(s, P, EPI_STORE, "cfm.lsc");
+      freeb[nfree++] = cur; freeb[nfree++] = skip;
+      cur = out;
     }
-    hipLaunchKernelGGL(film_mask_kernel, dim3(cdiv(T, 64), H, nb), dim3(64), 0, s->stream, E.h, E.film + ((size_t)idx * n + step) * 2 * H, E.len, H, T);
-    stts_dit_block(s, m, m->dec[idx], E.h, E.mods + (size_t)idx * nb * 6 * H, E.len, nb, H, F, hp.dec_heads, K, T, E.sc, "cfm");
+    float* fo = freeb[--nfree];
+    hipLaunchKernelGGL(film_mask_kernel, dim3(cdiv(T, 64), H, nb), dim3(64), 0, s->stream, cur, fo, E.film + ((size_t)idx * n + step) * 2 * H, E.len, H, T);
+    if (idx < NL / 2) skips[sp++] = cur; else freeb[nfree++] = cur;
+    cur = fo;
+    stts_dit_block(s, m, m->dec[idx], cur, E.mods + (size_t)idx * nb * 6 * H, E.len, nb, H, F, hp.dec_heads, K, T, E.sc, "cfm");
   }
-  P = conv_params(m->final_proj, E.h, E.dphi, nb, T, 1, 0);  // final_proj(x * mask) * mask
+  P = conv_params(m->final_proj, cur, E.dphi, nb, T, 1, 0);  // final_proj(x * mask) * mask
   P.in_mask = 1; P.out_mask = 1; P.len = E.len;
   launch_conv(s, P, EPI_STORE, "cfm.final_proj");
 }
