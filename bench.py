@@ -76,7 +76,7 @@ def stts_algorithmic_flops(hp, voc_model, Tx, Ty, n_steps):
     return Tx * (tok + tok_quad * Tx) + Ty * (frame + nb * n_steps * est_quad * Ty) + voc_model.algorithmic_flops(1, 0, Ty)
 
 
-def bench_multistream(args, torch, rank, world, local_rank, dist):
+def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=False):
     """configs[1]-shaped single utterance on the StableTTS / Matcha family: 50 symbols, 3 frames per
     symbol pinned through phone_duration_extra, 5 Euler steps with guidance, bundled HiFi-GAN V1 vocoder; host entry point
     (ids in, PCM-ready float waveform out), so the few KB of H2D and the 150 KB D2H are inside the timed region."""
@@ -121,6 +121,14 @@ def bench_multistream(args, torch, rank, world, local_rank, dist):
     assert np.isfinite(audio).all() and Ty == 3 * Tx
     flops = stts_algorithmic_flops(hp, voc, Tx, Ty, hp.n_timesteps)
     value = S_ * world * args.steps / elapsed
+    if as_object:  # secondary figure inside the default line: the second model family on the same utterance shape
+        ms = elapsed / args.steps * 1e3
+        model.close()
+        return {"value": round(value, 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
+                "workload": f"m2: StableTTS/Matcha multistream graph + HiFi-GAN V1, B=1, {Tx} symbols -> T_y={Ty}, {hp.n_timesteps} Euler steps, "
+                            "host entry point stts_synthesize (python bench.py --workload m2 for the full line)",
+                "algorithmic_gflop": round(flops / 1e9, 3), "achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 3),
+                "frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         so = os.path.join(ROOT, "oracle", "libvits_oracle.so")
@@ -377,6 +385,14 @@ def main():
                      "one_shot_host_call_ms": round(float(np.median(oneshot)), 3),
                      "note": "host API incl. H2D/D2H; acoustic half once over the utterance, decoder hipGraph replayed per chunk"}
 
+    multistream = None
+    if args.workload == "c2" and not args.no_batch32:
+        import copy
+
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup = max(5, min(args.steps, 20)), 3
+        multistream = bench_multistream(a2, torch, rank, world, local_rank, dist, as_object=True)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # TEST-INFRASTRUCTURE leg: the CPU oracle (plain C restatement of the reference arithmetic)
@@ -414,7 +430,7 @@ def main():
                                    f"-> T_y={Ty}, {valid_samples} valid samples/step/GPU, sid=2, scales=[0.8,1.0,0.8]",
                        "batch": B, "T_x": Tx, "T_y": Ty, "samples_per_step_per_gpu": valid_samples,
                        "parallelism": f"replicas x{world} (no collective)", "hipgraph": not args.no_graph},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "batch32": batch32, "streaming": streaming,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "batch32": batch32, "multistream": multistream, "streaming": streaming,
         }
         print(json.dumps(line))
     if dist is not None:
