@@ -9,10 +9,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    hdr = open(os.path.join(ROOT, "include", "vits_mi355.h")).read()
+def _header_functions(header="vits_mi355.h", prefix="vits_"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(vits_[a-z0-9_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_declares_the_expected_surface():
@@ -27,6 +27,20 @@ def test_product_library_exports_every_declared_symbol(hip_lib):
     missing = [n for n in _header_functions() if not hasattr(hip_lib.lib, n)]
     assert not missing, f"libvits_mi355.so lacks {missing}"
     assert hip_lib.is_device
+
+
+def test_stts_header_surface_is_exported_by_product_library_and_oracle(hip_lib, oracle_lib):
+    """include/stts_mi355.h (StableTTS / Matcha family): every declared entry point exists in libvits_mi355.so, and the
+    oracle exports the same surface under sttsref_; the hparams mirror has the header's size."""
+    names = _header_functions("stts_mi355.h", "stts_")
+    for must in ("stts_create", "stts_destroy", "stts_synthesize", "stts_last_error", "stts_get_hparams", "stts_stage_encoder",
+                 "stts_stage_durations", "stts_stage_estimator", "stts_stage_cfm"):
+        assert must in names
+    assert not [n for n in names if not hasattr(hip_lib.lib, n)]
+    assert not [n for n in names if not hasattr(oracle_lib.lib, "sttsref_" + n[len("stts_"):])]
+    from vosk_tts_amd.weights_stts import SttsHParams
+
+    assert ctypes.sizeof(SttsHParams) == 26 * 4
 
 
 def test_oracle_exports_the_stage_abi(oracle_lib):
