@@ -94,3 +94,27 @@ def test_stts_seeded_noise_and_errors(stts_pair):
         hip.synthesize(bad, g["scales"], 0)
     with pytest.raises(VitsError, match="speaker id"):
         hip.synthesize(g["ids"][0], g["scales"], 77)
+
+
+def test_stts_medium_utterance_vs_oracle_and_long_form_properties(stts_pair):
+    """60 symbols -> 300 frames against the oracle (2 Euler steps keep the CPU side short), then a 400-symbol / 1600-frame
+    utterance without an oracle run: finite, deterministic, length = 256 * sum(durations), mel-only call returns the
+    mel the vocoder consumed."""
+    hip, ref = stts_pair
+    rng = np.random.default_rng(23)
+    ids = rng.integers(1, 40, size=(5, 60)).astype(np.int64)
+    pde = np.full(60, 5.0, np.float32)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    a_ref, m_ref = ref.synthesize(ids, sc, 4, None, pde, seed=2, n_timesteps=2)
+    a_hip, m_hip = hip.synthesize(ids, sc, 4, None, pde, seed=2, n_timesteps=2)
+    assert m_hip.shape == (80, 300) and a_hip.shape == (300 * 256,)
+    assert_close("mel", m_ref, m_hip, E2E_TOL)
+    assert_close("audio", a_ref, a_hip, E2E_TOL)
+    ids = rng.integers(1, 40, size=(5, 400)).astype(np.int64)
+    pde = np.full(400, 4.0, np.float32)
+    a1, m1 = hip.synthesize(ids, sc, 1, None, pde, seed=9)
+    a2, m2 = hip.synthesize(ids, sc, 1, None, pde, seed=9)
+    assert a1.shape == (1600 * 256,) and np.isfinite(a1).all() and np.abs(a1).max() <= 1.0
+    assert np.array_equal(a1, a2) and np.array_equal(m1, m2)
+    _, m3 = hip.synthesize(ids, sc, 1, None, pde, seed=9, want_audio=False)
+    assert np.array_equal(m1, m3)
