@@ -88,6 +88,27 @@ int stts_stage_estimator(stts_model* m, const float* x, const float* mu, const i
 int stts_stage_cfm(stts_model* m, const float* mu_y, int64_t y_length, int32_t T, int64_t sid, const float* noise,
                    float temperature, int32_t n_timesteps, float* out);
 
+/* ---- word-embedding BERT encoder ----------------------------------------------------------------------------------
+ * The `bert/model.onnx` of BERT-conditioned voices (vosk_tts/model.py:59-63; called at synth.py:27-34): a HuggingFace
+ * BertModel exported by training/stabletts/matcha/onnx/bert-export.py:5-13 with output hidden_states[-3], i.e. the
+ * activations after layer n_layers - 2, shape [tokens, hidden].  The model itself is the third-party `transformers`
+ * BertModel (post-LN encoder: embeddings word + position + token_type -> LayerNorm(eps 1e-12); per layer self-attention,
+ * dense + residual + LayerNorm, dense/GELU(erf)/dense + residual + LayerNorm); parity is pinned to that implementation
+ * (tests/golden/bert_*.npz, oracle/gen_golden_stts.py).  One sentence per call, attention_mask all ones, as synth.py
+ * drives it.  Blob "BERTW001" (vosk_tts_amd/weights_bert.py), tensor names = BertModel.state_dict() keys. */
+typedef struct bert_hparams {
+  int32_t abi_version;
+  int32_t vocab_size, hidden, n_layers, out_layers, n_heads, intermediate, max_position, type_vocab;
+  float ln_eps;
+} bert_hparams;
+#define BERT_ABI_VERSION 1
+typedef struct bert_model bert_model;
+int stts_bert_create(const void* blob, size_t blob_bytes, int device, bert_model** out);
+void stts_bert_destroy(bert_model* m);
+int stts_bert_get_hparams(const bert_model* m, bert_hparams* out);
+/* input_ids / token_type_ids int64 [T] (token_type_ids may be NULL = zeros); out float [T, hidden] */
+int stts_bert_encode(bert_model* m, const int64_t* input_ids, const int64_t* token_type_ids, int32_t T, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,7 +162,37 @@ def frontend_golden():
     print("  stts_frontend.npz")
 
 
+def bert_golden():
+    """transformers.BertModel (the model behind bert/model.onnx, onnx/bert-export.py:5-13: output hidden_states[-3]) on
+    build-owned synthetic weights: a small geometry (hidden 128, 4 layers) and a 768-wide one (4 layers)."""
+    from transformers import BertConfig, BertModel
+
+    from vosk_tts_amd import weights_bert as BW
+
+    for name, hp in (("bert_small", BW.small_hparams(120, 128, 4)), ("bert_768", BW.small_hparams(120, 768, 4))):
+        cfg = BertConfig(vocab_size=hp.vocab_size, hidden_size=hp.hidden, num_hidden_layers=hp.n_layers, num_attention_heads=hp.n_heads,
+                         intermediate_size=hp.intermediate, max_position_embeddings=hp.max_position, type_vocab_size=hp.type_vocab,
+                         layer_norm_eps=hp.ln_eps, hidden_act="gelu", attn_implementation="eager")
+        net = BertModel(cfg).eval()
+        tens = BW.make_synthetic_weights(hp, SEED)
+        sd = net.state_dict()
+        with torch.no_grad():
+            for k, v in tens.items():
+                assert tuple(sd[k].shape) == v.shape, k
+                sd[k].copy_(torch.from_numpy(v))
+        rng = np.random.default_rng(55)
+        T = 17
+        ids = rng.integers(0, hp.vocab_size, size=(1, T)).astype(np.int64)
+        types = np.zeros((1, T), np.int64)
+        with torch.no_grad():
+            out = net(input_ids=torch.from_numpy(ids), attention_mask=torch.ones(1, T, dtype=torch.long), token_type_ids=torch.from_numpy(types),
+                      output_hidden_states=True)
+        hs = torch.cat(out["hidden_states"][-3:-2], -1).squeeze(0)  # bert-export.py:11
+        save(name, ids=ids[0], types=types[0], hidden=hs.numpy())
+
+
 def main():
+    bert_golden()  # before frontend_golden(): its onnxruntime stub module would confuse transformers' import probing
     frontend_golden()
     torch.manual_seed(0)
     torch.set_num_threads(8)

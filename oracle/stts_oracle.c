@@ -524,3 +524,132 @@ int SAPI(get_hparams)(const stts_model* m, stts_hparams* out) {
   *out = m->hp;
   return VITS_OK;
 }
+
+/* ================================================================== word-embedding BERT encoder
+ * transformers.BertModel as exported by onnx/bert-export.py:5-13 (output hidden_states[-3]).  Restated from the
+ * published architecture (Devlin et al. 2019; transformers modeling_bert: BertEmbeddings, BertSelfAttention,
+ * BertSelfOutput, BertIntermediate, BertOutput) and pinned to transformers' own output in tests/golden/bert_*.npz. */
+struct bert_model {
+  bert_hparams hp;
+  unsigned char* blob;
+  uint32_t n_entries;
+  const vits_blob_entry* entries;
+  int missing;
+};
+static const float* bget(bert_model* m, size_t nelem, const char* fmt, ...) {
+  char name[160];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(name, sizeof name, fmt, ap);
+  va_end(ap);
+  for (uint32_t i = 0; i < m->n_entries; ++i) {
+    const vits_blob_entry* e = &m->entries[i];
+    if (strncmp(e->name, name, sizeof e->name) == 0) {
+      if (e->nelem != nelem) { m->missing = 1; sfail(VITS_ERR_BLOB, "tensor %s: %llu elements, expected %zu", name, (unsigned long long)e->nelem, nelem); return NULL; }
+      return (const float*)(m->blob + e->offset);
+    }
+  }
+  m->missing = 1;
+  sfail(VITS_ERR_BLOB, "tensor %s missing from blob", name);
+  return NULL;
+}
+/* y[t] = W x[t] + b over rows of a [T, C] matrix */
+static void dense_rows(const float* x, int T, int Cin, const float* w, const float* b, int Cout, float* y) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int t = 0; t < T; ++t)
+    for (int co = 0; co < Cout; ++co) {
+      float a = b[co];
+      for (int ci = 0; ci < Cin; ++ci) a += w[(size_t)co * Cin + ci] * x[(size_t)t * Cin + ci];
+      y[(size_t)t * Cout + co] = a;
+    }
+}
+static void ln_rows(float* x, int T, int C, const float* g, const float* b, float eps) {
+  for (int t = 0; t < T; ++t) {
+    float mean = 0.f, var = 0.f;
+    for (int c = 0; c < C; ++c) mean += x[(size_t)t * C + c];
+    mean /= (float)C;
+    for (int c = 0; c < C; ++c) { const float d = x[(size_t)t * C + c] - mean; var += d * d; }
+    const float rstd = 1.0f / sqrtf(var / (float)C + eps);
+    for (int c = 0; c < C; ++c) x[(size_t)t * C + c] = (x[(size_t)t * C + c] - mean) * rstd * g[c] + b[c];
+  }
+}
+int SAPI(bert_encode)(bert_model* m, const int64_t* ids, const int64_t* types, int32_t T, float* out) {
+  if (!m || !ids || !out || T <= 0) return sfail(VITS_ERR_ARG, "bad argument");
+  const bert_hparams* hp = &m->hp;
+  const int H = hp->hidden, F = hp->intermediate, nh = hp->n_heads, dk = H / nh;
+  if (T > hp->max_position) return sfail(VITS_ERR_ARG, "%d tokens exceed max_position %d", T, hp->max_position);
+  const float* we = bget(m, (size_t)hp->vocab_size * H, "embeddings.word_embeddings.weight");
+  const float* pe = bget(m, (size_t)hp->max_position * H, "embeddings.position_embeddings.weight");
+  const float* te = bget(m, (size_t)hp->type_vocab * H, "embeddings.token_type_embeddings.weight");
+  const float* eg = bget(m, H, "embeddings.LayerNorm.weight");
+  const float* eb = bget(m, H, "embeddings.LayerNorm.bias");
+  if (m->missing) return VITS_ERR_BLOB;
+  float* x = fal((size_t)T * H);
+  for (int t = 0; t < T; ++t) {
+    const int64_t id = ids[t], ty = types ? types[t] : 0;
+    if (id < 0 || id >= hp->vocab_size || ty < 0 || ty >= hp->type_vocab) { free(x); return sfail(VITS_ERR_ARG, "token id out of range"); }
+    for (int c = 0; c < H; ++c) x[(size_t)t * H + c] = we[(size_t)id * H + c] + te[(size_t)ty * H + c] + pe[(size_t)t * H + c];
+  }
+  ln_rows(x, T, H, eg, eb, hp->ln_eps);
+  float* q = fal((size_t)T * H); float* k = fal((size_t)T * H); float* v = fal((size_t)T * H); float* c = fal((size_t)T * H);
+  float* f = fal((size_t)T * F); float* y = fal((size_t)T * H);
+  const float scale = 1.0f / sqrtf((float)dk);
+  for (int l = 0; l < hp->out_layers && !m->missing; ++l) {
+    dense_rows(x, T, H, bget(m, (size_t)H * H, "encoder.layer.%d.attention.self.query.weight", l), bget(m, H, "encoder.layer.%d.attention.self.query.bias", l), H, q);
+    dense_rows(x, T, H, bget(m, (size_t)H * H, "encoder.layer.%d.attention.self.key.weight", l), bget(m, H, "encoder.layer.%d.attention.self.key.bias", l), H, k);
+    dense_rows(x, T, H, bget(m, (size_t)H * H, "encoder.layer.%d.attention.self.value.weight", l), bget(m, H, "encoder.layer.%d.attention.self.value.bias", l), H, v);
+    if (m->missing) break;
+    for (int h = 0; h < nh; ++h)
+      for (int i = 0; i < T; ++i) {
+        float sc[2048];
+        float mx = -3.0e38f;
+        for (int j = 0; j < T; ++j) {
+          float s = 0.f;
+          for (int d = 0; d < dk; ++d) s += q[(size_t)i * H + h * dk + d] * k[(size_t)j * H + h * dk + d];
+          sc[j] = s * scale;
+          if (sc[j] > mx) mx = sc[j];
+        }
+        float den = 0.f;
+        for (int j = 0; j < T; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+        for (int d = 0; d < dk; ++d) {
+          float a = 0.f;
+          for (int j = 0; j < T; ++j) a += sc[j] * v[(size_t)j * H + h * dk + d];
+          c[(size_t)i * H + h * dk + d] = a / den;
+        }
+      }
+    dense_rows(c, T, H, bget(m, (size_t)H * H, "encoder.layer.%d.attention.output.dense.weight", l), bget(m, H, "encoder.layer.%d.attention.output.dense.bias", l), H, y);
+    for (size_t i = 0; i < (size_t)T * H; ++i) x[i] += y[i];
+    ln_rows(x, T, H, bget(m, H, "encoder.layer.%d.attention.output.LayerNorm.weight", l), bget(m, H, "encoder.layer.%d.attention.output.LayerNorm.bias", l), hp->ln_eps);
+    dense_rows(x, T, H, bget(m, (size_t)F * H, "encoder.layer.%d.intermediate.dense.weight", l), bget(m, F, "encoder.layer.%d.intermediate.dense.bias", l), F, f);
+    for (size_t i = 0; i < (size_t)T * F; ++i) f[i] = 0.5f * f[i] * (1.0f + erff(f[i] * 0.70710678118654752440f));
+    dense_rows(f, T, F, bget(m, (size_t)H * F, "encoder.layer.%d.output.dense.weight", l), bget(m, H, "encoder.layer.%d.output.dense.bias", l), H, y);
+    for (size_t i = 0; i < (size_t)T * H; ++i) x[i] += y[i];
+    ln_rows(x, T, H, bget(m, H, "encoder.layer.%d.output.LayerNorm.weight", l), bget(m, H, "encoder.layer.%d.output.LayerNorm.bias", l), hp->ln_eps);
+  }
+  if (!m->missing) memcpy(out, x, sizeof(float) * (size_t)T * H);
+  free(x); free(q); free(k); free(v); free(c); free(f); free(y);
+  return m->missing ? VITS_ERR_BLOB : VITS_OK;
+}
+int SAPI(bert_create)(const void* blob, size_t bytes, int device, bert_model** out) {
+  (void)device;
+  if (!blob || !out || bytes < 16 + sizeof(bert_hparams)) return sfail(VITS_ERR_ARG, "bad blob argument");
+  const unsigned char* p = (const unsigned char*)blob;
+  if (memcmp(p, "BERTW001", 8) != 0) return sfail(VITS_ERR_BLOB, "bad magic");
+  uint32_t hb; memcpy(&hb, p + 8, 4);
+  if (hb != sizeof(bert_hparams)) return sfail(VITS_ERR_BLOB, "hparams size %u != %zu", hb, sizeof(bert_hparams));
+  bert_model* m = (bert_model*)calloc(1, sizeof *m);
+  memcpy(&m->hp, p + 12, sizeof(bert_hparams));
+  if (m->hp.abi_version != BERT_ABI_VERSION || m->hp.max_position > 2048) { free(m); return sfail(VITS_ERR_BLOB, "abi version / size mismatch"); }
+  m->blob = (unsigned char*)malloc(bytes);
+  memcpy(m->blob, blob, bytes);
+  memcpy(&m->n_entries, m->blob + 12 + hb, 4);
+  m->entries = (const vits_blob_entry*)(m->blob + 16 + hb);
+  *out = m;
+  return VITS_OK;
+}
+void SAPI(bert_destroy)(bert_model* m) { if (m) { free(m->blob); free(m); } }
+int SAPI(bert_get_hparams)(const bert_model* m, bert_hparams* out) {
+  if (!m || !out) return sfail(VITS_ERR_ARG, "null argument");
+  *out = m->hp;
+  return VITS_OK;
+}

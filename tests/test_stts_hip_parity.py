@@ -118,3 +118,29 @@ def test_stts_medium_utterance_vs_oracle_and_long_form_properties(stts_pair):
     assert np.array_equal(a1, a2) and np.array_equal(m1, m2)
     _, m3 = hip.synthesize(ids, sc, 1, None, pde, seed=9, want_audio=False)
     assert np.array_equal(m1, m3)
+
+
+@pytest.mark.parametrize("name,hidden", [("bert_small", 128), ("bert_768", 768)])
+def test_bert_encoder_vs_transformers_golden(hip_lib, name, hidden):
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd.capi_stts import BertEncoder
+
+    g = golden(name)
+    enc = BertEncoder(hip_lib, BW.synthetic_blob(BW.small_hparams(120, hidden, 4), 1234))
+    assert_close("hidden_states[-3]", g["hidden"], enc.encode(g["ids"], g["types"]), STAGE_TOL)
+    enc.close()
+
+
+def test_bert_base_geometry_vs_oracle(hip_lib, oracle_lib):
+    """rubert-base geometry (12 x 768, 12 heads, 3072; 10 layers run for hidden_states[-3]) at 60 tokens, HIP vs oracle"""
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd.capi import VitsError
+    from vosk_tts_amd.capi_stts import BertEncoder
+
+    blob = BW.synthetic_blob(BW.base_hparams(300), 7)
+    hip, ref = BertEncoder(hip_lib, blob), BertEncoder(oracle_lib, blob)
+    ids = np.random.default_rng(3).integers(0, 300, size=60)
+    assert_close("bert-base", ref.encode(ids), hip.encode(ids), 2 * STAGE_TOL)
+    with pytest.raises(VitsError, match="token id"):
+        hip.encode(np.array([1, 2, 9999]))
+    hip.close()

@@ -69,3 +69,18 @@ def test_stts_zero_bert_equals_none_and_errors(stts_oracle):
         stts_oracle.synthesize(bad, g["scales"], 0)
     with pytest.raises(VitsError, match="speaker id"):
         stts_oracle.synthesize(g["ids"][0], g["scales"], 99)
+
+
+@pytest.mark.parametrize("name,hidden", [("bert_small", 128), ("bert_768", 768)])
+def test_bert_encoder_oracle_vs_transformers(oracle_lib, name, hidden):
+    """The word-embedding BERT encoder (bert/model.onnx = transformers.BertModel, output hidden_states[-3]) restated in C,
+    against activations of transformers' own BertModel on the same synthetic weights (oracle/gen_golden_stts.py)."""
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd.capi_stts import BertEncoder
+
+    g = golden(name)
+    enc = BertEncoder(oracle_lib, BW.synthetic_blob(BW.small_hparams(120, hidden, 4), 1234))
+    out = enc.encode(g["ids"], g["types"])
+    assert out.shape == g["hidden"].shape
+    assert_close("hidden_states[-3]", g["hidden"], out, TOL)
+    assert_close("run()", g["hidden"], enc.run(None, {"input_ids": [g["ids"]], "attention_mask": [np.ones_like(g["ids"])], "token_type_ids": [g["types"]]})[0], TOL)

@@ -134,3 +134,64 @@ class SttsModel:
         self.check(self._fn("stage_cfm")(self._h, _p(mu_y, c_f32p), int(y_length), T, int(sid), _p(noise, c_f32p), float(temperature),
                                          int(n_timesteps), _p(out, c_f32p)))
         return out
+
+
+class BertEncoder:
+    """stts_bert_* : the word-embedding BERT encoder (`bert/model.onnx` of the reference, vosk_tts/model.py:61).
+    `run(None, {"input_ids": [ids], "attention_mask": [...], "token_type_ids": [...]})[0]` -> float32 [T, hidden]
+    mirrors the onnxruntime call at synth.py:27-34."""
+
+    def __init__(self, vlib: VitsLib, blob, device=0, prefix=None):
+        from .weights_bert import BertHParams
+
+        self.vlib = vlib
+        self.prefix = prefix or ("stts_bert_" if vlib.prefix == "vits_" else "sttsref_bert_")
+        vp = ctypes.c_void_p
+        f = self._fn
+        f("create").argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+        f("destroy").argtypes = [vp]
+        f("destroy").restype = None
+        f("get_hparams").argtypes = [vp, ctypes.POINTER(BertHParams)]
+        f("encode").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, c_f32p]
+        self._err = getattr(vlib.lib, "stts_last_error" if vlib.prefix == "vits_" else "sttsref_last_error")
+        self._err.restype = ctypes.c_char_p
+        self._h = vp()
+        buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+        self._check(f("create")(ctypes.cast(buf, vp), len(blob), device, ctypes.byref(self._h)))
+        self.hp = BertHParams()
+        self._check(f("get_hparams")(self._h, ctypes.byref(self.hp)))
+
+    def _fn(self, name):
+        return getattr(self.vlib.lib, self.prefix + name)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise VitsError(rc, self._err().decode(errors="replace"))
+
+    def encode(self, input_ids, token_type_ids=None):
+        ids = _i64(input_ids).reshape(-1)
+        ty = None if token_type_ids is None else _i64(token_type_ids).reshape(-1)
+        out = np.empty((ids.shape[0], self.hp.hidden), np.float32)
+        self._check(self._fn("encode")(self._h, _p(ids, c_i64p), None if ty is None else _p(ty, c_i64p), ids.shape[0], _p(out, c_f32p)))
+        return out
+
+    def run(self, output_names, feed):
+        mask = np.asarray(feed.get("attention_mask", [[1]]))
+        if not np.all(mask == 1):
+            raise NotImplementedError("padded BERT batches are not part of the path (synth.py:27-34 encodes one sentence)")
+        ids = np.asarray(feed["input_ids"])
+        if ids.ndim != 2 or ids.shape[0] != 1:
+            raise ValueError("input_ids must be [1, T]")
+        ty = feed.get("token_type_ids")
+        return [self.encode(ids[0], None if ty is None else np.asarray(ty)[0])]
+
+    def close(self):
+        if self._h:
+            self._fn("destroy")(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

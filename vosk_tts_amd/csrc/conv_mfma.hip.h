@@ -78,7 +78,7 @@ struct ConvParams {
   int in_mask;        // zero input where t >= len[b]
   int reflect;        // ReflectionPad1d((1,0)) folded into staging: index -1 reads index 1
   const int* len;     // [B] lengths for masks
-  int relu;           // 1: ReLU, 2: SiLU (stabletts FFN / cond_proj) on acc + bias
+  int relu;           // 1: ReLU, 2: SiLU (stabletts FFN / cond_proj), 3: GELU-erf (BERT) on acc + bias
   const float* scale_b;  // per-batch per-row gate [B][scale_b_stride] applied after the mask, before the residual
   int scale_b_stride;    // (adaLN-Zero gates: x + gate * f(x) * mask, diffusion_transformer.py:112-113)
   int scale_b_off;
@@ -214,6 +214,9 @@ __device__ __forceinline__ void conv_epilogue_frag(const ConvParams& P, const Co
     } else if (P.relu == 2) {
 #pragma unroll
       for (int i = 0; i < NE; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
+    } else if (P.relu == 3) {  // GELU (erf), BERT intermediate
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f));
     }
     if (P.out_mask && col >= lenb) {
 #pragma unroll

@@ -94,6 +94,7 @@ struct LNParams {
   // adaLN (DiT blocks, stabletts diffusion_transformer.py:111,120-122): when > 0 the affine part is per batch item,
   // y = LN(x) * (1 + gamma[b*mod_stride + c]) + beta[b*mod_stride + c]   (LayerNorm without elementwise affine + modulate)
   int mod_stride;
+  float eps;  // 1e-5 (modules.LayerNorm / nn.LayerNorm default), 1e-12 for the BERT encoder
 };
 __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
   red[cg * LN_TL + tl] = v;
@@ -104,6 +105,8 @@ __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int c
   __syncthreads();
   return s;
 }
+// MAXV = channels per thread (C <= 16 * MAXV): instantiated for 12 / 24 / 48 so narrow tensors do not issue dead loads
+template <int MAXV>
 __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   __shared__ float red[LN_CG * LN_TL];
   const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
@@ -111,25 +114,25 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   const int t = blockIdx.x * LN_TL + tl;
   const bool in = t < P.T;
   const long long o0 = (long long)b * P.C * P.T + (in ? t : 0);
-  float v[LN_MAXV];
+  float v[MAXV];
   float sum = 0.f;
   // every load unconditional with a clamped channel index (validity is a select afterwards): a per-element `if` around
   // the load makes hipcc wait for each one in turn -- 12..24 dependent L2 round trips instead of one
   if (P.b) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
       v[i] = P.a[o0 + (long long)cc * P.T] + P.b[o0 + (long long)cc * P.T];
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
       v[i] = P.a[o0 + (long long)cc * P.T];
     }
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < MAXV; ++i) {
     const int c = cg + i * LN_CG;
     v[i] = (in && c < P.C) ? v[i] : 0.f;
     sum += v[i];
@@ -137,31 +140,38 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   const float mean = ln_group_sum(sum, red, tl, cg) / (float)P.C;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < MAXV; ++i) {
     const int c = cg + i * LN_CG;
     if (c < P.C) { const float d = v[i] - mean; sq += d * d; }
   }
-  const float rstd = 1.0f / sqrtf(ln_group_sum(sq, red, tl, cg) / (float)P.C + 1e-5f);
+  const float rstd = 1.0f / sqrtf(ln_group_sum(sq, red, tl, cg) / (float)P.C + P.eps);
   if (!in) return;
   const bool zero = P.mask && t >= P.len[b];
   const float* gp = P.gamma + (P.mod_stride ? (long long)b * P.mod_stride : 0);
   const float* bp = P.beta + (P.mod_stride ? (long long)b * P.mod_stride : 0);
   const float g1 = P.mod_stride ? 1.0f : 0.0f;  // adaLN: 1 + scale
-  float ga[LN_MAXV], be[LN_MAXV], ba[LN_MAXV];
+  float ga[MAXV], be[MAXV], ba[MAXV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < MAXV; ++i) {
     const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
     ga[i] = gp[cc]; be[i] = bp[cc];
     ba[i] = P.base ? P.base[o0 + (long long)cc * P.T] : 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < MAXV; ++i) {
     const int c = cg + i * LN_CG;
     float x = (v[i] - mean) * rstd * (g1 + ga[i]) + be[i];
     if (P.gelu) x = gelu_erf(x);
     x += ba[i];
     if (c < P.C) P.y[o0 + (long long)c * P.T] = zero ? 0.f : x;
   }
+}
+
+static void launch_layernorm(hipStream_t st, const LNParams& P, int B) {
+  const dim3 grid((P.T + LN_TL - 1) / LN_TL, B);
+  if (P.C <= 12 * LN_CG) hipLaunchKernelGGL(layernorm_c_kernel<12>, grid, dim3(256), 0, st, P);
+  else if (P.C <= 24 * LN_CG) hipLaunchKernelGGL(layernorm_c_kernel<24>, grid, dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(layernorm_c_kernel<48>, grid, dim3(256), 0, st, P);
 }
 
 // DDSConv first half (modules.py:100-102): y = gelu(LN1(dwconv_k,dil(x * mask))), same block shape;
@@ -1043,4 +1053,18 @@ __global__ void fill_rows_kernel(float* dst, const float* vec, int T) {  // dst[
 __global__ void clamp_kernel(float* a, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = fminf(1.f, fmaxf(-1.f, a[i]));
+}
+
+// BertEmbeddings (transformers modeling_bert): x[c][t] = word[ids[t]][c] + position[t][c] + token_type[types[t]][c]
+__global__ void bert_embed_kernel(const int64_t* ids, const int64_t* types, const float* we, const float* pe, const float* te, float* x,
+                                  int H, int T, int vocab, int type_vocab, int* err) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (t >= T) return;
+  long long id = ids[t], ty = types ? types[t] : 0;
+  if (id < 0 || id >= vocab || ty < 0 || ty >= type_vocab) { atomicOr(err, 1); id = 0; ty = 0; }
+  x[(long long)c * T + t] = we[id * H + c] + pe[(long long)t * H + c] + te[ty * H + c];
+}
+__global__ void transpose_ct_kernel(const float* x, float* y, int C, int T) {  // [C,T] -> [T,C]
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  if (c < C) y[(long long)t * C + c] = x[(long long)c * T + t];
 }

@@ -132,8 +132,8 @@ struct DitScratch { float *hn, *qkv, *att, *ffh; };
 
 static void stts_ln_mod(vits_session* s, const float* x, float* y, const float* shift, const float* scale, int mod_stride, int B, int H, int T) {
   ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
-  LNParams P{x, nullptr, nullptr, y, scale, shift, nullptr, H, T, 0, 0, 0, mod_stride};
-  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TL), B), dim3(256), 0, s->stream, P);
+  LNParams P{x, nullptr, nullptr, y, scale, shift, nullptr, H, T, 0, 0, 0, mod_stride, 1e-5f};
+  launch_layernorm(s->stream, P, B);
 }
 
 // DiTConVBlock.forward (diffusion_transformer.py:99-118) on h [B,H,T] in place; h must already be masked.
@@ -606,6 +606,162 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
   if (out_mel) { *out_mel = h_mel; *out_frames = ylen; }
   (void)H;
   return VITS_OK;
+}
+
+}  // extern "C"
+
+// ================================================================== word-embedding BERT encoder (include/stts_mi355.h)
+// transformers.BertModel up to hidden_states[-3] on the same kernels: tokens are columns ([H, T] channel-major), every
+// Linear is a 1x1 conv launch (q/k/v fused, GELU in the intermediate conv's epilogue), self-attention is the MFMA flash
+// kernel with a zero relative table, residual + LayerNorm(eps) is layernorm_c_kernel(a + b).
+struct BertLayerW { ConvW qkv, o, c1, c2; float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; };
+struct bert_model {
+  vits_model base;
+  bert_hparams hp;
+  float *we = nullptr, *pe = nullptr, *te = nullptr, *eg = nullptr, *eb = nullptr, *zero_rel = nullptr;
+  std::vector<BertLayerW> layers;
+};
+
+static ConvW bert_linear(vits_model* b, const char* name, int Cout, int Cin) {
+  const float* w = tget(b, 2, Cout, Cin, -1, "%s.weight", name);
+  const float* bias = tget(b, 1, Cout, -1, -1, "%s.bias", name);
+  if (b->missing) return ConvW();
+  return make_conv(b, Cout, Cin, 1, bias, [&](int r, int ci, int) { return w[(size_t)r * Cin + ci]; });
+}
+
+static int bert_load(bert_model* m) {
+  vits_model* b = &m->base;
+  const bert_hparams& hp = m->hp;
+  const int H = hp.hidden, F = hp.intermediate;
+  if (H % 32 || F % 32 || hp.n_heads <= 0 || H % hp.n_heads || H > 48 * LN_CG) return fail(VITS_ERR_UNSUPPORTED, "BERT geometry unsupported");
+  const int dk = H / hp.n_heads;
+  if (dk != 32 && dk != 64 && dk != 96) return fail(VITS_ERR_UNSUPPORTED, "head dim %d not in {32,64,96}", dk);
+  if (hp.out_layers < 0 || hp.out_layers > hp.n_layers) return fail(VITS_ERR_UNSUPPORTED, "out_layers out of range");
+  m->we = upload(b, tget(b, 2, hp.vocab_size, H, -1, "embeddings.word_embeddings.weight"), (size_t)hp.vocab_size * H);
+  m->pe = upload(b, tget(b, 2, hp.max_position, H, -1, "embeddings.position_embeddings.weight"), (size_t)hp.max_position * H);
+  m->te = upload(b, tget(b, 2, hp.type_vocab, H, -1, "embeddings.token_type_embeddings.weight"), (size_t)hp.type_vocab * H);
+  m->eg = upload(b, tget(b, 1, H, -1, -1, "embeddings.LayerNorm.weight"), H);
+  m->eb = upload(b, tget(b, 1, H, -1, -1, "embeddings.LayerNorm.bias"), H);
+  { std::vector<float> z(9 * 96, 0.f); m->zero_rel = upload(b, z.data(), z.size()); }
+  char nm[200];
+  for (int l = 0; l < hp.out_layers && !b->missing; ++l) {
+    BertLayerW L;
+    const float* wq = tget(b, 2, H, H, -1, "encoder.layer.%d.attention.self.query.weight", l);
+    const float* wk = tget(b, 2, H, H, -1, "encoder.layer.%d.attention.self.key.weight", l);
+    const float* wv = tget(b, 2, H, H, -1, "encoder.layer.%d.attention.self.value.weight", l);
+    const float* bq = tget(b, 1, H, -1, -1, "encoder.layer.%d.attention.self.query.bias", l);
+    const float* bk = tget(b, 1, H, -1, -1, "encoder.layer.%d.attention.self.key.bias", l);
+    const float* bv = tget(b, 1, H, -1, -1, "encoder.layer.%d.attention.self.value.bias", l);
+    if (b->missing) break;
+    std::vector<float> bias((size_t)3 * H);
+    memcpy(bias.data(), bq, sizeof(float) * H); memcpy(bias.data() + H, bk, sizeof(float) * H); memcpy(bias.data() + 2 * H, bv, sizeof(float) * H);
+    L.qkv = make_conv(b, 3 * H, H, 1, bias.data(), [&](int r, int ci, int) { return (r < H ? wq : (r < 2 * H ? wk : wv))[(size_t)(r % H) * H + ci]; });
+    snprintf(nm, sizeof nm, "encoder.layer.%d.attention.output.dense", l); L.o = bert_linear(b, nm, H, H);
+    snprintf(nm, sizeof nm, "encoder.layer.%d.intermediate.dense", l); L.c1 = bert_linear(b, nm, F, H);
+    snprintf(nm, sizeof nm, "encoder.layer.%d.output.dense", l); L.c2 = bert_linear(b, nm, H, F);
+    L.g1 = upload(b, tget(b, 1, H, -1, -1, "encoder.layer.%d.attention.output.LayerNorm.weight", l), H);
+    L.b1 = upload(b, tget(b, 1, H, -1, -1, "encoder.layer.%d.attention.output.LayerNorm.bias", l), H);
+    L.g2 = upload(b, tget(b, 1, H, -1, -1, "encoder.layer.%d.output.LayerNorm.weight", l), H);
+    L.b2 = upload(b, tget(b, 1, H, -1, -1, "encoder.layer.%d.output.LayerNorm.bias", l), H);
+    m->layers.push_back(L);
+  }
+  return b->missing ? VITS_ERR_BLOB : VITS_OK;
+}
+
+extern "C" {
+
+int stts_bert_create(const void* blob, size_t bytes, int device, bert_model** out) {
+  if (!blob || !out || bytes < 16 + sizeof(bert_hparams)) return fail(VITS_ERR_ARG, "bad blob argument");
+  const unsigned char* p = static_cast<const unsigned char*>(blob);
+  if (memcmp(p, "BERTW001", 8) != 0) return fail(VITS_ERR_BLOB, "bad magic");
+  uint32_t hb;
+  memcpy(&hb, p + 8, 4);
+  if (hb != sizeof(bert_hparams)) return fail(VITS_ERR_BLOB, "hparams size %u != %zu", hb, sizeof(bert_hparams));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VITS_ERR_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(VITS_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  bert_model* m = new bert_model();
+  memcpy(&m->hp, p + 12, sizeof(bert_hparams));
+  if (m->hp.abi_version != BERT_ABI_VERSION) { delete m; return fail(VITS_ERR_BLOB, "abi version mismatch"); }
+  vits_model* b = &m->base;
+  b->device = device; b->acoustic = false;
+  b->blob = p; b->blob_bytes = bytes;
+  memcpy(&b->n_entries, p + 12 + hb, 4);
+  b->entries = reinterpret_cast<const vits_blob_entry*>(p + 16 + hb);
+  int rc = VITS_OK;
+  if (16 + hb + (size_t)b->n_entries * sizeof(vits_blob_entry) > bytes) rc = fail(VITS_ERR_BLOB, "truncated table");
+  for (uint32_t i = 0; rc == VITS_OK && i < b->n_entries; ++i)
+    if (b->entries[i].offset + b->entries[i].nelem * 4 > bytes) rc = fail(VITS_ERR_BLOB, "truncated data");
+  if (rc == VITS_OK) rc = bert_load(m);
+  b->blob = nullptr; b->entries = nullptr;
+  if (rc != VITS_OK) { for (void* a : b->allocs) hipFree(a); delete m; return rc; }
+  hipDeviceSynchronize();
+  *out = m;
+  return VITS_OK;
+}
+
+void stts_bert_destroy(bert_model* m) {
+  if (!m) return;
+  hipSetDevice(m->base.device);
+  for (vits_session* s : m->base.pool) session_free(s);
+  for (void* a : m->base.allocs) hipFree(a);
+  delete m;
+}
+
+int stts_bert_get_hparams(const bert_model* m, bert_hparams* out) {
+  if (!m || !out) return fail(VITS_ERR_ARG, "null argument");
+  *out = m->hp;
+  return VITS_OK;
+}
+
+int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, int32_t T, float* out) {
+  if (!m || !ids || !out || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  const bert_hparams& hp = m->hp;
+  if (T > hp.max_position) return fail(VITS_ERR_ARG, "%d tokens exceed max_position %d", T, hp.max_position);
+  const int H = hp.hidden, F = hp.intermediate, nh = hp.n_heads, dk = H / nh;
+  HIP_TRY(hipSetDevice(m->base.device));
+  vits_session* s = nullptr;
+  TRY(pool_acquire(&m->base, &s));
+  struct Rel { vits_model* b; vits_session* s; std::vector<void*> tmp; ~Rel() { hipStreamSynchronize(s->stream); pool_release(b, s); for (void* p : tmp) hipFree(p); } } rel{&m->base, s, {}};
+  TRY(stts_arena(s, ((size_t)T * (H * 4 + 3 * H + F) + 64) * sizeof(float) + 64 * 1024));
+  float* x = bump<float>(s, (size_t)H * T); float* y = bump<float>(s, (size_t)H * T); float* att = bump<float>(s, (size_t)H * T);
+  float* qkv = bump<float>(s, (size_t)3 * H * T); float* ff = bump<float>(s, (size_t)F * T); float* ot = bump<float>(s, (size_t)H * T);
+  int* d_len = bump<int>(s, 1);
+  void* d_ids = nullptr; void* d_ty = nullptr;
+  if (hipMalloc(&d_ids, sizeof(int64_t) * T) != hipSuccess) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  rel.tmp.push_back(d_ids);
+  if (types) { if (hipMalloc(&d_ty, sizeof(int64_t) * T) != hipSuccess) return fail(VITS_ERR_NOMEM, "device alloc failed"); rel.tmp.push_back(d_ty); }
+  HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int64_t) * T, hipMemcpyHostToDevice, s->stream));
+  if (types) HIP_TRY(hipMemcpyAsync(d_ty, types, sizeof(int64_t) * T, hipMemcpyHostToDevice, s->stream));
+  const int tl = T;
+  HIP_TRY(hipMemcpyAsync(d_len, &tl, sizeof(int), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(bert_embed_kernel, dim3(cdiv(T, 64), H), dim3(64), 0, s->stream, (const int64_t*)d_ids, (const int64_t*)d_ty, m->we, m->pe, m->te, y, H, T,
+                     hp.vocab_size, hp.type_vocab, s->d_err);
+  {
+    LNParams P{y, nullptr, nullptr, x, m->eg, m->eb, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps};
+    launch_layernorm(s->stream, P, 1);
+  }
+  const dim3 agrid(cdiv(T, 32), nh, 1);
+  const size_t lds = (size_t)4 * (dk * 33 + 10 * 32 + 9 * 32) * sizeof(float);
+  for (const BertLayerW& L : m->layers) {
+    ConvParams P = conv_params(L.qkv, x, qkv, 1, T, 1, 0);
+    launch_conv(s, P, EPI_STORE, "bert.qkv");
+    if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
+    else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
+    else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
+    P = conv_params(L.o, att, y, 1, T, 1, 0);
+    launch_conv(s, P, EPI_STORE, "bert.o");
+    { LNParams Q{y, x, nullptr, x, L.g1, L.b1, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps}; launch_layernorm(s->stream, Q, 1); }  // LayerNorm(dense(ctx) + x)
+    P = conv_params(L.c1, x, ff, 1, T, 1, 0); P.relu = 3;
+    launch_conv(s, P, EPI_STORE, "bert.ffn1");
+    P = conv_params(L.c2, ff, y, 1, T, 1, 0);
+    launch_conv(s, P, EPI_STORE, "bert.ffn2");
+    { LNParams Q{y, x, nullptr, x, L.g2, L.b2, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps}; launch_layernorm(s->stream, Q, 1); }
+  }
+  hipLaunchKernelGGL(transpose_ct_kernel, dim3(cdiv(H, 256), T), dim3(256), 0, s->stream, x, ot, H, T);
+  HIP_TRY(hipMemcpyAsync(out, ot, sizeof(float) * (size_t)T * H, hipMemcpyDeviceToHost, s->stream));
+  return check_err(s);
 }
 
 }  // extern "C"
