@@ -157,8 +157,35 @@ def frontend_golden():
                 ids, _ = synth.g2p_multistream(sent, None, word_pos=wp) if wp else synth.g2p_multistream(sent, None)
             flat.extend(ids)
             offs.append(len(flat))
+    # multistream_v3 front-end (g2p_multistream_scales, synth.py:360-456) and get_word_bert's row selection (synth.py:25-44)
+    # with the toy WordPiece vocabulary and a stand-in encoder whose row i is filled with the value i
+    import tempfile
+
+    from tokenizers import BertWordPieceTokenizer
+
+    from vosk_tts_amd.toymodel import BERT_VOCAB
+
+    v3_sentences = ["прив+ет _ м+ир.", '"Да" _ - нет... ладно _', "од+ин, дв+а _ тр+и!"]
+    v3_ids, v3_pde, v3_offs = [], [], [0]
+    for sent in v3_sentences:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ids, _, pde = synth.g2p_multistream_scales(sent, None)
+        v3_ids.extend(ids); v3_pde.extend(pde); v3_offs.append(len(v3_ids))
+    with tempfile.TemporaryDirectory() as d:
+        vp = os.path.join(d, "vocab.txt")
+        with open(vp, "w", encoding="utf-8") as f:
+            f.write("\n".join(BERT_VOCAB) + "\n")
+        model.tokenizer = BertWordPieceTokenizer(vocab=vp, unk_token="[UNK]", lowercase=True)
+        model.bert_onnx = types.SimpleNamespace(run=lambda names, feed: [np.arange(len(feed["input_ids"][0]), dtype=np.float32)[:, None].repeat(4, 1)])
+        wb_rows, wb_offs = [], [0]
+        for sent in sentences + v3_sentences:
+            for nopunc in (False, True):
+                rows = synth.get_word_bert(sent.lower(), nopunc=nopunc)[:, 0].astype(np.int64)
+                wb_rows.extend(rows.tolist()); wb_offs.append(len(wb_rows))
     np.savez_compressed(os.path.join(OUT, "stts_frontend.npz"), sentences=np.array(sentences), ids=np.array(flat, np.int64),
-                        offsets=np.array(offs, np.int64))
+                        offsets=np.array(offs, np.int64), v3_sentences=np.array(v3_sentences), v3_ids=np.array(v3_ids, np.int64),
+                        v3_pde=np.array(v3_pde, np.float32), v3_offsets=np.array(v3_offs, np.int64),
+                        wb_rows=np.array(wb_rows, np.int64), wb_offsets=np.array(wb_offs, np.int64))
     print("  stts_frontend.npz")
 
 

@@ -318,3 +318,69 @@ def test_multistream_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
         model.onnx.run(None, dict(feed, input=ids[:, :3]))
     with pytest.raises(ValueError):
         model.onnx.run(None, dict(feed, bogus=np.zeros(1)))
+
+
+def test_multistream_v3_frontend_and_word_bert_rows_match_reference():
+    """g2p_multistream_scales ('_' pause marks -> phone_duration_extra 20.0; synth.py:360-456) and the row selection of
+    get_word_bert (synth.py:36-42) against outputs of the reference's own functions (tests/golden/stts_frontend.npz)."""
+    from tokenizers import BertWordPieceTokenizer
+
+    from vosk_tts_amd.multistream import g2p_multistream, word_bert_rows
+    from vosk_tts_amd.toymodel import BERT_VOCAB, multistream_phoneme_id_map
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stts_frontend.npz"))
+    dic = {"привет": "p rj i0 vj e1 t", "мир": "mj i1 r"}
+    idmap = multistream_phoneme_id_map()
+    for k, sent in enumerate(g["v3_sentences"]):
+        lo, hi = g["v3_offsets"][k], g["v3_offsets"][k + 1]
+        ids, bert, pde = g2p_multistream(str(sent), dic, idmap, None, pause_marks=True)
+        assert np.array_equal(np.array(ids, np.int64), g["v3_ids"][lo:hi]) and bert == []
+        assert np.array_equal(np.array(pde, np.float32), g["v3_pde"][lo:hi]) and 20.0 in pde
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        vp = os.path.join(d, "vocab.txt")
+        with open(vp, "w", encoding="utf-8") as f:
+            f.write("\n".join(BERT_VOCAB) + "\n")
+        tok = BertWordPieceTokenizer(vocab=vp, unk_token="[UNK]", lowercase=True)
+        k = 0
+        for sent in list(g["sentences"]) + list(g["v3_sentences"]):
+            for nopunc in (False, True):
+                enc = tok.encode(str(sent).lower().replace("+", "").replace("_", ""))
+                want = g["wb_rows"][g["wb_offsets"][k]:g["wb_offsets"][k + 1]]
+                assert word_bert_rows(enc.tokens, nopunc) == want.tolist(), (sent, nopunc)
+                k += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_type", ["multistream_v1", "multistream_v2", "multistream_v3"])
+def test_bert_conditioned_multistream_end_to_end_on_gpu(tmp_path, oracle_lib, model_type):
+    """bert/ present: tokenizer + BERT encoder feed per-word vectors to the five-stream graph (synth.py:64-76);
+    v3 adds phone_duration_extra from '_' marks.  The Synth result equals the oracle driven with the same feed."""
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd.capi_stts import BertEncoder, SttsModel
+    from vosk_tts_amd.toymodel import write_toy_multistream_model
+
+    d = write_toy_multistream_model(str(tmp_path / "ms"), model_type=model_type, with_bert=True)
+    model = Model(model_path=d, device=0)
+    assert model.tokenizer is not None
+    synth = Synth(model)
+    text = "прив+ет _ м+ир, да!" if model_type == "multistream_v3" else "прив+ет м+ир, да!"
+    args, scale = synth._feed(text, 2, None, None, None, None)
+    T = args["input"].shape[2]
+    assert args["input"].shape == (1, 5, T) and args["bert"].shape == (1, 768, T) and np.abs(args["bert"]).max() > 0
+    if model_type == "multistream_v3":
+        assert args["phone_duration_extra"].shape == (1, T) and args["phone_duration_extra"].max() == 20.0
+    else:
+        assert args["phone_duration_extra"] is None
+    wav = model.onnx.run(None, dict(args, **{"vits.seed": 4}))[0]
+    # the same feed through the oracle (BERT vectors recomputed by the oracle's encoder from the same tokens)
+    ref_bert = BertEncoder(oracle_lib, open(os.path.join(d, "bert", "model.bertw"), "rb").read())
+    tokens = model.tokenizer.encode((text.lower() if model_type == "multistream_v3" else text).replace("+", "").replace("_", ""))
+    assert_close("BERT hidden states", ref_bert.encode(tokens.ids, tokens.type_ids), model.bert_onnx.encode(tokens.ids, tokens.type_ids), 2e-4)
+    ref = SttsModel(oracle_lib, open(os.path.join(d, "model.sttsw"), "rb").read(), oracle_lib.create(open(os.path.join(d, "vocoder.vitsw"), "rb").read()))
+    pde = None if args["phone_duration_extra"] is None else args["phone_duration_extra"][0]
+    want, _ = ref.synthesize(args["input"][0], args["scales"], 2, args["bert"][0], pde, seed=4)
+    assert_close("wav vs oracle", want, wav[0], 5e-4)
+    pcm = synth.synth_audio(text, speaker_id=2)
+    assert pcm.dtype == np.int16 and pcm.size % 256 == 0 and pcm.size > 0

@@ -98,9 +98,21 @@ class Model:
 
         with open(model_path / "config.json") as f:
             self.config = json.load(f)
-        if os.path.exists(model_path / "bert/vocab.txt"):
-            logging.warning("bert/ found but BERT-conditioned flavours are not built (SURVEY.md §8f); ignoring it")
+        # BERT word embeddings (model.py:59-63): WordPiece tokenizer + encoder; the encoder weights are a BERTW001 blob
+        # (vosk_tts_amd/weights_bert.py) instead of bert/model.onnx
         self.tokenizer = None
+        if os.path.exists(model_path / "bert/vocab.txt"):
+            if os.path.exists(model_path / "bert/model.bertw"):
+                from tokenizers import BertWordPieceTokenizer
+
+                from .capi_stts import BertEncoder
+
+                self.tokenizer = BertWordPieceTokenizer(vocab=str(model_path / "bert/vocab.txt"), unk_token="[UNK]", lowercase=True)
+                with open(model_path / "bert/model.bertw", "rb") as f:
+                    self.bert_onnx = BertEncoder(self.onnx._lib, f.read(), device)
+            else:
+                logging.warning("bert/vocab.txt found without bert/model.bertw: BERT conditioning disabled "
+                                "(convert the encoder with vosk_tts_amd.weights_bert.pack_blob)")
 
     def get_model_path(self, model_name, lang):
         if model_name is None:

@@ -14,6 +14,8 @@ import re
 from .g2p import convert
 
 _TOKENS = re.compile(r"(\.\.\.|- |[ ,.?!;:\"()])")
+_TOKENS_V3 = re.compile(r"(\.\.\.|- |[ ,.?!;:\"()_])")  # multistream_v3: '_' marks a forced pause (synth.py:363)
+PAUSE_FRAMES = 20.0  # phone_duration_extra of a '_' mark (synth.py:432-435)
 _SENTENCE_MARKS = ("...", ".", "!", "?", "-")  # priority order of the reference's elif chain (synth.py:331-340)
 
 
@@ -24,11 +26,11 @@ def word_positions(phones):
     return [p + ("_B" if i == 0 else "_E" if i == len(phones) - 1 else "_I") for i, p in enumerate(phones)]
 
 
-def _symbols(text, dic, word_pos):
+def _symbols(text, dic, word_pos, tokens=_TOKENS):
     """[(symbol, punctuation list, in_quote, word index)] in reading order, '^' first, ' ' + '$' last"""
     out = [("^", [], 0, 0)]
     quote, pending, widx = 0, [], 1
-    for tok in _TOKENS.split(text.replace(" -", "- ").lower()):
+    for tok in tokens.split(text.replace(" -", "- ").lower()):
         if tok == "":
             continue
         if tok == '"':
@@ -38,7 +40,7 @@ def _symbols(text, dic, word_pos):
         elif tok == " ":
             out.append((" ", pending, quote, widx))
             pending = []
-        elif _TOKENS.fullmatch(tok):
+        elif tokens.fullmatch(tok):
             pending.append(tok)
         else:
             phones = (dic[tok] if tok in dic else convert(tok)).split()
@@ -52,9 +54,11 @@ def _symbols(text, dic, word_pos):
     return out
 
 
-def g2p_multistream(text, dic, phoneme_id_map, bert_embeddings=None, word_pos=False):
-    """-> (ids: list of 5-tuples, one per symbol; bert: list of per-symbol vectors or [])"""
-    syms = _symbols(text, dic, word_pos)
+def g2p_multistream(text, dic, phoneme_id_map, bert_embeddings=None, word_pos=False, pause_marks=False):
+    """-> (ids: list of 5-tuples, one per symbol; bert: list of per-symbol vectors or [])
+    pause_marks=True is g2p_multistream_scales (multistream_v3, synth.py:360-456): '_' is a punctuation token, word
+    positions are always on, and a third list carries 20.0 for symbols whose boundary holds a '_' (else 0.0)."""
+    syms = _symbols(text, dic, word_pos or pause_marks, _TOKENS_V3 if pause_marks else _TOKENS)
     last, last_sentence = " ", " "
     ids, bert = [None] * len(syms), []
     for k in range(len(syms) - 1, -1, -1):  # the two "last ..." streams accumulate from the END of the utterance
@@ -69,4 +73,16 @@ def g2p_multistream(text, dic, phoneme_id_map, bert_embeddings=None, word_pos=Fa
         ids[k] = (phoneme_id_map[sym], phoneme_id_map[here], quote, phoneme_id_map[last], phoneme_id_map[last_sentence])
     if bert_embeddings is not None:
         bert = [bert_embeddings[widx] for (_, _, _, widx) in syms]
+    if pause_marks:
+        return ids, bert, [PAUSE_FRAMES if "_" in puncs else 0.0 for (_, puncs, _, _) in syms]
     return ids, bert
+
+
+_BERT_PUNCT = re.compile(r"[-,.?!;:\"]")
+
+
+def word_bert_rows(tokens, nopunc=False):
+    """Rows of the BERT output that stand for words (synth.py:36-42): the first word piece of every token ('#'-prefixed
+    continuation pieces are dropped), optionally without punctuation tokens.  [CLS] and [SEP] are kept, as in the
+    reference, so row 0 belongs to '^' and the last row to the closing ' ' / '$'."""
+    return [i for i, t in enumerate(tokens) if t[0] != "#" and not (nopunc and _BERT_PUNCT.match(t))]

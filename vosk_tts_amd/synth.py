@@ -38,20 +38,37 @@ class Synth:
         text = re.sub("—", "-", text.strip())
         model_type = self.model.config.get("model_type") or ""
         bert_embs = None
-        if self.model.tokenizer is not None:
-            raise NotImplementedError("BERT-conditioned flavours (synth.py:64-76,82-99) need the rubert encoder; see SURVEY.md §8f rank 2")
-        if model_type == "multistream_v2":
-            # the tokenizer-less multistream_v2 branch (synth.py:77-81): five id streams, zero BERT embeddings
+        phone_duration_extra = None
+        have_bert = self.model.tokenizer is not None
+        if model_type.startswith("multistream"):
+            # synth.py:64-87: v3 = lower-cased text for BERT + '_' pause marks, v2 = word positions, v1 = plain phonemes;
+            # v2 also runs without a tokenizer (zero BERT vectors, synth.py:77-81)
             from .multistream import g2p_multistream
 
-            stream_ids, _ = g2p_multistream(text, self.model.dic, self.model.config["phoneme_id_map"], None, word_pos=True)
+            idmap = self.model.config["phoneme_id_map"]
+            if model_type == "multistream_v3" and have_bert:
+                bert = self.get_word_bert(text.lower(), nopunc=True)
+                stream_ids, per_symbol, extra = g2p_multistream(text, self.model.dic, idmap, bert, pause_marks=True)
+                phone_duration_extra = np.expand_dims(np.array(extra, dtype=np.float32), 0)
+            elif model_type in ("multistream_v1", "multistream_v2") and have_bert:
+                bert = self.get_word_bert(text, nopunc=True)
+                stream_ids, per_symbol = g2p_multistream(text, self.model.dic, idmap, bert, word_pos=model_type == "multistream_v2")
+            elif model_type == "multistream_v2":
+                stream_ids, _ = g2p_multistream(text, self.model.dic, idmap, None, word_pos=True)
+                per_symbol = None
+            else:
+                # without a tokenizer the reference falls through to g2p_noembed for v1/v3 (synth.py:100-103), which a
+                # five-stream graph cannot take
+                raise NotImplementedError(f"{model_type} needs bert/ (vocab.txt + model.bertw) next to the model")
             ids = np.expand_dims(np.transpose(np.array(stream_ids, dtype=np.int64)), 0)  # [1, 5, T]
-            bert_embs = np.zeros((1, 768, ids.shape[2]), dtype=np.float32)
+            if per_symbol is None:
+                bert_embs = np.zeros((1, 768, ids.shape[2]), dtype=np.float32)
+            else:
+                bert_embs = np.expand_dims(np.transpose(np.array(per_symbol, dtype=np.float32)), 0)  # [1, 768, T]
             lengths = np.array([ids.shape[2]], dtype=np.int64)
-        elif model_type.startswith("multistream"):
-            # without a tokenizer the reference falls through to g2p_noembed for v1/v3 (synth.py:100-103), which a 5-stream
-            # graph cannot take; only v2 is drivable without BERT
-            raise NotImplementedError(f"{model_type} needs the BERT front-end (synth.py:64-70,82-87)")
+        elif have_bert:
+            raise NotImplementedError("BERT-conditioned VITS flavours (synth.py:88-99): the text encoder of those graphs is not in "
+                                      "the reference tree (SURVEY.md §8f rank 2)")
         else:
             phoneme_ids = self.g2p_noembed(text)
             ids = np.expand_dims(np.array(phoneme_ids, dtype=np.int64), 0)
@@ -61,8 +78,18 @@ class Synth:
             speaker_id = 0
         sid = np.array([speaker_id], dtype=np.int64)
         args = {"input": ids, "input_lengths": lengths, "scales": scales, "sid": sid, "bert": bert_embs,
-                "phone_duration_extra": None}
+                "phone_duration_extra": phone_duration_extra}
         return args, scale
+
+    def get_word_bert(self, text, nopunc=False):
+        """Word-level BERT vectors (synth.py:25-44): encode the text without stress marks, run the encoder, keep the
+        rows of first word pieces (optionally dropping punctuation tokens).  -> float32 [n_words + 2, 768]"""
+        from .multistream import word_bert_rows
+
+        tokens = self.model.tokenizer.encode(text.replace("+", "").replace("_", ""))
+        bert = self.model.bert_onnx.run(None, {"input_ids": [tokens.ids], "attention_mask": [tokens.attention_mask],
+                                               "token_type_ids": [tokens.type_ids]})[0]
+        return bert[word_bert_rows(tokens.tokens, nopunc)]
 
     def synth_audio(self, text, speaker_id=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None):
         args, scale = self._feed(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)

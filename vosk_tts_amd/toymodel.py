@@ -45,8 +45,24 @@ def multistream_phoneme_id_map():
     return {p: i + 2 for i, p in enumerate(syms)}
 
 
-def write_toy_multistream_model(path, seed=1234, n_spks=5, inference=None):
-    """model.sttsw + vocoder.vitsw + dictionary + config.json (model_type multistream_v2, no bert/ directory)"""
+_RU = "абвгдеёжзийклмнопрстуфхцчшщъыьэюя"
+BERT_VOCAB = (["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(",.?!;:\"()-") + list(_RU) + ["##" + c for c in _RU] +
+              ["привет", "мир", "да", "нет"])
+
+
+def write_bert_dir(path, seed=1234, n_layers=4):
+    """bert/vocab.txt (WordPiece, model.py:59-60) + bert/model.bertw (768-wide synthetic encoder, weights_bert.py)"""
+    from . import weights_bert as BW
+
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "vocab.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(BERT_VOCAB) + "\n")
+    with open(os.path.join(path, "model.bertw"), "wb") as f:
+        f.write(BW.synthetic_blob(BW.small_hparams(len(BERT_VOCAB), 768, n_layers), seed))
+
+
+def write_toy_multistream_model(path, seed=1234, n_spks=5, inference=None, model_type="multistream_v2", with_bert=False):
+    """model.sttsw + vocoder.vitsw + dictionary + config.json; with_bert adds bert/ (tokenizer vocabulary + encoder)"""
     from . import weights_stts as S
 
     os.makedirs(path, exist_ok=True)
@@ -59,7 +75,9 @@ def write_toy_multistream_model(path, seed=1234, n_spks=5, inference=None):
         f.write("привет 1.0 p rj i0 vj e1 t\nмир 0.9 mj i1 r\n")
     cfg = {"audio": {"sample_rate": hp.sampling_rate},
            "inference": inference or {"noise_level": 0.8, "speech_rate": 1.0, "duration_noise_level": 0.8, "scale": 1.0},
-           "phoneme_id_map": idmap, "num_speakers": n_spks, "model_type": "multistream_v2"}
+           "phoneme_id_map": idmap, "num_speakers": n_spks, "model_type": model_type}
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, ensure_ascii=False)
+    if with_bert:
+        write_bert_dir(os.path.join(path, "bert"), seed)
     return path
