@@ -1,5 +1,6 @@
 """B=1 decoder ResBlock convs through vits_op_conv1d with the K-split tile shape forced by VITS_KS_SHAPE
-(run once per shape: VITS_CONV_DBG=20 VITS_KS_SHAPE=21 python tools/ks_shapes.py)."""
+(run once per shape: VITS_CONV_DBG=20 VITS_KS_SHAPE=12 python tools/ks_shapes.py; the 64x32 / 64x64 tiles this
+was also used for were measured slower for B=1 -- DESIGN.md §6 -- and their instantiations removed again)."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa

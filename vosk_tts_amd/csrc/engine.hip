@@ -750,9 +750,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   if (small) {
     const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
     const bool multi = P.g[0].x2 != nullptr;
-    static const int ks_shape = getenv("VITS_KS_SHAPE") ? atoi(getenv("VITS_KS_SHAPE")) : 0;  // tools/: force MI,NI (e.g. 21)
-    if (ks_shape == 22 && !multi) { ps.set_kernel("conv_mfma_ks_kernel<2,2,STORE,1>"); launch_ks<2, 2, EPI_STORE>(s, P, halo); return; }
-    if (ks_shape == 21 && !multi) { ps.set_kernel("conv_mfma_ks_kernel<2,1,STORE,1>"); launch_ks<2, 1, EPI_STORE>(s, P, halo); return; }
+    static const int ks_shape = getenv("VITS_KS_SHAPE") ? atoi(getenv("VITS_KS_SHAPE")) : 0;  // tools/ks_shapes.py: 11 or 12 forces the tile
     if (P.x_split) { ps.set_kernel("conv_mfma_ks_kernel<1,1,STORE,2>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); return; }
     if (ks_shape == 12 || (ks_shape == 0 && blocks32 > 2048)) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(s, P, halo); }
     else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); }
