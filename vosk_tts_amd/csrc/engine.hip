@@ -786,7 +786,7 @@ static void mark_masked(vits_session* s, ConvParams& P, const int* len) {
 static void launch_ln(vits_session* s, const float* a, const float* b, const float* base, float* y, const float* gamma,
                       const float* beta, const int* len, int B, int C, int T, int gelu, int mask) {
   ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
-  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask, (s->ragged && len) ? 1 : 0, 0, 1e-5f};
+  LNParams P{a, b, base, y, gamma, beta, len, C, T, gelu, mask, (s->ragged && len) ? 1 : 0, 0, 1e-5f, nullptr, nullptr};
   launch_layernorm(s->stream, P, B);
 }
 

@@ -95,6 +95,10 @@ struct LNParams {
   // y = LN(x) * (1 + gamma[b*mod_stride + c]) + beta[b*mod_stride + c]   (LayerNorm without elementwise affine + modulate)
   int mod_stride;
   float eps;  // 1e-5 (modules.LayerNorm / nn.LayerNorm default), 1e-12 for the BERT encoder
+  // FiLM folded in front (stabletts DitWrapper, components/decoder.py:15-16,31-33): when pre != nullptr the input is first
+  // mapped to x' = (pre[c] * x + pre[C + c]) * [t < len[b]], x' is written to pre_out (the block's residual stream) and the
+  // LayerNorm runs on x'
+  const float* pre; float* pre_out;
 };
 __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
   red[cg * LN_TL + tl] = v;
@@ -129,6 +133,15 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
     for (int i = 0; i < MAXV; ++i) {
       const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
       v[i] = P.a[o0 + (long long)cc * P.T];
+    }
+  }
+  if (P.pre) {
+    const bool live = in && t < P.len[b];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+      v[i] = live ? P.pre[cc] * v[i] + P.pre[P.C + cc] : 0.f;
+      if (in && c < P.C) P.pre_out[o0 + (long long)c * P.T] = v[i];
     }
   }
 #pragma unroll

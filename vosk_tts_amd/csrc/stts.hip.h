@@ -130,18 +130,23 @@ static void stts_attention(vits_session* s, const stts_model* m, const float* qk
 
 struct DitScratch { float *hn, *qkv, *att, *ffh; };
 
-static void stts_ln_mod(vits_session* s, const float* x, float* y, const float* shift, const float* scale, int mod_stride, int B, int H, int T) {
+static void stts_ln_mod(vits_session* s, const float* x, float* y, const float* shift, const float* scale, int mod_stride, int B, int H, int T,
+                        const float* film = nullptr, float* film_out = nullptr, const int* len = nullptr) {
   ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
-  LNParams P{x, nullptr, nullptr, y, scale, shift, nullptr, H, T, 0, 0, 0, mod_stride, 1e-5f};
+  LNParams P{x, nullptr, nullptr, y, scale, shift, len, H, T, 0, 0, 0, mod_stride, 1e-5f, film, film_out};
   launch_layernorm(s->stream, P, B);
 }
 
 // DiTConVBlock.forward (diffusion_transformer.py:99-118) on h [B,H,T] in place; h must already be masked.
 // mod [B][6H]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+// film != nullptr: the block input is FiLM(h_in) * mask (DitWrapper.forward), produced inside the first LayerNorm launch
+// and written to h (h_in is left untouched)
 static void stts_dit_block(vits_session* s, const stts_model* m, const DitW& W, float* h, const float* mod, const int* len, int B,
-                           int H, int F, int nh, int K, int T, const DitScratch& sc, const char* tag) {
+                           int H, int F, int nh, int K, int T, const DitScratch& sc, const char* tag, const float* film = nullptr,
+                           const float* h_in = nullptr) {
   char nm[64];
-  stts_ln_mod(s, h, sc.hn, mod, mod + H, 6 * H, B, H, T);
+  if (film) stts_ln_mod(s, h_in, sc.hn, mod, mod + H, 6 * H, B, H, T, film, h, len);
+  else stts_ln_mod(s, h, sc.hn, mod, mod + H, 6 * H, B, H, T);
   ConvParams P = conv_params(W.qkv, sc.hn, sc.qkv, B, T, 1, 0);
   snprintf(nm, sizeof nm, "%s.qkv", tag); launch_conv(s, P, EPI_STORE, nm);
   stts_attention(s, m, sc.qkv, len, sc.att, B, H, T, nh);
@@ -281,11 +286,11 @@ static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int 
       freeb[nfree++] = cur; freeb[nfree++] = skip;
       cur = out;
     }
-    float* fo = freeb[--nfree];
-    hipLaunchKernelGGL(film_mask_kernel, dim3(cdiv(T, 64), H, nb), dim3(64), 0, s->stream, cur, fo, E.film + ((size_t)idx * n + step) * 2 * H, E.len, H, T);
+    float* fo = freeb[--nfree];  // FiLM(cur) * mask lands here (inside the block's first LayerNorm launch)
+    stts_dit_block(s, m, m->dec[idx], fo, E.mods + (size_t)idx * nb * 6 * H, E.len, nb, H, F, hp.dec_heads, K, T, E.sc, "cfm",
+                   E.film + ((size_t)idx * n + step) * 2 * H, cur);
     if (idx < NL / 2) skips[sp++] = cur; else freeb[nfree++] = cur;
     cur = fo;
-    stts_dit_block(s, m, m->dec[idx], cur, E.mods + (size_t)idx * nb * 6 * H, E.len, nb, H, F, hp.dec_heads, K, T, E.sc, "cfm");
   }
   P = conv_params(m->final_proj, cur, E.dphi, nb, T, 1, 0);  // final_proj(x * mask) * mask
   P.in_mask = 1; P.out_mask = 1; P.len = E.len;
@@ -739,7 +744,7 @@ int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, in
   hipLaunchKernelGGL(bert_embed_kernel, dim3(cdiv(T, 64), H), dim3(64), 0, s->stream, (const int64_t*)d_ids, (const int64_t*)d_ty, m->we, m->pe, m->te, y, H, T,
                      hp.vocab_size, hp.type_vocab, s->d_err);
   {
-    LNParams P{y, nullptr, nullptr, x, m->eg, m->eb, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps};
+    LNParams P{y, nullptr, nullptr, x, m->eg, m->eb, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr};
     launch_layernorm(s->stream, P, 1);
   }
   const dim3 agrid(cdiv(T, 32), nh, 1);
@@ -752,12 +757,12 @@ int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, in
     else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
     P = conv_params(L.o, att, y, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.o");
-    { LNParams Q{y, x, nullptr, x, L.g1, L.b1, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps}; launch_layernorm(s->stream, Q, 1); }  // LayerNorm(dense(ctx) + x)
+    { LNParams Q{y, x, nullptr, x, L.g1, L.b1, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr}; launch_layernorm(s->stream, Q, 1); }  // LayerNorm(dense(ctx) + x)
     P = conv_params(L.c1, x, ff, 1, T, 1, 0); P.relu = 3;
     launch_conv(s, P, EPI_STORE, "bert.ffn1");
     P = conv_params(L.c2, ff, y, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.ffn2");
-    { LNParams Q{y, x, nullptr, x, L.g2, L.b2, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps}; launch_layernorm(s->stream, Q, 1); }
+    { LNParams Q{y, x, nullptr, x, L.g2, L.b2, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr}; launch_layernorm(s->stream, Q, 1); }
   }
   hipLaunchKernelGGL(transpose_ct_kernel, dim3(cdiv(H, 256), T), dim3(256), 0, s->stream, x, ot, H, T);
   HIP_TRY(hipMemcpyAsync(out, ot, sizeof(float) * (size_t)T * H, hipMemcpyDeviceToHost, s->stream));
