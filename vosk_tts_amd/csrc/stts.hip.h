@@ -213,6 +213,7 @@ struct SttsEst {
   float *cat, *h, *h2, *dphi, *film, *mods, *lsc[3 + 8], *a1, *a2;
   DitScratch sc;
   int* len;
+  std::vector<float> host_sinus;
 };
 static size_t stts_est_bytes(const stts_hparams& hp, int nb, int T, int n_steps) {
   const size_t H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers;
@@ -237,7 +238,8 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
   float* sinus = bump<float>(s, (size_t)n * H); float* t1 = bump<float>(s, (size_t)n * F); float* temb = bump<float>(s, (size_t)n * H);
   E.film = bump<float>(s, (size_t)NL * n * 2 * H);
   {
-    std::vector<float> hs((size_t)n * H);
+    std::vector<float>& hs = E.host_sinus;  // must outlive the asynchronous copy below: owned by the call's SttsEst
+    hs.resize((size_t)n * H);
     const int half = H / 2;
     const float lg = logf(10000.0f) / (float)(half - 1);
     for (int k = 0; k < n; ++k)
@@ -246,7 +248,6 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
         hs[(size_t)k * H + j] = sinf(a); hs[(size_t)k * H + half + j] = cosf(a);
       }
     hipMemcpyAsync(sinus, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, s->stream);
-    hipStreamSynchronize(s->stream);  // hs is a stack-lifetime buffer
   }
   stts_gemv(s, m->t0w, m->t0b, sinus, H, t1, F, F, H, n, 1);
   stts_gemv(s, m->t2w, m->t2b, t1, F, temb, H, H, F, n, 0);
@@ -593,14 +594,18 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
     h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)(S ? S : 1)));
     vits_session* sv = nullptr;
     if (!d_audio || !h_audio) rc = fail(VITS_ERR_NOMEM, "alloc failed");
-    if (rc == VITS_OK) rc = check_err(s);  // the mel must be complete before the vocoder's own stream reads it
     if (rc == VITS_OK) rc = pool_acquire(v, &sv);
     if (rc == VITS_OK) rc = session_reserve(sv, 1, 1, (int)ylen);
     if (rc == VITS_OK) {
+      // the vocoder's launches go onto THIS call's stream (its session only lends the decoder workspace): the mel is
+      // consumed in stream order, no host synchronisation between the two halves
+      hipStream_t own = sv->stream;
+      sv->stream = s->stream;
       run_decoder(sv, d_mel, false, 1, (int)ylen, d_audio, S, nullptr);
-      hipLaunchKernelGGL(clamp_kernel, dim3(cdiv((int)S, 256)), dim3(256), 0, sv->stream, d_audio, (long long)S);
-      hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, sv->stream);
-      rc = check_err(sv);
+      sv->stream = own;
+      hipLaunchKernelGGL(clamp_kernel, dim3(cdiv((int)S, 256)), dim3(256), 0, s->stream, d_audio, (long long)S);
+      hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, s->stream);
+      rc = check_err(s);
     }
     if (sv) pool_release(v, sv);
   } else {
