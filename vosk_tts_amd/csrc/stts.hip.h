@@ -319,7 +319,18 @@ struct SttsCall {  // pooled session + temporaries of one entry-point call
   stts_model* m; vits_session* s = nullptr; std::vector<void*> tmp;
   explicit SttsCall(stts_model* m_) : m(m_) {}
   ~SttsCall() {
-    if (s) { hipStreamSynchronize(s->stream); pool_release(&m->base, s); }
+    if (s) {
+      hipStreamSynchronize(s->stream);
+      if (!tmp.empty()) {  // the staging area overflowed during this call: grow it once, for the next one
+        const size_t want = s->stage_used + (s->stage_used >> 2) + (1 << 20);
+        if (s->stage) hipFree(s->stage);
+        s->stage = nullptr; s->stage_bytes = 0;
+        void* p = nullptr;
+        if (hipMalloc(&p, want) == hipSuccess) { s->stage = static_cast<char*>(p); s->stage_bytes = want; }
+      }
+      s->stage_used = 0;
+      pool_release(&m->base, s);
+    }
     for (void* p : tmp) hipFree(p);
   }
   int begin(size_t arena_bytes) {
@@ -328,9 +339,15 @@ struct SttsCall {  // pooled session + temporaries of one entry-point call
     TRY(pool_acquire(&m->base, &s));
     return stts_arena(s, arena_bytes);
   }
+  // inputs / outputs of the call: bump-allocated from the pooled session's staging area (no hipMalloc / hipFree in the
+  // steady state); falls back to hipMalloc, freed at the end of the call, when the area is too small
   template <typename T> T* dev(size_t n) {
+    const size_t bytes = align_up((n ? n : 1) * sizeof(T), 256);
+    const size_t off = s->stage_used;
+    s->stage_used += bytes;
+    if (off + bytes <= s->stage_bytes) return reinterpret_cast<T*>(s->stage + off);
     void* d = nullptr;
-    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
     tmp.push_back(d);
     return static_cast<T*>(d);
   }
