@@ -54,6 +54,35 @@ def test_conv1d_kernel_vs_oracle(hip_lib, oracle_lib, B, Cin, Cout, T, K, dil, s
     assert_close("conv1d", want, got, 2e-5)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_conv1d_randomised_shapes_on_every_kernel(hip_lib, oracle_lib, mode):
+    """30 seeded random shapes (odd lengths, 1..11 taps, dilations up to the halo limit, C_in multiples of 16, C_out not
+    multiples of 32, single columns, T just past tile boundaries) through the automatic dispatch (0), the big-tile kernel
+    (1) and the K-split kernel (2): every tile / halo / padding-row edge of the conv kernels against the oracle."""
+    from vosk_tts_amd.capi import op_conv1d
+
+    rng = np.random.default_rng(100 + mode)
+    hip_lib.lib.vits_debug_force_tile(mode)
+    try:
+        for _ in range(30):
+            K = int(rng.choice([1, 2, 3, 5, 7, 11]))
+            dil = int(rng.integers(1, max(1, 50 // max(K - 1, 1)) + 1)) if K > 1 else 1
+            dil = min(dil, 9)
+            Cin = 16 * int(rng.integers(1, 13))
+            Cout = int(rng.choice([1, 17, 29, 32, 50, 72, 96, 130, 192]))
+            T = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 513]))
+            B = int(rng.integers(1, 4))
+            slope = float(rng.choice([1.0, 0.1, 0.01]))
+            x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+            w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+            bias = rng.standard_normal(Cout).astype(np.float32) if rng.random() < 0.7 else None
+            want = op_conv1d(oracle_lib, x, w, bias, dil, slope)
+            got = op_conv1d(hip_lib, x, w, bias, dil, slope)
+            assert_close(f"conv1d B={B} Cin={Cin} Cout={Cout} T={T} K={K} dil={dil} slope={slope} mode={mode}", want, got, 2e-5)
+    finally:
+        hip_lib.lib.vits_debug_force_tile(0)
+
+
 def test_conv1d_is_transpose_detecting(hip_lib, oracle_lib):
     """asymmetric weights: identity on channel c -> output row c only (catches swapped C/D layout)."""
     from vosk_tts_amd.capi import op_conv1d
