@@ -70,6 +70,16 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t T_x, const float*
                     const float* phone_duration_extra, const stts_synth_opts* opts, float** out_audio, int64_t* out_samples,
                     float** out_mel, int64_t* out_frames);
 
+/* Batch of B independent utterances (throughput; not part of the reference, whose synthesise() takes one): item b gives
+ * exactly what stts_synthesize returns for ids[b][:, :lengths[b]], sid[b], bert[b], phone_duration_extra[b] and seed
+ * opts->seed + b -- every kernel masks or zero-pads per item, the unmasked convs of the estimator see zeros beyond each
+ * item's own padded length, the vocoder decodes every item as if alone.  ids [B,5,T_x], lengths [B], sid [B],
+ * bert [B,768,T_x] or NULL, phone_duration_extra [B,T_x] or NULL; opts->noise must be NULL.
+ * out_audio: library-owned float [B, *out_samples], zero beyond out_lengths[b] samples. */
+int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t T_x, const float* scales,
+                          const int64_t* sid, const float* bert, const float* phone_duration_extra, const stts_synth_opts* opts,
+                          float** out_audio, int64_t* out_samples, int64_t* out_lengths);
+
 /* ---- stage-level entry points (parity tests; host buffers) ---- */
 /* TextEncoder.forward (text_encoder.py:111-139): x = cat(emb*sqrt(160), 4 x punc_emb*4, bert_proj(bert)) [B,256,T]
  * (returned unmasked, as the reference does) and mu_dp = dp_encoder(x, dur_spk_emb(sid)) [B,50,T]. */

@@ -144,3 +144,31 @@ def test_bert_base_geometry_vs_oracle(hip_lib, oracle_lib):
     with pytest.raises(VitsError, match="token id"):
         hip.encode(np.array([1, 2, 9999]))
     hip.close()
+
+
+def test_stts_batch_items_equal_their_single_utterance_calls(stts_pair):
+    """stts_synthesize_batch: B = 4 ragged utterances (different lengths, speakers, BERT vectors, forced pauses) in one
+    pass; every item must equal its own single-utterance call with seed + b (same kernels, per-item masks / zero padding
+    / solo vocoding), and the first item is also checked against the oracle."""
+    hip, ref = stts_pair
+    rng = np.random.default_rng(41)
+    B, Tx = 4, 22
+    lengths = np.array([22, 9, 15, 4], np.int64)
+    ids = rng.integers(1, 40, size=(B, 5, Tx)).astype(np.int64)
+    bert = rng.standard_normal((B, 768, Tx)).astype(np.float32)
+    pde = np.zeros((B, Tx), np.float32)
+    pde[0, 3] = 6.0; pde[2, 1] = 9.0
+    sid = np.array([0, 3, 6, 1], np.int64)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    audio, olen = hip.synthesize_batch(ids, lengths, sc, sid, bert, pde, seed=30, n_timesteps=3)
+    assert audio.shape[0] == B and audio.shape[1] == olen.max() and np.all(olen % 256 == 0) and len(set(olen.tolist())) > 1
+    for b in range(B):
+        L = int(lengths[b])
+        one, _ = hip.synthesize(ids[b][:, :L], sc, int(sid[b]), bert[b][:, :L], pde[b][:L], seed=30 + b, n_timesteps=3, want_mel=False)
+        assert one.shape[0] == olen[b]
+        # not bit-for-bit: the batch is big enough for the big-tile conv kernel where the single call takes the K-split one
+        assert_close(f"item {b}", one, audio[b, :olen[b]], 2e-5)
+        assert not audio[b, olen[b]:].any()
+    L = int(lengths[0])
+    want, _ = ref.synthesize(ids[0][:, :L], sc, int(sid[0]), bert[0][:, :L], pde[0][:L], seed=30, n_timesteps=3, want_mel=False)
+    assert_close("item 0 vs oracle", want, audio[0, :olen[0]], E2E_TOL)

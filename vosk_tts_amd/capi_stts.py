@@ -30,6 +30,9 @@ class SttsModel:
         f("get_hparams").argtypes = [vp, ctypes.POINTER(SttsHParams)]
         f("synthesize").argtypes = [vp, c_i64p, ctypes.c_int32, c_f32p, ctypes.c_int64, c_f32p, c_f32p, ctypes.POINTER(SttsOpts),
                                     ctypes.POINTER(c_f32p), c_i64p, ctypes.POINTER(c_f32p), c_i64p]
+        if vlib.prefix == "vits_":  # the batch entry point exists in the product library only
+            f("synthesize_batch").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_i64p, c_f32p, c_f32p,
+                                              ctypes.POINTER(SttsOpts), ctypes.POINTER(c_f32p), c_i64p, c_i64p]
         f("stage_encoder").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p, c_f32p, c_f32p]
         f("stage_durations").argtypes = [vp, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, c_i32p, c_i64p]
         f("stage_estimator").argtypes = [vp, c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p]
@@ -99,6 +102,23 @@ class SttsModel:
         if want_mel:
             melo = np.ctypeslib.as_array(mel, shape=(self.hp.n_feats, nf.value)).copy(); free(mel)
         return audio, melo
+
+    def synthesize_batch(self, ids, lengths, scales, sid, bert=None, phone_duration_extra=None, seed=0, n_timesteps=0):
+        """B independent utterances in one pass (stts_synthesize_batch): ids [B,5,T], lengths [B], sid [B];
+        returns (audio float32 [B,S] zero-padded, out_lengths int64 [B] in samples).  Item b equals
+        synthesize(ids[b][:, :lengths[b]], ..., seed=seed + b)."""
+        ids = _i64(ids); lengths = _i64(lengths); sid = _i64(sid); scales = _f32(scales)
+        B, five, T = ids.shape
+        b = None if bert is None else _f32(bert)
+        p = None if phone_duration_extra is None else _f32(phone_duration_extra)
+        opts = SttsOpts(); opts.seed = seed; opts.n_timesteps = n_timesteps
+        au = c_f32p(); ns = ctypes.c_int64(); ol = np.zeros(B, np.int64)
+        self.check(self._fn("synthesize_batch")(self._h, _p(ids, c_i64p), _p(lengths, c_i64p), B, T, _p(scales, c_f32p), _p(sid, c_i64p),
+                                                None if b is None else _p(b, c_f32p), None if p is None else _p(p, c_f32p),
+                                                ctypes.byref(opts), ctypes.byref(au), ctypes.byref(ns), _p(ol, c_i64p)))
+        audio = np.ctypeslib.as_array(au, shape=(B, ns.value)).copy()
+        self.vlib._fn("free_output")(au)
+        return audio, ol
 
     # ---- stages --------------------------------------------------------------------------------
     def encoder(self, ids, lengths, sid, bert=None):

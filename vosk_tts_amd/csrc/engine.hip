@@ -1023,15 +1023,18 @@ static float* run_flow(vits_session* s, int B, int Ty) {
 static void set_rag(ConvParams& P, const int* rag, int in_mul, int in_add, int out_mul, int out_add) {
   P.rag = rag; P.rag_in_mul = in_mul; P.rag_in_add = in_add; P.rag_out_mul = out_mul; P.rag_out_add = out_add;
 }
+// rag_halo >= 0 (with ragged): frames computed beyond each item's length.  VITS_RAGGED_HALO reproduces the reference's
+// padded-batch result on every valid sample; 0 decodes every item as if it were alone (zeros beyond its own end at every
+// stage), which is what a batch of independent utterances of the StableTTS path wants.
 static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, int Ty, float* d_audio, long long audio_bstride,
-                        float* d_mb, bool ragged = false) {
+                        float* d_mb, bool ragged = false, int rag_halo = VITS_RAGGED_HALO) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   int C = hp.dec_initial_channel, T = Ty;
   const int* rag = nullptr;
   int rate = 1;  // columns per frame at the current stage
-  if (ragged && B > 1 && hp.dec_type == 0 && !getenv("VITS_NO_RAGGED")) {
-    hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, B, Ty, VITS_RAGGED_HALO);
+  if (ragged && B > 1 && !getenv("VITS_NO_RAGGED")) {
+    hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, B, Ty, rag_halo);
     rag = s->len_rag;
   }
   float* cur = s->dec_bufs[0];
@@ -1121,8 +1124,9 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
     P.M = m->conv_post.Mpad; P.Cout = 1; P.Tout = T; P.Tout_stride = T; P.y_bstride = T;
     P.in_slope = 0.01f; P.in_scale = in_scale;
+    set_rag(P, rag, rate, 0, rate, 0);
     launch_conv(s, P, EPI_STORE, "dec.conv_post");
-    hipLaunchKernelGGL(tanh_copy_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s->stream, post, d_audio, T, (long long)T, audio_bstride);
+    hipLaunchKernelGGL(tanh_copy_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s->stream, post, d_audio, T, (long long)T, audio_bstride, rag, rate);
   }
 }
 

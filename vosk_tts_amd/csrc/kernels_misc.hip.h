@@ -914,9 +914,12 @@ __global__ void pqmf_synthesis_kernel(const float* mb, const float* filt, float*
 }
 
 // plain HiFi-GAN tail: tanh (models.py:889)
-__global__ void tanh_copy_kernel(const float* x, float* y, int T, long long x_bstride, long long y_bstride) {
+// rag (optional): item b is valid for rag[b] * rag_mul columns, beyond that the output is 0 (those tiles were never computed)
+__global__ void tanh_copy_kernel(const float* x, float* y, int T, long long x_bstride, long long y_bstride, const int* rag, int rag_mul) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (t < T) y[(long long)b * y_bstride + t] = tanhf(x[(long long)b * x_bstride + t]);
+  if (t >= T) return;
+  const bool live = !rag || t < rag[b] * rag_mul;
+  y[(long long)b * y_bstride + t] = live ? tanhf(x[(long long)b * x_bstride + t]) : 0.f;
 }
 
 // Streaming decode: copies the frame window [start, start+W) of z [C, T] (row stride T) into a dense [C, W] buffer.
@@ -1024,44 +1027,54 @@ __global__ void copy_rows_kernel(const float* src, long long sb, float* dst, lon
   if (t < T) dst[(long long)b * db + (long long)r * T + t] = src[(long long)b * sb + (long long)r * T + t];
 }
 // z = randn * temperature (flow_matching.py:52) into the state rows of both CFG batch items
+// Batch of B utterances (blockIdx.z): item b's state also lives in CFG item B + b when cfg != 0; its library noise uses
+// the Philox stream of seed + b, i.e. exactly what a single-utterance call with that seed draws.
 __global__ void cfm_init_kernel(float* cat, long long cat_b, const float* noise, long long nstride, float temperature, uint64_t seed,
-                                int NF, int T, int nb) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+                                int NF, int T, int B, int cfg) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
-  const float v = (noise ? noise[(long long)c * nstride + t] : philox_normal(seed, 3u, (uint32_t)c, (uint32_t)t)) * temperature;
-  for (int b = 0; b < nb; ++b) cat[(long long)b * cat_b + (long long)c * T + t] = v;
+  const float v = (noise ? noise[(long long)c * nstride + t] : philox_normal(seed + (uint64_t)b, 3u, (uint32_t)c, (uint32_t)t)) * temperature;
+  cat[(long long)b * cat_b + (long long)c * T + t] = v;
+  if (cfg) cat[(long long)(B + b) * cat_b + (long long)c * T + t] = v;
 }
 // solve_euler step with classifier-free guidance (flow_matching.py:84-93,177-189):
 // x <- x + dt * (d0 + g * (d0 - d1)); the state lives in rows [0,NF) of every batch item of the in_proj input
-__global__ void cfm_euler_kernel(float* cat, long long cat_b, const float* d, float dt, float g, int NF, int T, int nb) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+__global__ void cfm_euler_kernel(float* cat, long long cat_b, const float* d, float dt, float g, int NF, int T, int B, int cfg) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   const long long o = (long long)c * T + t;
-  float d0 = d[o];
-  if (nb > 1) d0 = d0 + g * (d0 - d[(long long)NF * T + o]);
-  const float x = cat[o] + dt * d0;
-  for (int b = 0; b < nb; ++b) cat[(long long)b * cat_b + o] = x;
+  float d0 = d[(long long)b * NF * T + o];
+  if (cfg) d0 = d0 + g * (d0 - d[(long long)(B + b) * NF * T + o]);
+  const float x = cat[(long long)b * cat_b + o] + dt * d0;
+  cat[(long long)b * cat_b + o] = x;
+  if (cfg) cat[(long long)(B + b) * cat_b + o] = x;
 }
 // generate_path + matmul as a gather (matcha_tts.py:163-174): frame t belongs to the token j with cum[j-1] <= t < cum[j]
 __global__ void stts_expand_kernel(const float* x, const int* cum, int Tx, float* mu_y, int CC, int T, const float* pde, float* pau) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
-  int lo = 0, hi = Tx;  // first j with cum[j] > t
+  cum += (long long)b * Tx;
+  int lo = 0, hi = Tx;  // first j with cum[j] > t (padded tokens repeat the last cumulative count, so they are never hit)
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] > t) hi = mid; else lo = mid + 1; }
   const bool valid = lo < Tx;
-  mu_y[(long long)c * T + t] = valid ? x[(long long)c * Tx + lo] : 0.f;
-  if (c == 0) pau[t] = (valid && pde) ? pde[lo] : 0.f;
+  mu_y[((long long)b * CC + c) * T + t] = valid ? x[((long long)b * CC + c) * Tx + lo] : 0.f;
+  if (c == 0) pau[(long long)b * T + t] = (valid && pde) ? pde[(long long)b * Tx + lo] : 0.f;
 }
 // decoder_outputs[:, :, :y_len] with the frames of forced pauses replaced by frame 0 (matcha_tts.py:180-192), denormalised
-__global__ void stts_mel_kernel(const float* cat, int T, const float* pau, float* mel, int ylen, float mel_std, float mel_mean) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-  if (t >= ylen) return;
-  const float v = pau[t] > 0.f ? cat[(long long)c * T] : cat[(long long)c * T + t];
-  mel[(long long)c * ylen + t] = v * mel_std + mel_mean;
+// batch: item b reads its state from cat + b*cat_b, writes mel [B, NF, Tm] (zeros beyond its own length len[b])
+__global__ void stts_mel_kernel(const float* cat, long long cat_b, int T, const float* pau, float* mel, int NF, int Tm, const int* len,
+                                float mel_std, float mel_mean) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= Tm) return;
+  const float* cb = cat + (long long)b * cat_b;
+  float v = 0.f;
+  if (t < len[b]) v = (pau[(long long)b * T + t] > 0.f ? cb[(long long)c * T] : cb[(long long)c * T + t]) * mel_std + mel_mean;
+  mel[((long long)b * NF + c) * Tm + t] = v;
 }
-__global__ void fill_rows_kernel(float* dst, const float* vec, int T) {  // dst[c][t] = vec[c]  (fake_content.repeat, flow_matching.py:184)
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-  if (t < T) dst[(long long)c * T + t] = vec[c];
+// dst[r][t] = vec[r % C]  (fake_content.repeat over frames and batch items, flow_matching.py:183-184)
+__global__ void fill_rows_kernel(float* dst, const float* vec, int T, int C) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (t < T) dst[(long long)r * T + t] = vec[r % C];
 }
 __global__ void clamp_kernel(float* a, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

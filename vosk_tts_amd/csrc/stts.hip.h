@@ -212,7 +212,9 @@ struct SttsEst {
   int nb, T, n_steps;
   float *cat, *h, *h2, *dphi, *film, *mods, *lsc[3 + 8], *a1, *a2;
   DitScratch sc;
-  int* len;
+  int* len;   // [nb] valid frames per item (masks)
+  int* lenT;  // [nb] frames per item rounded up to a multiple of 4: where a single-utterance run's tensors END, i.e. where the
+              // unmasked convs (cond_proj, long-skip) see zero padding; equals T for one utterance
   std::vector<float> host_sinus;
 };
 static size_t stts_est_bytes(const stts_hparams& hp, int nb, int T, int n_steps) {
@@ -222,11 +224,13 @@ static size_t stts_est_bytes(const stts_hparams& hp, int nb, int T, int n_steps)
   return fl * sizeof(float) + 256 * 1024;
 }
 // c [nb][G] device, mu [nb][enc_hidden][T] device (item 1 = fake content when nb == 2), tvals host [n_steps]
-static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu, const int* d_len, const float* tvals) {
+static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu, const int* d_len, const float* tvals,
+                           const int* d_lenT = nullptr) {
   const stts_hparams& hp = m->hp;
   const int H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers, G = hp.spk_emb_dim, K = hp.dec_kernel;
   const int nb = E.nb, T = E.T, n = E.n_steps;
   E.len = const_cast<int*>(d_len);
+  E.lenT = const_cast<int*>(d_lenT);
   E.cat = bump<float>(s, (size_t)nb * (NF + H) * T); E.h = bump<float>(s, (size_t)nb * H * T); E.dphi = bump<float>(s, (size_t)nb * NF * T);
   E.sc.hn = bump<float>(s, (size_t)nb * H * T); E.sc.qkv = bump<float>(s, (size_t)nb * 3 * H * T); E.sc.att = bump<float>(s, (size_t)nb * H * T);
   E.sc.ffh = bump<float>(s, (size_t)nb * F * T);
@@ -256,9 +260,16 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
   E.mods = bump<float>(s, (size_t)NL * nb * 6 * H);
   stts_modulations(s, m->dec, d_c, nb, H, G, tmp, E.mods);
   // mu = cond_proj(mu): conv -> SiLU -> conv -> SiLU -> conv, no masks (decoder.py:82-88,121); lands in rows [NF, NF+H) of cat
-  ConvParams P = conv_params(m->cp0, d_mu, E.a1, nb, T, 1, K / 2); P.relu = 2; launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
-  P = conv_params(m->cp2, E.a1, E.a2, nb, T, 1, K / 2); P.relu = 2; launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
-  P = conv_params(m->cp4, E.a2, E.cat + (size_t)NF * T, nb, T, 1, K / 2); P.y_bstride = (long long)(NF + H) * T; launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
+  // in a batch every item must see zeros beyond ITS OWN padded length (in_mask with lenT) to equal its single-utterance run
+  ConvParams P = conv_params(m->cp0, d_mu, E.a1, nb, T, 1, K / 2); P.relu = 2;
+  if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+  launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
+  P = conv_params(m->cp2, E.a1, E.a2, nb, T, 1, K / 2); P.relu = 2;
+  if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+  launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
+  P = conv_params(m->cp4, E.a2, E.cat + (size_t)NF * T, nb, T, 1, K / 2); P.y_bstride = (long long)(NF + H) * T;
+  if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+  launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
 }
 // one Decoder.forward (decoder.py:105-138) over the nb batch items; state x = rows [0,NF) of E.cat; result in E.dphi
 static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int step) {
@@ -283,6 +294,7 @@ static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int 
       P = conv_params(m->lsc[idx - NL / 2], cur, out, nb, T, 1, K / 2);
       P.x_bstride = (long long)H * T;  // each of the two inputs is a dense [nb, H, T] tensor
       P.g[0].x2 = skip; P.x_split = H;
+      if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
       launch_conv(s, P, EPI_STORE, "cfm.lsc");
       freeb[nfree++] = cur; freeb[nfree++] = skip;
       cur = out;
@@ -386,17 +398,18 @@ static void stts_durations_host(const stts_hparams& hp, const float* mu_dp, int 
 
 // BASECFM.forward + solve_euler with guidance (flow_matching.py:36-108,177-189) for one utterance, all on device.
 // d_mu2 [nb][enc_hidden][T] (item 1 pre-filled with fake_content), result: state rows of E.cat item 0
+// B utterances; E.nb = B (no guidance) or 2B (items [B,2B) = the unconditional branch of items [0,B))
 static void stts_run_cfm(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu2, const int* d_len, const float* d_noise,
-                         long long nstride, float temperature, uint64_t seed) {
+                         long long nstride, float temperature, uint64_t seed, int B = 1, const int* d_lenT = nullptr) {
   const stts_hparams& hp = m->hp;
-  const int NF = hp.n_feats, H = hp.dec_hidden, T = E.T;
+  const int NF = hp.n_feats, H = hp.dec_hidden, T = E.T, cfg = E.nb > B ? 1 : 0;
   std::vector<float> tv, dtv;
   stts_time_grid(E.n_steps, tv, dtv);
-  stts_est_setup(s, m, E, d_c, d_mu2, d_len, tv.data());
-  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, E.nb);
+  stts_est_setup(s, m, E, d_c, d_mu2, d_len, tv.data(), d_lenT);
+  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, B, cfg);
   for (int k = 0; k < E.n_steps; ++k) {
     stts_est_step(s, m, E, k);
-    hipLaunchKernelGGL(cfm_euler_kernel, dim3(cdiv(T, 64), NF), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, E.dphi, dtv[k], hp.guidance_scale, NF, T, E.nb);
+    hipLaunchKernelGGL(cfm_euler_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, E.dphi, dtv[k], hp.guidance_scale, NF, T, B, cfg);
   }
 }
 
@@ -525,7 +538,7 @@ int stts_stage_cfm(stts_model* m, const float* mu_y, int64_t y_length, int32_t T
   HIP_TRY(hipMemcpyAsync(d_mu2, mu_y, sizeof(float) * (size_t)CC * T, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(d_c, hp.n_spks > 1 ? m->spk_emb + (size_t)sid * G : m->zero_vec, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
   if (nb == 2) {  // fake_content.repeat(1, 1, T), fake_speaker (flow_matching.py:183-185)
-    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_mu2 + (size_t)CC * T, m->fake_content, T);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_mu2 + (size_t)CC * T, m->fake_content, T, CC);
     HIP_TRY(hipMemcpyAsync(d_c + G, m->fake_speaker, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
   }
   SttsEst E; E.nb = nb; E.T = T; E.n_steps = n;
@@ -578,10 +591,10 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
   float* d_c = call.dev<float>((size_t)nb * G);
   float* d_mel = call.dev<float>((size_t)NF * (ylen ? ylen : 1));
   if (!d_cum || !d_len || !d_mu2 || !d_pau || !d_c || !d_mel) return fail(VITS_ERR_NOMEM, "device alloc failed");
-  hipLaunchKernelGGL(stts_expand_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_x, d_cum, Tx, d_mu2, CC, T, d_pde, d_pau);
+  hipLaunchKernelGGL(stts_expand_kernel, dim3(cdiv(T, 64), CC, 1), dim3(64), 0, s->stream, d_x, d_cum, Tx, d_mu2, CC, T, d_pde, d_pau);
   HIP_TRY(hipMemcpyAsync(d_c, hp.n_spks > 1 ? m->spk_emb + (size_t)sid * G : m->zero_vec, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
   if (nb == 2) {
-    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_mu2 + (size_t)CC * T, m->fake_content, T);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), CC), dim3(64), 0, s->stream, d_mu2 + (size_t)CC * T, m->fake_content, T, CC);
     HIP_TRY(hipMemcpyAsync(d_c + G, m->fake_speaker, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
   }
   float* d_noise = nullptr;
@@ -594,7 +607,8 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
   }
   SttsEst E; E.nb = nb; E.T = T; E.n_steps = n;
   stts_run_cfm(s, m, E, d_c, d_mu2, d_len, d_noise, nstride, temperature, opts ? opts->seed : 0);
-  hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv((int)ylen, 64), NF), dim3(64), 0, s->stream, E.cat, T, d_pau, d_mel, (int)ylen, hp.mel_std, hp.mel_mean);
+  hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv((int)ylen, 64), NF, 1), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, T, d_pau, d_mel, NF, (int)ylen, d_len,
+                     hp.mel_std, hp.mel_mean);
   float* h_mel = nullptr;
   if (out_mel) {
     h_mel = static_cast<float*>(malloc(sizeof(float) * (size_t)NF * ylen));
@@ -632,6 +646,101 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
   if (out_audio) { *out_audio = h_audio; *out_samples = S; }
   if (out_mel) { *out_mel = h_mel; *out_frames = ylen; }
   (void)H;
+  return VITS_OK;
+}
+
+int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                          const int64_t* sid, const float* bert, const float* pde, const stts_synth_opts* opts, float** out_audio,
+                          int64_t* out_samples, int64_t* out_lengths) {
+  if (!m || !ids || !lengths || !scales || !out_audio || !out_samples || !out_lengths || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  if (!m->vocoder) return fail(VITS_ERR_ARG, "no vocoder attached");
+  if (opts && opts->noise) return fail(VITS_ERR_ARG, "injected noise is a single-utterance option");
+  for (int b = 0; b < B; ++b) if (lengths[b] <= 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+  TRY(stts_check_sid(m, sid, B));
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats, CC = hp.enc_hidden, G = hp.spk_emb_dim, H = hp.dec_hidden;
+  const float temperature = scales[0], length_scale = scales[1];
+  const int n = (opts && opts->n_timesteps > 0) ? opts->n_timesteps : hp.n_timesteps, cfg = hp.guidance_scale > 0.f ? 1 : 0, nb = cfg ? 2 * B : B;
+  SttsCall call(m);
+  TRY(call.begin(stts_enc_bytes(hp, B, Tx)));
+  vits_session* s = call.s;
+  // ---- text encoder (masked per item) + durations on the host
+  int64_t* d_ids = call.up(ids, (size_t)B * 5 * Tx);
+  std::vector<int> lx(B);
+  for (int b = 0; b < B; ++b) lx[b] = (int)lengths[b];
+  int* d_lenx = call.up(lx.data(), B);
+  float* d_bert = bert ? call.up(bert, (size_t)B * hp.bert_dim * Tx) : call.dev<float>((size_t)B * hp.bert_dim * Tx);
+  float* d_x = call.dev<float>((size_t)B * CC * Tx);
+  float* d_mu = call.dev<float>((size_t)B * hp.dp_out * Tx);
+  if (!d_ids || !d_lenx || !d_bert || !d_x || !d_mu) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  if (!bert) HIP_TRY(hipMemsetAsync(d_bert, 0, sizeof(float) * (size_t)B * hp.bert_dim * Tx, s->stream));
+  stts_run_encoder(s, m, d_ids, d_lenx, sid, B, Tx, d_bert, d_x, d_mu);
+  std::vector<float> mu_dp((size_t)B * hp.dp_out * Tx);
+  HIP_TRY(hipMemcpyAsync(mu_dp.data(), d_mu, sizeof(float) * mu_dp.size(), hipMemcpyDeviceToHost, s->stream));
+  TRY(check_err(s));
+  std::vector<int32_t> dur((size_t)B * Tx);
+  std::vector<int64_t> ylen(B);
+  stts_durations_host(hp, mu_dp.data(), B, Tx, length_scale, pde, dur.data(), ylen.data());
+  std::vector<int> cum((size_t)B * Tx), l2((size_t)2 * B), lT((size_t)2 * B);
+  int T = 4, Tm = 1;
+  for (int b = 0; b < B; ++b) {  // only the item's own tokens count (a single-utterance call has no padded tokens)
+    int a = 0;
+    for (int j = 0; j < Tx; ++j) { if (j < lengths[b]) a += dur[(size_t)b * Tx + j]; cum[(size_t)b * Tx + j] = a; }
+    ylen[b] = a;
+    if (a > (1 << 22)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+    const int Tb = (a + 3) / 4 * 4;  // fix_len_compatibility per item
+    l2[b] = l2[B + b] = a; lT[b] = lT[B + b] = Tb;
+    if (Tb > T) T = Tb;
+    if (a > Tm) Tm = a;
+  }
+  // ---- flow matching over all items (and their CFG twins) at once
+  TRY(stts_arena(s, stts_est_bytes(hp, nb, T, n)));
+  int* d_cum = call.up(cum.data(), (size_t)B * Tx);
+  float* d_pde = pde ? call.up(pde, (size_t)B * Tx) : nullptr;
+  int* d_len = call.up(l2.data(), (size_t)2 * B);
+  int* d_lenT = call.up(lT.data(), (size_t)2 * B);
+  float* d_mu2 = call.dev<float>((size_t)nb * CC * T);
+  float* d_pau = call.dev<float>((size_t)B * T);
+  float* d_c = call.dev<float>((size_t)nb * G);
+  float* d_mel = call.dev<float>((size_t)B * NF * Tm);
+  if (!d_cum || !d_len || !d_lenT || !d_mu2 || !d_pau || !d_c || !d_mel) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  hipLaunchKernelGGL(stts_expand_kernel, dim3(cdiv(T, 64), CC, B), dim3(64), 0, s->stream, d_x, d_cum, Tx, d_mu2, CC, T, d_pde, d_pau);
+  for (int b = 0; b < B; ++b) {
+    HIP_TRY(hipMemcpyAsync(d_c + (size_t)b * G, hp.n_spks > 1 ? m->spk_emb + (size_t)sid[b] * G : m->zero_vec, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
+    if (cfg) HIP_TRY(hipMemcpyAsync(d_c + (size_t)(B + b) * G, m->fake_speaker, sizeof(float) * G, hipMemcpyDeviceToDevice, s->stream));
+  }
+  if (cfg) hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), B * CC), dim3(64), 0, s->stream, d_mu2 + (size_t)B * CC * T, m->fake_content, T, CC);
+  SttsEst E; E.nb = nb; E.T = T; E.n_steps = n;
+  stts_run_cfm(s, m, E, d_c, d_mu2, d_len, nullptr, T, temperature, opts ? opts->seed : 0, B, d_lenT);
+  hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv(Tm, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, T, d_pau, d_mel, NF, Tm, d_len,
+                     hp.mel_std, hp.mel_mean);
+  // ---- vocoder over the ragged batch, every item decoded as if alone (rag halo 0)
+  vits_model* v = m->vocoder;
+  const int64_t S = (int64_t)Tm * v->hp.hop_length;
+  float* d_audio = call.dev<float>((size_t)B * S);
+  float* h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)B * S));
+  vits_session* sv = nullptr;
+  int rc = (!d_audio || !h_audio) ? fail(VITS_ERR_NOMEM, "alloc failed") : VITS_OK;
+  if (rc == VITS_OK) rc = pool_acquire(v, &sv);
+  if (rc == VITS_OK) rc = session_reserve(sv, B, 1, Tm);
+  if (rc == VITS_OK) {
+    hipStream_t own = sv->stream;
+    sv->stream = s->stream;
+    sv->tile_keys.clear();
+    sv->ragged = B > 1;
+    hipMemcpyAsync(sv->len_y, d_len, sizeof(int) * B, hipMemcpyDeviceToDevice, s->stream);
+    run_decoder(sv, d_mel, false, B, Tm, d_audio, S, nullptr, true, 0);
+    sv->ragged = false;
+    sv->stream = own;
+    hipLaunchKernelGGL(clamp_kernel, dim3(cdiv((int)(B * S), 256)), dim3(256), 0, s->stream, d_audio, (long long)B * S);
+    hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream);
+    rc = check_err(s);
+  }
+  if (sv) pool_release(v, sv);
+  if (rc != VITS_OK) { free(h_audio); return rc; }
+  *out_audio = h_audio;
+  *out_samples = S;
+  for (int b = 0; b < B; ++b) out_lengths[b] = ylen[b] * v->hp.hop_length;
   return VITS_OK;
 }
 
