@@ -92,13 +92,26 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
     voc = lib.create(vblob, local_rank)
     model = SttsModel(lib, blob, voc, local_rank)
     rng = np.random.default_rng(1234 + rank)
-    Tx = 50
-    ids = rng.integers(1, 62, size=(5, Tx)).astype(np.int64)
-    pde = np.full(Tx, 3.0, np.float32)
     scales = np.array([0.8, 1.0, 0.8], np.float32)
+    batched = args.workload == "m3"
+    if batched:  # configs[2] shape: 32 ragged utterances of 20..200 symbols, 3 frames per symbol
+        B = 32
+        lengths = rng.integers(20, 201, size=B).astype(np.int64)
+        Tx = int(lengths.max())
+        ids = rng.integers(1, 62, size=(B, 5, Tx)).astype(np.int64)
+        pde = np.full((B, Tx), 3.0, np.float32)
+        sid = np.full(B, 2, np.int64)
 
-    def step(i):
-        return model.synthesize(ids, scales, 2, None, pde, seed=7 + i, want_mel=False)[0]
+        def step(i):
+            a, ol = model.synthesize_batch(ids, lengths, scales, sid, None, pde, seed=7 + i)
+            return a, ol
+    else:
+        Tx = 50
+        ids = rng.integers(1, 62, size=(5, Tx)).astype(np.int64)
+        pde = np.full(Tx, 3.0, np.float32)
+
+        def step(i):
+            return model.synthesize(ids, scales, 2, None, pde, seed=7 + i, want_mel=False)[0]
 
     for i in range(args.warmup):
         step(i)
@@ -116,10 +129,17 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    S_ = int(audio.shape[0])
-    Ty = S_ // hp.hop_length
-    assert np.isfinite(audio).all() and Ty == 3 * Tx
-    flops = stts_algorithmic_flops(hp, voc, Tx, Ty, hp.n_timesteps)
+    if batched:
+        audio, olen = audio
+        S_ = int(olen.sum())
+        Ty = int(olen.max()) // hp.hop_length
+        assert np.isfinite(audio).all() and np.array_equal(olen, lengths * 3 * hp.hop_length)
+        flops = sum(stts_algorithmic_flops(hp, voc, int(l), int(3 * l), hp.n_timesteps) for l in lengths)
+    else:
+        S_ = int(audio.shape[0])
+        Ty = S_ // hp.hop_length
+        assert np.isfinite(audio).all() and Ty == 3 * Tx
+        flops = stts_algorithmic_flops(hp, voc, Tx, Ty, hp.n_timesteps)
     value = S_ * world * args.steps / elapsed
     if as_object:  # secondary figure inside the default line: the second model family on the same utterance shape
         ms = elapsed / args.steps * 1e3
@@ -141,21 +161,28 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
             n, t_cpu = 0, 0.0
             while t_cpu < args.cpu_seconds and n < 20:
                 c0 = time.perf_counter()
-                ref.synthesize(ids, scales, 2, None, pde, seed=7, want_mel=False)
+                if batched:  # bounded sample: the first utterance of the batch
+                    ref.synthesize(ids[0][:, :int(lengths[0])], scales, 2, None, pde[0][:int(lengths[0])], seed=7, want_mel=False)
+                else:
+                    ref.synthesize(ids, scales, 2, None, pde, seed=7, want_mel=False)
                 t_cpu += time.perf_counter() - c0
                 n += 1
-            cpu_baseline = {"value": round(S_ * n / t_cpu, 1), "unit": "samples/s", "cores": int(olib.lib.vitsref_num_threads()), "kind": "port",
-                            "sample": f"{n} forward(s) of the same utterance through oracle/libvits_oracle.so (sttsref_synthesize, OpenMP), {t_cpu:.1f} s",
-                            "x_realtime": round(S_ * n / t_cpu / SAMPLE_RATE, 2)}
+            cs = int(lengths[0]) * 3 * hp.hop_length if batched else S_
+            cpu_baseline = {"value": round(cs * n / t_cpu, 1), "unit": "samples/s", "cores": int(olib.lib.vitsref_num_threads()), "kind": "port",
+                            "sample": f"{n} forward(s) of {'the first utterance of the batch' if batched else 'the same utterance'} ({cs} samples) through "
+                                      f"oracle/libvits_oracle.so (sttsref_synthesize, OpenMP), {t_cpu:.1f} s",
+                            "x_realtime": round(cs * n / t_cpu / SAMPLE_RATE, 2)}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         print(json.dumps({
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
-            "config": {"workload": f"m2: StableTTS/Matcha multistream graph (seeded synthetic weights) + bundled HiFi-GAN V1, B=1, {Tx} symbols x 5 streams, "
-                                   f"zero BERT vectors, durations pinned 3/symbol -> T_y={Ty}, {hp.n_timesteps} Euler steps with guidance {hp.guidance_scale:g}, "
-                                   f"{S_} samples/step/GPU, host entry point stts_synthesize", "batch": 1, "T_x": Tx, "T_y": Ty,
+            "config": {"workload": f"{args.workload}: StableTTS/Matcha multistream graph (seeded synthetic weights) + bundled HiFi-GAN V1, "
+                                   + (f"B=32 ragged {int(lengths.min())}..{int(lengths.max())} symbols" if batched else f"B=1, {Tx} symbols") + " x 5 streams, "
+                                   f"zero BERT vectors, durations pinned 3/symbol -> T_y<={Ty}, {hp.n_timesteps} Euler steps with guidance {hp.guidance_scale:g}, "
+                                   f"{S_} valid samples/step/GPU, host entry point " + ("stts_synthesize_batch" if batched else "stts_synthesize"),
+                       "batch": 32 if batched else 1, "T_x": Tx, "T_y": Ty,
                        "samples_per_step_per_gpu": S_, "parallelism": f"replicas x{world} (no collective)", "hipgraph": False},
             "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
@@ -171,8 +198,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "m2"],
-                    help="c1..c5: BASELINE configs on the VITS2 graph; m2: the configs[1] shape on the StableTTS (multistream) family")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "m2", "m3"],
+                    help="c1..c5: BASELINE configs on the VITS2 graph; m2 / m3: the configs[1] / configs[2] shapes on the StableTTS (multistream) family")
     ap.add_argument("--no-batch32", action="store_true", help="skip the extra c3 (batch=32) measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget for the CPU-oracle baseline leg")
@@ -203,7 +230,7 @@ def main():
     from vosk_tts_amd import weights as W
     from vosk_tts_amd.capi import VitsDeviceSession, VitsLib
 
-    if args.workload == "m2":
+    if args.workload in ("m2", "m3"):
         return bench_multistream(args, torch, rank, world, local_rank, dist)
 
     hp = W.default_hparams()
