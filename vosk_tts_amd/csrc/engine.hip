@@ -756,7 +756,15 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); }
     return;
   }
-  if (P.ups_u && (P.ups_cout % 64)) { ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(s, P, halo); return; }
+  // 32-row outputs (polyphase upsamplers with C_out % 64 != 0, the 32-channel last stage of HiFi-GAN V1): a 64-row tile
+  // would spend half its MFMAs on padding rows -> 32 x 128 tiles
+  if ((P.ups_u && (P.ups_cout % 64)) || (!P.ups_u && P.M % 64 == 32)) {
+    ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(s, P, halo); return;
+  }
+  // 64-row outputs at batch size: 64 x 128 tiles (twice the columns per weight fragment of the 64 x 64 tile)
+  if (!P.ups_u && P.M == 64 && (long)cdiv(P.Tout, 128) * P.B * P.n_groups >= 512) {
+    ps.set_kernel("conv_mfma_kernel<2,2,1,2,STORE>"); launch_cfg<2, 2, 1, 2, EPI_STORE>(s, P, halo); return;
+  }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
   if (m_fits && big_blocks >= 512) { ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return; }

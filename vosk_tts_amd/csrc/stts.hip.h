@@ -130,10 +130,17 @@ static void stts_attention(vits_session* s, const stts_model* m, const float* qk
 
 struct DitScratch { float *hn, *qkv, *att, *ffh; };
 
+// Batches of ragged items (s->ragged): column tiles that start at or beyond len[b] are not dispatched.  Safe for every
+// conv of this path: a tile boundary is a multiple of 32, so it is never below the item's length rounded up to 4 (the
+// extent a single-utterance run has), and everything beyond is read through masks or zero-padding selects only.
+static void stts_skip(vits_session* s, ConvParams& P, const int* len) {
+  if (s->ragged && len) { P.skip_len = 1; if (!P.len) P.len = len; }
+}
+
 static void stts_ln_mod(vits_session* s, const float* x, float* y, const float* shift, const float* scale, int mod_stride, int B, int H, int T,
                         const float* film = nullptr, float* film_out = nullptr, const int* len = nullptr) {
   ProfScope ps(s, "layernorm", 0, "layernorm_c_kernel");
-  LNParams P{x, nullptr, nullptr, y, scale, shift, len, H, T, 0, 0, 0, mod_stride, 1e-5f, film, film_out};
+  LNParams P{x, nullptr, nullptr, y, scale, shift, len, H, T, 0, 0, (s->ragged && len) ? 1 : 0, mod_stride, 1e-5f, film, film_out};
   launch_layernorm(s->stream, P, B);
 }
 
@@ -146,19 +153,23 @@ static void stts_dit_block(vits_session* s, const stts_model* m, const DitW& W, 
                            const float* h_in = nullptr) {
   char nm[64];
   if (film) stts_ln_mod(s, h_in, sc.hn, mod, mod + H, 6 * H, B, H, T, film, h, len);
-  else stts_ln_mod(s, h, sc.hn, mod, mod + H, 6 * H, B, H, T);
+  else stts_ln_mod(s, h, sc.hn, mod, mod + H, 6 * H, B, H, T, nullptr, nullptr, len);
   ConvParams P = conv_params(W.qkv, sc.hn, sc.qkv, B, T, 1, 0);
+  stts_skip(s, P, len);
   snprintf(nm, sizeof nm, "%s.qkv", tag); launch_conv(s, P, EPI_STORE, nm);
   stts_attention(s, m, sc.qkv, len, sc.att, B, H, T, nh);
   P = conv_params(W.o, sc.att, h, B, T, 1, 0);  // x = x + gate_msa * attn(...) * x_mask
   P.out_mask = 1; P.len = len; P.scale_b = mod; P.scale_b_stride = 6 * H; P.scale_b_off = 2 * H; P.g[0].res = h;
+  stts_skip(s, P, len);
   snprintf(nm, sizeof nm, "%s.o", tag); launch_conv(s, P, EPI_STORE, nm);
-  stts_ln_mod(s, h, sc.hn, mod + 3 * H, mod + 4 * H, 6 * H, B, H, T);
+  stts_ln_mod(s, h, sc.hn, mod + 3 * H, mod + 4 * H, 6 * H, B, H, T, nullptr, nullptr, len);
   P = conv_params(W.c1, sc.hn, sc.ffh, B, T, 1, K / 2);  // FFN: conv_1(x * mask) -> SiLU (diffusion_transformer.py:25-27)
   P.in_mask = 1; P.len = len; P.relu = 2;
+  stts_skip(s, P, len);
   snprintf(nm, sizeof nm, "%s.ffn1", tag); launch_conv(s, P, EPI_STORE, nm);
   P = conv_params(W.c2, sc.ffh, h, B, T, 1, K / 2);  // conv_2(. * mask) * mask ; x = x + gate_mlp * mlp
   P.in_mask = 1; P.out_mask = 1; P.len = len; P.scale_b = mod; P.scale_b_stride = 6 * H; P.scale_b_off = 5 * H; P.g[0].res = h;
+  stts_skip(s, P, len);
   snprintf(nm, sizeof nm, "%s.ffn2", tag); launch_conv(s, P, EPI_STORE, nm);
 }
 
@@ -263,12 +274,15 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
   // in a batch every item must see zeros beyond ITS OWN padded length (in_mask with lenT) to equal its single-utterance run
   ConvParams P = conv_params(m->cp0, d_mu, E.a1, nb, T, 1, K / 2); P.relu = 2;
   if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+  stts_skip(s, P, E.lenT);
   launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
   P = conv_params(m->cp2, E.a1, E.a2, nb, T, 1, K / 2); P.relu = 2;
   if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+  stts_skip(s, P, E.lenT);
   launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
   P = conv_params(m->cp4, E.a2, E.cat + (size_t)NF * T, nb, T, 1, K / 2); P.y_bstride = (long long)(NF + H) * T;
   if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+  stts_skip(s, P, E.lenT);
   launch_conv(s, P, EPI_STORE, "cfm.cond_proj");
 }
 // one Decoder.forward (decoder.py:105-138) over the nb batch items; state x = rows [0,NF) of E.cat; result in E.dphi
@@ -277,6 +291,7 @@ static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int 
   const int H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers, K = hp.dec_kernel;
   const int nb = E.nb, T = E.T, n = E.n_steps;
   ConvParams P = conv_params(m->in_proj, E.cat, E.h, nb, T, 1, 0);
+  stts_skip(s, P, E.len);
   launch_conv(s, P, EPI_STORE, "cfm.in_proj");
   // Buffer choreography without copies: FiLM runs out of place, so for the first NL/2 blocks the tensor it READ is left
   // untouched and IS the long-skip output (lsc_outputs.append(x)); the second half consumes them in reverse through the
@@ -295,6 +310,7 @@ static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int 
       P.x_bstride = (long long)H * T;  // each of the two inputs is a dense [nb, H, T] tensor
       P.g[0].x2 = skip; P.x_split = H;
       if (E.lenT) { P.in_mask = 1; P.len = E.lenT; }
+      stts_skip(s, P, E.lenT);
       launch_conv(s, P, EPI_STORE, "cfm.lsc");
       freeb[nfree++] = cur; freeb[nfree++] = skip;
       cur = out;
@@ -307,6 +323,7 @@ static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int 
   }
   P = conv_params(m->final_proj, cur, E.dphi, nb, T, 1, 0);  // final_proj(x * mask) * mask
   P.in_mask = 1; P.out_mask = 1; P.len = E.len;
+  stts_skip(s, P, E.len);
   launch_conv(s, P, EPI_STORE, "cfm.final_proj");
 }
 
@@ -711,6 +728,13 @@ int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* leng
   }
   if (cfg) hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(T, 64), B * CC), dim3(64), 0, s->stream, d_mu2 + (size_t)B * CC * T, m->fake_content, T, CC);
   SttsEst E; E.nb = nb; E.T = T; E.n_steps = n;
+  // ragged batch: compact tile maps so that no kernel dispatches the padding of the shorter items
+  s->tile_tabs = call.dev<int>((size_t)32 * (nb + 1));
+  if (!s->tile_tabs) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  s->tile_keys.clear();
+  s->B = nb;
+  s->ragged = B > 1;
+  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->tile_tabs = nullptr; s->tile_keys.clear(); } } ragged_off{s};
   stts_run_cfm(s, m, E, d_c, d_mu2, d_len, nullptr, T, temperature, opts ? opts->seed : 0, B, d_lenT);
   hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv(Tm, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, T, d_pau, d_mel, NF, Tm, d_len,
                      hp.mel_std, hp.mel_mean);
