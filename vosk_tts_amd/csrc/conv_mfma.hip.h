@@ -73,7 +73,7 @@ struct ConvParams {
   long long y_bstride;
   float in_slope;     // leaky-relu slope applied at staging (1 = identity)
   float in_scale;     // multiplies the (summed) input at staging
-  int x_split;        // K-split kernel, NIN == 2: input channels >= x_split come from g.x2 (channel ci - x_split):
+  int x_split;        // input channels >= x_split come from g.x2 (channel ci - x_split; K-split kernel: NIN == 2):
                       // a conv over cat((x, x2), dim=1) without materialising the concatenation; multiple of 16
   int in_mask;        // zero input where t >= len[b]
   int reflect;        // ReflectionPad1d((1,0)) folded into staging: index -1 reads index 1
@@ -377,9 +377,18 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   CONV_STAGE_COLS(JT)
   auto load_chunk = [&](int c) {
     long long roff[4];
+    // channel-concatenated second input (x_split): chunks at or beyond the split read g.x2 at channel ci - x_split
+    const bool second = P.x_split && c * CONV_CI_T >= P.x_split;  // block-uniform
+    const int cb = second ? c * CONV_CI_T - P.x_split : c * CONV_CI_T;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) roff[rr] = (long long)(P.x_ch_off + (c * CONV_CI_T + wave + 4 * rr) * P.x_ch_sign) * P.Tin_stride;
-    if (xb2) {
+    for (int rr = 0; rr < 4; ++rr) roff[rr] = (long long)(P.x_ch_off + (cb + wave + 4 * rr) * P.x_ch_sign) * P.Tin_stride;
+    if (P.x_split) {
+      const float* src = second ? xb2 : xb;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) stg[rr][j] = src[roff[rr] + toff[j]];
+    } else if (xb2) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll

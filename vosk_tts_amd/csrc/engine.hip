@@ -730,7 +730,6 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
   static const long ks_threshold = getenv("VITS_KS_THRESHOLD") ? atol(getenv("VITS_KS_THRESHOLD")) : 512;
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
-  if (P.x_split) small = true;  // channel-concatenated inputs exist in the K-split kernel only
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   if (epi == EPI_GATE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo); }
