@@ -495,6 +495,42 @@ int SAPI(synthesize)(stts_model* m, const int64_t* ids, int32_t Tx, const float*
   return rc;
 }
 
+/* ---- batch of independent utterances: by definition item b is the single-utterance path on its own inputs with
+ * seed + b (include/stts_mi355.h); the oracle simply loops */
+int SAPI(synthesize_batch)(stts_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                           const int64_t* sid, const float* bert, const float* pde, const stts_synth_opts* opts, float** out_audio,
+                           int64_t* out_samples, int64_t* out_lengths) {
+  if (!m || !ids || !lengths || !scales || !out_audio || !out_samples || !out_lengths || B <= 0 || Tx <= 0) return sfail(VITS_ERR_ARG, "bad argument");
+  if (opts && opts->noise) return sfail(VITS_ERR_ARG, "injected noise is a single-utterance option");
+  float** wav = (float**)calloc(B, sizeof(float*));
+  int64_t smax = 0;
+  int rc = VITS_OK;
+  for (int b = 0; b < B && rc == VITS_OK; ++b) {
+    const int L = (int)lengths[b];
+    if (L <= 0 || L > Tx) { rc = sfail(VITS_ERR_ARG, "length out of range"); break; }
+    int64_t* idb = (int64_t*)malloc(sizeof(int64_t) * 5 * L);
+    float* bb = bert ? (float*)malloc(sizeof(float) * (size_t)m->hp.bert_dim * L) : NULL;
+    for (int s5 = 0; s5 < 5; ++s5) memcpy(idb + (size_t)s5 * L, ids + ((size_t)b * 5 + s5) * Tx, sizeof(int64_t) * L);
+    if (bb) for (int c = 0; c < m->hp.bert_dim; ++c) memcpy(bb + (size_t)c * L, bert + ((size_t)b * m->hp.bert_dim + c) * Tx, sizeof(float) * L);
+    stts_synth_opts o = {0};
+    if (opts) o = *opts;
+    o.seed = (opts ? opts->seed : 0) + (uint64_t)b;
+    int64_t ns = 0;
+    rc = SAPI(synthesize)(m, idb, L, scales, sid ? sid[b] : 0, bb, pde ? pde + (size_t)b * Tx : NULL, &o, &wav[b], &ns, NULL, NULL);
+    out_lengths[b] = ns;
+    if (ns > smax) smax = ns;
+    free(idb); free(bb);
+  }
+  if (rc == VITS_OK) {
+    float* all = (float*)calloc((size_t)B * (smax ? smax : 1), sizeof(float));
+    for (int b = 0; b < B; ++b) memcpy(all + (size_t)b * smax, wav[b], sizeof(float) * (size_t)out_lengths[b]);
+    *out_audio = all; *out_samples = smax;
+  }
+  for (int b = 0; b < B; ++b) free(wav[b]);
+  free(wav);
+  return rc;
+}
+
 /* ---- lifecycle */
 int SAPI(create)(const void* blob, size_t bytes, vits_model* vocoder, int device, stts_model** out) {
   (void)device;

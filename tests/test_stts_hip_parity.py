@@ -169,6 +169,6 @@ def test_stts_batch_items_equal_their_single_utterance_calls(stts_pair):
         # not bit-for-bit: the batch is big enough for the big-tile conv kernel where the single call takes the K-split one
         assert_close(f"item {b}", one, audio[b, :olen[b]], 2e-5)
         assert not audio[b, olen[b]:].any()
-    L = int(lengths[0])
-    want, _ = ref.synthesize(ids[0][:, :L], sc, int(sid[0]), bert[0][:, :L], pde[0][:L], seed=30, n_timesteps=3, want_mel=False)
-    assert_close("item 0 vs oracle", want, audio[0, :olen[0]], E2E_TOL)
+    want, wlen = ref.synthesize_batch(ids, lengths, sc, sid, bert, pde, seed=30, n_timesteps=3)
+    assert np.array_equal(wlen, olen) and want.shape == audio.shape
+    assert_close("batch vs oracle", want, audio, E2E_TOL)

@@ -30,9 +30,8 @@ class SttsModel:
         f("get_hparams").argtypes = [vp, ctypes.POINTER(SttsHParams)]
         f("synthesize").argtypes = [vp, c_i64p, ctypes.c_int32, c_f32p, ctypes.c_int64, c_f32p, c_f32p, ctypes.POINTER(SttsOpts),
                                     ctypes.POINTER(c_f32p), c_i64p, ctypes.POINTER(c_f32p), c_i64p]
-        if vlib.prefix == "vits_":  # the batch entry point exists in the product library only
-            f("synthesize_batch").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_i64p, c_f32p, c_f32p,
-                                              ctypes.POINTER(SttsOpts), ctypes.POINTER(c_f32p), c_i64p, c_i64p]
+        f("synthesize_batch").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_i64p, c_f32p, c_f32p,
+                                          ctypes.POINTER(SttsOpts), ctypes.POINTER(c_f32p), c_i64p, c_i64p]
         f("stage_encoder").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p, c_f32p, c_f32p]
         f("stage_durations").argtypes = [vp, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, c_i32p, c_i64p]
         f("stage_estimator").argtypes = [vp, c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p]
