@@ -146,6 +146,11 @@ typedef struct vits_synth_opts {
 } vits_synth_opts;
 
 #define VITS_FLAG_NONE 0
+/* Batches whose items must not depend on their neighbours (a server batching unrelated requests): every item gives what
+ * a single-utterance call with seed + b gives -- its own Philox noise streams, and the decoder sees zeros beyond the
+ * item's own end instead of the reference's padded-batch continuation (in the reference a batched item
+ * differs from its solo run over its last ~14 frames).  Default (flag clear) = the reference's padded-batch result. */
+#define VITS_FLAG_SOLO_BATCH 1
 
 /* Host-buffer entry point (what the Python Session.run adapter calls).
  *   ids      int64 [B,T_x] (padded with anything past lengths[b])

@@ -467,3 +467,27 @@ def test_stabletts_hifigan_v1_vocoder(hip_lib, oracle_lib):
     with pytest.raises(VitsError, match="vocoder-only"):
         hip.text_encoder(np.array([[1, 2]]), [2], [0])
     hip.close()
+
+
+def test_solo_batch_items_equal_their_single_utterance_calls(hip_default, oracle_default):
+    """VITS_FLAG_SOLO_BATCH: a ragged batch of free-running utterances where item b equals the single call with seed + b
+    (own noise streams, decoder sees zeros beyond the item's own end) -- unlike the default, which reproduces the
+    reference's padded-batch result whose tails depend on the padding."""
+    rng = np.random.default_rng(77)
+    B, Tx = 3, 30
+    lens = np.array([30, 12, 21], np.int64)
+    ids = rng.integers(1, 62, size=(B, Tx)).astype(np.int64)
+    sid = np.array([1, 4, 7], np.int64)
+    sc = [0.667, 1.0, 0.8]
+    audio, olen = hip_default.synthesize(ids, lens, sc, sid, seed=50, solo=True)
+    padded, plen = hip_default.synthesize(ids, lens, sc, sid, seed=50)
+    for b in range(B):
+        L = int(lens[b])
+        one, ol = hip_default.synthesize(ids[b:b + 1, :L], [L], sc, sid[b:b + 1], seed=50 + b)
+        assert ol[0] == olen[b]
+        assert_close(f"item {b}", one[0], audio[b, :olen[b]], 2e-5)  # kernel choice differs with batch size, not bit-for-bit
+        assert not audio[b, olen[b]:].any()
+    want, wl = oracle_default.synthesize(ids[1:2, :12], [12], sc, sid[1:2], seed=51)
+    assert wl[0] == olen[1]
+    assert_close("item 1 vs oracle", want[0], audio[1, :olen[1]], E2E_TOL)
+    assert plen.shape == olen.shape  # default semantics still run (different noise rows, so no sample comparison)

@@ -170,7 +170,7 @@ class VitsModel:
         except Exception:
             pass
 
-    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames):
+    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo=False):
         opts = SynthOpts()
         keep = []
         if noise_dp is not None:
@@ -191,12 +191,14 @@ class VitsModel:
             opts.forced_durations = _p(a, c_i32p)
         opts.seed = seed
         opts.max_frames = max_frames
+        opts.flags = 1 if solo else 0  # VITS_FLAG_SOLO_BATCH
         return opts, keep
 
     # ---- the hot path -----------------------------------------------------
     def synthesize(self, ids, lengths, scales, sid, noise_dp=None, noise_prior=None, forced_durations=None, seed=0,
-                   max_frames=0):
-        """One .run(): returns (audio float32 [B,S], out_lengths int64 [B])."""
+                   max_frames=0, solo=False):
+        """One .run(): returns (audio float32 [B,S], out_lengths int64 [B]).  solo=True (VITS_FLAG_SOLO_BATCH): every
+        item equals its own single-utterance call with seed + b instead of the reference's padded-batch result."""
         ids = _i64(ids)
         B, Tx = ids.shape
         lengths = _i64(lengths)
@@ -204,7 +206,7 @@ class VitsModel:
         scales = _f32(scales)
         if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
             raise ValueError("bad feed shapes")
-        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames)
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo)
         out = c_f32p()
         ns = ctypes.c_int64()
         olen = np.zeros(B, dtype=np.int64)

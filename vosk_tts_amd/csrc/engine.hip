@@ -470,6 +470,7 @@ struct vits_session {
   std::map<GKey, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool ragged = false;  // full-path calls with B > 1: skip padding tiles of masked stages (set per call)
+  bool solo = false;    // VITS_FLAG_SOLO_BATCH: every item as if synthesized alone (noise streams, decoder halo 0)
 
   // named views (valid after plan())
   int B = 0, Tx = 0, Ty = 0;
@@ -940,7 +941,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   P.out_mask = 1; P.len = s->len_x;
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.proj");
-  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx);
+  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx, s->solo ? 1 : 0);
   int swap = 0;
   const float cst = (float)log(exp(1.0 - 1e-3) - 1.0);
   (void)cst;
@@ -973,7 +974,7 @@ static void run_expand(vits_session* s, const float* d_noise, long long noise_st
                        float* z_p, int B, int Tx, int Ty) {
   const int I = s->m->hp.inter_channels;
   hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(Ty, 64), 8, B), dim3(64), 0, s->stream, s->stats, s->cum, s->len_y, d_noise,
-                     noise_stride, noise_scale, seed, z_p, I, Tx, Ty);
+                     noise_stride, noise_scale, seed, z_p, I, Tx, Ty, s->solo ? 1 : 0);
 }
 
 // ---- a12-a14: ResidualCouplingTransformersBlock.forward(reverse=True) (models.py:750-757).
@@ -1423,8 +1424,9 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   int64_t* d_sid = hs.to_dev(sid, B);
   if (!d_ids || !d_len) return fail(VITS_ERR_NOMEM, "device alloc failed");
   s->ragged = B > 1;
+  s->solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
   s->tile_keys.clear();
-  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; } } ragged_off{s};
+  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->solo = false; } } ragged_off{s};
   set_lengths(s, d_len, s->len_x, B, Tx);
   run_cond(s, d_sid, B);
   run_text_encoder(s, d_ids, B, Tx);
@@ -1488,11 +1490,12 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   TRY(acoustic_host(hs, ids, lengths, B, Tx, scales, sid, opts, ylen, Ty, z));
   vits_session* s = hs.s;
   s->ragged = B > 1;
-  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; } } ragged_off{s};
+  s->solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
+  struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->solo = false; } } ragged_off{s};
   const int64_t S = Ty * hp.hop_length;
   float* d_audio = hs.dev_alloc<float>((size_t)B * S);
   if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
-  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr, true);
+  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr, true, s->solo ? 0 : VITS_RAGGED_HALO);
   float* h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)B * S));
   if (!h_audio) return fail(VITS_ERR_NOMEM, "host alloc failed");
   hipError_t e = hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream);

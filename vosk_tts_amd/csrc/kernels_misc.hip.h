@@ -685,11 +685,13 @@ __global__ void __launch_bounds__(256, 2) relpos_attention_mfma_kernel(const flo
 
 // ----------------------------------------------------------------------------- duration predictor
 // z[b,c,t] = noise * noise_scale_w  (models.py:96)
-__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T) {
+// solo != 0 (VITS_FLAG_SOLO_BATCH): item b draws what a single-utterance call with seed + b would draw
+__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T, int solo) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   const long long o = ((long long)b * 2 + c) * T + t;
-  const float e = noise ? noise[o] : philox_normal(seed, 1, (uint32_t)(b * 2 + c), (uint32_t)t);
+  const float e = noise ? noise[o] : (solo ? philox_normal(seed + (uint64_t)b, 1, (uint32_t)c, (uint32_t)t)
+                                            : philox_normal(seed, 1, (uint32_t)(b * 2 + c), (uint32_t)t));
   z[o] = e * nsw;
 }
 
@@ -817,7 +819,7 @@ __global__ void durations_kernel(const float* logw, const int* forced, const int
 // stats: [B, 2I, Tx] (m rows [0,I), logs rows [I,2I)).  Frames >= y_len: z_p = eps*noise_scale.
 __global__ void expand_prior_kernel(const float* stats, const int* cum, const int* ylen, const float* noise,
                                     long long noise_stride, float noise_scale, uint64_t seed, float* z_p, int I, int Tx,
-                                    int Ty) {
+                                    int Ty, int solo) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
   if (f >= Ty) return;
   const int* cb = cum + (long long)b * Tx;
@@ -831,7 +833,8 @@ __global__ void expand_prior_kernel(const float* stats, const int* cum, const in
     const float mu = tok >= 0 ? stats[((long long)b * 2 * I + c) * Tx + tok] : 0.f;
     const float ls = tok >= 0 ? stats[((long long)b * 2 * I + I + c) * Tx + tok] : 0.f;
     const float e = noise ? noise[((long long)b * I + c) * noise_stride + f]
-                          : philox_normal(seed, 2, (uint32_t)(b * I + c), (uint32_t)f);
+                          : (solo ? philox_normal(seed + (uint64_t)b, 2, (uint32_t)c, (uint32_t)f)
+                                  : philox_normal(seed, 2, (uint32_t)(b * I + c), (uint32_t)f));
     z_p[((long long)b * I + c) * Ty + f] = mu + e * expf(ls) * noise_scale;
   }
 }
