@@ -172,3 +172,59 @@ def test_stts_batch_items_equal_their_single_utterance_calls(stts_pair):
     want, wlen = ref.synthesize_batch(ids, lengths, sc, sid, bert, pde, seed=30, n_timesteps=3)
     assert np.array_equal(wlen, olen) and want.shape == audio.shape
     assert_close("batch vs oracle", want, audio, E2E_TOL)
+
+
+def test_stts_single_speaker_model_and_custom_steps(hip_lib, oracle_lib):
+    """n_spks = 1: no speaker tables in the blob, the speaker vectors are zeros (matcha_tts.py:136-139 skips the embedding);
+    guidance and the Euler loop still run; 1 and 7 steps against the oracle."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.capi_stts import SttsModel
+
+    hp = S.default_hparams(30, 1)
+    blob = S.synthetic_blob(hp, 99)
+    assert "spk_emb.weight" in S.make_synthetic_weights(hp, 99)  # the spec still carries the (unused) table of one row
+    vblob = W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234)
+    hip = SttsModel(hip_lib, blob, hip_lib.create(vblob, 0))
+    ref = SttsModel(oracle_lib, blob, oracle_lib.create(vblob))
+    ids = np.random.default_rng(5).integers(1, 30, size=(5, 11)).astype(np.int64)
+    pde = np.full(11, 4.0, np.float32)
+    sc = np.array([0.6, 0.9, 0.8], np.float32)
+    for steps in (1, 7):
+        _, m_ref = ref.synthesize(ids, sc, 0, None, pde, seed=1, n_timesteps=steps, want_audio=False)
+        _, m_hip = hip.synthesize(ids, sc, 0, None, pde, seed=1, n_timesteps=steps, want_audio=False)
+        assert m_hip.shape == (80, 44)
+        assert_close(f"mel ({steps} steps)", m_ref, m_hip, E2E_TOL)
+    hip.close()
+
+
+def test_stts_is_reentrant_from_threads(stts_pair):
+    """the gRPC server shares one Synth across a thread pool (server/tts_server.py:39-40,57): concurrent
+    stts_synthesize / stts_synthesize_batch calls on one model give exactly the results of sequential calls"""
+    import threading
+
+    hip, _ = stts_pair
+    rng = np.random.default_rng(61)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    jobs = []
+    for k in range(6):
+        T = int(rng.integers(6, 30))
+        jobs.append((rng.integers(1, 40, size=(5, T)).astype(np.int64), np.full(T, 3.0, np.float32), int(rng.integers(0, 7)), 100 + k))
+    want = [hip.synthesize(i, sc, s, None, p, seed=sd, n_timesteps=2, want_mel=False)[0] for (i, p, s, sd) in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                i, p, s, sd = jobs[k]
+                got[k] = hip.synthesize(i, sc, s, None, p, seed=sd, n_timesteps=2, want_mel=False)[0]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs
+    for k in range(len(jobs)):
+        assert np.array_equal(want[k], got[k]), k
