@@ -228,3 +228,18 @@ def test_stts_is_reentrant_from_threads(stts_pair):
     assert not errs
     for k in range(len(jobs)):
         assert np.array_equal(want[k], got[k]), k
+
+
+def test_stts_tiny_utterances_vs_oracle(stts_pair):
+    """1..5 symbols, 1..2 frames each (T_y as small as 1, padded to 4): every tile / mask edge of the path"""
+    hip, ref = stts_pair
+    rng = np.random.default_rng(71)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    for Tx, d in ((1, 1.0), (2, 1.0), (3, 2.0), (5, 1.0)):
+        ids = rng.integers(1, 40, size=(5, Tx)).astype(np.int64)
+        pde = np.full(Tx, d, np.float32)
+        a_ref, m_ref = ref.synthesize(ids, sc, 3, None, pde, seed=8, n_timesteps=2)
+        a_hip, m_hip = hip.synthesize(ids, sc, 3, None, pde, seed=8, n_timesteps=2)
+        assert m_hip.shape == (80, int(Tx * d)) and a_hip.shape == (int(Tx * d) * 256,)
+        assert_close(f"mel Tx={Tx}", m_ref, m_hip, E2E_TOL)
+        assert_close(f"audio Tx={Tx}", a_ref, a_hip, E2E_TOL)
