@@ -11,6 +11,7 @@ cd $R
 python bench.py > $O/${TAG}_default_bench.json.txt 2> $O/${TAG}_default_bench.err
 for w in c3 c4 c5; do python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_${w}_bench.json.txt 2>> $O/${TAG}_default_bench.err; done
 python bench.py --workload m2 --steps 30 --warmup 3 > $O/${TAG}_m2_bench.json.txt 2>> $O/${TAG}_default_bench.err
+python bench.py --workload m3 --steps 5 --warmup 2 --cpu-seconds 5 > $O/${TAG}_m3_bench.json.txt 2>> $O/${TAG}_default_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${TAG}_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o trace -- python $R/bench.py > $O/${TAG}_default_bench_under_rocprof.json.txt 2>> $O/${TAG}_default_bench.err
