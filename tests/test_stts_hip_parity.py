@@ -225,9 +225,56 @@ def test_stts_is_reentrant_from_threads(stts_pair):
     ths = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
     [t.start() for t in ths]
     [t.join() for t in ths]
-    assert not errs
+    assert not errs, errs
     for k in range(len(jobs)):
-        assert np.array_equal(want[k], got[k]), k
+        assert want[k].shape == got[k].shape, (k, want[k].shape, got[k].shape)
+        d = np.abs(want[k] - got[k])
+        assert np.array_equal(want[k], got[k]), (k, int((d > 0).sum()), want[k].size, float(np.nanmax(d)), int(np.isnan(got[k]).sum()),
+                                                 np.argwhere(d > 0)[[0, -1]].ravel().tolist())
+
+
+def test_stts_fresh_sessions_on_recycled_poisoned_memory(stts_pair, hip_lib):
+    """a new model's first calls, issued from 8 threads at once (every thread creates its sessions), on device memory that was
+    just released full of 0xFF bytes and with NaN-poisoned workspaces: nothing may depend on what a fresh allocation holds
+    (regression: the sessions' error word was cleared on the null stream, unordered with the non-blocking session stream)"""
+    import threading
+
+    import torch
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.capi_stts import SttsModel
+
+    hip, _ = stts_pair
+    rng = np.random.default_rng(67)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    jobs = [(rng.integers(1, 40, size=(5, T)).astype(np.int64), np.full(T, 2.0, np.float32), k % 7, 200 + k) for k, T in enumerate((5, 9, 14, 20, 27, 33, 11, 3))]
+    want = [hip.synthesize(i, sc, s, None, p, seed=sd, n_timesteps=2) for (i, p, s, sd) in jobs]
+    for _ in range(3):
+        junk = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for n in (1, 64, 1 << 10, 1 << 16, 1 << 22, 1 << 26)]
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()
+        hip_lib.lib.vits_debug_poison_workspace(1)
+        try:
+            fresh = SttsModel(hip_lib, S.synthetic_blob(S.default_hparams(40, 7), 1234), hip_lib.create(W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234), 0))
+            got, errs = [None] * len(jobs), []
+
+            def work(k):
+                try:
+                    i, p, s, sd = jobs[k]
+                    got[k] = fresh.synthesize(i, sc, s, None, p, seed=sd, n_timesteps=2)
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            fresh.close()
+        finally:
+            hip_lib.lib.vits_debug_poison_workspace(0)
+        assert not errs, errs
+        for k in range(len(jobs)):
+            assert np.array_equal(want[k][0], got[k][0]) and np.array_equal(want[k][1], got[k][1]), k
 
 
 def test_stts_tiny_utterances_vs_oracle(stts_pair):

@@ -574,7 +574,10 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     s->arena_bytes = want;
   }
   plan(s, B, Tx, Ty);
-  if (g_poison) hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);  // 0xFFFFFFFF = NaN
+  if (g_poison) {  // 0xFFFFFFFF = NaN; synchronised: stts_synthesize runs the decoder of this session on ITS stream
+    hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);
+    hipStreamSynchronize(s->stream);
+  }
   return VITS_OK;
 }
 
@@ -584,7 +587,10 @@ static int session_new(vits_model* m, vits_session** out) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void**)&s->d_err, sizeof(int)));
-  HIP_TRY(hipMemset(s->d_err, 0, sizeof(int)));
+  // on the session's own stream: it is non-blocking, i.e. NOT ordered after null-stream work, and hipMemset on device
+  // memory may return before it ran -- a plain hipMemset here raced with the first forward's error-word read
+  HIP_TRY(hipMemsetAsync(s->d_err, 0, sizeof(int), s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   *out = s;

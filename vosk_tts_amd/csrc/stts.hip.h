@@ -106,6 +106,7 @@ static int stts_load(stts_model* m) {
 // ---- workspace: a bump arena on a pooled session of &m->base (stream + error word + events)
 static int stts_arena(vits_session* s, size_t bytes) {
   s->arena_used = 0;
+  if (g_poison && s->arena) hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);  // vits_debug_poison_workspace: NaN
   if (bytes <= s->arena_bytes) return VITS_OK;
   if (s->arena) { hipStreamSynchronize(s->stream); hipFree(s->arena); s->arena = nullptr; s->arena_bytes = 0; }
   void* p = nullptr;
@@ -113,6 +114,7 @@ static int stts_arena(vits_session* s, size_t bytes) {
   if (hipMalloc(&p, want) != hipSuccess) return fail(VITS_ERR_NOMEM, "workspace hipMalloc of %zu bytes failed", want);
   s->arena = static_cast<char*>(p);
   s->arena_bytes = want;
+  if (g_poison) hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);
   return VITS_OK;
 }
 
@@ -366,6 +368,7 @@ struct SttsCall {  // pooled session + temporaries of one entry-point call
     hipError_t e = hipSetDevice(m->base.device);
     if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
     TRY(pool_acquire(&m->base, &s));
+    if (g_poison && s->stage) hipMemsetAsync(s->stage, 0xFF, s->stage_bytes, s->stream);
     return stts_arena(s, arena_bytes);
   }
   // inputs / outputs of the call: bump-allocated from the pooled session's staging area (no hipMalloc / hipFree in the
@@ -377,6 +380,7 @@ struct SttsCall {  // pooled session + temporaries of one entry-point call
     if (off + bytes <= s->stage_bytes) return reinterpret_cast<T*>(s->stage + off);
     void* d = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    if (g_poison) hipMemsetAsync(d, 0xFF, bytes, s->stream);
     tmp.push_back(d);
     return static_cast<T*>(d);
   }
