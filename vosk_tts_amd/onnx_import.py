@@ -116,33 +116,134 @@ def _tensor(buf):
     return name, arr.reshape(shape)
 
 
+class OnnxGraph:
+    """Initializers + nodes of one ONNX file, with the exporter's renamings undone.
+
+    What `torch.onnx.export` (TorchScript exporter, the one training/vits2/onnx_export.py:94-110 and
+    matcha/onnx/export.py:96-117 call) does to parameters, as observed on real exports of the reference modules
+    (oracle/gen_onnx_fixtures.py):
+      * a parameter normally becomes an initializer under its state_dict name;
+      * byte-identical parameters are de-duplicated: one initializer survives and every other name is the OUTPUT of
+        an `Identity` node fed by it (e.g. untrained LayerNorm gammas, zero-initialised `post` convs);
+      * an `nn.Linear` weight is constant-folded into its transpose under an anonymous name ("onnx::MatMul_123") that
+        feeds the node "/<module/path>/MatMul"; a bias may likewise sit behind "/<module/path>/Add";
+      * other folded expressions keep no name at all: ElementwiseAffine's `exp(-logs)` leaves "onnx::Exp_N" = -logs
+        feeding "/dp/flows.0/Exp";
+      * node names carry the module path: "a.b.0.c" -> "/a/b.0/c/<Op>[_k]".
+    `param(name)` resolves a state_dict name through all of these."""
+
+    def __init__(self, path_or_bytes):
+        data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
+        self.inits = {}
+        self.nodes = []  # (name, op_type, inputs, outputs)
+        self.alias = {}  # Identity output -> input
+        for fno, wt, v in _fields(memoryview(data)):
+            if fno != 7 or wt != 2:  # ModelProto.graph
+                continue
+            for gno, gwt, gv in _fields(v):
+                if gno == 5 and gwt == 2:  # initializer
+                    name, arr = _tensor(gv)
+                    if arr is not None:
+                        self.inits[name] = arr
+                elif gno == 1 and gwt == 2:  # node
+                    ins, outs, name, op, tens = [], [], "", "", None
+                    for nno, nwt, nv in _fields(gv):
+                        if nno == 1:
+                            ins.append(bytes(nv).decode("utf-8", "replace"))
+                        elif nno == 2:
+                            outs.append(bytes(nv).decode("utf-8", "replace"))
+                        elif nno == 3:
+                            name = bytes(nv).decode("utf-8", "replace")
+                        elif nno == 4:
+                            op = bytes(nv).decode("utf-8", "replace")
+                        elif nno == 5 and nwt == 2:
+                            for ano, awt, av in _fields(nv):
+                                if ano == 5 and awt == 2:
+                                    tens = _tensor(av)[1]
+                    self.nodes.append((name, op, ins, outs))
+                    if op == "Constant" and tens is not None and outs:  # Constant tensors count as initializers
+                        self.inits.setdefault(outs[0], tens)
+                    elif op == "Identity" and len(ins) == 1 and len(outs) == 1:
+                        self.alias[outs[0]] = ins[0]
+        self._by_name = {n[0]: n for n in self.nodes if n[0]}
+
+    def tensors(self):
+        """name -> ndarray: the initializers plus every de-duplicated name (Identity outputs)."""
+        out = dict(self.inits)
+        for name in self.alias:
+            a = self._follow(name)
+            if a is not None:
+                out.setdefault(name, a)
+        return out
+
+    def _follow(self, name):
+        for _ in range(8):
+            if name in self.inits:
+                return self.inits[name]
+            if name not in self.alias:
+                return None
+            name = self.alias[name]
+        return None
+
+    @staticmethod
+    def scope(module_path):
+        """state_dict module path -> node-name scope: "flow.flows.0.post" -> "/flow/flows.0/post/"."""
+        out = ""
+        for part in module_path.split("."):
+            out += ("." if part.isdigit() else "/") + part
+        return out + "/"
+
+    def _node_init(self, node_name, index=None):
+        n = self._by_name.get(node_name)
+        if n is None:
+            return None
+        cands = [n[2][index]] if index is not None and index < len(n[2]) else n[2]
+        for i in cands:
+            a = self._follow(i)
+            if a is not None:
+                return a
+        return None
+
+    def param(self, name):
+        """ndarray for a state_dict name, or None."""
+        a = self._follow(name)
+        if a is not None:
+            return a
+        mod, _, leaf = name.rpartition(".")
+        sc = self.scope(mod)
+        if leaf == "weight":
+            a = self._node_init(sc + "MatMul")  # nn.Linear: folded transpose
+            if a is not None and a.ndim == 2:
+                return np.ascontiguousarray(a.T)
+            for op in ("Conv", "ConvTranspose"):
+                a = self._node_init(sc + op, 1)
+                if a is not None:
+                    return a
+        elif leaf == "bias":
+            for op in ("Conv", "ConvTranspose"):
+                a = self._node_init(sc + op, 2)
+                if a is not None:
+                    return a
+            a = self._node_init(sc + "Add")
+            if a is not None:
+                return a
+        elif leaf == "logs":  # ElementwiseAffine reverse (modules.py): x * exp(-logs) -> the folded constant is -logs
+            a = self._node_init(sc + "Exp")
+            if a is None:
+                a = self.anonymous("Exp", (2, 1))
+            if a is not None:
+                return -np.asarray(a) + 0.0  # + 0.0: -(+0) would give -0
+        return None
+
+    def anonymous(self, prefix, shape):
+        """the unique anonymous initializer "onnx::<prefix>_N" of this shape (exporters that do not name nodes), or None."""
+        c = [a for k, a in self.inits.items() if k.startswith("onnx::" + prefix) and tuple(a.shape) == tuple(shape)]
+        return c[0] if len(c) == 1 else None
+
+
 def read_initializers(path_or_bytes):
-    """name -> ndarray for every initializer (and Constant node output) of an ONNX model file."""
-    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
-    buf = memoryview(data)
-    out = {}
-    for fno, wt, v in _fields(buf):
-        if fno != 7 or wt != 2:  # ModelProto.graph
-            continue
-        for gno, gwt, gv in _fields(v):
-            if gno == 5 and gwt == 2:  # initializer
-                name, arr = _tensor(gv)
-                if arr is not None:
-                    out[name] = arr
-            elif gno == 1 and gwt == 2:  # node: pick up Constant tensors by output name
-                outputs, op, tens = [], "", None
-                for nno, nwt, nv in _fields(gv):
-                    if nno == 2:
-                        outputs.append(bytes(nv).decode("utf-8", "replace"))
-                    elif nno == 4:
-                        op = bytes(nv).decode("utf-8", "replace")
-                    elif nno == 5 and nwt == 2:
-                        for ano, awt, av in _fields(nv):
-                            if ano == 5 and awt == 2:
-                                tens = _tensor(av)[1]
-                if op == "Constant" and tens is not None and outputs:
-                    out.setdefault(outputs[0], tens)
-    return out
+    """name -> ndarray for every initializer, Constant node output and de-duplicated parameter name of an ONNX file."""
+    return OnnxGraph(path_or_bytes).tensors()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -172,7 +273,8 @@ def infer_hparams(t):
             hp.n_speakers, hp.gin_channels = t["emb_g.weight"].shape
         else:
             hp.n_speakers, hp.gin_channels = 0, 0
-        hp.enc_cond_layer = 2 if "enc_p.encoder.spk_emb_linear.weight" in t else -1
+        # the Linear's weight is folded into an anonymous transposed MatMul constant by the exporter; its bias keeps the name
+        hp.enc_cond_layer = 2 if ("enc_p.encoder.spk_emb_linear.bias" in t or "enc_p.encoder.spk_emb_linear.weight" in t) else -1
         hp.dp_filter_channels = need("dp.pre.weight").shape[0]
         hp.dp_kernel_size = need("dp.convs.convs_sep.0.weight").shape[2]
         hp.dp_dds_layers = sum(1 for k in t if k.startswith("dp.convs.convs_sep.") and k.endswith(".weight"))
@@ -214,7 +316,8 @@ def import_onnx(path_or_bytes, config=None):
     `config`: optional dict with the values that shapes cannot reveal — "upsample_rates",
     "resblock_dilation_sizes", "gen_istft_hop_size", "subbands", "sampling_rate", "hop_length"
     (keys of training/vits2/configs/*.json "model"/"data")."""
-    t = read_initializers(path_or_bytes)
+    g = OnnxGraph(path_or_bytes)
+    t = g.tensors()
     if any(k.startswith(("bert", "enc_p.bert")) for k in t):
         raise NotImplementedError("BERT-conditioned flavour: not part of the VITS2 hot path (SURVEY.md §8f rank 2)")
     hp = infer_hparams(t)
@@ -230,10 +333,16 @@ def import_onnx(path_or_bytes, config=None):
             setattr(hp, field, int(config[key]))
     tensors, missing, bad = {}, [], []
     for name, shape, _kind, _fan, _gain in W.tensor_specs(hp):
-        if name not in t:
+        a = t.get(name)
+        if a is None:
+            a = g.param(name)
+        if a is None and name.endswith(".weight") and len(shape) == 2:  # Linear weight of an exporter without node names
+            a = g.anonymous("MatMul", shape[::-1])
+            a = None if a is None else np.ascontiguousarray(a.T)
+        if a is None:
             missing.append(name)
             continue
-        a = np.asarray(t[name], dtype=np.float32)
+        a = np.asarray(a, dtype=np.float32)
         if tuple(a.shape) != tuple(shape):
             bad.append(f"{name}: {tuple(a.shape)} != {tuple(shape)}")
             continue
@@ -269,9 +378,13 @@ def _enc_field(fno, wt, payload):
     return _enc_varint(fno << 3 | 2) + _enc_varint(len(payload)) + payload
 
 
-def write_minimal_onnx(path, tensors, use_float_data=()):
-    """ModelProto{ir_version, graph{initializer...}} with raw_data (or float_data for names in use_float_data)."""
+def write_minimal_onnx(path, tensors, use_float_data=(), nodes=()):
+    """ModelProto{ir_version, graph{node..., initializer...}} with raw_data (or float_data for names in use_float_data);
+    nodes: (name, op_type, inputs, outputs) tuples."""
     graph = bytearray()
+    for name, op, ins, outs in nodes:
+        graph += _enc_field(1, 2, b"".join(_enc_field(1, 2, i.encode()) for i in ins) + b"".join(_enc_field(2, 2, o.encode()) for o in outs)
+                            + _enc_field(3, 2, name.encode()) + _enc_field(4, 2, op.encode()))
     for name, a in tensors.items():
         a = np.ascontiguousarray(a, dtype="<f4")
         tp = b"".join(_enc_field(1, 0, int(d)) for d in a.shape) + _enc_field(2, 0, 1) + _enc_field(8, 2, name.encode())
