@@ -384,3 +384,24 @@ def test_bert_conditioned_multistream_end_to_end_on_gpu(tmp_path, oracle_lib, mo
     assert_close("wav vs oracle", want, wav[0], 5e-4)
     pcm = synth.synth_audio(text, speaker_id=2)
     assert pcm.dtype == np.int16 and pcm.size % 256 == 0 and pcm.size > 0
+
+
+@pytest.mark.gpu
+def test_model_loads_the_reference_file_layout_of_a_multistream_voice_on_gpu(tmp_path):
+    """a directory as the reference ships it (vosk_tts/model.py:46,62): model.onnx with the vocoder embedded and bert/model.onnx,
+    no blobs - Model imports the initializers on load and synthesises exactly what the blob directory does"""
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd.toymodel import multistream_dir_to_reference_layout, write_toy_multistream_model
+
+    a = write_toy_multistream_model(str(tmp_path / "blobs"), model_type="multistream_v1", with_bert=True)
+    b = multistream_dir_to_reference_layout(write_toy_multistream_model(str(tmp_path / "onnx"), model_type="multistream_v1", with_bert=True))
+    assert sorted(os.listdir(b)) == ["bert", "config.json", "dictionary", "model.onnx"] and "model.onnx" in os.listdir(os.path.join(b, "bert"))
+    ma, mb = Model(model_path=a, device=0), Model(model_path=b, device=0)
+    assert mb.tokenizer is not None
+    text = "прив+ет м+ир, да!"
+    fa, _ = Synth(ma)._feed(text, 1, None, None, None, None)
+    fb, _ = Synth(mb)._feed(text, 1, None, None, None, None)
+    assert np.array_equal(fa["bert"], fb["bert"]) and np.abs(fb["bert"]).max() > 0
+    wa = ma.onnx.run(None, dict(fa, **{"vits.seed": 9}))[0]
+    wb = mb.onnx.run(None, dict(fb, **{"vits.seed": 9}))[0]
+    assert np.array_equal(wa, wb) and wa.size > 0

@@ -141,3 +141,71 @@ def test_real_torch_export_of_the_reference_model_imports_bit_exactly():
             assert len(g.alias) > 20
         hp2, got = oi.import_onnx(data, cfgm)
         assert W.pack_blob(hp2, got) == W.pack_blob(hp, t), case
+
+
+@pytest.mark.skipif(not _reference_present(), reason="container-only: runs the reference's own ONNX export procedures")
+def test_real_exports_of_the_multistream_model_and_of_bert_import_bit_exactly():
+    """matcha/onnx/export.py's MatchaWithVocoder (reference MatchaTTS + in-tree HiFi-GAN V1, synthetic weights) and
+    bert-export.py's BertModel -> real torch.onnx exports -> importers -> byte-identical STTSW001 / VITSW001 / BERTW001 blobs,
+    every hyper-parameter (incl. n_timesteps, guidance scale, mel statistics read off the traced graph) recovered."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import onnx_export_ref as X
+
+    BertConfig, BertModel = X.transformers_bert()
+    from vosk_tts_amd import onnx_import as oi
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd import weights_stts as S
+
+    hp = BW.small_hparams(120, 128, 4)
+    cfg = BertConfig(vocab_size=hp.vocab_size, hidden_size=hp.hidden, num_hidden_layers=hp.n_layers, num_attention_heads=hp.n_heads,
+                     intermediate_size=hp.intermediate, max_position_embeddings=hp.max_position, type_vocab_size=hp.type_vocab,
+                     layer_norm_eps=hp.ln_eps, hidden_act="gelu", attn_implementation="eager")
+    net = BertModel(cfg).eval()
+    tens = BW.make_synthetic_weights(hp, 31)
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, v in tens.items():
+            sd[k].copy_(torch.from_numpy(v))
+    hp2, got = oi.import_bert_onnx(X.export_bert(net), {"n_heads": hp.n_heads})
+    assert BW.pack_blob(hp2, got) == BW.pack_blob(hp, tens)
+
+    import gen_golden_stts as G
+
+    shp, snet, voc = G.build()  # reference MatchaTTS + HiFi-GAN V1 carrying the synthetic blobs' tensors
+    voc.decode = voc.forward   # export.py:30 calls vocoder.decode(): Vocos' method; the in-tree generator is called directly (cli.py)
+    data = X.export_stts(snet, voc, n_timesteps=3)
+    hp3, t3, v3 = oi.import_stts_onnx(data)
+    shp.n_timesteps = 3
+    assert S.pack_blob(hp3, t3) == S.pack_blob(shp, S.make_synthetic_weights(shp, G.SEED))
+    vhp = W.hifigan_v1_vocoder_hparams()
+    assert W.pack_blob(*v3) == W.pack_blob(vhp, W.make_synthetic_weights(vhp, G.SEED))
+    # a foreign embedded vocoder is reported, not guessed
+    g = oi.OnnxGraph(data)
+    foreign = {("vocoder.backbone." + k[len("vocoder."):] if k.startswith("vocoder.") else k): v for k, v in g.inits.items() if v.dtype == np.float32 and v.size > 1}
+    with pytest.raises(NotImplementedError, match="Vocos"):
+        oi.import_stts_onnx(oi.write_minimal_onnx(os.path.join(os.environ.get("TMPDIR", "/tmp"), "foreign_voc.onnx"), foreign))
+
+
+def test_multistream_and_bert_files_written_by_the_minimal_writer_import(tmp_path):
+    """portable twin of the container-only test above: initializer-only files under the exporter's names"""
+    from vosk_tts_amd import onnx_import as oi
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.toymodel import multistream_dir_to_reference_layout, write_toy_multistream_model
+
+    d = write_toy_multistream_model(str(tmp_path / "ms"), with_bert=True)
+    blobs = {n: open(os.path.join(d, n), "rb").read() for n in ("model.sttsw", "vocoder.vitsw", "bert/model.bertw")}
+    multistream_dir_to_reference_layout(d)
+    assert not os.path.exists(os.path.join(d, "model.sttsw")) and os.path.exists(os.path.join(d, "bert", "model.onnx"))
+    hp, t, voc = oi.import_stts_onnx(os.path.join(d, "model.onnx"))
+    assert S.pack_blob(hp, t) == blobs["model.sttsw"] and W.pack_blob(*voc) == blobs["vocoder.vitsw"]
+    bhp, bt = oi.import_bert_onnx(os.path.join(d, "bert", "model.onnx"))
+    assert BW.pack_blob(bhp, bt) == blobs["bert/model.bertw"]
+    with pytest.raises(NotImplementedError, match="multistream"):
+        oi.import_stts_onnx(oi.write_minimal_onnx(str(tmp_path / "x.onnx"), {"enc_p.emb.weight": np.zeros((4, 4), np.float32)}))

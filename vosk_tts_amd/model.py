@@ -3,7 +3,9 @@ replaced by the MI355X-native engine.
 
 A model directory holds (reference layout, model.py:46-63):
     model.vitsw   weight blob for the HIP engine (see vosk_tts_amd/weights.py) — or the reference's model.onnx,
-                  whose initializers are imported on load (vosk_tts_amd/onnx_import.py)
+                  whose initializers are imported on load (vosk_tts_amd/onnx_import.py); multistream voices:
+                  model.sttsw + vocoder.vitsw, or their model.onnx with the vocoder embedded; bert/model.bertw or
+                  the reference's bert/model.onnx
     dictionary    word prob phonemes... ; the highest-probability pronunciation wins (model.py:48-55)
     config.json   inference defaults, phoneme_id_map, model_type, no_blank (synth.py:50-56,64,88,177)
 Attributes kept: .onnx (object with .run(None, feed)), .dic, .config, .tokenizer.
@@ -70,15 +72,25 @@ class Model:
         elif (model_path / "model.onnx").exists():
             # a reference model directory (model.py:46): pull the initializers out of the exported graph
             from . import weights as W
-            from .onnx_import import import_onnx
+            from . import onnx_import as oi
 
-            cfg = {}
+            cfg, raw = {}, {}
             if (model_path / "config.json").exists():
                 with open(model_path / "config.json") as f:
                     raw = json.load(f)
                 cfg = dict(raw.get("model", {}), **raw.get("data", {})) if isinstance(raw, dict) else {}
-            hp, tensors = import_onnx(str(model_path / "model.onnx"), cfg)
-            blob = W.pack_blob(hp, tensors)
+            if str(raw.get("model_type", "")).startswith("multistream"):
+                # StableTTS / Matcha export with the vocoder embedded (matcha/onnx/export.py:21-32)
+                from . import weights_stts as S
+                from .session_stts import SttsSession
+
+                hp, tensors, voc = oi.import_stts_onnx(str(model_path / "model.onnx"), cfg)
+                if voc is None:
+                    raise NotImplementedError("model.onnx has no embedded vocoder: a mel-only export cannot produce audio")
+                self.onnx = SttsSession(S.pack_blob(hp, tensors), W.pack_blob(*voc), device=device)
+            else:
+                hp, tensors = oi.import_onnx(str(model_path / "model.onnx"), cfg)
+                blob = W.pack_blob(hp, tensors)
         else:
             raise FileNotFoundError(f"neither {blob_path} nor model.onnx found in {model_path}")
         if not hasattr(self, "onnx"):
@@ -102,17 +114,24 @@ class Model:
         # (vosk_tts_amd/weights_bert.py) instead of bert/model.onnx
         self.tokenizer = None
         if os.path.exists(model_path / "bert/vocab.txt"):
+            bert_blob = None
             if os.path.exists(model_path / "bert/model.bertw"):
+                with open(model_path / "bert/model.bertw", "rb") as f:
+                    bert_blob = f.read()
+            elif os.path.exists(model_path / "bert/model.onnx"):  # the reference's file (model.py:62): import its initializers
+                from . import weights_bert as BW
+                from .onnx_import import import_bert_onnx
+
+                bert_blob = BW.pack_blob(*import_bert_onnx(str(model_path / "bert/model.onnx")))
+            if bert_blob is not None:
                 from tokenizers import BertWordPieceTokenizer
 
                 from .capi_stts import BertEncoder
 
                 self.tokenizer = BertWordPieceTokenizer(vocab=str(model_path / "bert/vocab.txt"), unk_token="[UNK]", lowercase=True)
-                with open(model_path / "bert/model.bertw", "rb") as f:
-                    self.bert_onnx = BertEncoder(self.onnx._lib, f.read(), device)
+                self.bert_onnx = BertEncoder(self.onnx._lib, bert_blob, device)
             else:
-                logging.warning("bert/vocab.txt found without bert/model.bertw: BERT conditioning disabled "
-                                "(convert the encoder with vosk_tts_amd.weights_bert.pack_blob)")
+                logging.warning("bert/vocab.txt found without bert/model.bertw or bert/model.onnx: BERT conditioning disabled")
 
     def get_model_path(self, model_name, lang):
         if model_name is None:

@@ -188,10 +188,21 @@ class OnnxGraph:
     @staticmethod
     def scope(module_path):
         """state_dict module path -> node-name scope: "flow.flows.0.post" -> "/flow/flows.0/post/"."""
-        out = ""
+        return OnnxGraph.scopes(module_path)[0]
+
+    @staticmethod
+    def scopes(module_path):
+        """candidate node-name scopes of a module path.  A numbered child of a ModuleList (never called itself) appears as
+        "/flows.0", one of a Sequential (called, so it has a scope of its own) as "/bert_proj/bert_proj.1"."""
+        outs = [""]
+        prev = ""
         for part in module_path.split("."):
-            out += ("." if part.isdigit() else "/") + part
-        return out + "/"
+            if part.isdigit():
+                outs = [o + "." + part for o in outs] + [o + "/" + prev + "." + part for o in outs]
+            else:
+                outs = [o + "/" + part for o in outs]
+            prev = part
+        return [o + "/" for o in outs]
 
     def _node_init(self, node_name, index=None):
         n = self._by_name.get(node_name)
@@ -210,7 +221,13 @@ class OnnxGraph:
         if a is not None:
             return a
         mod, _, leaf = name.rpartition(".")
-        sc = self.scope(mod)
+        for sc in self.scopes(mod):
+            a = self._param_in_scope(sc, leaf)
+            if a is not None:
+                return a
+        return None
+
+    def _param_in_scope(self, sc, leaf):
         if leaf == "weight":
             a = self._node_init(sc + "MatMul")  # nn.Linear: folded transpose
             if a is not None and a.ndim == 2:
@@ -229,8 +246,6 @@ class OnnxGraph:
                 return a
         elif leaf == "logs":  # ElementwiseAffine reverse (modules.py): x * exp(-logs) -> the folded constant is -logs
             a = self._node_init(sc + "Exp")
-            if a is None:
-                a = self.anonymous("Exp", (2, 1))
             if a is not None:
                 return -np.asarray(a) + 0.0  # + 0.0: -(+0) would give -0
         return None
@@ -339,6 +354,9 @@ def import_onnx(path_or_bytes, config=None):
         if a is None and name.endswith(".weight") and len(shape) == 2:  # Linear weight of an exporter without node names
             a = g.anonymous("MatMul", shape[::-1])
             a = None if a is None else np.ascontiguousarray(a.T)
+        if a is None and name.endswith(".logs"):
+            a = g.anonymous("Exp", shape)
+            a = None if a is None else -np.asarray(a) + 0.0
         if a is None:
             missing.append(name)
             continue
@@ -357,6 +375,202 @@ def convert(onnx_path, blob_path, config=None):
     hp, tensors = import_onnx(onnx_path, config)
     W.save_blob(blob_path, hp, tensors)
     return hp
+
+
+# ---------------------------------------------------------------------------------------------------
+# StableTTS / Matcha "multistream" graphs (training/stabletts/matcha/onnx/export.py) and bert/model.onnx
+# ---------------------------------------------------------------------------------------------------
+
+
+def _collect(g, prefix, specs, what):
+    """tensors of `specs` from graph `g` (state_dict names under `prefix`), loud about anything missing or misshapen"""
+    t = g.tensors()
+    out, missing, bad = {}, [], []
+    for name, shape, *_ in specs:
+        a = t.get(prefix + name)
+        if a is None:
+            a = g.param(prefix + name)
+        if a is None and name.endswith(".weight") and len(shape) == 2:
+            a = g.anonymous("MatMul", shape[::-1])
+            a = None if a is None else np.ascontiguousarray(a.T)
+        if a is None:
+            missing.append(name)
+            continue
+        a = np.asarray(a, dtype=np.float32)
+        if tuple(a.shape) != tuple(shape):
+            bad.append(f"{name}: {tuple(a.shape)} != {tuple(shape)}")
+            continue
+        out[name] = np.ascontiguousarray(a)
+    if missing or bad:
+        raise NotImplementedError(f"model.onnx does not match the {what} tensor inventory: {len(missing)} missing (e.g. {missing[:3]}), "
+                                  f"{len(bad)} with unexpected shapes (e.g. {bad[:2]})")
+    return out
+
+
+def _count(prefix_re, t):
+    import re
+
+    r = re.compile(prefix_re)
+    return len({m.group(1) for k in t for m in [r.match(k)] if m})
+
+
+def import_stts_onnx(path_or_bytes, config=None):
+    """A multistream `model.onnx` -> (SttsHParams, acoustic tensors, vocoder) where vocoder is (HParams, tensors) of a
+    vocoder-only VITSW001 blob, or None when the embedded vocoder is not the in-tree HiFi-GAN generator.
+
+    The exported module is MatchaWithVocoder (export.py:21-32): parameters sit under "matcha." and "vocoder."; a mel-only
+    export (vocoder None, :56-58) has no prefix.  Sizes come from tensor shapes; what shapes cannot tell is read off the graph:
+    n_timesteps and guidance_scale from the traced Euler loop (estimator calls, the scalar of the guidance blend), mel_std / mel_mean =
+    the scalars of the final `mel * std + mean` (matcha/utils/model.py denormalize) at "/matcha/Mul_k" -> "/matcha/Add".
+    `config` may override: n_timesteps, guidance_scale, mel_mean, mel_std, enc_heads, dec_heads, hop_length, sampling_rate,
+    upsample_rates (vocoder).  Reference's export calls `vocoder.decode(mel)` - a method the third-party Vocos has and the
+    in-tree HiFi-GAN `Generator` has not (matcha/cli.py:72-98); a Vocos / BigVGAN vocoder is reported, not imported."""
+    from . import weights_stts as S
+
+    config = config or {}
+    g = OnnxGraph(path_or_bytes)
+    t = g.tensors()
+    pre = "matcha." if any(k.startswith("matcha.") for k in t) else ""
+    root = "/matcha" if pre else ""
+
+    def need(name):
+        if pre + name not in t:
+            raise NotImplementedError(f"not a StableTTS / Matcha multistream graph: initializer {pre + name!r} not found")
+        return t[pre + name]
+
+    hp = S.default_hparams()
+    emb, punc = need("encoder.emb.weight"), need("encoder.punc_emb.weight")
+    hp.n_vocab, hp.emb_dim, hp.punc_dim = emb.shape[0], emb.shape[1], punc.shape[1]
+    hp.bert_proj_dim = need("encoder.bert_proj.1.bias").shape[0]
+    e0 = "encoder.dp_encoder.encoder.0"
+    hp.enc_hidden = need(e0 + ".attn.conv_q.weight").shape[0]
+    c1 = need(e0 + ".mlp.conv_1.weight")
+    hp.enc_filter, hp.enc_kernel = c1.shape[0], c1.shape[2]
+    hp.enc_layers = _count(r"(?:matcha\.)?encoder\.dp_encoder\.encoder\.(\d+)\.attn\.conv_q\.weight", t)
+    hp.spk_emb_dim = need(e0 + ".adaLN_modulation.0.weight").shape[1]
+    hp.dp_out = need("encoder.dp_encoder.proj.weight").shape[0]
+    hp.bert_dim = 768
+    w = g.param(pre + "encoder.bert_proj.1.weight")
+    if w is not None:
+        hp.bert_dim = w.shape[1]
+    hp.n_spks = t[pre + "spk_emb.weight"].shape[0] if pre + "spk_emb.weight" in t else 1
+    d = "decoder.estimator"
+    hp.dec_hidden = need(d + ".blocks.0.block.attn.conv_q.weight").shape[0]
+    c1 = need(d + ".blocks.0.block.mlp.conv_1.weight")
+    hp.dec_filter, hp.dec_kernel = c1.shape[0], c1.shape[2]
+    hp.dec_layers = _count(r"(?:matcha\.)?decoder\.estimator\.blocks\.(\d+)\.block\.attn\.conv_q\.weight", t)
+    hp.n_feats = need(d + ".final_proj.weight").shape[0]
+    import re
+
+    # every traced estimator call repeats the module's nodes under "<module>_k"; with classifier-free guidance there are two
+    # calls per Euler step (flow_matching.py:177-189) and a `dphi + g * (dphi - dphi_avg)`: Sub -> Mul(scalar g) -> Add
+    calls = {n[0] for n in g.nodes if re.fullmatch(re.escape(root) + r"/decoder/estimator/in_proj(_\d+)?/Conv", n[0])}
+    subs = {n[3][0] for n in g.nodes if n[1] == "Sub" and re.fullmatch(re.escape(root) + r"/decoder/Sub(_\d+)?", n[0]) and n[3]}
+    gs = []
+    for n in g.nodes:
+        if n[1] == "Mul" and re.fullmatch(re.escape(root) + r"/decoder/Mul(_\d+)?", n[0]) and any(i in subs for i in n[2]):
+            gs += [float(g._follow(i).reshape(-1)[0]) for i in n[2] if g._follow(i) is not None and g._follow(i).size == 1]
+    if gs and max(gs) - min(gs) < 1e-7:
+        hp.guidance_scale = gs[0]
+        hp.n_timesteps = len(gs)
+    elif calls:
+        hp.guidance_scale = 0.0
+        hp.n_timesteps = len(calls)
+    add = g._by_name.get(root + "/Add")  # denormalize: the last arithmetic of synthesise (matcha_tts.py:205)
+    if add is not None:
+        mean = [g._follow(i) for i in add[2] if g._follow(i) is not None and g._follow(i).size == 1]
+        prod = [n for n in g.nodes if n[3] and n[3][0] in add[2] and n[1] == "Mul"]
+        std = [g._follow(i) for n in prod for i in n[2] if g._follow(i) is not None and g._follow(i).size == 1]
+        if len(mean) == 1 and len(std) == 1:
+            hp.mel_mean, hp.mel_std = float(mean[0].reshape(-1)[0]), float(std[0].reshape(-1)[0])
+    for key in ("n_timesteps", "enc_heads", "dec_heads", "hop_length", "sampling_rate"):
+        if key in config:
+            setattr(hp, key, int(config[key]))
+    for key in ("guidance_scale", "mel_mean", "mel_std"):
+        if key in config:
+            setattr(hp, key, float(config[key]))
+    specs = S.tensor_specs(hp)
+    if hp.n_spks <= 1 and pre + "spk_emb.weight" not in t:  # single-speaker checkpoints have no speaker tables (matcha_tts.py:62-64)
+        specs = [sp for sp in specs if sp[0] not in ("spk_emb.weight", "dur_spk_emb.weight")]
+    tensors = _collect(g, pre, specs, "StableTTS")
+    for nm in ("spk_emb.weight", "dur_spk_emb.weight"):
+        tensors.setdefault(nm, np.zeros((1, hp.spk_emb_dim), np.float32))
+    tensors = {n: tensors[n] for n, *_ in S.tensor_specs(hp)}
+    # ---- embedded vocoder
+    vocoder = None
+    vnames = [k for k in t if k.startswith("vocoder.")]
+    if vnames:
+        if "vocoder.conv_pre.weight" in t and "vocoder.ups.0.weight" in t and "vocoder.conv_post.weight" in t:
+            vocoder = _import_hifigan(g, t, "vocoder.", config)
+        else:
+            fam = "Vocos" if any("backbone" in k or "head.out" in k for k in vnames) else "unknown"
+            raise NotImplementedError(f"embedded vocoder of family {fam!r} ({vnames[0]} ...): only the in-tree HiFi-GAN generator "
+                                      "(matcha/hifigan/models.py) is built; pass a mel-only export or see DESIGN.md section 8")
+    return hp, tensors, vocoder
+
+
+def _import_hifigan(g, t, pre, config):
+    """HiFi-GAN generator (matcha/hifigan/models.py:148-199, weight norm removed) -> vocoder-only VITSW001 tensors ("dec." names)"""
+    hp = W.hifigan_v1_vocoder_hparams()
+    cp = t[pre + "conv_pre.weight"]
+    hp.dec_initial_channel, hp.inter_channels = cp.shape[0], cp.shape[1]
+    ups = sorted({int(k.split(".")[2]) for k in t if k.startswith(pre + "ups.") and k.endswith(".weight")})
+    hp.n_ups = len(ups)
+    rates = config.get("upsample_rates")
+    for i in ups:
+        k = t[f"{pre}ups.{i}.weight"].shape[2]
+        hp.up_kernels[i] = k
+        hp.up_rates[i] = int(rates[i]) if rates else k // 2  # every HiFi-GAN config of the reference uses kernel = 2 x rate (hifigan/config.py)
+    n_rb = len({int(k.split(".")[2]) for k in t if k.startswith(pre + "resblocks.")})
+    hp.n_resk = n_rb // max(hp.n_ups, 1)
+    for j in range(hp.n_resk):
+        hp.res_kernels[j] = t[f"{pre}resblocks.{j}.convs1.0.weight"].shape[2]
+    hp.n_resd = sum(1 for k in t if k.startswith(pre + "resblocks.0.convs1.") and k.endswith(".weight"))
+    for j, dl in enumerate(config.get("resblock_dilation_sizes", [])):
+        for d, v in enumerate(dl):
+            hp.res_dilations[j][d] = int(v)
+    specs = [(n[len("dec."):],) + tuple(rest) for n, *rest in W.tensor_specs(hp)]
+    tensors = _collect(g, pre, specs, "HiFi-GAN vocoder")
+    return hp, {"dec." + k: v for k, v in tensors.items()}
+
+
+def import_bert_onnx(path_or_bytes, config=None):
+    """`bert/model.onnx` (matcha/onnx/bert-export.py: BertModel, output hidden_states[-3]) -> (BertHParams, tensors).
+    Constant folding prunes the two unused top layers and the pooler, so the layer count of the file IS out_layers; Linear
+    weights are folded transposes behind "/.../MatMul" nodes, LayerNorm parameters keep their names.  `config`: n_heads
+    (default hidden // 64, BERT-base), ln_eps (1e-12)."""
+    from . import weights_bert as B
+
+    config = config or {}
+    g = OnnxGraph(path_or_bytes)
+    t = g.tensors()
+    keys = [k for k in t if k.endswith("embeddings.word_embeddings.weight")]
+    if not keys:
+        raise NotImplementedError("not a BertModel export: no embeddings.word_embeddings.weight initializer")
+    pre = keys[0][: -len("embeddings.word_embeddings.weight")]
+    hp = B.base_hparams()
+    we = t[keys[0]]
+    hp.vocab_size, hp.hidden = we.shape
+    hp.max_position = t[pre + "embeddings.position_embeddings.weight"].shape[0]
+    hp.type_vocab = t[pre + "embeddings.token_type_embeddings.weight"].shape[0]
+    hp.out_layers = _count(re_escape(pre) + r"encoder\.layer\.(\d+)\.attention\.output\.LayerNorm\.weight", t)
+    hp.n_layers = hp.out_layers + 2
+    inter = g.param(pre + "encoder.layer.0.intermediate.dense.weight")
+    if inter is None:
+        inter = g.anonymous("MatMul", (hp.hidden, 4 * hp.hidden))
+        inter = None if inter is None else inter.T
+    if inter is None:
+        raise NotImplementedError("BertModel export: intermediate.dense weight not found")
+    hp.intermediate = inter.shape[0]
+    hp.n_heads = int(config.get("n_heads", max(hp.hidden // 64, 1)))
+    hp.ln_eps = float(config.get("ln_eps", 1e-12))
+    return hp, _collect(g, pre, B.tensor_specs(hp), "BertModel")
+
+
+def re_escape(s):
+    import re
+
+    return re.escape(s)
 
 
 # tiny writer used by the tests (and handy for fixtures): the inverse of read_initializers for float32 tensors

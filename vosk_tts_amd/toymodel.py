@@ -81,3 +81,27 @@ def write_toy_multistream_model(path, seed=1234, n_spks=5, inference=None, model
     if with_bert:
         write_bert_dir(os.path.join(path, "bert"), seed)
     return path
+
+
+def multistream_dir_to_reference_layout(path):
+    """Rewrite a toy multistream directory into the REFERENCE's file layout (vosk_tts/model.py:46,62): model.onnx with the
+    acoustic model under "matcha." and the HiFi-GAN generator under "vocoder." (MatchaWithVocoder, matcha/onnx/export.py:21-32),
+    bert/model.onnx; the blobs are removed.  Files come from onnx_import.write_minimal_onnx (initializers only, no graph), so
+    what the graph would tell (n_timesteps, mel statistics) stays at the defaults the toy blobs use."""
+    from . import onnx_import as oi
+    from . import weights_bert as BW
+    from . import weights_stts as S
+
+    _hp, t = W.unpack_blob_generic(open(os.path.join(path, "model.sttsw"), "rb").read(), S.SttsHParams, S.MAGIC)
+    _vhp, vt = W.unpack_blob(open(os.path.join(path, "vocoder.vitsw"), "rb").read())
+    tensors = {"matcha." + k: v for k, v in t.items()}
+    tensors.update({"vocoder." + k[len("dec."):]: v for k, v in vt.items()})
+    oi.write_minimal_onnx(os.path.join(path, "model.onnx"), tensors)
+    os.remove(os.path.join(path, "model.sttsw"))
+    os.remove(os.path.join(path, "vocoder.vitsw"))
+    b = os.path.join(path, "bert", "model.bertw")
+    if os.path.exists(b):
+        _bhp, bt = W.unpack_blob_generic(open(b, "rb").read(), BW.BertHParams, BW.MAGIC)
+        oi.write_minimal_onnx(os.path.join(path, "bert", "model.onnx"), bt)
+        os.remove(b)
+    return path

@@ -378,12 +378,17 @@ def pack_blob(hp, tensors, magic=MAGIC):
 
 
 def unpack_blob(blob):
-    if blob[:8] != MAGIC:
-        raise ValueError("not a VITSW001 blob")
+    return unpack_blob_generic(blob, HParams, MAGIC)
+
+
+def unpack_blob_generic(blob, hp_type, magic):
+    """(hparams struct, {name: ndarray}) of any blob of this container family (VITSW001 / STTSW001 / BERTW001)"""
+    if blob[:8] != magic:
+        raise ValueError(f"not a {magic.decode()} blob")
     (hb,) = struct.unpack_from("<I", blob, 8)
-    if hb != ctypes.sizeof(HParams):
+    if hb != ctypes.sizeof(hp_type):
         raise ValueError("hparams size mismatch")
-    hp = HParams.from_buffer_copy(blob[12:12 + hb])
+    hp = hp_type.from_buffer_copy(blob[12:12 + hb])
     (n,) = struct.unpack_from("<I", blob, 12 + hb)
     pos = 16 + hb
     tensors = {}
