@@ -103,6 +103,8 @@ struct vits_model {
   vits_hparams hp;
   int device = 0;
   std::vector<void*> allocs;
+  char* slab = nullptr;  // current weight slab (weight_alloc)
+  size_t slab_bytes = 0, slab_used = 0;
   const unsigned char* blob = nullptr;  // only during create
   size_t blob_bytes = 0;
   uint32_t n_entries = 0;
@@ -161,11 +163,41 @@ static bool thas(const vits_model* m, const char* name) {  // optional tensors
   return false;
 }
 
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Weights live in a few large slabs (bump allocation, 256-byte aligned) instead of one hipMalloc per tensor: 2 MB-fragment
+// mappings, a layer's tensors adjacent, ~470 fewer allocations per model.  (Measured: no effect on the forward's time, so
+// address translation of the small per-tensor allocations was not what bounds the short-utterance kernels.)
+static void* weight_alloc(vits_model* m, size_t bytes) {
+  static const bool no_slab = getenv("VITS_NO_SLAB") != nullptr;  // A/B switch for tools/
+  bytes = align_up(bytes ? bytes : 4, 256);
+  if (no_slab) {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    m->allocs.push_back(d);
+    return d;
+  }
+  if (m->slab_used + bytes > m->slab_bytes) {
+    size_t want = m->blob_bytes + m->blob_bytes / 4 + ((size_t)8 << 20);  // first slab: the whole model with packing slack
+    if (!m->allocs.empty()) want = (size_t)32 << 20;
+    if (want < bytes) want = bytes;
+    want = align_up(want, (size_t)2 << 20);
+    void* d = nullptr;
+    if (hipMalloc(&d, want) != hipSuccess) return nullptr;
+    m->allocs.push_back(d);
+    m->slab = static_cast<char*>(d);
+    m->slab_bytes = want;
+    m->slab_used = 0;
+  }
+  void* p = m->slab + m->slab_used;
+  m->slab_used += bytes;
+  return p;
+}
+
 static float* upload(vits_model* m, const float* host, size_t n) {
   if (!host) return nullptr;
-  void* d = nullptr;
-  if (hipMalloc(&d, (n ? n : 1) * sizeof(float)) != hipSuccess) { m->missing = true; fail(VITS_ERR_NOMEM, "hipMalloc of %zu floats failed", n); return nullptr; }
-  m->allocs.push_back(d);
+  void* d = weight_alloc(m, n * sizeof(float));
+  if (!d) { m->missing = true; fail(VITS_ERR_NOMEM, "hipMalloc of %zu floats failed", n); return nullptr; }
   if (hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { m->missing = true; fail(VITS_ERR_DEVICE, "hipMemcpy H2D failed"); return nullptr; }
   return static_cast<float*>(d);
 }
@@ -490,9 +522,9 @@ struct vits_session {
   // session, so a steady stream of vits_synthesize calls does no hipMalloc / hipFree (both synchronise the device)
   char* stage = nullptr;
   size_t stage_bytes = 0, stage_used = 0;
+
 };
 
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
 static T* bump(vits_session* s, size_t n) {
@@ -682,12 +714,13 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo) {
   P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
   const size_t lds = (size_t)4 * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
+  const dim3 grid(nblk);
   if (EPI == EPI_STORE && MI * NI == 1 && P.x_split)
-    hipLaunchKernelGGL((conv_mfma_ks_kernel<1, 1, EPI_STORE, 2>), dim3(nblk), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv_mfma_ks_kernel<1, 1, EPI_STORE, 2>), grid, dim3(256), lds, st, P);
   else if (EPI == EPI_STORE && P.g[0].x2)
-    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, (EPI == EPI_STORE ? 3 : 1)>), dim3(nblk), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, (EPI == EPI_STORE ? 3 : 1)>), grid, dim3(256), lds, st, P);
   else
-    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, 1>), dim3(nblk), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, 1>), grid, dim3(256), lds, st, P);
 }
 
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
