@@ -87,3 +87,38 @@ def assert_close(name, ref, got, rtol, atol_frac=None):
     err = np.abs(ref - got).max()
     assert err <= rtol * max(scale, 1e-30), f"{name}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / max(scale, 1e-30):.3e} > {rtol})"
     return err / max(scale, 1e-30)
+
+
+def load_reference_mas():
+    """the reference's own compiled MAS core (oracle/_ref/mas/, built by __graft_entry__.build() where /root/reference exists;
+    the .so travels to the GPU box) or None"""
+    import glob
+    import importlib.util
+
+    so = glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "mas", "core*.so"))
+    if not so:
+        return None
+    spec = importlib.util.spec_from_file_location("core", so[0])
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    except ImportError:
+        return None
+    return mod
+
+
+def random_mas_cases(seed):
+    """[(values float32 [B,Ty,Tx], t_ys int32 [B], t_xs int32 [B])]: ragged extents, t_x == t_y, one token, quantised scores (ties)"""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    cases = []
+    for B, Ty, Tx in ((1, 1, 1), (3, 17, 5), (4, 64, 23), (2, 130, 130), (5, 257, 40)):
+        v = rng.standard_normal((B, Ty, Tx)).astype(np.float32)
+        if B == 4:
+            v = np.round(v * 2) / 2  # exact ties
+        t_xs = rng.integers(1, Tx + 1, size=B).astype(np.int32)
+        t_ys = np.array([rng.integers(tx, Ty + 1) for tx in t_xs], np.int32)
+        t_xs[0], t_ys[0] = Tx, Ty
+        cases.append((v, t_ys, t_xs))
+    return cases

@@ -410,6 +410,15 @@ def test_monotonic_alignment_search(hip_lib, oracle_lib):
 
     with pytest.raises(VitsError):
         hip_lib.mas_maximum_path(values, t_ys + 5000, t_xs)
+    # and directly against the reference's compiled core (oracle/_ref/mas travels to the GPU box with the snapshot)
+    from conftest import load_reference_mas, random_mas_cases
+
+    ref = load_reference_mas()
+    if ref is not None:
+        for v, ty, tx in random_mas_cases(92):
+            want_ref = np.zeros(v.shape, np.int32)
+            ref.maximum_path_c(want_ref, v.copy(), ty, tx)
+            assert np.array_equal(hip_lib.mas_maximum_path(v, ty, tx), want_ref), v.shape
 
 
 def test_long_form_properties_at_c5_size(hip_default):

@@ -124,6 +124,20 @@ def test_monotonic_alignment_search(oracle_lib):
         oracle_lib.mas_maximum_path(v, g["t_ys"] + 1000, g["t_xs"])
 
 
+def test_monotonic_alignment_search_vs_the_compiled_reference(oracle_lib):
+    """oracle/_ref/mas: the reference's own core.pyx compiled from /root/reference (build()); the restatement must agree bit
+    for bit on random ragged batches, including what it does to `values` (the reference accumulates in place; ours does not)"""
+    from conftest import load_reference_mas, random_mas_cases
+
+    ref = load_reference_mas()
+    if ref is None:
+        pytest.skip("oracle/_ref/mas not built (no /root/reference at build time)")
+    for v, t_ys, t_xs in random_mas_cases(91):
+        want = np.zeros(v.shape, np.int32)
+        ref.maximum_path_c(want, v.copy(), t_ys, t_xs)
+        assert np.array_equal(oracle_lib.mas_maximum_path(v, t_ys, t_xs), want), v.shape
+
+
 def test_constants(oracle_lib, oracle_default):
     import ctypes
 
