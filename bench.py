@@ -76,6 +76,30 @@ def stts_algorithmic_flops(hp, voc_model, Tx, Ty, n_steps):
     return Tx * (tok + tok_quad * Tx) + Ty * (frame + nb * n_steps * est_quad * Ty) + voc_model.algorithmic_flops(1, 0, Ty)
 
 
+_EPI_NAMES = {"0": "STORE", "1": "GATE", "2": "RESSKIP", "3": "COUPLE"}
+
+
+def rocprof_avg_us(csv_path, kernel):
+    """AverageNs of `kernel` (the engine's name, e.g. conv_mfma_ks_kernel<1,1,STORE,1>) in a rocprofv3 kernel_stats.csv, or None"""
+    import csv
+    import re
+
+    if not os.path.exists(csv_path):
+        return None
+    with open(csv_path, newline="") as f:
+        for row in csv.DictReader(f):
+            m = re.match(r"(?:void )?(\w+)<([^>]*)>", row.get("Name", ""))
+            if not m:
+                continue
+            args = [a.strip() for a in m.group(2).split(",")]
+            epi_pos = 2 if m.group(1) == "conv_mfma_ks_kernel" else 4 if m.group(1) == "conv_mfma_kernel" else None
+            if epi_pos is not None and epi_pos < len(args):
+                args[epi_pos] = _EPI_NAMES.get(args[epi_pos], args[epi_pos])
+            if f"{m.group(1)}<{','.join(args)}>" == kernel:
+                return round(float(row["AverageNs"]) / 1e3, 2)
+    return None
+
+
 def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=False):
     """configs[1]-shaped single utterance on the StableTTS / Matcha family: 50 symbols, 3 frames per
     symbol pinned through phone_duration_extra, 5 Euler steps with guidance, bundled HiFi-GAN V1 vocoder; host entry point
@@ -352,6 +376,14 @@ def main():
             "by_op_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])
                              if v[2] > 0 and v[1] > 0},
         }
+
+        # The event brackets above include the dispatch of the bracketed launch (~2.5 us at B=1); rocprofv3 --kernel-trace --stats
+        # reports kernel begin -> end.  The committed summary of this workload's run is quoted beside the live figure.
+        prof_csv = os.path.join(ROOT, "profiles", f"r1_{wname}_only_bench_rocprofv3_kernel_stats.csv")
+        if not os.path.exists(prof_csv) and wname in ("c2", "c3"):  # the default command runs the c2 and the c3 leg
+            prof_csv = os.path.join(ROOT, "profiles", "r1_default_bench_rocprofv3_kernel_stats.csv")
+        roofline["avg_launch_us_rocprofv3"] = rocprof_avg_us(prof_csv, dom_name)
+        roofline["rocprofv3_summary"] = os.path.relpath(prof_csv, ROOT) if roofline["avg_launch_us_rocprofv3"] is not None else None
 
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected
         # by tools/pmc_passes.sh (separate rocprofv3 --pmc passes of THIS command, FETCH_SIZE/WRITE_SIZE calibrated with
