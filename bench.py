@@ -417,7 +417,7 @@ def main():
                    "x_realtime": round(1.0 / R3["rtf"], 1), "batch": R3["B"], "T_x": R3["Tx"], "T_y": R3["Ty"],
                    "samples_per_step_per_gpu": R3["valid_samples"],
                    "workload": "c3: B=32 ragged 20..200 tokens padded, durations pinned 3/token, fp32",
-                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_gbps_at_avg_launch", "kernel", "avg_launch_us", "forward") if k in R3["roofline"]}}
+                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_gbps_at_avg_launch", "kernel", "avg_launch_us", "avg_launch_us_rocprofv3", "rocprofv3_summary", "forward") if k in R3["roofline"]}}
 
     streaming = None
     if args.workload == "c5" and rank == 0:
