@@ -525,8 +525,10 @@ __global__ void __launch_bounds__(256, 2) relpos_attention_mfma_kernel(const flo
   float qf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) qf[s] = qb[(long long)(2 * s + h) * T + ic] * scale;
+  // ek == nullptr: plain scaled-dot-product attention (StableTTS DiT blocks, BERT) -- no relative-position work at all
+  const bool rel = ek != nullptr;
   // QE^T[r][q] (attentions.py:175-177): A = E_k[r = l31][d = 2s + h]
-  {
+  if (rel) {
     f32x16 qe;
 #pragma unroll
     for (int e = 0; e < 16; ++e) qe[e] = 0.f;
@@ -587,7 +589,7 @@ __global__ void __launch_bounds__(256, 2) relpos_attention_mfma_kernel(const flo
     // next tile's K fragments fly under the softmax and the PV MFMAs
     if (jt + 4 < ntiles) load_k(jt + 4);
     // ---- relative-key bias on the diagonal band, key mask, tile max
-    const bool near = (j0 + 31 >= i0 - W) && (j0 <= i0 + 31 + W);
+    const bool near = rel && (j0 + 31 >= i0 - W) && (j0 <= i0 + 31 + W);
     float mx = -3.0e38f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {

@@ -1,6 +1,6 @@
 // stts.hip.h — StableTTS / Matcha ("multistream") inference on the MI355X, C ABI of include/stts_mi355.h.
 // Included at the end of engine.hip: the contractions (1x1 / k=3 convs, fused qkv, cond_proj, long-skip convs) run on
-// the shared fp32-MFMA conv kernels, attention on relpos_attention_mfma_kernel with an all-zero relative table (RoPE is
+// the shared fp32-MFMA conv kernels, attention on relpos_attention_mfma_kernel without relative tables (RoPE is
 // applied to q/k beforehand), the adaLN / FiLM / Euler glue on the small kernels at the end of kernels_misc.hip.h.
 // Reference citations are relative to /root/reference/training/stabletts/matcha/.
 #include "../../include/stts_mi355.h"
@@ -124,10 +124,10 @@ static void stts_attention(vits_session* s, const stts_model* m, const float* qk
   ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T, "relpos_attention_mfma_kernel");
   dim3 grid(cdiv(T, 32), nh, B);
   const size_t lds = (size_t)4 * (dk * 33 + 10 * 32 + 9 * 32) * sizeof(float);
-  // window 4 with all-zero relative key/value tables: the banded terms add exactly 0 (F.scaled_dot_product_attention has none)
-  if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), grid, dim3(256), lds, s->stream, qkv, m->zero_vec, m->zero_vec, len, out, H, T, 4);
-  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), grid, dim3(256), lds, s->stream, qkv, m->zero_vec, m->zero_vec, len, out, H, T, 4);
-  else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), grid, dim3(256), lds, s->stream, qkv, m->zero_vec, m->zero_vec, len, out, H, T, 4);
+  // null relative tables: the kernel skips the banded relative-position terms (F.scaled_dot_product_attention has none)
+  if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), grid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, len, out, H, T, 4);
+  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), grid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, len, out, H, T, 4);
+  else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), grid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, len, out, H, T, 4);
 }
 
 struct DitScratch { float *hn, *qkv, *att, *ffh; };
@@ -777,12 +777,12 @@ int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* leng
 // ================================================================== word-embedding BERT encoder (include/stts_mi355.h)
 // transformers.BertModel up to hidden_states[-3] on the same kernels: tokens are columns ([H, T] channel-major), every
 // Linear is a 1x1 conv launch (q/k/v fused, GELU in the intermediate conv's epilogue), self-attention is the MFMA flash
-// kernel with a zero relative table, residual + LayerNorm(eps) is layernorm_c_kernel(a + b).
+// kernel without relative tables, residual + LayerNorm(eps) is layernorm_c_kernel(a + b).
 struct BertLayerW { ConvW qkv, o, c1, c2; float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; };
 struct bert_model {
   vits_model base;
   bert_hparams hp;
-  float *we = nullptr, *pe = nullptr, *te = nullptr, *eg = nullptr, *eb = nullptr, *zero_rel = nullptr;
+  float *we = nullptr, *pe = nullptr, *te = nullptr, *eg = nullptr, *eb = nullptr;
   std::vector<BertLayerW> layers;
 };
 
@@ -806,7 +806,6 @@ static int bert_load(bert_model* m) {
   m->te = upload(b, tget(b, 2, hp.type_vocab, H, -1, "embeddings.token_type_embeddings.weight"), (size_t)hp.type_vocab * H);
   m->eg = upload(b, tget(b, 1, H, -1, -1, "embeddings.LayerNorm.weight"), H);
   m->eb = upload(b, tget(b, 1, H, -1, -1, "embeddings.LayerNorm.bias"), H);
-  { std::vector<float> z(9 * 96, 0.f); m->zero_rel = upload(b, z.data(), z.size()); }
   char nm[200];
   for (int l = 0; l < hp.out_layers && !b->missing; ++l) {
     BertLayerW L;
@@ -911,9 +910,9 @@ int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, in
   for (const BertLayerW& L : m->layers) {
     ConvParams P = conv_params(L.qkv, x, qkv, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.qkv");
-    if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
-    else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
-    else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), agrid, dim3(256), lds, s->stream, qkv, m->zero_rel, m->zero_rel, d_len, att, H, T, 4);
+    if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), agrid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, d_len, att, H, T, 4);
+    else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), agrid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, d_len, att, H, T, 4);
+    else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), agrid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, d_len, att, H, T, 4);
     P = conv_params(L.o, att, y, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.o");
     { LNParams Q{y, x, nullptr, x, L.g1, L.b1, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr}; launch_layernorm(s->stream, Q, 1); }  // LayerNorm(dense(ctx) + x)
