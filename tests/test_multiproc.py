@@ -88,3 +88,19 @@ def test_two_process_replicas_match_single_process(tmp_path, oracle_lib, tiny_bl
         # compare the part no padding can reach (receptive field < 25 frames)
         safe = max(0, (len(req) * 2 - 25)) * 256
         np.testing.assert_allclose(audio[:safe], want[0, :safe], rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
+
+
+def test_bench_reads_rocprofv3_kernel_stats(tmp_path):
+    """bench.rocprof_avg_us maps the engine's kernel names (EPI by name) onto the template arguments rocprofv3 prints"""
+    import bench
+
+    p = tmp_path / "k.csv"
+    p.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                 '"void conv_mfma_ks_kernel<1, 1, 0, 1>(ConvParams)",10,158400,15840.4,50.0,1,2,3\n'
+                 '"void conv_mfma_kernel<2, 2, 2, 2, 0>(ConvParams)",5,5630300,1126060.0,43.0,1,2,3\n'
+                 '"void conv_mfma_ks_kernel<2, 1, 1, 1>(ConvParams)",16,271000,16954.5,7.0,1,2,3\n')
+    assert bench.rocprof_avg_us(str(p), "conv_mfma_ks_kernel<1,1,STORE,1>") == 15.84
+    assert bench.rocprof_avg_us(str(p), "conv_mfma_kernel<2,2,2,2,STORE>") == 1126.06
+    assert bench.rocprof_avg_us(str(p), "conv_mfma_ks_kernel<2,1,GATE,1>") == 16.95
+    assert bench.rocprof_avg_us(str(p), "conv_mfma_ks_kernel<1,1,COUPLE,1>") is None
+    assert bench.rocprof_avg_us(str(tmp_path / "absent.csv"), "x") is None

@@ -209,3 +209,42 @@ def test_multistream_and_bert_files_written_by_the_minimal_writer_import(tmp_pat
     assert BW.pack_blob(bhp, bt) == blobs["bert/model.bertw"]
     with pytest.raises(NotImplementedError, match="multistream"):
         oi.import_stts_onnx(oi.write_minimal_onnx(str(tmp_path / "x.onnx"), {"enc_p.emb.weight": np.zeros((4, 4), np.float32)}))
+
+
+def test_node_scope_candidates():
+    """module path -> node-name scopes as the TorchScript exporter writes them: a numbered child of a ModuleList keeps the
+    list's name ("/flows.0"), one of a Sequential sits inside the Sequential's own scope ("/bert_proj/bert_proj.1")"""
+    from vosk_tts_amd.onnx_import import OnnxGraph
+
+    assert OnnxGraph.scope("flow.flows.0.post") == "/flow/flows.0/post/"
+    assert "/matcha/encoder/bert_proj/bert_proj.1/" in OnnxGraph.scopes("matcha.encoder.bert_proj.1")
+    assert "/enc_p/encoder/norm_layers_1.3/" in OnnxGraph.scopes("enc_p.encoder.norm_layers_1.3")
+    assert OnnxGraph.scopes("dp.pre") == ["/dp/pre/"]
+
+
+def test_wire_reader_roundtrips_random_tensors():
+    """property test of the hand-rolled protobuf reader against the independent minimal writer: random names, ranks, shapes
+    (incl. zero-sized and scalar tensors), raw_data and float_data encodings"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from vosk_tts_amd import onnx_import as oi
+
+    shapes = st.lists(st.integers(0, 5), min_size=0, max_size=4)
+    names = st.text(alphabet="abcdefghijklmnopqrstuvwxyz._0123456789:", min_size=1, max_size=40)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.dictionaries(names, shapes, min_size=1, max_size=6), st.integers(0, 2**31 - 1))
+    def check(spec, seed):
+        import tempfile
+
+        rng = np.random.default_rng(seed)
+        tens = {k: rng.standard_normal(tuple(v)).astype(np.float32) for k, v in spec.items()}
+        floaty = {k for i, k in enumerate(tens) if i % 2 and tens[k].size}
+        with tempfile.TemporaryDirectory() as d:
+            got = oi.read_initializers(oi.write_minimal_onnx(os.path.join(d, "m.onnx"), tens, use_float_data=floaty))
+        assert set(got) == set(tens)
+        for k in tens:
+            assert got[k].shape == tens[k].shape and np.array_equal(got[k], tens[k]), k
+
+    check()

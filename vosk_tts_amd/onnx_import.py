@@ -600,7 +600,7 @@ def write_minimal_onnx(path, tensors, use_float_data=(), nodes=()):
         graph += _enc_field(1, 2, b"".join(_enc_field(1, 2, i.encode()) for i in ins) + b"".join(_enc_field(2, 2, o.encode()) for o in outs)
                             + _enc_field(3, 2, name.encode()) + _enc_field(4, 2, op.encode()))
     for name, a in tensors.items():
-        a = np.ascontiguousarray(a, dtype="<f4")
+        a = np.asarray(a, dtype="<f4")  # (ascontiguousarray would turn a 0-d tensor into [1])
         tp = b"".join(_enc_field(1, 0, int(d)) for d in a.shape) + _enc_field(2, 0, 1) + _enc_field(8, 2, name.encode())
         if name in use_float_data:
             tp += _enc_field(4, 2, a.tobytes())
