@@ -169,6 +169,16 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths,
                     float** out_audio, int64_t* out_samples, int64_t* out_lengths);
 void vits_free_output(float* p);
 
+/* The same call with the tail of Synth.synth_audio (vosk_tts/synth.py:127-130) done on the device:
+ * pcm = int16(clip(audio * pcm_scale * 32767, -32767, 32767))  (audio_float_to_int16, synth.py:16-23; numpy's astype
+ * truncates toward zero like a C cast).  Half the bytes over PCIe and no host pass over the samples.
+ * *out_pcm is a library-owned int16 [B, *out_samples] buffer, released with vits_free_pcm16. */
+int vits_synthesize_pcm16(vits_model* m, const int64_t* ids, const int64_t* lengths,
+                          int32_t B, int32_t T_x, const float* scales, const int64_t* sid,
+                          const vits_synth_opts* opts, float pcm_scale,
+                          int16_t** out_pcm, int64_t* out_samples, int64_t* out_lengths);
+void vits_free_pcm16(int16_t* p);
+
 /* ---- streaming synthesis of one utterance --------------------------------------------------
  * BASELINE.json configs[4] ("long-form streaming synthesis, chunked flow+vocoder") and the transport the reference
  * already declares: `rpc ... returns (stream AudioChunk)` (server/tts_service.proto:46-54,91-95; tts_server.py:54
@@ -217,6 +227,9 @@ int vits_session_sync(vits_session* s);
 /* use_graph: replay the forward as a cached hipGraph (default 1).  profile: run eagerly and
  * bracket every kernel launch with HIP events (for vits_session_profile_report). */
 int vits_session_set_options(vits_session* s, int use_graph, int profile);
+/* on != 0: run the stochastic duration predictor even when durations are forced (its logw is then unused): lets a
+ * fixed-work benchmark time the whole of SynthesizerTrn.infer instead of skipping rows a6-a9. */
+int vits_session_set_sdp_always(vits_session* s, int on);
 /* Per-kernel-family totals of the profiled forwards since the last report, one line per family:
  * "<op-name> <kernel-instantiation> <launches> <total_ms> <algorithmic_flops>". */
 int vits_session_profile_report(vits_session* s, char* buf, size_t cap);
@@ -257,6 +270,13 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
 void vits_debug_force_tile(int mode);
 /* Test hook: 0 = fp32-MFMA flash attention (default), 1 = the scalar-VALU attention kernel. */
 void vits_debug_attention_impl(int impl);
+/* Test hook: 1 (default) = vits_synthesize replays captured hipGraphs over bucketed shapes when no noise tensor is
+ * injected; 0 = always the eager path (one launch per kernel, exact-size workspace).  Both give the same samples. */
+void vits_debug_fast_path(int on);
+/* Test hook: waves per workgroup of the K-split conv kernel: 0 = size heuristic (default), 4 / 8 / 16 forced. */
+void vits_debug_ks_waves(int nw);
+/* Test hook: 0 = fused exp/sin + iSTFT + PQMF tail kernel (default), 1 = the separate istft / pqmf kernels. */
+void vits_debug_tail_impl(int impl);
 /* Test hook: fill every newly laid-out workspace with NaN bit patterns (stale-padding detector). */
 void vits_debug_poison_workspace(int on);
 

@@ -83,6 +83,65 @@ def test_conv1d_randomised_shapes_on_every_kernel(hip_lib, oracle_lib, mode):
         hip_lib.lib.vits_debug_force_tile(0)
 
 
+@pytest.mark.parametrize("nw", [4, 8, 16])
+def test_ksplit_kernel_wave_counts(hip_lib, hip_default, hip_tiny, oracle_lib, oracle_default, oracle_tiny, nw):
+    """The K-split kernel splits the contraction over 4, 8 or 16 waves at tap granularity (launch heuristic:
+    engine.hip ks_pick_waves).  Force each wave count on the K-split kernel: random conv shapes (fewer taps than waves,
+    taps not a multiple of the wave count, 1..11 taps) and every epilogue through the stage fixtures."""
+    from vosk_tts_amd.capi import op_conv1d
+
+    rng = np.random.default_rng(700 + nw)
+    hip_lib.lib.vits_debug_force_tile(2)
+    hip_lib.lib.vits_debug_ks_waves(nw)
+    try:
+        for _ in range(16):
+            K = int(rng.choice([1, 2, 3, 5, 7, 11]))
+            dil = min(int(rng.integers(1, max(1, 50 // max(K - 1, 1)) + 1)) if K > 1 else 1, 9)
+            Cin = 16 * int(rng.integers(1, 17))
+            Cout = int(rng.choice([1, 29, 32, 72, 96, 192, 384]))
+            T = int(rng.choice([1, 31, 33, 50, 150, 600]))
+            B = int(rng.integers(1, 3))
+            slope = float(rng.choice([1.0, 0.1]))
+            x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+            w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+            bias = rng.standard_normal(Cout).astype(np.float32)
+            want = op_conv1d(oracle_lib, x, w, bias, dil, slope)
+            got = op_conv1d(hip_lib, x, w, bias, dil, slope)
+            assert_close(f"conv1d nw={nw} B={B} Cin={Cin} Cout={Cout} T={T} K={K} dil={dil}", want, got, 2e-5)
+        _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)
+        _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
+    finally:
+        hip_lib.lib.vits_debug_force_tile(0)
+        hip_lib.lib.vits_debug_ks_waves(0)
+
+
+def test_fused_tail_kernel_equals_separate_istft_and_pqmf(hip_lib, hip_default, oracle_default):
+    """exp/sin + iSTFT + PQMF in one launch (default) vs the two separately written kernels: dense, several block
+    boundaries (T_y = 70 -> 4480 sub-band samples = 18 blocks), and a ragged batch through the full path."""
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal((2, 192, 70)).astype(np.float32)
+    a_ref, mb_ref = oracle_default.decoder(z)
+    try:
+        for impl in (1, 0):
+            hip_lib.lib.vits_debug_tail_impl(impl)
+            a, mb = hip_default.decoder(z)
+            assert_close(f"audio_mb tail impl {impl}", mb_ref, mb, STAGE_TOL)
+            assert_close(f"audio tail impl {impl}", a_ref, a, STAGE_TOL)
+        ids, lengths = _synthetic_batch(rng, 3, 5, 40)
+        dur = rng.integers(1, 4, size=ids.shape).astype(np.int32)
+        sid = np.array([1, 2, 3], np.int64)
+        got = []
+        for impl in (1, 0):
+            hip_lib.lib.vits_debug_tail_impl(impl)
+            got.append(hip_default.synthesize(ids, lengths, [0.667, 1.0, 0.8], sid, forced_durations=dur, seed=4))
+        assert np.array_equal(got[0][1], got[1][1])
+        assert_close("ragged batch, fused vs separate tail", got[0][0], got[1][0], 1e-5)
+        for b in range(3):  # defined zeros beyond len + 32 frames on both
+            assert np.all(got[1][0][b, int(got[1][1][b]) + 33 * 256:] == 0.0)
+    finally:
+        hip_lib.lib.vits_debug_tail_impl(0)
+
+
 def test_conv1d_is_transpose_detecting(hip_lib, oracle_lib):
     """asymmetric weights: identity on channel c -> output row c only (catches swapped C/D layout)."""
     from vosk_tts_amd.capi import op_conv1d
@@ -270,6 +329,81 @@ def test_c3_shaped_ragged_batch_parity(hip_default, oracle_default):
     # ragged decode: nothing is computed past len + 32 frames, and what lies beyond is defined (zeros)
     for b in range(B):
         assert np.all(a_hip[b, int(l_hip[b]) + 33 * 256:] == 0.0)
+
+
+def _bench_workload(name, rank=0, world=1):
+    """exactly what bench.py times: make_workload with the bench's rng seed"""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench.make_workload(name, np.random.default_rng(1234), rank, world)
+
+
+def _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, n_oracle_items, seed):
+    """A full-size ragged batch (B = 32, up to 200 tokens / 600 frames) through vits_synthesize with the bench's pinned
+    durations.  The oracle cannot run the whole batch in seconds, so (the decoder has no masks, an item of a
+    padded batch differs from its solo run only within the decoder's receptive field of its end): a few items (shortest,
+    longest, two mid) are compared with the oracle's run of that item alone on the samples at least 32 frames before the
+    item's end; the longest item -- whose end is the batch's end -- on all samples; all other items through the
+    size-independent properties: finite, exact lengths, defined zeros beyond len + 32 frames, and equality with the same
+    item synthesized in a different batch composition (first half of the batch alone)."""
+    B, Tx = ids.shape
+    hop = 256
+    sid = np.full(B, 2, np.int64)
+    scales = np.array([0.8, 1.0, 0.8], np.float32)
+    ylens = dur.sum(1).astype(np.int64)
+    a_hip, l_hip = hip_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=seed)
+    assert np.array_equal(l_hip, ylens * hop) and a_hip.shape == (B, int(ylens.max()) * hop)
+    assert np.isfinite(a_hip).all()
+    for b in range(B):
+        assert np.all(a_hip[b, (int(ylens[b]) + 33) * hop:] == 0.0)
+        assert np.abs(a_hip[b, :int(ylens[b]) * hop]).max() > 1e-4
+    order = np.argsort(ylens)
+    picks = sorted({int(order[0]), int(order[-1]), int(order[B // 3]), int(order[2 * B // 3])})[:n_oracle_items]
+    # the oracle runs item b alone with the SAME noise the batch drew for it: Philox stream rows are (b*I + c), so build the
+    # batch's prior noise for that item by a 1-item call is not possible -> inject explicit noise on both sides instead
+    rng = np.random.default_rng(seed)
+    noise = rng.standard_normal((B, 192, int(ylens.max()))).astype(np.float32)
+    a_inj, _ = hip_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+    for b in picks:
+        L, Ty = int(lengths[b]), int(ylens[b])
+        a_ref, l_ref = oracle_default.synthesize(ids[b:b + 1, :L], lengths[b:b + 1], scales, sid[b:b + 1],
+                                                 noise_prior=noise[b:b + 1, :, :Ty], forced_durations=dur[b:b + 1, :L])
+        assert int(l_ref[0]) == Ty * hop
+        n = Ty * hop if Ty == int(ylens.max()) else max(Ty - 32, 0) * hop
+        assert_close(f"item {b} (T_x={L}, T_y={Ty}) vs oracle solo run", a_ref[0, :n], a_inj[b, :n], E2E_TOL)
+    # batch-composition independence below len - 32 frames (padded-batch semantics only touch an item's tail)
+    half = B // 2
+    Txh = int(lengths[:half].max())
+    a_half, l_half = hip_default.synthesize(ids[:half, :Txh], lengths[:half], scales, sid[:half],
+                                            noise_prior=noise[:half, :, :int(ylens[:half].max())], forced_durations=dur[:half, :Txh])
+    for b in range(half):
+        n = max(int(ylens[b]) - 32, 0) * hop
+        assert_close(f"item {b}: batch of {B} vs batch of {half}", a_half[b, :n], a_inj[b, :n], 1e-5)
+    return a_hip
+
+
+def test_c3_full_size_batch_parity(hip_default, oracle_default):
+    """BASELINE configs[2] at full size: the exact batch bench.py times as "c3" (B = 32, 20..200 tokens, 3 frames/token)."""
+    ids, lengths, dur = _bench_workload("c3")
+    assert ids.shape[0] == 32 and 20 <= lengths.min() and lengths.max() <= 200
+    _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 4, seed=7)
+
+
+def test_c4_shard_parity(hip_default, oracle_default):
+    """BASELINE configs[3]: 256 requests sharded over 8 GPUs by plan_shards; rank 3's shard of 32 through the same path."""
+    ids, lengths, dur = _bench_workload("c4", rank=3, world=8)
+    assert ids.shape[0] == 32
+    _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 3, seed=11)
+    # the shards partition the request list: every request appears in exactly one shard
+    from vosk_tts_amd.batching import plan_shards
+
+    all_len = np.random.default_rng(1234).integers(20, 201, size=256)
+    shards = plan_shards(all_len, 8, max_batch=32)
+    assert sorted(int(i) for sh in shards for i in sh) == list(range(256))
 
 
 def test_ragged_batch_with_poisoned_workspace(hip_lib, default_blob, oracle_default):
@@ -500,3 +634,86 @@ def test_solo_batch_items_equal_their_single_utterance_calls(hip_default, oracle
     assert wl[0] == olen[1]
     assert_close("item 1 vs oracle", want[0], audio[1, :olen[1]], E2E_TOL)
     assert plen.shape == olen.shape  # default semantics still run (different noise rows, so no sample comparison)
+
+
+# ----------------------------------------------------------------------------------- vits_synthesize fast path
+def _both_paths(hip_lib, fn):
+    """fn() through the graph-replayed fast path and through the eager path"""
+    out = []
+    try:
+        for on in (1, 0):
+            hip_lib.lib.vits_debug_fast_path(on)
+            out.append(fn())
+    finally:
+        hip_lib.lib.vits_debug_fast_path(1)
+    return out
+
+
+def test_fast_path_equals_eager_path_over_shapes(hip_lib, hip_default, oracle_default):
+    """The host entry point replays captured graphs over bucketed shapes (T_x to a multiple of 8, T_y to a multiple of 32,
+    scalars in a device block).  Same samples as the exact-size eager path for single utterances at bucket edges, a ragged
+    batch, solo batches, with pinned and with free-running durations; one shape also against the oracle."""
+    rng = np.random.default_rng(77)
+    scales = np.array([0.667, 1.1, 0.8], np.float32)
+    for B, Tx in ((1, 1), (1, 7), (1, 8), (1, 9), (1, 50), (3, 21), (2, 64)):
+        lengths = rng.integers(max(1, Tx // 2), Tx + 1, size=B).astype(np.int64)
+        lengths[0] = Tx
+        ids = rng.integers(1, 62, size=(B, Tx)).astype(np.int64)
+        sid = rng.integers(0, 200, size=B).astype(np.int64)
+        dur = rng.integers(0, 5, size=(B, Tx)).astype(np.int32)
+        for kw in (dict(forced_durations=dur, seed=5), dict(seed=6), dict(forced_durations=dur, seed=7, solo=True)):
+            (a_f, l_f), (a_e, l_e) = _both_paths(hip_lib, lambda: hip_default.synthesize(ids, lengths, scales, sid, **kw))
+            assert np.array_equal(l_f, l_e), (B, Tx, kw.keys())
+            assert a_f.shape == a_e.shape
+            assert_close(f"fast vs eager B={B} Tx={Tx} {sorted(kw)}", _valid(a_e, l_e), _valid(a_f, l_f), 2e-5)
+            if B > 1 and not kw.get("solo"):
+                for b in range(B):
+                    assert np.all(a_f[b, int(l_f[b]) + 33 * 256:] == 0.0)
+    ids = rng.integers(1, 62, size=(1, 23)).astype(np.int64)
+    dur = rng.integers(1, 4, size=(1, 23)).astype(np.int32)
+    a_ref, l_ref = oracle_default.synthesize(ids, [23], scales, [4], forced_durations=dur, seed=9)
+    a_hip, l_hip = hip_default.synthesize(ids, [23], scales, [4], forced_durations=dur, seed=9)
+    assert np.array_equal(l_ref, l_hip)
+    assert_close("fast path vs oracle", a_ref, a_hip, E2E_TOL)
+
+
+def test_fast_path_one_graph_serves_different_requests(hip_default, oracle_default):
+    """Seeds, scales, ids and speakers change between calls of the same shape bucket without a re-capture: results follow
+    the inputs (vs the oracle for each), repeat exactly for repeated inputs, and the frame bucket changes with length_scale."""
+    rng = np.random.default_rng(31)
+    Tx = 19
+    dur = rng.integers(1, 4, size=(1, Tx)).astype(np.int32)
+    outs = []
+    for k, (seed, ns, ls, sid) in enumerate(((1, 0.667, 1.0, 2), (2, 0.667, 1.0, 2), (1, 0.3, 1.0, 2), (1, 0.667, 2.0, 2), (1, 0.667, 1.0, 9),
+                                             (1, 0.667, 1.0, 2))):
+        ids = rng.integers(1, 62, size=(1, Tx)).astype(np.int64) if k else np.full((1, Tx), 5, np.int64)
+        if k == 5:
+            ids = np.full((1, Tx), 5, np.int64)
+        sc = np.array([ns, ls, 0.8], np.float32)
+        a, l = hip_default.synthesize(ids, [Tx], sc, [sid], forced_durations=dur, seed=seed)
+        a_ref, l_ref = oracle_default.synthesize(ids, [Tx], sc, [sid], forced_durations=dur, seed=seed)
+        assert np.array_equal(l, l_ref)
+        assert_close(f"request {k}", a_ref, a, E2E_TOL)
+        outs.append(a)
+    assert np.array_equal(outs[0], outs[5])  # same request, same samples
+    assert np.abs(outs[0] - outs[1][:, :outs[0].shape[1]]).max() > 1e-3
+
+
+def test_pcm16_output_equals_numpy_conversion(hip_lib, hip_default):
+    """vits_synthesize_pcm16 == int16(clip(audio * scale * 32767)) of vits_synthesize for the same request
+    (Synth.synth_audio's tail, vosk_tts/synth.py:127-130), on both paths; scale large enough to clip."""
+    rng = np.random.default_rng(12)
+    ids = rng.integers(1, 62, size=(2, 30)).astype(np.int64)
+    lengths = np.array([30, 17], np.int64); sid = np.array([2, 3], np.int64)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    for scale in (1.0, 37.5):
+        def both():
+            a, l = hip_default.synthesize(ids, lengths, sc, sid, seed=3)
+            p, lp = hip_default.synthesize_pcm16(ids, lengths, sc, sid, pcm_scale=scale, seed=3)
+            return a, l, p, lp
+        for a, l, p, lp in _both_paths(hip_lib, both):
+            assert p.dtype == np.int16 and p.shape == a.shape and np.array_equal(l, lp)
+            want = np.clip((a * np.float32(scale)) * np.float32(32767.0), -32767.0, 32767.0).astype("int16")
+            assert np.array_equal(want, p)
+            if scale > 1:
+                assert (np.abs(p) == 32767).any()

@@ -104,6 +104,12 @@ class VitsLib:
                                           c_i32p]
         self.is_device = bool(f("is_device_backend")())
         if self.is_device:
+            c_i16p = ctypes.POINTER(ctypes.c_int16)
+            f("synthesize_pcm16").argtypes = [ctypes.c_void_p, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_i64p,
+                                              ctypes.POINTER(SynthOpts), ctypes.c_float, ctypes.POINTER(c_i16p), c_i64p, c_i64p]
+            f("free_pcm16").argtypes = [c_i16p]
+            f("free_pcm16").restype = None
+            f("session_set_sdp_always").argtypes = [ctypes.c_void_p, ctypes.c_int]
             f("session_create").argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.POINTER(ctypes.c_void_p)]
             f("session_destroy").argtypes = [ctypes.c_void_p]
@@ -218,6 +224,28 @@ class VitsModel:
         finally:
             self.lib._fn("free_output")(out)
         return audio, olen
+
+    def synthesize_pcm16(self, ids, lengths, scales, sid, pcm_scale=1.0, noise_dp=None, noise_prior=None, forced_durations=None,
+                         seed=0, max_frames=0, solo=False):
+        """synthesize() with Synth.synth_audio's `* scale` and audio_float_to_int16 (vosk_tts/synth.py:127-130) done on the
+        device: returns (pcm int16 [B,S], out_lengths int64 [B])."""
+        ids = _i64(ids)
+        B, Tx = ids.shape
+        lengths = _i64(lengths); sid = _i64(sid); scales = _f32(scales)
+        if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
+            raise ValueError("bad feed shapes")
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo)
+        out = ctypes.POINTER(ctypes.c_int16)()
+        ns = ctypes.c_int64()
+        olen = np.zeros(B, dtype=np.int64)
+        self.lib.check(self.lib._fn("synthesize_pcm16")(self._h, _p(ids, c_i64p), _p(lengths, c_i64p), B, Tx, _p(scales, c_f32p),
+                                                        _p(sid, c_i64p), ctypes.byref(opts), float(pcm_scale), ctypes.byref(out),
+                                                        ctypes.byref(ns), _p(olen, c_i64p)))
+        try:
+            pcm = np.ctypeslib.as_array(out, shape=(B, ns.value)).copy()
+        finally:
+            self.lib._fn("free_pcm16")(out)
+        return pcm, olen
 
     def stream(self, ids, scales, sid, chunk_frames=64, noise_dp=None, noise_prior=None, forced_durations=None, seed=0):
         """Streaming synthesis of ONE utterance (vits_stream_*): a generator of float32 chunks of
@@ -360,6 +388,10 @@ class VitsDeviceSession:
 
     def set_options(self, use_graph=True, profile=False):
         self.lib.check(self.lib._fn("session_set_options")(self._h, int(use_graph), int(profile)))
+
+    def set_sdp_always(self, on=True):
+        """run the duration predictor even when durations are forced (fixed-work benchmark of the whole infer())"""
+        self.lib.check(self.lib._fn("session_set_sdp_always")(self._h, int(on)))
 
     def profile_report(self):
         """-> {(op_name, kernel_instantiation): (launches, total_ms, flops)}"""

@@ -49,6 +49,7 @@ struct ConvGroup {
   const float* w;     // packed weights (pack_conv_weights)
   const float* bias;  // [Cout] or null
   float* y;           // output
+  float* y2;          // optional second copy of the output (EPI_STORE, same layout): saves a device-to-device copy
   const float* res;   // residual added after mask (EPI_STORE) or null
   int K;              // taps
   int dil;            // dilation
@@ -237,6 +238,11 @@ __device__ __forceinline__ void conv_epilogue_frag(const ConvParams& P, const Co
 #pragma unroll
     for (int i = 0; i < NE; ++i)
       if (ok[i]) G.y[o[i]] = v[i];
+    if (G.y2) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        if (ok[i]) G.y2[o[i]] = v[i];
+    }
   } else if (EPI == EPI_RESSKIP) {
     const bool valid = col < lenb;
     float bv[NE], old[NE];
@@ -551,10 +557,14 @@ __device__ __forceinline__ float ks_ld(const float* base, unsigned byte_off) {
 }
 struct ks_true { static constexpr bool value = true; };
 struct ks_false { static constexpr bool value = false; };
-template <int MI, int NI, int EPI, int NIN>
-__global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
+// NW = waves per workgroup (4, 8 or 16) that split the contraction at TAP granularity (tap q = chunk*K + kk belongs
+// to wave q % NW).  More waves = shorter serial MFMA chains per wave and 2..4 waves per SIMD to hide the issue latency
+// of the fragment loads; the register budget per wave shrinks accordingly (KS_U taps per pipeline stage).
+template <int MI, int NI, int EPI, int NIN, int NW>
+__global__ void __launch_bounds__(NW * 64) conv_mfma_ks_kernel(const ConvParams P) {
   constexpr int M_T = MI * 32;
   constexpr int N_T = NI * 32;
+  constexpr int NE = 16 / NW;  // accumulator elements each wave finishes after the reduction
   extern __shared__ float lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -609,21 +619,23 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
     if (mb >= n_mblocks) mb = 0;
     wp[mi] = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64;
   }
-  const int my_chunks = wave < nchunks ? (nchunks - wave + 3) / 4 : 0;
-  const int my_taps = my_chunks * K;
-  const int c_last = wave + 4 * (my_chunks > 0 ? my_chunks - 1 : 0);
+  const int total_taps = nchunks * K;
+  const int my_taps = wave < total_taps ? (total_taps - wave + NW - 1) / NW : 0;
+  const int q_last = wave + NW * (my_taps > 0 ? my_taps - 1 : 0);  // this wave's last tap (clamp target of dead prefetches)
+  const int c_last = q_last / K, k_last = q_last - c_last * K;
 
   // One "tap" = 8 MFMA k-steps of one (chunk, kk).  Taps are processed in super-steps of KS_U taps,
   // double-buffered in registers: while super-step s computes, the A and B fragments of super-step
-  // s+1 (KS_U * 512 MFMA cycles ahead, > HBM latency) are in flight.  Every load is unconditional
-  // with clamped indices so hipcc can emit counted s_waitcnt.
-  constexpr int KS_U = 4;
+  // s+1 are in flight.  Every load is unconditional with clamped indices so hipcc can emit counted s_waitcnt.
+  constexpr int KS_U = NW >= 16 ? 1 : (NW == 8 ? (MI * NI > 1 ? 2 : 4) : 4);  // 4 waves per SIMD leave 128 registers per wave
   struct TapBuf {
     f32x4 a[KS_U][MI][2];
     float bq[KS_U][8][NI];
     unsigned ok[KS_U];
   };
-  int lc = wave, lk = 0;  // load cursor (chunk, tap-in-chunk) of this wave's tap stream
+  int lc = wave / K, lk = wave - (wave / K) * K;  // load cursor (chunk, tap-in-chunk) of this wave's tap stream
+  int lq = wave;
+  const int step_c = NW / K, step_k = NW - step_c * K;  // cursor advance of NW taps, one division per wave
   const unsigned lane16 = (unsigned)lane * 16u;
   const float* xq2 = NIN > 2 ? xu2 : xu;               // NIN == 3: MRF mean of three inputs (x3 may be absent)
   const float* xq3 = NIN > 2 ? (xu3 ? xu3 : xu2) : xu;
@@ -633,16 +645,15 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
 
   // Software pipeline inside ONE wave, pinned at source level: before every MFMA of the current
   // super-step the wave issues one slice of the NEXT super-step's loads (weights at p == 0, one B
-  // fragment per k-step), and a sched_barrier after each pair keeps hipcc from regrouping them.  The
-  // load latency (L2 ~500, HBM ~900 cycles) is thereby covered by KS_U*8 = 32 MFMAs (2048 cycles), the
-  // address math runs in the MFMA shadow, and all loads are unconditional (clamped + select), which
-  // keeps the body one basic block with counted s_waitcnt.
+  // fragment per k-step), and a sched_barrier after each pair keeps hipcc from regrouping them.
+  // All loads are unconditional (clamped + select), which keeps the body one basic block with counted s_waitcnt.
   auto pipe_step = [&](auto has_cur, auto act, const TapBuf& cur, TapBuf& nxt) {
 #pragma unroll
     for (int u = 0; u < KS_U; ++u) {
-      const bool live = lc <= c_last;
+      const bool live = lq <= q_last;
       const int cc = live ? lc : c_last;
-      const int sg = 2 * (cc * K + lk);
+      const int kc = live ? lk : k_last;
+      const int sg = 2 * (cc * K + kc);
       const bool second = NIN == 2 && cc >= split_chunk;  // wave-uniform
       const float* xsrc = second ? xu2 : xu;
       const long long coff = (long long)(second ? cc - split_chunk : cc) * CONV_CI_T * rs;
@@ -650,7 +661,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
       unsigned okb = 0;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        int t = tcol[ni] + lk * dil;
+        int t = tcol[ni] + kc * dil;
         t = (t == -1 && refl_t >= 0) ? refl_t : t;
         okb |= ((t >= 0) & (t < t_lim) & live) ? (1u << ni) : 0u;
         lo[ni] = (hoff + (unsigned)(t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t))) * 4u;  // BYTE offset: keeps the saddr + 32-bit voffset form
@@ -676,11 +687,9 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
           for (int ni = 0; ni < NI; ++ni) okb_[ni] = (cur.ok[u] >> ni) & 1u;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            // leaky-relu for 0 <= slope <= 1 is max(v, slope*v); the edge/mask flag is a 0/1 multiplier:
-            // 3 VALU per MFMA instead of 5 (a single wave per SIMD is issue-bound, every slot counts)
+            // leaky-relu for 0 <= slope <= 1 is max(v, slope*v); the edge/mask flag is a select (stale padding may hold
+            // NaN).  in_slope == 1 (every encoder / flow conv) skips the activation.
             const float x_ = cur.bq[u][p][ni];
-            // select, not multiply: stale padding may hold NaN.  in_slope == 1 (every encoder / flow conv) skips the
-            // activation: a lone wave per SIMD pays ~7 cycles per VALU op next to each 64-cycle MFMA (tools/mfmaprobe)
             const float bv = okb_[ni] ? (decltype(act)::value ? fmaxf(x_, x_ * in_slope) : x_) : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -689,9 +698,11 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      const bool wrap = (lk + 1 == K);
-      lk = wrap ? 0 : lk + 1;
-      lc = wrap ? lc + 4 : lc;
+      // advance the cursor by NW taps (scalar)
+      lq += NW;
+      lk += step_k;
+      lc += step_c + (lk >= K ? 1 : 0);
+      lk -= lk >= K ? K : 0;
     }
   };
 
@@ -722,17 +733,17 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   __syncthreads();
   CONV_DBG(3);
   const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
-  float sum[MI][NI][4];
+  float sum[MI][NI][NE];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ee = 0; ee < 4; ++ee) {
-        const int e = 4 * wave + ee;
+      for (int ee = 0; ee < NE; ++ee) {
+        const int e = NE * wave + ee;
         float a = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) a += red[(((w * MI + mi) * NI + ni) * 16 + e) * 64 + lane];
+        for (int w = 0; w < NW; ++w) a += red[(((w * MI + mi) * NI + ni) * 16 + e) * 64 + lane];
         sum[mi][ni][ee] = a;
       }
   CONV_DBG(4);
@@ -740,10 +751,10 @@ __global__ void __launch_bounds__(256) conv_mfma_ks_kernel(const ConvParams P) {
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + ni * 32 + l31;
     if (EPI == EPI_GATE) {
-      conv_epilogue_gate<4>(P, G, b, (m0 >> 6) * 32 + 4 * h, 4 * wave, col, sum[0][ni], sum[MI - 1][ni]);
+      conv_epilogue_gate<NE>(P, G, b, (m0 >> 6) * 32 + 4 * h, NE * wave, col, sum[0][ni], sum[MI - 1][ni]);
     } else {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) conv_epilogue_frag<EPI, 4>(P, G, b, lenb, m0 + mi * 32 + 4 * h, 4 * wave, col, sum[mi][ni]);
+      for (int mi = 0; mi < MI; ++mi) conv_epilogue_frag<EPI, NE>(P, G, b, lenb, m0 + mi * 32 + 4 * h, NE * wave, col, sum[mi][ni]);
     }
   }
   CONV_DBG(5);

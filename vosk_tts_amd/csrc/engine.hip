@@ -54,6 +54,8 @@ static int g_force_tile = 0;
 static int g_attn_impl = 0;
 // tests: fill every freshly planned workspace with NaN so stale padding can never hide as zeros
 static int g_poison = 0;
+// 0 = fused exp/sin + iSTFT + PQMF kernel (default), 1 = the two separate kernels (independent cross-check in tests)
+static int g_tail_impl = 0;
 
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
@@ -130,6 +132,10 @@ struct vits_model {
 
   std::mutex pool_mu;
   std::vector<vits_session*> pool;
+  // fast path: idle front sessions by (B, T_x bucket), least-recently-used eviction under a device-memory cap
+  std::multimap<std::pair<int, int>, vits_session*> fronts;
+  uint64_t use_clock = 0;
+  size_t fronts_bytes = 0;
 };
 
 static const float* tget(vits_model* m, int ndim, int d0, int d1, int d2, const char* fmt, ...) {
@@ -501,6 +507,7 @@ struct vits_session {
   typedef std::tuple<const void*, const void*, const void*, const void*, void*, int, int, int, uint64_t, float, float, float> GKey;
   std::map<GKey, hipGraphExec_t> graphs;
   bool use_graph = true;
+  const SynthDev* dv = nullptr;  // device parameter block of the graph-replayed fast path (null: scalars by value)
   bool ragged = false;  // full-path calls with B > 1: skip padding tiles of masked stages (set per call)
   bool solo = false;    // VITS_FLAG_SOLO_BATCH: every item as if synthesized alone (noise streams, decoder halo 0)
 
@@ -523,6 +530,24 @@ struct vits_session {
   char* stage = nullptr;
   size_t stage_bytes = 0, stage_used = 0;
 
+  // ---- graph-replayed fast path of vits_synthesize (see "fast path" below).  A FRONT session is laid out for
+  // (B, T_x bucket) and owns phase 1 (text encoder .. durations); its BACK sessions, one per frame bucket, own phase 2
+  // (prior .. decoder) and read the front's phase-1 results in place.
+  bool rag_b1 = false;             // single utterance in a frame bucket: decoder sees zeros beyond the item's own end
+  bool sdp_always = false;         // device-session option: run the duration predictor even when durations are forced
+  char *io_h = nullptr, *io_d = nullptr;  // per-call inputs: pinned host mirror and device copy (SynthDev | lengths | sid | ids | forced)
+  size_t io_bytes = 0, io_len = 0, io_sid = 0, io_ids = 0, io_forced = 0;
+  int64_t* h_ylen = nullptr;       // pinned [B] + one int error word behind it
+  hipGraphExec_t g1[4] = {nullptr, nullptr, nullptr, nullptr};  // [forced*2 + solo]
+  std::map<int, vits_session*> backs;
+  vits_session* front = nullptr;
+  float* out_d = nullptr;          // back: fp32 audio [B, T_y bucket * hop] on the device
+  int16_t* pcm_d = nullptr;        // back: int16 PCM, same shape
+  char* out_h = nullptr;           // back: pinned host copy of whichever output the call asked for
+  size_t out_elems = 0;
+  hipGraphExec_t g2[4] = {nullptr, nullptr, nullptr, nullptr};  // [solo*2 + pcm]
+  uint64_t last_use = 0;
+  size_t cache_bytes = 0;          // device bytes this session pins while cached (front: incl. its backs)
 };
 
 
@@ -634,6 +659,15 @@ static void session_free(vits_session* s) {
   hipSetDevice(s->m->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   drop_graphs(s);
+  for (auto& kv : s->backs) session_free(kv.second);
+  s->backs.clear();
+  for (int i = 0; i < 4; ++i) { if (s->g1[i]) hipGraphExecDestroy(s->g1[i]); if (s->g2[i]) hipGraphExecDestroy(s->g2[i]); }
+  if (s->io_h) hipHostFree(s->io_h);
+  if (s->io_d) hipFree(s->io_d);
+  if (s->h_ylen) hipHostFree(s->h_ylen);
+  if (s->out_d) hipFree(s->out_d);
+  if (s->pcm_d) hipFree(s->pcm_d);
+  if (s->out_h) hipHostFree(s->out_h);
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
   if (s->stage) hipFree(s->stage);
@@ -667,6 +701,11 @@ struct ProfScope {
     s->prof.push_back(r);
   }
   void set_kernel(const char* k) { if (on) s->prof.back().kernel = k; }
+  void add_template_arg(int v) {  // "name<a,b>" -> "name<a,b,v>"
+    if (!on) return;
+    std::string& k = s->prof.back().kernel;
+    if (!k.empty() && k.back() == '>') { k.pop_back(); k += "," + std::to_string(v) + ">"; }
+  }
   ~ProfScope() { if (on) hipEventRecord(s->prof.back().e1, s->stream); }
 };
 
@@ -685,7 +724,7 @@ static const int* tile_table(vits_session* s, const int* len, int mul, int add, 
 
 static void attach_tile_table(vits_session* s, ConvParams& P, int N_T) {
   P.tile_start = nullptr;
-  if (!s || !s->arena) return;
+  if (!s || !s->arena || s->B == 1) return;  // a single utterance in a padded bucket: the few dead tiles exit early instead
   if (P.rag) P.tile_start = tile_table(s, P.rag, P.rag_out_mul, P.rag_out_add, P.Tout, N_T);
   else if (P.skip_len) P.tile_start = tile_table(s, P.len, 1, 0, P.Tout, N_T);
 }
@@ -703,8 +742,34 @@ static void launch_cfg(vits_session* s, ConvParams& P, int halo) {
   hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MI, NI, EPI>), dim3(nblk), dim3(256), lds, st, P);
 }
 
+// waves per workgroup of the K-split kernel: 0 = heuristic (ks_pick_waves), else forced (tests / tools: VITS_KS_WAVES)
+static int g_ks_waves = 0;
+static int ks_pick_waves(const ConvParams& P, long nblk) {
+  static const int env_nw = getenv("VITS_KS_WAVES") ? atoi(getenv("VITS_KS_WAVES")) : 0;
+  const int force = g_ks_waves ? g_ks_waves : env_nw;
+  if (force == 4 || force == 8 || force == 16) return force;
+  int taps = 0;
+  for (int g = 0; g < P.n_groups; ++g) { const int t = P.Cin / CONV_CI_T * P.g[g].K; if (t > taps) taps = t; }
+  // few workgroups (less than one per CU): 16 waves each, i.e. 4 per SIMD, as long as every wave still gets >= 2 taps;
+  // up to two workgroups per CU: 8 waves (the register file holds 2 x 8 waves of <= 128 registers)
+  if (nblk <= 256 && taps >= 32) return 16;
+  if (nblk <= 512 && taps >= 16) return 8;
+  return 4;
+}
+
+template <int MI, int NI, int EPI, int NIN, int NW>
+static void launch_ks_inst(hipStream_t st, const ConvParams& P, dim3 grid) {
+  constexpr size_t lds = (size_t)NW * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
+  auto kern = conv_mfma_ks_kernel<MI, NI, EPI, NIN, NW>;
+  if (lds > 64 * 1024) {
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)once;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, P);
+}
+
 template <int MI, int NI, int EPI>
-static void launch_ks(vits_session* s, ConvParams& P, int halo) {
+static void launch_ks(vits_session* s, ConvParams& P, int halo, ProfScope* ps = nullptr) {
   hipStream_t st = s->stream;
   constexpr int M_T = MI * 32, N_T = NI * 32;
   attach_tile_table(s, P, N_T);
@@ -713,14 +778,21 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo) {
   P.ntiles_n = cdiv(P.Tout, N_T);
   P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
-  const size_t lds = (size_t)4 * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
   const dim3 grid(nblk);
-  if (EPI == EPI_STORE && MI * NI == 1 && P.x_split)
-    hipLaunchKernelGGL((conv_mfma_ks_kernel<1, 1, EPI_STORE, 2>), grid, dim3(256), lds, st, P);
-  else if (EPI == EPI_STORE && P.g[0].x2)
-    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, (EPI == EPI_STORE ? 3 : 1)>), grid, dim3(256), lds, st, P);
-  else
-    hipLaunchKernelGGL((conv_mfma_ks_kernel<MI, NI, EPI, 1>), grid, dim3(256), lds, st, P);
+  const int nw = NI == 1 ? ks_pick_waves(P, nblk) : 4;  // the 32x64 tile is only chosen for launches with thousands of workgroups
+  if (ps) ps->add_template_arg(nw);
+#define KS_GO(MI_, NI_, EPI_, NIN_)                                                            \
+  do {                                                                                         \
+    if constexpr ((NI_) == 1) {                                                                \
+      if (nw == 16) { launch_ks_inst<MI_, NI_, EPI_, NIN_, 16>(st, P, grid); break; }          \
+      if (nw == 8) { launch_ks_inst<MI_, NI_, EPI_, NIN_, 8>(st, P, grid); break; }            \
+    }                                                                                          \
+    launch_ks_inst<MI_, NI_, EPI_, NIN_, 4>(st, P, grid);                                      \
+  } while (0)
+  if (EPI == EPI_STORE && MI * NI == 1 && P.x_split) KS_GO(1, 1, EPI_STORE, 2);
+  else if (EPI == EPI_STORE && P.g[0].x2) KS_GO(MI, NI, EPI, (EPI == EPI_STORE ? 3 : 1));
+  else KS_GO(MI, NI, EPI, 1);
+#undef KS_GO
 }
 
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
@@ -772,17 +844,17 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   if (epi == EPI_GATE) {
-    if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo); }
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo, &ps); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
     return;
   }
   if (epi == EPI_RESSKIP) {
-    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,RESSKIP,1>"); launch_ks<1, 1, EPI_RESSKIP>(s, P, halo); }
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,RESSKIP,1>"); launch_ks<1, 1, EPI_RESSKIP>(s, P, halo, &ps); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,RESSKIP>"); launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(s, P, halo); }
     return;
   }
   if (epi == EPI_COUPLE) {
-    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(s, P, halo); }
+    if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(s, P, halo, &ps); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(s, P, halo); }
     return;
   }
@@ -790,9 +862,9 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
     const bool multi = P.g[0].x2 != nullptr;
     static const int ks_shape = getenv("VITS_KS_SHAPE") ? atoi(getenv("VITS_KS_SHAPE")) : 0;  // tools/ks_shapes.py: 11 or 12 forces the tile
-    if (P.x_split) { ps.set_kernel("conv_mfma_ks_kernel<1,1,STORE,2>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); return; }
-    if (ks_shape == 12 || (ks_shape == 0 && blocks32 > 2048)) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(s, P, halo); }
-    else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(s, P, halo); }
+    if (P.x_split) { ps.set_kernel("conv_mfma_ks_kernel<1,1,STORE,2>"); launch_ks<1, 1, EPI_STORE>(s, P, halo, &ps); return; }
+    if (ks_shape == 12 || (ks_shape == 0 && blocks32 > 2048)) { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,2,STORE,3>" : "conv_mfma_ks_kernel<1,2,STORE,1>"); launch_ks<1, 2, EPI_STORE>(s, P, halo, &ps); }
+    else { ps.set_kernel(multi ? "conv_mfma_ks_kernel<1,1,STORE,3>" : "conv_mfma_ks_kernel<1,1,STORE,1>"); launch_ks<1, 1, EPI_STORE>(s, P, halo, &ps); }
     return;
   }
   // 32-row outputs (polyphase upsamplers with C_out % 64 != 0, the 32-channel last stage of HiFi-GAN V1): a 64-row tile
@@ -980,7 +1052,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   P.out_mask = 1; P.len = s->len_x;
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.proj");
-  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx, s->solo ? 1 : 0);
+  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx, s->solo ? 1 : 0, s->dv);
   int swap = 0;
   const float cst = (float)log(exp(1.0 - 1e-3) - 1.0);
   (void)cst;
@@ -1005,15 +1077,15 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
 // ---- a10: durations / cumsum / y_lengths
 static void run_durations(vits_session* s, const int* d_forced, float length_scale, int B, int Tx, int Tcap) {
   hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s->stream, s->logw, d_forced, s->len_x, length_scale, Tx, s->dur,
-                     s->cum, s->len_y, s->ylen64, Tcap, s->d_err);
+                     s->cum, s->len_y, s->ylen64, Tcap, s->d_err, s->dv);
 }
 
 // ---- a10/a11: expand prior + sample -> z_p [B,I,Ty]
 static void run_expand(vits_session* s, const float* d_noise, long long noise_stride, float noise_scale, uint64_t seed,
                        float* z_p, int B, int Tx, int Ty) {
   const int I = s->m->hp.inter_channels;
-  hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(Ty, 64), 8, B), dim3(64), 0, s->stream, s->stats, s->cum, s->len_y, d_noise,
-                     noise_stride, noise_scale, seed, z_p, I, Tx, Ty, s->solo ? 1 : 0);
+  hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(Ty, 64), cdiv(I, EXPAND_CPB), B), dim3(256), 0, s->stream, s->stats, s->cum, s->len_y,
+                     d_noise, noise_stride, noise_scale, seed, z_p, I, Tx, Ty, s->solo ? 1 : 0, s->dv);
 }
 
 // ---- a12-a14: ResidualCouplingTransformersBlock.forward(reverse=True) (models.py:750-757).
@@ -1032,9 +1104,9 @@ static float* run_flow(vits_session* s, int B, int Ty) {
     P.x_ch_off = I - 1; P.x_ch_sign = -1; P.x_bstride = (long long)I * Ty;
     P.out_mask = 1; P.len = s->len_y;
     mark_masked(s, P, s->len_y);
+    P.g[0].y2 = s->x;  // second copy: the pre-transformer updates its input in place, fh stays the residual base
     launch_conv(s, P, EPI_STORE, "flow.pre");
     // h = h + pre_transformer(h * mask)  (models.py:377)
-    hipMemcpyAsync(s->x, s->fh, sizeof(float) * (size_t)B * H * Ty, hipMemcpyDeviceToDevice, s->stream);
     run_encoder(s, C.enc, s->x, s->len_y, B, Ty, -1, -1, s->fh, s->fx);
     // WN (modules.py:148-176): fx is the running x, fskip the output accumulator
     for (int i = 0; i < L; ++i) {
@@ -1080,7 +1152,8 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
   int C = hp.dec_initial_channel, T = Ty;
   const int* rag = nullptr;
   int rate = 1;  // columns per frame at the current stage
-  if (ragged && B > 1 && !getenv("VITS_NO_RAGGED")) {
+  static const bool no_ragged_env = getenv("VITS_NO_RAGGED") != nullptr;
+  if (ragged && (B > 1 || s->rag_b1) && !no_ragged_env) {
     hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, B, Ty, rag_halo);
     rag = s->len_rag;
   }
@@ -1153,15 +1226,23 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     set_rag(P, rag, rate, 0, rate, 1);
     launch_conv(s, P, EPI_STORE, "dec.conv_post");
     const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, Tm = T * hop;
-    {
-      ProfScope ps(s, "istft", 0, "istft_kernel");
-      hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm,
-                         rag, rate * hop);
-    }
-    {
-      ProfScope ps(s, "pqmf", 0, "pqmf_synthesis_kernel");
-      hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3(cdiv(Tm * S, 256), B), dim3(256), 0, s->stream, mb, m->pqmf, d_audio, S,
-                         hp.pqmf_taps, Tm, audio_bstride, rag, rate * hop * S);
+    if (g_tail_impl == 0) {  // one launch: exp/sin, iSTFT and PQMF through LDS
+      ProfScope ps(s, "istft_pqmf", 0, "istft_pqmf_kernel");
+      TailParams tp{post, m->istft_basis, m->pqmf, mb, d_audio, S, N, hop, Tp, Tm, hp.pqmf_taps, audio_bstride, rag, rate * hop};
+      const int HM = (hp.pqmf_taps / 2 + S - 1) / S + 1, nsub = TAIL_MB + 2 * HM, FR = (nsub + N) / hop + 2;
+      const size_t lds = ((size_t)2 * S * (N / 2 + 1) * FR + (size_t)S * nsub) * sizeof(float);
+      hipLaunchKernelGGL(istft_pqmf_kernel, dim3(cdiv(Tm, TAIL_MB), B), dim3(256), lds, s->stream, tp);
+    } else {
+      {
+        ProfScope ps(s, "istft", 0, "istft_kernel");
+        hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm,
+                           rag, rate * hop);
+      }
+      {
+        ProfScope ps(s, "pqmf", 0, "pqmf_synthesis_kernel");
+        hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3(cdiv(Tm * S, 256), B), dim3(256), 0, s->stream, mb, m->pqmf, d_audio, S,
+                           hp.pqmf_taps, Tm, audio_bstride, rag, rate * hop * S);
+      }
     }
   } else {
     memset(&P, 0, sizeof P);
@@ -1238,7 +1319,7 @@ static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t*
   set_lengths(s, d_len, s->len_x, B, Tx);
   run_cond(s, d_sid, B);
   run_text_encoder(s, d_ids, B, Tx);
-  if (!d_forced) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx);
+  if (!d_forced || s->sdp_always) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx);  // logw unused when durations are pinned
   run_durations(s, d_forced, scales[1], B, Tx, Ty);
   run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
   float* z = run_flow(s, B, Ty);
@@ -1286,6 +1367,7 @@ void vits_destroy(vits_model* m) {
   if (!m) return;
   hipSetDevice(m->device);
   for (vits_session* s : m->pool) session_free(s);
+  for (auto& kv : m->fronts) session_free(kv.second);
   for (void* a : m->allocs) hipFree(a);
   delete m;
 }
@@ -1517,10 +1599,253 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   return VITS_OK;
 }
 
-int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
-                    const int64_t* sid, const vits_synth_opts* opts, float** out_audio, int64_t* out_samples, int64_t* out_lengths) {
-  if (!m || !ids || !lengths || !scales || !out_audio || !out_samples || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
-  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+// ---- fast path of the host entry point --------------------------------------------------------------------------
+// What Synth.synth_audio brackets (vosk_tts/synth.py:122-131) is ids on the host -> waveform on the host, one request at a
+// time, each with its own scales and a fresh noise draw.  Replaying that as captured hipGraphs needs three things:
+//   * per-call scalars (scales, seed, pcm scale) live in a device block the kernels read (SynthDev), inputs are copied
+//     through ONE pinned staging buffer by a memcpy node of the graph -> a graph depends on shapes only;
+//   * shapes are bucketed: T_x up to a multiple of 8, T_y up to a multiple of 32.  Every stage up to the flow masks per
+//     item (exactly the ragged-batch machinery), and the decoder of a bucketed single utterance reads zeros beyond the
+//     item's own end at every stage (rag halo 0) -- the arithmetic of the exact-size run on every valid sample;
+//   * T_y is only known after the duration predictor: phase 1 (text encoder .. durations) is one graph of a FRONT
+//     session keyed by (B, T_x bucket); phase 2 (prior sample, flow, decoder, optional int16 conversion, D2H) one graph of
+//     a BACK session per frame bucket, which reads the front's stats / cum / cond vectors / lengths in place.
+// Per call: fill the pinned block, launch graph 1, wait (the one host round trip the path needs), launch graph 2, wait,
+// copy out.  No hipMalloc / hipFree / re-plan in steady state.  Calls that inject noise tensors (parity tests) take the
+// eager path below (vits_synthesize_eager), which is also the A/B reference of the fast path in tests.
+static int g_fast_path = 1;
+static size_t fast_cache_cap() {
+  static const size_t cap = getenv("VITS_CACHE_MB") ? (size_t)atol(getenv("VITS_CACHE_MB")) << 20 : (size_t)24 << 30;
+  return cap;
+}
+
+static size_t session_device_bytes(const vits_session* s) {
+  size_t n = s->arena_bytes + s->io_bytes + s->out_elems * (sizeof(float) + sizeof(int16_t));
+  for (auto& kv : s->backs) n += session_device_bytes(kv.second);
+  return n;
+}
+
+static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
+  {
+    std::lock_guard<std::mutex> g(m->pool_mu);
+    auto it = m->fronts.find(std::make_pair(B, TxB));
+    if (it != m->fronts.end()) {
+      *out = it->second;
+      m->fronts_bytes -= it->second->cache_bytes;
+      m->fronts.erase(it);
+      return VITS_OK;
+    }
+  }
+  vits_session* s = nullptr;
+  TRY(session_new(m, &s));
+  int rc = session_reserve(s, B, TxB, 1);
+  if (rc != VITS_OK) { session_free(s); return rc; }
+  // per-call input block: [SynthDev | lengths int64 [B] | sid int64 [B] | ids int64 [B,TxB] | forced int32 [B,TxB]]
+  s->io_len = align_up(sizeof(SynthDev), 64);
+  s->io_sid = s->io_len + align_up(sizeof(int64_t) * B, 64);
+  s->io_ids = s->io_sid + align_up(sizeof(int64_t) * B, 64);
+  s->io_forced = s->io_ids + align_up(sizeof(int64_t) * (size_t)B * TxB, 64);
+  s->io_bytes = s->io_forced + align_up(sizeof(int32_t) * (size_t)B * TxB, 64);
+  if (hipHostMalloc((void**)&s->io_h, s->io_bytes) != hipSuccess || hipMalloc((void**)&s->io_d, s->io_bytes) != hipSuccess ||
+      hipHostMalloc((void**)&s->h_ylen, sizeof(int64_t) * (B + 1)) != hipSuccess) {
+    session_free(s);
+    return fail(VITS_ERR_NOMEM, "fast-path staging buffers");
+  }
+  memset(s->io_h, 0, s->io_bytes);
+  *out = s;
+  return VITS_OK;
+}
+
+static void front_release(vits_model* m, vits_session* s) {
+  std::vector<vits_session*> evict;
+  {
+    std::lock_guard<std::mutex> g(m->pool_mu);
+    s->last_use = ++m->use_clock;
+    s->cache_bytes = session_device_bytes(s);
+    m->fronts.emplace(std::make_pair(s->B, s->Tx), s);
+    m->fronts_bytes += s->cache_bytes;
+    while ((m->fronts_bytes > fast_cache_cap() && m->fronts.size() > 1) || m->fronts.size() > 48) {
+      auto lru = m->fronts.begin();
+      for (auto it = m->fronts.begin(); it != m->fronts.end(); ++it)
+        if (it->second->last_use < lru->second->last_use) lru = it;
+      m->fronts_bytes -= lru->second->cache_bytes;
+      evict.push_back(lru->second);
+      m->fronts.erase(lru);
+    }
+  }
+  for (vits_session* e : evict) session_free(e);
+}
+
+// back session of `F` for frame bucket TyB (created on first use; at most 6 buckets stay cached per front)
+static int back_get(vits_session* F, int TyB, vits_session** out) {
+  auto it = F->backs.find(TyB);
+  if (it != F->backs.end()) { it->second->last_use = ++F->last_use; *out = it->second; return VITS_OK; }
+  if (F->backs.size() >= 6) {
+    auto lru = F->backs.begin();
+    for (auto jt = F->backs.begin(); jt != F->backs.end(); ++jt)
+      if (jt->second->last_use < lru->second->last_use) lru = jt;
+    hipStreamSynchronize(F->stream);
+    session_free(lru->second);
+    F->backs.erase(lru);
+  }
+  vits_model* m = F->m;
+  vits_session* s = new vits_session();
+  s->m = m;
+  s->stream = F->stream;
+  s->own_stream = false;
+  s->front = F;
+  int rc = VITS_OK;
+  if (hipMalloc((void**)&s->d_err, sizeof(int)) != hipSuccess || hipMemsetAsync(s->d_err, 0, sizeof(int), s->stream) != hipSuccess)
+    rc = fail(VITS_ERR_NOMEM, "back session");
+  if (rc == VITS_OK) rc = session_reserve(s, F->B, F->Tx, TyB);
+  s->out_elems = (size_t)F->B * TyB * m->hp.hop_length;
+  if (rc == VITS_OK && (hipMalloc((void**)&s->out_d, s->out_elems * sizeof(float)) != hipSuccess ||
+                        hipMalloc((void**)&s->pcm_d, s->out_elems * sizeof(int16_t)) != hipSuccess ||
+                        hipHostMalloc((void**)&s->out_h, s->out_elems * sizeof(float)) != hipSuccess))
+    rc = fail(VITS_ERR_NOMEM, "fast-path output buffers (%zu samples)", s->out_elems);
+  if (rc != VITS_OK) { s->stream = nullptr; session_free(s); return rc; }
+  // phase 2 reads the front's phase-1 results in place
+  s->stats = F->stats; s->cum = F->cum; s->condv = F->condv; s->len_y = F->len_y; s->len_x = F->len_x; s->ylen64 = F->ylen64;
+  s->dv = reinterpret_cast<const SynthDev*>(F->io_d);
+  s->last_use = ++F->last_use;
+  F->backs[TyB] = s;
+  *out = s;
+  return VITS_OK;
+}
+
+static int capture_end(vits_session* s, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture(s->stream, &g));
+  hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  return VITS_OK;
+}
+
+static int phase1_launch(vits_session* F, bool forced, bool solo) {
+  const int gi = (forced ? 2 : 0) + (solo ? 1 : 0);
+  if (!F->g1[gi]) {
+    const int B = F->B, TxB = F->Tx;
+    HIP_TRY(hipStreamBeginCapture(F->stream, hipStreamCaptureModeThreadLocal));
+    hipMemcpyAsync(F->io_d, F->io_h, F->io_bytes, hipMemcpyHostToDevice, F->stream);
+    F->ragged = true; F->solo = solo; F->tile_keys.clear();
+    F->dv = reinterpret_cast<const SynthDev*>(F->io_d);
+    const int64_t* d_len = reinterpret_cast<const int64_t*>(F->io_d + F->io_len);
+    const int64_t* d_sid = reinterpret_cast<const int64_t*>(F->io_d + F->io_sid);
+    const int64_t* d_ids = reinterpret_cast<const int64_t*>(F->io_d + F->io_ids);
+    const int32_t* d_forced = reinterpret_cast<const int32_t*>(F->io_d + F->io_forced);
+    set_lengths(F, d_len, F->len_x, B, TxB);
+    run_cond(F, d_sid, B);
+    run_text_encoder(F, d_ids, B, TxB);
+    if (!forced) run_duration(F, F->x, nullptr, 0.f, 0, B, TxB);
+    run_durations(F, forced ? d_forced : nullptr, 1.f, B, TxB, 0);
+    hipMemcpyAsync(F->h_ylen, F->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, F->stream);
+    hipMemcpyAsync(F->h_ylen + B, F->d_err, sizeof(int), hipMemcpyDeviceToHost, F->stream);
+    F->ragged = false; F->solo = false;
+    TRY(capture_end(F, &F->g1[gi]));
+  }
+  HIP_TRY(hipGraphLaunch(F->g1[gi], F->stream));
+  return VITS_OK;
+}
+
+static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm) {
+  const int gi = (solo ? 2 : 0) + (pcm ? 1 : 0);
+  if (!Bk->g2[gi]) {
+    const int B = F->B, TxB = F->Tx, TyB = Bk->Ty;
+    const long long stride = (long long)TyB * F->m->hp.hop_length;
+    HIP_TRY(hipStreamBeginCapture(F->stream, hipStreamCaptureModeThreadLocal));
+    Bk->ragged = true; Bk->solo = solo; Bk->rag_b1 = true; Bk->tile_keys.clear();
+    run_expand(Bk, nullptr, TyB, 0.f, 0, Bk->zA, B, TxB, TyB);
+    float* z = run_flow(Bk, B, TyB);
+    // a lone utterance decodes as the exact-size run does (zeros beyond its end); batches keep the reference's padded-batch
+    // continuation over the halo unless the caller asked for independent items
+    run_decoder(Bk, z, true, B, TyB, Bk->out_d, stride, nullptr, true, (solo || B == 1) ? 0 : VITS_RAGGED_HALO);
+    if (pcm) {
+      hipLaunchKernelGGL(pcm16_kernel, dim3(cdiv((int)stride, 256), B), dim3(256), 0, F->stream, Bk->out_d, stride, Bk->pcm_d, stride, stride, 1.f, Bk->dv);
+      hipMemcpyAsync(Bk->out_h, Bk->pcm_d, Bk->out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, F->stream);
+    } else {
+      hipMemcpyAsync(Bk->out_h, Bk->out_d, Bk->out_elems * sizeof(float), hipMemcpyDeviceToHost, F->stream);
+    }
+    Bk->ragged = false; Bk->solo = false;
+    TRY(capture_end(F, &Bk->g2[gi]));
+  }
+  HIP_TRY(hipGraphLaunch(Bk->g2[gi], F->stream));
+  return VITS_OK;
+}
+
+static int device_error_word(int e) {
+  if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
+  if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
+  if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
+  return VITS_OK;
+}
+
+static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                      const int64_t* sid, const vits_synth_opts* opts, bool pcm, float pcm_scale, void** out, int64_t* out_samples,
+                      int64_t* out_lengths) {
+  const vits_hparams& hp = m->hp;
+  HIP_TRY(hipSetDevice(m->device));
+  const int TxB = (Tx + 7) / 8 * 8;
+  const bool forced = opts && opts->forced_durations, solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
+  vits_session* F = nullptr;
+  TRY(front_acquire(m, B, TxB, &F));
+  struct Rel { vits_model* m; vits_session* s; ~Rel() { front_release(m, s); } } rel{m, F};
+  // ---- inputs -> pinned block
+  SynthDev* hv = reinterpret_cast<SynthDev*>(F->io_h);
+  hv->scales[0] = scales[0]; hv->scales[1] = scales[1]; hv->scales[2] = scales[2];
+  hv->pcm_scale = pcm_scale;
+  hv->seed = opts ? opts->seed : 0;
+  int64_t* h_len = reinterpret_cast<int64_t*>(F->io_h + F->io_len);
+  int64_t* h_sid = reinterpret_cast<int64_t*>(F->io_h + F->io_sid);
+  int64_t* h_ids = reinterpret_cast<int64_t*>(F->io_h + F->io_ids);
+  int32_t* h_forced = reinterpret_cast<int32_t*>(F->io_h + F->io_forced);
+  for (int b = 0; b < B; ++b) {
+    h_len[b] = lengths[b];
+    h_sid[b] = sid ? sid[b] : 0;
+    memcpy(h_ids + (size_t)b * TxB, ids + (size_t)b * Tx, sizeof(int64_t) * Tx);
+    for (int t = Tx; t < TxB; ++t) h_ids[(size_t)b * TxB + t] = 0;
+    if (forced) {
+      memcpy(h_forced + (size_t)b * TxB, opts->forced_durations + (size_t)b * Tx, sizeof(int32_t) * Tx);
+      for (int t = Tx; t < TxB; ++t) h_forced[(size_t)b * TxB + t] = 0;
+    }
+  }
+  // ---- phase 1 and the one host round trip
+  TRY(phase1_launch(F, forced, solo));
+  HIP_TRY(hipStreamSynchronize(F->stream));
+  {
+    int e = 0;
+    memcpy(&e, F->h_ylen + B, sizeof(int));
+    if (e) {
+      hipMemsetAsync(F->d_err, 0, sizeof(int), F->stream);
+      return device_error_word(e);
+    }
+  }
+  int64_t Ty = 1;
+  for (int b = 0; b < B; ++b) if (F->h_ylen[b] > Ty) Ty = F->h_ylen[b];
+  if (opts && opts->max_frames > 0 && Ty > opts->max_frames) return fail(VITS_ERR_ARG, "T_y %lld exceeds max_frames %d", (long long)Ty, opts->max_frames);
+  if (Ty > (1 << 24)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  const int TyB = (int)((Ty + 31) / 32 * 32);
+  // ---- phase 2
+  vits_session* Bk = nullptr;
+  TRY(back_get(F, TyB, &Bk));
+  TRY(phase2_launch(F, Bk, solo, pcm));
+  const int64_t S = Ty * hp.hop_length, stride = (int64_t)TyB * hp.hop_length;
+  const size_t esz = pcm ? sizeof(int16_t) : sizeof(float);
+  char* h_out = static_cast<char*>(malloc(esz * (size_t)B * S));
+  if (!h_out) { hipStreamSynchronize(F->stream); return fail(VITS_ERR_NOMEM, "host alloc failed"); }
+  HIP_TRY(hipStreamSynchronize(F->stream));
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { free(h_out); return fail(VITS_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(le)); }
+  for (int b = 0; b < B; ++b) memcpy(h_out + esz * (size_t)b * S, Bk->out_h + esz * (size_t)b * stride, esz * (size_t)S);
+  *out = h_out;
+  *out_samples = S;
+  if (out_lengths) for (int b = 0; b < B; ++b) out_lengths[b] = F->h_ylen[b] * hp.hop_length;
+  return VITS_OK;
+}
+
+static int synth_eager(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                       const int64_t* sid, const vits_synth_opts* opts, bool pcm, float pcm_scale, void** out, int64_t* out_samples,
+                       int64_t* out_lengths) {
   const vits_hparams& hp = m->hp;
   HostStage hs(m);
   std::vector<int64_t> ylen;
@@ -1535,16 +1860,51 @@ int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   float* d_audio = hs.dev_alloc<float>((size_t)B * S);
   if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
   run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr, true, s->solo ? 0 : VITS_RAGGED_HALO);
-  float* h_audio = static_cast<float*>(malloc(sizeof(float) * (size_t)B * S));
-  if (!h_audio) return fail(VITS_ERR_NOMEM, "host alloc failed");
-  hipError_t e = hipMemcpyAsync(h_audio, d_audio, sizeof(float) * (size_t)B * S, hipMemcpyDeviceToHost, s->stream);
+  const size_t esz = pcm ? sizeof(int16_t) : sizeof(float);
+  const void* d_src = d_audio;
+  if (pcm) {
+    int16_t* d_pcm = hs.dev_alloc<int16_t>((size_t)B * S);
+    if (!d_pcm) return fail(VITS_ERR_NOMEM, "device alloc failed");
+    hipLaunchKernelGGL(pcm16_kernel, dim3(cdiv((int)S, 256), B), dim3(256), 0, s->stream, d_audio, (long long)S, d_pcm, (long long)S, (long long)S, pcm_scale,
+                       (const SynthDev*)nullptr);
+    d_src = d_pcm;
+  }
+  void* h_out = malloc(esz * (size_t)B * S);
+  if (!h_out) return fail(VITS_ERR_NOMEM, "host alloc failed");
+  hipError_t e = hipMemcpyAsync(h_out, d_src, esz * (size_t)B * S, hipMemcpyDeviceToHost, s->stream);
   int rc = e == hipSuccess ? check_err(s) : fail(VITS_ERR_DEVICE, "D2H failed: %s", hipGetErrorString(e));
-  if (rc != VITS_OK) { free(h_audio); return rc; }
-  *out_audio = h_audio;
+  if (rc != VITS_OK) { free(h_out); return rc; }
+  *out = h_out;
   *out_samples = S;
   if (out_lengths) for (int b = 0; b < B; ++b) out_lengths[b] = ylen[b] * hp.hop_length;
   return VITS_OK;
 }
+
+static int synth_dispatch(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                          const int64_t* sid, const vits_synth_opts* opts, bool pcm, float pcm_scale, void** out, int64_t* out_samples,
+                          int64_t* out_lengths) {
+  if (!m || !ids || !lengths || !scales || !out || !out_samples || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  if (!m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
+  for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
+  static const bool env_off = getenv("VITS_NO_FASTPATH") != nullptr;
+  const bool injected = opts && (opts->noise_dp || opts->noise_prior);
+  if (g_fast_path && !env_off && !injected) return synth_fast(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
+  return synth_eager(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
+}
+
+int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                    const int64_t* sid, const vits_synth_opts* opts, float** out_audio, int64_t* out_samples, int64_t* out_lengths) {
+  return synth_dispatch(m, ids, lengths, B, Tx, scales, sid, opts, false, 1.f, reinterpret_cast<void**>(out_audio), out_samples, out_lengths);
+}
+
+int vits_synthesize_pcm16(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
+                          const int64_t* sid, const vits_synth_opts* opts, float pcm_scale, int16_t** out_pcm, int64_t* out_samples,
+                          int64_t* out_lengths) {
+  return synth_dispatch(m, ids, lengths, B, Tx, scales, sid, opts, true, pcm_scale, reinterpret_cast<void**>(out_pcm), out_samples, out_lengths);
+}
+
+void vits_free_pcm16(int16_t* p) { free(p); }
+void vits_debug_fast_path(int on) { g_fast_path = on; }
 
 void vits_free_output(float* p) { free(p); }
 
@@ -1742,6 +2102,8 @@ int vits_session_last_ms(vits_session* s, float* ms) {
 
 void vits_debug_force_tile(int mode) { g_force_tile = mode; }
 void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
+void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
+void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
 
 int vits_session_sync(vits_session* s) {
@@ -1753,6 +2115,13 @@ int vits_session_set_options(vits_session* s, int use_graph, int profile) {
   if (!s) return fail(VITS_ERR_ARG, "null session");
   s->use_graph = use_graph != 0;
   s->profile = profile != 0;
+  return VITS_OK;
+}
+
+int vits_session_set_sdp_always(vits_session* s, int on) {
+  if (!s) return fail(VITS_ERR_ARG, "null session");
+  if (s->sdp_always != (on != 0)) drop_graphs(s);
+  s->sdp_always = on != 0;
   return VITS_OK;
 }
 
@@ -1824,7 +2193,7 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
         int nb = -1, nb2 = -1, nb3 = -1;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<2, 2, 2, 2, EPI_STORE>, 256, 2 * CONV_CI_T * (128 + 64) * 4);
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, conv_mfma_kernel<2, 2, 1, 1, EPI_STORE>, 256, 2 * CONV_CI_T * (64 + 64) * 4);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, conv_mfma_ks_kernel<1, 1, EPI_STORE, 1>, 256, 16384);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, conv_mfma_ks_kernel<1, 1, EPI_STORE, 1, 4>, 256, 16384);
         hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)conv_mfma_kernel<2, 2, 2, 2, EPI_STORE>);
         fprintf(stderr, "   occupancy API (blocks/CU): T128 %d  T64 %d  ks %d ; T128 numRegs %d sharedStatic %zu localMem %zu maxDynShared %d\n", nb, nb2, nb3, fa.numRegs,
                 fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes);

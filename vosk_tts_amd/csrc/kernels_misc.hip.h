@@ -29,6 +29,15 @@ __device__ inline float philox_normal(uint64_t seed, uint32_t stream, uint32_t r
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
+// Per-call scalars of a forward that is replayed as a captured hipGraph: the kernels that need them read this block from
+// device memory instead of taking them by value, so ONE graph serves requests with different scales / seeds
+// (vits_synthesize fast path, engine.hip).  Kernels take a nullable pointer: null = use the by-value argument.
+struct SynthDev {
+  float scales[3];            // [noise_scale, length_scale, noise_scale_w]  (onnx_export.py:62-64)
+  float pcm_scale;            // Synth.synth_audio's `scale` (vosk_tts/synth.py:128) for the int16 output
+  unsigned long long seed;    // Philox seed
+};
+
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // ----------------------------------------------------------------------------- small utilities
@@ -688,9 +697,10 @@ __global__ void __launch_bounds__(256, 2) relpos_attention_mfma_kernel(const flo
 // ----------------------------------------------------------------------------- duration predictor
 // z[b,c,t] = noise * noise_scale_w  (models.py:96)
 // solo != 0 (VITS_FLAG_SOLO_BATCH): item b draws what a single-utterance call with seed + b would draw
-__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T, int solo) {
+__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T, int solo, const SynthDev* dv) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
+  if (dv) { nsw = dv->scales[2]; seed = dv->seed; }
   const long long o = ((long long)b * 2 + c) * T + t;
   const float e = noise ? noise[o] : (solo ? philox_normal(seed + (uint64_t)b, 1, (uint32_t)c, (uint32_t)t)
                                             : philox_normal(seed, 1, (uint32_t)(b * 2 + c), (uint32_t)t));
@@ -784,8 +794,9 @@ __global__ void ea_logw_kernel(const float* z, int row, const float* m, const fl
 // w = exp(logw)*mask*length_scale; w_ceil; y_len = max(1, sum) (models.py:1689-1691); inclusive
 // cumsum for generate_path (commons.py:128-143).  One block per batch item.
 __global__ void durations_kernel(const float* logw, const int* forced, const int* len, float length_scale, int T,
-                                 int* dur, int* cum, int* ylen32, int64_t* ylen64, int Tcap, int* err) {
+                                 int* dur, int* cum, int* ylen32, int64_t* ylen64, int Tcap, int* err, const SynthDev* dv) {
   __shared__ int part[256];
+  if (dv) length_scale = dv->scales[1];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int L = len[b];
   const int per = (T + 255) / 256;
@@ -819,11 +830,15 @@ __global__ void durations_kernel(const float* logw, const int* forced, const int
 // expand m_p/logs_p to frame rate by gather (instead of the reference's one-hot matmul,
 // models.py:1696-1698) and sample the prior z_p = m_p + eps*exp(logs_p)*noise_scale (:1700).
 // stats: [B, 2I, Tx] (m rows [0,I), logs rows [I,2I)).  Frames >= y_len: z_p = eps*noise_scale.
-__global__ void expand_prior_kernel(const float* stats, const int* cum, const int* ylen, const float* noise,
-                                    long long noise_stride, float noise_scale, uint64_t seed, float* z_p, int I, int Tx,
-                                    int Ty, int solo) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+// Block = 64 frames x 4 channel lanes; blockIdx.y strides the channels so a single utterance (T_y ~ 150) still spreads over
+// dozens of workgroups and every thread handles only a few channels after ONE binary search.
+#define EXPAND_CPB 16  // channels per block (4 lanes x 4 channels)
+__global__ void __launch_bounds__(256) expand_prior_kernel(const float* stats, const int* cum, const int* ylen, const float* noise,
+                                                           long long noise_stride, float noise_scale, uint64_t seed, float* z_p,
+                                                           int I, int Tx, int Ty, int solo, const SynthDev* dv) {
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63), cl = threadIdx.x >> 6, b = blockIdx.z;
   if (f >= Ty) return;
+  if (dv) { noise_scale = dv->scales[0]; seed = dv->seed; }  // device parameter block (graph replay) instead of by value
   const int* cb = cum + (long long)b * Tx;
   int tok = -1;
   if (f < ylen[b] && f < cb[Tx - 1]) {
@@ -831,9 +846,14 @@ __global__ void expand_prior_kernel(const float* stats, const int* cum, const in
     while (lo < hi) { int mid = (lo + hi) >> 1; if (cb[mid] > f) hi = mid; else lo = mid + 1; }
     tok = lo;
   }
-  for (int c = blockIdx.y; c < I; c += gridDim.y) {
-    const float mu = tok >= 0 ? stats[((long long)b * 2 * I + c) * Tx + tok] : 0.f;
-    const float ls = tok >= 0 ? stats[((long long)b * 2 * I + I + c) * Tx + tok] : 0.f;
+  const int tk = tok >= 0 ? tok : 0;
+#pragma unroll
+  for (int i = 0; i < EXPAND_CPB / 4; ++i) {
+    const int c = blockIdx.y * EXPAND_CPB + i * 4 + cl;
+    if (c >= I) break;
+    const float mu_ = stats[((long long)b * 2 * I + c) * Tx + tk];
+    const float ls_ = stats[((long long)b * 2 * I + I + c) * Tx + tk];
+    const float mu = tok >= 0 ? mu_ : 0.f, ls = tok >= 0 ? ls_ : 0.f;
     const float e = noise ? noise[((long long)b * I + c) * noise_stride + f]
                           : (solo ? philox_normal(seed + (uint64_t)b, 2, (uint32_t)c, (uint32_t)f)
                                   : philox_normal(seed, 2, (uint32_t)(b * I + c), (uint32_t)f));
@@ -856,10 +876,31 @@ __global__ void ragged_tiles_kernel(const int* len, int B, int mul, int add, int
   tile_start[B] = run;
 }
 
-// rag[b] = min(Ty, len_y[b] + halo): frames each item of a ragged batch needs in the (mask-free) decoder
+// rag[b] = min(T_end, len_y[b] + halo): frames each item of a ragged batch needs in the (mask-free) decoder, where
+// T_end = min(Ty, max_b len_y[b]) is where the reference's padded batch tensor ends (Ty may be a larger capacity bucket:
+// beyond the longest item the decoder must see the tensor edge, i.e. zeros, exactly like the exact-size run)
 __global__ void ragged_len_kernel(const int* len_y, int* rag, int B, int Ty, int halo) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) { const int v = len_y[b] + halo; rag[b] = v < Ty ? v : Ty; }
+  if (b >= B) return;
+  int mx = 0;
+  for (int i = 0; i < B; ++i) mx = len_y[i] > mx ? len_y[i] : mx;
+  const int end = mx < Ty ? mx : Ty;
+  const int v = len_y[b] + halo;
+  rag[b] = v < end ? v : end;
+}
+
+// Synth.audio_float_to_int16 after `audio * scale` (vosk_tts/synth.py:16-23,128-130) on the device:
+// int16(clip(a * scale * 32767, -32767, 32767)), numpy's astype truncates toward zero like the C cast
+__global__ void pcm16_kernel(const float* audio, long long a_bstride, int16_t* out, long long o_bstride, long long n, float scale,
+                             const SynthDev* dv) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n) return;
+  if (dv) scale = dv->pcm_scale;
+  float v = audio[(long long)b * a_bstride + i] * scale;
+  v = v * 32767.0f;
+  v = fminf(fmaxf(v, -32767.0f), 32767.0f);
+  out[(long long)b * o_bstride + i] = (int16_t)(int)v;
 }
 
 // ----------------------------------------------------------------------------- decoder tail
@@ -916,6 +957,92 @@ __global__ void pqmf_synthesis_kernel(const float* mb, const float* filt, float*
     }
   }
   audio[(long long)b * audio_bstride + t] = a;
+}
+
+// Fused decoder tail for one utterance or a batch: exp / sin of subband_conv_post's output, OnnxSTFT.inverse and
+// PQMF.synthesis in ONE launch (the two kernels above stay as the independently written cross-check used by tests via
+// vits_debug_tail_impl).  A block owns TAIL_MB sub-band samples of every sub-band (= TAIL_MB*S output samples):
+//   1. mag*cos(phase), mag*sin(phase) of the frames its samples touch -> LDS (each (frame, bin) evaluated once instead of
+//      once per overlapping output sample: 16x fewer transcendentals),
+//   2. the sub-band samples [m0 - HM, m0 + TAIL_MB + HM) by the same windowed-basis sum as istft_kernel -> LDS (and -> mb),
+//   3. the polyphase PQMF FIR over LDS -> audio.
+// Same operand order as the separate kernels, so results agree to rounding of the re-used products.
+#define TAIL_MB 256
+struct TailParams {
+  const float* post; const float* basis; const float* filt; float* mb; float* audio;
+  int S, N, hop, Tp, Tm, taps;
+  long long audio_bstride;
+  const int* rag; int rag_mul;  // item b is valid for rag[b]*rag_mul sub-band samples (ragged batches), null = dense
+};
+__global__ void __launch_bounds__(256) istft_pqmf_kernel(const TailParams P) {
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, b = blockIdx.y, m0 = blockIdx.x * TAIL_MB;
+  const int S = P.S, N = P.N, hop = P.hop, Tp = P.Tp, Tm = P.Tm;
+  const int cut = N / 2 + 1, C = S * (N + 2), L = P.taps + 1, padl = P.taps / 2;
+  const int HM = (padl + S - 1) / S + 1;
+  const int n_lo = m0 - HM, nsub = TAIL_MB + 2 * HM;
+  const int FR = (nsub + N) / hop + 2;
+  const int n_valid = P.rag ? (P.rag[b] * P.rag_mul < Tm ? P.rag[b] * P.rag_mul : Tm) : Tm;  // sub-band samples that exist
+  int f_hi_lim = Tp - 1;
+  if (P.rag) { const int lim = P.rag[b] * P.rag_mul / hop; f_hi_lim = lim < f_hi_lim ? lim : f_hi_lim; }  // conv_post columns that were computed
+  int f_lo = n_lo + N / 2 - N + 1;
+  f_lo = f_lo <= 0 ? 0 : (f_lo + hop - 1) / hop;
+  int f_hi = (n_lo + nsub - 1 + N / 2) / hop;
+  f_hi = f_hi < f_hi_lim ? f_hi : f_hi_lim;
+  const int nfr = f_hi - f_lo + 1;
+  float* re = sm;
+  float* im = sm + S * cut * FR;
+  float* sub = im + S * cut * FR;
+  for (int i = tid; i < S * cut * nfr; i += 256) {
+    const int fr = i % nfr, sk = i / nfr, s = sk / cut, k = sk - s * cut;
+    const float* pb = P.post + ((long long)b * C + (long long)s * (N + 2)) * Tp + f_lo + fr;
+    const float mag = expf(pb[(long long)k * Tp]);
+    const float ph = PI_F * sinf(pb[(long long)(cut + k) * Tp]);
+    float sn, cs;
+    sincosf(ph, &sn, &cs);
+    re[sk * FR + fr] = mag * cs;
+    im[sk * FR + fr] = mag * sn;
+  }
+  __syncthreads();
+  for (int i = tid; i < S * nsub; i += 256) {
+    const int s = i / nsub, q = i - s * nsub, n = n_lo + q;
+    float a = 0.f;
+    if (n >= 0 && n < n_valid) {
+      const int np = n + N / 2;
+      int t_hi = np / hop;
+      t_hi = t_hi < f_hi_lim ? t_hi : f_hi_lim;
+      int t_lo = (np - N + hop) / hop;
+      if (np - N + 1 <= 0) t_lo = 0;
+      for (int t = t_lo; t <= t_hi; ++t) {
+        const int j = np - t * hop;
+        const float* rp = re + (s * cut) * FR + (t - f_lo);
+        const float* ip = im + (s * cut) * FR + (t - f_lo);
+        for (int k = 0; k < cut; ++k) a += rp[k * FR] * P.basis[k * N + j] + ip[k * FR] * P.basis[(cut + k) * N + j];
+      }
+      a *= (float)N / (float)hop;
+      if (P.mb && q >= HM && q < HM + TAIL_MB) P.mb[((long long)b * S + s) * Tm + n] = a;
+    }
+    sub[i] = a;
+  }
+  __syncthreads();
+  const int To = Tm * S;
+  for (int r = 0; r < S; ++r) {
+    const int t = m0 * S + r * 256 + tid;
+    if (t >= To) continue;
+    float a = 0.f;
+    if (t < n_valid * S) {
+      const int j0 = ((padl - t) % S + S) % S;
+      for (int s = 0; s < S; ++s) {
+        const float* xb = sub + s * nsub - n_lo;
+        for (int j = j0; j < L; j += S) {
+          const int u = t + j - padl;  // a multiple of S by construction of j0
+          const int m = u >= 0 ? u / S : -((-u) / S);
+          a += P.filt[s * L + j] * (xb[m] * (float)S);
+        }
+      }
+    }
+    P.audio[(long long)b * P.audio_bstride + t] = a;
+  }
 }
 
 // plain HiFi-GAN tail: tanh (models.py:889)

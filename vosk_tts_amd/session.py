@@ -86,6 +86,18 @@ class VitsSession:
         self.last_lengths = lengths
         return [audio[:, None, None, :]]
 
+    def run_pcm16(self, input_feed, scale=1.0):
+        """run() followed by `audio.squeeze() * scale` and Synth.audio_float_to_int16 (vosk_tts/synth.py:127-130), with the
+        conversion done on the device (vits_synthesize_pcm16): returns int16 [B, S] -- bit-identical to converting run()'s
+        float output with numpy, half the bytes over PCIe."""
+        feed, ids, sid, seed = self._validated(None, input_feed)
+        pcm, lengths = self._model.synthesize_pcm16(
+            ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
+            pcm_scale=float(scale), noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
+            forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)))
+        self.last_lengths = lengths
+        return pcm
+
     def run_stream(self, output_names, input_feed, chunk_frames=64):
         """Streaming form of run() for ONE utterance (extension; the reference's transport is already
         `stream AudioChunk`, server/tts_service.proto:46-54): yields float32 [n] chunks of chunk_frames*256

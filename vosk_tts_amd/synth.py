@@ -95,10 +95,16 @@ class Synth:
         args, scale = self._feed(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
 
         start_time = time.perf_counter()
-        audio = self.model.onnx.run(None, args)[0]
-        audio = audio.squeeze()
-        audio = audio * scale
-        audio = self.audio_float_to_int16(audio)
+        run_pcm16 = getattr(self.model.onnx, "run_pcm16", None)
+        if run_pcm16 is not None:
+            # same three steps as below (squeeze, * scale, audio_float_to_int16) fused behind the boundary: the device
+            # converts and only int16 crosses PCIe (vits_synthesize_pcm16)
+            audio = run_pcm16(args, scale).squeeze()
+        else:
+            audio = self.model.onnx.run(None, args)[0]
+            audio = audio.squeeze()
+            audio = audio * scale
+            audio = self.audio_float_to_int16(audio)
         end_time = time.perf_counter()
 
         audio_duration_sec = audio.shape[-1] / 22050
