@@ -266,7 +266,8 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
                    int32_t C_out, int32_t T, int32_t K, int32_t dilation, float lrelu_slope, float* y);
 
 /* Test hook: 0 = choose the conv kernel by problem size (default), 1 = always the big-tile kernel,
- * 2 = always the K-split small-N kernel.  Process-wide. */
+ * 2 = always the K-split small-N kernel, 3 = the small-tile (16x16x4 MFMA, LDS-staged) kernel wherever a launch is
+ * eligible for it.  Process-wide. */
 void vits_debug_force_tile(int mode);
 /* Test hook: 0 = fp32-MFMA flash attention (default), 1 = the scalar-VALU attention kernel. */
 void vits_debug_attention_impl(int impl);

@@ -54,11 +54,12 @@ def test_conv1d_kernel_vs_oracle(hip_lib, oracle_lib, B, Cin, Cout, T, K, dil, s
     assert_close("conv1d", want, got, 2e-5)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_conv1d_randomised_shapes_on_every_kernel(hip_lib, oracle_lib, mode):
     """30 seeded random shapes (odd lengths, 1..11 taps, dilations up to the halo limit, C_in multiples of 16, C_out not
     multiples of 32, single columns, T just past tile boundaries) through the automatic dispatch (0), the big-tile kernel
-    (1) and the K-split kernel (2): every tile / halo / padding-row edge of the conv kernels against the oracle."""
+    (1), the K-split kernel (2) and the small-tile 16x16x4 kernel (3, where eligible: halo <= 48): every tile / halo /
+    padding-row edge of the conv kernels against the oracle."""
     from vosk_tts_amd.capi import op_conv1d
 
     rng = np.random.default_rng(100 + mode)
@@ -202,10 +203,10 @@ def test_stages_edge_empty_item_single_token(hip_default, oracle_default):
     _stages_vs(hip_default, oracle_default, golden("edge_b3"), STAGE_TOL)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_every_epilogue_on_both_conv_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny, mode):
-    """The size heuristic picks the K-split kernel for these small fixtures; force each kernel in turn so
-    the gate / res-skip / coupling / polyphase epilogues of BOTH implementations are checked."""
+    """The size heuristic picks the small-tile kernel for these small fixtures; force each kernel in turn so
+    the gate / res-skip / coupling / polyphase epilogues of ALL THREE implementations are checked."""
     hip_lib.lib.vits_debug_force_tile(mode)
     try:
         _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)
@@ -573,10 +574,12 @@ def test_long_form_properties_at_c5_size(hip_default):
     assert float(np.max(np.abs(half[0, :100000] - one[0, :100000]))) > 1e-3
 
 
-@pytest.mark.parametrize("B,T", [(2, 37), (16, 160)])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 37), (1, 50), (3, 333), (8, 200), (16, 160)])
 def test_duration_predictor_both_dds_paths(hip_default, oracle_default, B, T):
-    """StochasticDurationPredictor reverse (models.py:56-63,93-101) at a single-utterance size (fused one-launch-per-
-    DDSConv-layer kernel) and at a batch size beyond its B*T <= 2048 gate (depthwise+LN, MFMA 1x1, LN launches)."""
+    """StochasticDurationPredictor reverse (models.py:56-63,93-101) on all three DDSConv forms: few columns (B*T <= 1024:
+    every layer is one small-tile conv launch whose prologue finishes the previous layer and builds this layer's 1x1 input;
+    T = 333 with dilation 9 crosses many 16-column tiles), B*T <= 2048 (one workgroup-per-8-columns layer kernel), and beyond
+    (depthwise+LN, MFMA 1x1, LN launches)."""
     rng = np.random.default_rng(31)
     x = rng.standard_normal((B, 192, T)).astype(np.float32)
     lens = rng.integers(T // 2, T + 1, size=B).astype(np.int64)

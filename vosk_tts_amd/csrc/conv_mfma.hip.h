@@ -47,6 +47,7 @@ struct ConvGroup {
   const float* x2;    // optional 2nd/3rd inputs summed at staging (MRF mean, models.py:1030-1036)
   const float* x3;
   const float* w;     // packed weights (pack_conv_weights)
+  const float* w16;   // the same weights in 16x16x4 fragment order (conv_small.hip.h) or null
   const float* bias;  // [Cout] or null
   float* y;           // output
   float* y2;          // optional second copy of the output (EPI_STORE, same layout): saves a device-to-device copy
@@ -97,6 +98,15 @@ struct ConvParams {
   int first;          // EPI_RESSKIP: first layer (store skip instead of accumulate)
   int last;           // EPI_RESSKIP: last layer (M == H, everything is skip; apply mask)
   int ntiles_m, ntiles_n;
+  // DDSConv prologue of the small-tile kernel (conv_small.hip.h, PRO == 1): the B operand of this 1x1 conv is computed from
+  // the previous layer's raw tensors instead of being read:
+  //   x_in = dds_y2 ? (x + gelu(LN(dds_y2; dds_g2, dds_b2))) * mask : x * mask          (modules.py:105-107 of the layer before)
+  //   B    = dds_sw ? gelu(LN(depthwise_conv(x_in; dds_sw, dds_sb, dds_dil); dds_g1, dds_b1)) : x_in   (modules.py:100-102)
+  // dds_xout (optional) receives x_in.  x is g.x; all tensors [B, C_in, T]; P.len gives the mask.
+  const float* dds_y2; const float* dds_g2; const float* dds_b2;
+  const float* dds_sw; const float* dds_sb; const float* dds_g1; const float* dds_b1;
+  float* dds_xout;
+  int dds_dil;
   int row_len;        // LDS row = N_T + halo
   long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
   // Ragged batches: item b only needs columns up to rag[b] frames (its length + a halo wider than the

@@ -1,0 +1,320 @@
+// conv_small.hip.h — Conv1d for the FEW-COLUMN regime of a single utterance (text encoder over T_x tokens, duration
+// predictor, flow over T_y frames: N = B*T <= ~1000 columns, C = 192..768 channels).
+//
+// What bounds that regime (measured): not the matrix cores and not HBM, but how fast ONE compute unit can pull
+// its weight slab — a 32-row tile of a K = 960 conv is 123 KB per workgroup, a CU sustains only ~7-13 B/cycle of it, and with
+// 32 x 32 tiles a [384 x 150] output has just 60 workgroups on 256 CUs.  So this kernel makes the workgroups SMALL and MANY:
+//   * 16 x 16 output tile per workgroup on v_mfma_f32_16x16x4_f32 (exact fp32, same 64 FLOP/clk/SIMD rate as the 32x32x2
+//     form): 4x the workgroups of the K-split kernel, each streaming half the weight bytes; column tiles of one M-tile sit on
+//     the same XCD (block id -> XCD is id % 8), so all but the first read their slab from that XCD's L2;
+//   * the workgroup stages its whole B operand ONCE in LDS — every input channel, 16 columns + halo — cooperatively and
+//     coalesced along time (leaky-relu / mask / channel flip applied once per element instead of once per fragment per tap);
+//     every tap of every wave then reads shifted columns of that tile with ds_read_b32 (row pitch == 16 mod 32: the two
+//     k-rows a half-wave touches fall into disjoint banks);
+//   * all weight fragments of a wave (<= C16_MAXU dwordx4 per lane, pre-packed in 16x16x4 A-fragment order) are requested
+//     BEFORE the staging barrier: the weight stream, the longest latency of the kernel, flies under the staging phase and
+//     nothing in the MFMA loop waits on global memory;
+//   * the NW waves split the contraction by tap units (16 channels x 1 tap = 4 MFMAs), two independent accumulators per wave
+//     hide the 16x16x4 dependent-issue latency, partial tiles meet in LDS and 256 threads run the shared epilogues
+//     (conv_mfma.hip.h: bias / cond / ReLU / mask / residual, WN gate, res-skip, coupling tail) one element each.
+// Reference ops served: attentions.py:133-136,292-293 (q/k/v/o, FFN), modules.py:126-141 (WN in / res-skip layers),
+// models.py:374-393 (coupling pre / post), models.py:56-63 + modules.py:96-108,363-366 (duration predictor 1x1 convs).
+#pragma once
+#include "conv_mfma.hip.h"
+
+#define C16_MAXU 20  // tap units a wave keeps in registers (one dwordx4 of weights per lane each)
+
+// src(row, ci, kk) -> packed[((mb * n_u + u) * 64 + lane) * 4 + q], tap unit u = chunk*K + kk, k4-step q:
+// ci = chunk*16 + 4q + (lane>>4), row = mb*16 + (lane&15).
+// A (16x16x4 MFMA): lane l holds A[i = l&15][k = l>>4]; B: lane l holds B[k = l>>4][j = l&15];
+// C/D: lane l, register r: row 4*(l>>4) + r, column l&15.
+template <typename F>
+static void pack_conv_weights16(float* dst, int Mpad16, int Cin, int K, F src) {
+  const int n_u = Cin / CONV_CI_T * K;
+  for (int mb = 0; mb < Mpad16 / 16; ++mb)
+    for (int u = 0; u < n_u; ++u)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int q = 0; q < 4; ++q) {
+          const int chunk = u / K, kk = u % K;
+          const int ci = chunk * CONV_CI_T + 4 * q + (lane >> 4);
+          const int row = mb * 16 + (lane & 15);
+          dst[(((size_t)mb * n_u + u) * 64 + lane) * 4 + q] = src(row, ci, kk);
+        }
+}
+
+// LDS row pitch for a staged row of `row` floats: == 16 (mod 32) so that B-fragment reads are bank-conflict free
+static inline int c16_row_pitch(int row) { return row <= 16 ? 16 : (row <= 48 ? 48 : 80); }
+
+// ---- DDSConv prologue (PRO == 1; 256 threads, C_in <= 256, 3-tap depthwise conv) ---------------------------------------
+// thread = (column j = tid & 15, channel group cg = tid >> 4), channels cg + 16 i.  Channel LayerNorms are two-pass
+// (mean, then centred second moment) like modules.LayerNorm / F.layer_norm; the 16 channel groups meet in LDS.
+#define DDS_MAXI 16  // channels per thread (C_in <= 256)
+template <int NT>
+__device__ __forceinline__ void c16_colsum(float (&v)[NT], float* red, int cg, int j) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k) red[(cg * NT + k) * 16 + j] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[(g * NT + k) * 16 + j];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ float c16_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGroup& G, int b, int mt, int n0, float* tile, float* red) {
+  const int tid = threadIdx.x, j = tid & 15, cg = tid >> 4;
+  const int D = P.Cin, T = P.Tin, nci = D >> 4;
+  const int L = P.len[b] < T ? P.len[b] : T;
+  const float invD = 1.0f / (float)D;
+  const bool dw = P.dds_sw != nullptr;
+  const int dil = P.dds_dil;
+  const long long bo = (long long)b * P.x_bstride;
+  const float* xb = G.x + bo;
+  const float* yb = P.dds_y2 ? P.dds_y2 + bo : nullptr;
+  int tk[3], tkc[3];
+  bool tin[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    tk[k] = n0 + j + (dw ? (k - 1) * dil : 0);
+    tin[k] = tk[k] >= 0 && tk[k] < L;
+    tkc[k] = tk[k] < 0 ? 0 : (tk[k] >= T ? T - 1 : tk[k]);
+  }
+  // x_in at the three tap columns (finish mode: only k == 1 matters, the other two repeat it)
+  float xin[3][DDS_MAXI];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < DDS_MAXI; ++i) {
+      const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+      xin[k][i] = xb[(long long)cc * T + tkc[k]];
+    }
+  if (yb) {
+    float yv[3][DDS_MAXI];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < DDS_MAXI; ++i) {
+        const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+        yv[k][i] = yb[(long long)cc * T + tkc[k]];
+      }
+    float g2[DDS_MAXI], b2[DDS_MAXI];
+#pragma unroll
+    for (int i = 0; i < DDS_MAXI; ++i) {
+      const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+      g2[i] = P.dds_g2[cc]; b2[i] = P.dds_b2[cc];
+    }
+    float mean[3], var[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      mean[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < DDS_MAXI; ++i) mean[k] += i < nci ? yv[k][i] : 0.f;
+    }
+    c16_colsum<3>(mean, red, cg, j);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      mean[k] *= invD;
+      var[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < DDS_MAXI; ++i) { const float d = yv[k][i] - mean[k]; var[k] += i < nci ? d * d : 0.f; }
+    }
+    c16_colsum<3>(var, red, cg, j);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float rstd = 1.0f / sqrtf(var[k] * invD + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < DDS_MAXI; ++i) {
+        const float y = c16_gelu((yv[k][i] - mean[k]) * rstd * g2[i] + b2[i]);
+        xin[k][i] = tin[k] ? xin[k][i] + y : 0.f;  // x = (x + y) * mask, masked every layer (every read of x is masked)
+      }
+    }
+    if (P.dds_xout && mt == 0 && tk[1] < T) {
+      float* xo = P.dds_xout + bo;
+#pragma unroll
+      for (int i = 0; i < DDS_MAXI; ++i)
+        if (i < nci) xo[(long long)(cg + 16 * i) * T + tk[1]] = xin[1][i];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < DDS_MAXI; ++i) xin[k][i] = tin[k] ? xin[k][i] : 0.f;
+  }
+  if (!dw) {
+#pragma unroll
+    for (int i = 0; i < DDS_MAXI; ++i)
+      if (i < nci) tile[(cg + 16 * i) * 16 + j] = xin[1][i];
+    return;
+  }
+  // y = conv_sep(x * mask) -> LN1 -> GELU
+  float y1[DDS_MAXI];
+  float m1[1] = {0.f};
+#pragma unroll
+  for (int i = 0; i < DDS_MAXI; ++i) {
+    const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+    float a = P.dds_sb[cc];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a += P.dds_sw[cc * 3 + k] * xin[k][i];
+    y1[i] = a;
+    m1[0] += i < nci ? a : 0.f;
+  }
+  c16_colsum<1>(m1, red, cg, j);
+  m1[0] *= invD;
+  float v1[1] = {0.f};
+#pragma unroll
+  for (int i = 0; i < DDS_MAXI; ++i) { const float d = y1[i] - m1[0]; v1[0] += i < nci ? d * d : 0.f; }
+  c16_colsum<1>(v1, red, cg, j);
+  const float rstd1 = 1.0f / sqrtf(v1[0] * invD + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < DDS_MAXI; ++i) {
+    const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+    if (i < nci) tile[c * 16 + j] = c16_gelu((y1[i] - m1[0]) * rstd1 * P.dds_g1[cc] + P.dds_b1[cc]);
+  }
+}
+
+template <int EPI, int NW, int MAXU, int PRO = 0>
+__global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> (M-tile, batch item, column tile): every column tile of an M-tile on the XCD mt % 8
+  const int Lb = blockIdx.x, xcd = Lb & 7, slot = Lb >> 3;
+  const int per = P.ntiles_n * P.B;
+  const int mt = xcd + 8 * (slot / per);
+  if (mt >= P.ntiles_m) return;
+  const int rr = slot - (slot / per) * per;
+  const int b = rr / P.ntiles_n, nt = rr - b * P.ntiles_n;
+  const ConvGroup& G = P.g[0];
+  const int n0 = nt * 16, m0 = mt * 16;
+  const int K = G.K, dil = G.dil;
+  int t_lim = P.Tin;
+  int lenb = 0x7fffffff;
+  if (P.in_mask || P.out_mask || P.skip_len || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) lenb = P.len[b];
+  if (P.in_mask) t_lim = lenb < t_lim ? lenb : t_lim;
+  if (P.skip_len && n0 >= lenb) return;  // masked stage of a ragged batch / padded bucket: the tile is all padding
+  const int ROW = 16 + (K - 1) * dil, ROWP = P.row_len;
+  const int total_u = P.Cin / CONV_CI_T * K;
+  const int my_units = wave < total_u ? (total_u - wave + NW - 1) / NW : 0;
+
+  // ---- 1. every weight fragment of this wave, requested up front (uniform base + lane*16 bytes)
+  const f32x4* wp = reinterpret_cast<const f32x4*>(G.w16) + (size_t)mt * total_u * 64 + lane;
+  // (unconditional with a clamped unit index: a guarded load makes hipcc wait for the weight stream before it issues
+  // the staging loads; MAXU is instantiated at 8 and C16_MAXU so short contractions do not issue dead loads)
+  f32x4 a[MAXU];
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = wave + NW * i;
+    a[i] = wp[(size_t)(u < total_u ? u : total_u - 1) * 64];
+  }
+
+  // ---- 2. stage the B operand: all C_in channels x ROW columns, rpi rows per wave-instruction
+  if (PRO == 1) {
+    c16_stage_dds(P, G, b, mt, n0, lds, lds + P.Cin * 16);
+  } else {
+    const int rpi = ROW <= 16 ? 4 : (ROW <= 21 ? 3 : (ROW <= 32 ? 2 : 1));
+    const int seg = 64 / rpi;
+    const int rsub = lane / seg, j = lane - rsub * seg;
+    const bool jok = j < ROW && rsub < rpi;
+    const int t = n0 - G.pad_l + j;
+    const bool tok = jok && t >= 0 && t < t_lim;
+    const int tc = t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t);
+    const float* xb = G.x + (long long)b * P.x_bstride;
+    const float* xb2 = G.x2 ? G.x2 + (long long)b * P.x_bstride : xb;
+    const float slope = P.in_slope, scale = P.in_scale;
+    const int Cin = P.Cin, split = P.x_split ? P.x_split : 0x7fffffff;
+    const int step = NW * rpi;
+    // batches of C16_SB rows per thread: every load of a batch is issued before the first LDS write, so a batch costs one
+    // memory round trip (C_in = 192, 4 waves, 3 rows per instruction: the whole tile is ONE batch)
+    constexpr int C16_SB = 16;
+    const int chs = P.x_ch_sign * P.Tin_stride;           // element offset of one channel step (negative: Flip folded in)
+    const int ch0 = P.x_ch_off * P.Tin_stride + tc;         // (x_ch_off + c*sign) >= 0 for every channel
+    for (int cb = wave * rpi; cb < Cin; cb += step * C16_SB) {
+      float v[C16_SB];
+      if (P.x_split == 0) {  // uniform base pointer + 32-bit lane offset: one address add per load
+#pragma unroll
+        for (int k = 0; k < C16_SB; ++k) {
+          const int c = cb + k * step + rsub;
+          const int cc = c < Cin ? c : Cin - 1;
+          v[k] = ks_ld(xb, (unsigned)(ch0 + cc * chs) * 4u);
+        }
+      } else {               // channel-concatenated second input (cat((x, x2), dim=1) never materialised)
+#pragma unroll
+        for (int k = 0; k < C16_SB; ++k) {
+          const int c = cb + k * step + rsub;
+          const int cc = c < Cin ? c : Cin - 1;
+          const bool second = cc >= split;
+          v[k] = ks_ld(second ? xb2 : xb, (unsigned)(ch0 + (second ? cc - split : cc) * chs) * 4u);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < C16_SB; ++k) {
+        const int c = cb + k * step + rsub;
+        const float o = tok ? conv_act_in(v[k], scale, slope) : 0.f;  // select, not multiply: stale padding may hold NaN
+        if (jok && c < Cin) lds[c * ROWP + j] = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. MFMAs: unit u = (chunk c, tap kk); k4-step q covers channels 16c + 4q + (lane>>4)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* bl = lds + (lane >> 4) * ROWP + (lane & 15);
+    int uc = wave / K, uk = wave - (wave / K) * K;
+    const int step_c = NW / K, step_k = NW - step_c * K;
+    // B fragments are read one unit ahead of the MFMAs that consume them (LDS latency ~ one unit's MFMA time)
+    float bc[4], bn[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* bp = bl + uc * (CONV_CI_T * ROWP) + uk * dil;
+      bc[0] = bp[0]; bc[1] = bp[4 * ROWP]; bc[2] = bp[8 * ROWP]; bc[3] = bp[12 * ROWP];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      if (i < my_units) {
+        uk += step_k;
+        uc += step_c + (uk >= K ? 1 : 0);
+        uk -= uk >= K ? K : 0;
+        if (i + 1 < my_units) {
+          const float* bp = bl + uc * (CONV_CI_T * ROWP) + uk * dil;
+          bn[0] = bp[0]; bn[1] = bp[4 * ROWP]; bn[2] = bp[8 * ROWP]; bn[3] = bp[12 * ROWP];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0], bc[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1], bc[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][2], bc[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][3], bc[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+      }
+    }
+  }
+
+  // ---- 4. cross-wave reduction (the staged tile is dead: reuse its LDS) and one-element-per-thread epilogue
+  __syncthreads();
+  float* red = lds;  // [wave][r][lane]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
+  __syncthreads();
+  if (EPI == EPI_GATE) {
+    // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8*mt .. 8*mt + 7
+    if (tid >= 128) return;
+    const int ch = tid >> 4, col = tid & 15;
+    float at[1] = {0.f}, as[1] = {0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      at[0] += red[(w * 4 + (ch & 3)) * 64 + (ch >> 2) * 16 + col];
+      as[0] += red[(w * 4 + (ch & 3)) * 64 + ((ch >> 2) + 2) * 16 + col];
+    }
+    conv_epilogue_gate<1>(P, G, b, mt * 8 + ch, 0, n0 + col, at, as);
+    return;
+  }
+  if (tid >= 256) return;
+  const int row = tid >> 4, col = tid & 15;
+  float v[1] = {0.f};
+#pragma unroll
+  for (int w = 0; w < NW; ++w) v[0] += red[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + col];
+  conv_epilogue_frag<EPI, 1>(P, G, b, lenb, m0 + row, 0, n0 + col, v);
+}

@@ -23,6 +23,7 @@
 
 #include "../../include/vits_mi355.h"
 #include "conv_mfma.hip.h"
+#include "conv_small.hip.h"
 #include "kernels_misc.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
@@ -60,6 +61,7 @@ static int g_tail_impl = 0;
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
   float* w = nullptr;     // packed, MFMA fragment order
+  float* w16 = nullptr;   // packed for the small-tile kernel (16x16x4 fragment order), null when not built
   float* bias = nullptr;  // original row order
   int M = 0, Mpad = 0, Cin = 0, K = 0, n_sg = 0;
 };
@@ -209,8 +211,11 @@ static float* upload(vits_model* m, const float* host, size_t n) {
 }
 
 // Generic packer: rows x Cin x K from a row-source functor (row may be remapped / zero padded).
-template <typename F>
-static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, F src) {
+// small16: also pack for conv16_kernel (encoder / duration predictor / flow convs; the decoder never runs in the few-column
+// regime with a single group, so its convs skip the second copy).  src16: row source of that packing when its row order
+// differs (WN gate: [8 tanh | 8 sigmoid] per 16-row block instead of [32 | 32]).
+template <typename F, typename F16>
+static ConvW make_conv2(vits_model* m, int M, int Cin, int K, const float* bias, F src, bool small16, F16 src16) {
   ConvW c;
   c.M = M; c.Mpad = cdiv(M, 32) * 32; c.Cin = Cin; c.K = K;
   if (Cin % CONV_CI_T != 0) { m->missing = true; fail(VITS_ERR_UNSUPPORTED, "conv C_in=%d is not a multiple of %d", Cin, CONV_CI_T); return c; }
@@ -218,16 +223,26 @@ static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, 
   std::vector<float> packed((size_t)c.Mpad * Cin * K);
   pack_conv_weights(packed.data(), c.Mpad, Cin, K, [&](int row, int ci, int kk) -> float { return row < M ? src(row, ci, kk) : 0.f; });
   c.w = upload(m, packed.data(), packed.size());
+  if (small16) {
+    const int Mp16 = cdiv(M, 16) * 16;
+    packed.assign((size_t)Mp16 * Cin * K, 0.f);
+    pack_conv_weights16(packed.data(), Mp16, Cin, K, [&](int row, int ci, int kk) -> float { return row < M ? src16(row, ci, kk) : 0.f; });
+    c.w16 = upload(m, packed.data(), packed.size());
+  }
   c.bias = bias ? upload(m, bias, M) : nullptr;
   return c;
 }
+template <typename F>
+static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, F src, bool small16 = true) {
+  return make_conv2(m, M, Cin, K, bias, src, small16, src);
+}
 
 // nn.Conv1d weight [Cout, Cin, K] (+ optional bias)
-static ConvW conv_from(vits_model* m, const char* name, int Cout, int Cin, int K, bool has_bias) {
+static ConvW conv_from(vits_model* m, const char* name, int Cout, int Cin, int K, bool has_bias, bool small16 = true) {
   const float* w = tget(m, 3, Cout, Cin, K, "%s.weight", name);
   const float* b = has_bias ? tget(m, 1, Cout, -1, -1, "%s.bias", name) : nullptr;
   if (m->missing) return ConvW();
-  return make_conv(m, Cout, Cin, K, b, [&](int r, int ci, int kk) { return w[((size_t)r * Cin + ci) * K + kk]; });
+  return make_conv(m, Cout, Cin, K, b, [&](int r, int ci, int kk) { return w[((size_t)r * Cin + ci) * K + kk]; }, small16);
 }
 
 static void load_encoder(vits_model* m, EncoderW& E, const char* pfx, int n_layers, int H, int F, int K) {
@@ -300,7 +315,7 @@ static int load_decoder(vits_model* m) {
   const int I = hp.inter_channels;
   char nm[200];
   int C = hp.dec_initial_channel;
-  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true);
+  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true, false);
   m->ups.resize(hp.n_ups);
   m->rb.resize((size_t)hp.n_ups * hp.n_resk);
   for (int i = 0; i < hp.n_ups && !m->missing; ++i) {
@@ -327,7 +342,7 @@ static int load_decoder(vits_model* m) {
       const int r = row / Co, co = row % Co;
       const int k = r + p - u * (dmin[r] + j);
       return (k >= 0 && k < Ku) ? w[((size_t)ci * Co + co) * Ku + k] : 0.f;
-    });
+    }, false);
     U.w.bias = upload(m, b, Co);
     C = Co;
     for (int j = 0; j < hp.n_resk && !m->missing; ++j) {
@@ -337,16 +352,16 @@ static int load_decoder(vits_model* m) {
         R.dil[d] = hp.res_dilations[j][d];
         if ((R.K - 1) * R.dil[d] > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "resblock receptive field too wide");
         snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", i * hp.n_resk + j, d);
-        R.c1[d] = conv_from(m, nm, C, C, R.K, true);
+        R.c1[d] = conv_from(m, nm, C, C, R.K, true, false);
         snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", i * hp.n_resk + j, d);
-        R.c2[d] = conv_from(m, nm, C, C, R.K, true);
+        R.c2[d] = conv_from(m, nm, C, C, R.K, true, false);
       }
     }
   }
   if (m->missing) return VITS_ERR_BLOB;
   if (hp.dec_type == 0) {
     const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, cut = N / 2 + 1;
-    m->conv_post = conv_from(m, "dec.subband_conv_post", S * (N + 2), C, 7, false);
+    m->conv_post = conv_from(m, "dec.subband_conv_post", S * (N + 2), C, 7, false, false);
     // OnnxSTFT inverse basis (stft.py:191-214): pinv(scale*[Re F;Im F]).T * hann == irfft synthesis rows / scale
     std::vector<float> basis((size_t)2 * cut * N);
     const double PI_D = 3.14159265358979323846, scale = (double)N / hop;
@@ -375,7 +390,7 @@ static int load_decoder(vits_model* m) {
     m->pqmf = upload(m, filt.data(), filt.size());
   } else {
     // VITS' Generator has no conv_post bias (models.py:866); the HiFi-GAN bundled with StableTTS has one
-    m->conv_post = conv_from(m, "dec.conv_post", 1, C, 7, thas(m, "dec.conv_post.bias"));
+    m->conv_post = conv_from(m, "dec.conv_post", 1, C, 7, thas(m, "dec.conv_post.bias"), false);
   }
   return m->missing ? VITS_ERR_BLOB : VITS_OK;
 }
@@ -462,9 +477,13 @@ static int load_model(vits_model* m) {
       const float* w = tget(m, 3, 2 * H, H, K5, "flow.flows.%d.enc.in_layers.%d.weight", 2 * f, i);
       const float* b = tget(m, 1, 2 * H, -1, -1, "flow.flows.%d.enc.in_layers.%d.bias", 2 * f, i);
       if (m->missing) break;
-      c.in_layers.push_back(make_conv(m, 2 * H, H, K5, b, [&](int r, int ci, int kk) {
+      c.in_layers.push_back(make_conv2(m, 2 * H, H, K5, b, [&](int r, int ci, int kk) {
         const int j = r / 64, q = r % 64;
         const int orig = q < 32 ? j * 32 + q : H + j * 32 + (q - 32);
+        return w[((size_t)orig * H + ci) * K5 + kk];
+      }, true, [&](int r, int ci, int kk) {  // small-tile kernel: [8 tanh | 8 sigmoid] per 16 rows
+        const int j = r / 16, q = r % 16;
+        const int orig = q < 8 ? j * 8 + q : H + j * 8 + (q - 8);
         return w[((size_t)orig * H + ci) * K5 + kk];
       }));
       snprintf(nm, sizeof nm, "flow.flows.%d.enc.res_skip_layers.%d", 2 * f, i);
@@ -523,6 +542,7 @@ struct vits_session {
   float *x = nullptr, *qkv = nullptr, *att = nullptr, *y1 = nullptr, *ffh = nullptr, *stats = nullptr;
   float *condv = nullptr;
   float *dh = nullptr, *dy = nullptr, *dy2 = nullptr, *dc = nullptr, *dz = nullptr, *dpr = nullptr, *logw = nullptr, *dfh = nullptr;
+  float *dq1 = nullptr, *dq2 = nullptr;  // second x / y pair of the per-layer DDSConv launches (ping-pong with dy / dy2)
   float *zA = nullptr, *zB = nullptr, *fh = nullptr, *fx = nullptr, *facts = nullptr, *fskip = nullptr;
   std::vector<float*> dec_bufs;
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
@@ -580,6 +600,7 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->stats = bump<float>(s, B * 2 * I * Tx);
   s->dh = bump<float>(s, B * D * Tx); s->dy = bump<float>(s, B * D * Tx); s->dy2 = bump<float>(s, B * D * Tx);
   s->dc = bump<float>(s, B * D * Tx); s->dfh = bump<float>(s, B * D * Tx);
+  s->dq1 = bump<float>(s, B * D * Tx); s->dq2 = bump<float>(s, B * D * Tx);
   s->dz = bump<float>(s, (size_t)B * 2 * Tx); s->dpr = bump<float>(s, (size_t)B * 32 * Tx); s->logw = bump<float>(s, (size_t)B * Tx);
   s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
   s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
@@ -795,6 +816,75 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo, ProfScope* ps = 
 #undef KS_GO
 }
 
+// ---- small-tile kernel (conv_small.hip.h): eligibility + launch
+template <int EPI, int NW, int MAXU>
+static void launch_c16_inst(hipStream_t st, const ConvParams& P, dim3 grid, size_t lds) {
+  auto kern = conv16_kernel<EPI, NW, MAXU>;
+  if (lds > 64 * 1024) {
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)once;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, P);
+}
+// returns 0 when the launch cannot take the small-tile kernel, else the wave count it would run with
+static int c16_waves(const ConvParams& P, int epi) {
+  const ConvGroup& G = P.g[0];
+  if (P.n_groups != 1 || !G.w16 || P.ups_u || G.x3 || (G.x2 && !P.x_split) || P.reflect || P.rag || P.Cin % CONV_CI_T) return 0;
+  if (epi == EPI_GATE && (P.H % 8)) return 0;
+  const int halo = (G.K - 1) * G.dil;
+  if (halo > 48) return 0;
+  const size_t lds = (size_t)P.Cin * c16_row_pitch(16 + halo) * sizeof(float);
+  if (lds > 150 * 1024) return 0;
+  const int units = P.Cin / CONV_CI_T * G.K;
+  if (units <= 4 * C16_MAXU) return 4;
+  if (units <= 8 * C16_MAXU) return 8;
+  return 0;
+}
+static void launch_c16(vits_session* s, ConvParams& P, int epi, int nw) {
+  const ConvGroup& G = P.g[0];
+  P.tile_start = nullptr;
+  P.ntiles_m = cdiv(epi == EPI_GATE ? 2 * P.H : P.Cout, 16);
+  P.ntiles_n = cdiv(P.Tout, 16);
+  P.row_len = c16_row_pitch(16 + (G.K - 1) * G.dil);
+  size_t lds = (size_t)P.Cin * P.row_len * sizeof(float);
+  const size_t red = (size_t)nw * 4 * 64 * sizeof(float);
+  if (lds < red) lds = red;
+  const dim3 grid(8 * cdiv(P.ntiles_m, 8) * P.ntiles_n * P.B);
+  hipStream_t st = s->stream;
+  const bool few = cdiv(P.Cin / CONV_CI_T * G.K, nw) <= 8;
+#define C16_GO(EPI_)                                                                  \
+  do {                                                                                \
+    if (nw == 8) {                                                                    \
+      if (few) launch_c16_inst<EPI_, 8, 8>(st, P, grid, lds);                         \
+      else launch_c16_inst<EPI_, 8, C16_MAXU>(st, P, grid, lds);                      \
+    } else {                                                                          \
+      if (few) launch_c16_inst<EPI_, 4, 8>(st, P, grid, lds);                         \
+      else launch_c16_inst<EPI_, 4, C16_MAXU>(st, P, grid, lds);                      \
+    }                                                                                 \
+  } while (0)
+  if (epi == EPI_GATE) C16_GO(EPI_GATE);
+  else if (epi == EPI_RESSKIP) C16_GO(EPI_RESSKIP);
+  else if (epi == EPI_COUPLE) C16_GO(EPI_COUPLE);
+  else C16_GO(EPI_STORE);
+#undef C16_GO
+}
+
+// 1x1 conv whose B operand is produced by the DDSConv prologue (conv_small.hip.h PRO == 1); P.dds_* set by the caller
+static bool c16_dds_ok(const ConvParams& P, int dds_K) {
+  return P.g[0].w16 && P.g[0].K == 1 && P.Cin % 16 == 0 && P.Cin <= 16 * DDS_MAXI && dds_K == 3 && P.Cin / CONV_CI_T <= 4 * C16_MAXU && P.len;
+}
+static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, double flops) {
+  ProfScope ps(s, name, flops, "conv16_kernel<STORE,dds>");
+  P.tile_start = nullptr;
+  P.ntiles_m = cdiv(P.Cout, 16);
+  P.ntiles_n = cdiv(P.Tout, 16);
+  P.row_len = 16;
+  const size_t lds = ((size_t)P.Cin * 16 + 16 * 3 * 16) * sizeof(float);
+  const dim3 grid(8 * cdiv(P.ntiles_m, 8) * P.ntiles_n * P.B);
+  if (P.Cin / CONV_CI_T <= 4 * 8) hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, 8, 1>), grid, dim3(256), lds, s->stream, P);
+  else hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, C16_MAXU, 1>), grid, dim3(256), lds, s->stream, P);
+}
+
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
 // Large problems (>= 2 workgroups per CU with 64x64 tiles) use the big-tile kernel (more operand
 // reuse); everything smaller uses the K-split kernel so that one utterance still fills the chip.
@@ -843,6 +933,18 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   static const long ks_threshold = getenv("VITS_KS_THRESHOLD") ? atol(getenv("VITS_KS_THRESHOLD")) : 512;
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
+  // few-column regime (a single utterance's encoder / duration predictor / flow): many small workgroups, LDS-staged B
+  static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
+  if (g_force_tile == 3 || (g_force_tile == 0 && (long)P.B * P.Tout <= c16_cols)) {
+    const int nw16 = c16_waves(P, epi);
+    if (nw16) {
+      static const char* names[4] = {"conv16_kernel<STORE>", "conv16_kernel<GATE>", "conv16_kernel<RESSKIP>", "conv16_kernel<COUPLE>"};
+      ps.set_kernel(names[epi]);
+      ps.add_template_arg(nw16);
+      launch_c16(s, P, epi, nw16);
+      return;
+    }
+  }
   if (epi == EPI_GATE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo, &ps); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
@@ -888,7 +990,7 @@ static ConvParams conv_params(const ConvW& W, const float* x, float* y, int B, i
   ConvParams P;
   memset(&P, 0, sizeof P);
   P.n_groups = 1;
-  P.g[0].x = x; P.g[0].w = W.w; P.g[0].bias = W.bias; P.g[0].y = y;
+  P.g[0].x = x; P.g[0].w = W.w; P.g[0].w16 = W.w16; P.g[0].bias = W.bias; P.g[0].y = y;
   P.g[0].K = W.K; P.g[0].dil = dil; P.g[0].pad_l = pad_l; P.g[0].n_sg = W.n_sg;
   P.B = B; P.Cin = W.Cin; P.x_ch_off = 0; P.x_ch_sign = 1;
   P.x_bstride = (long long)W.Cin * T; P.Tin = T; P.Tin_stride = T;
@@ -1038,6 +1140,51 @@ static float* run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
   return h;
 }
 
+// DDSConv.forward (modules.py:96-108) on h [B,D,T] (h already includes +g) followed by the 1x1 `proj` conv that consumes it
+// (dp.proj, models.py:59-63; ConvFlow.proj, modules.py:367-368): out = proj(DDSConv(h)) * mask.
+// Few-column regime: every layer is ONE launch of the small-tile conv kernel whose prologue builds the layer's 1x1 input from
+// the previous layer's raw tensors (finish LN2 + GELU + residual, depthwise conv, LN1, GELU: conv_small.hip.h), and `proj`
+// finishes the last layer the same way -- n_layers + 1 launches of ~16 x T/16 small workgroups.  Larger problems keep one
+// workgroup-per-8-columns fused layer kernel or the three-launch form, then the plain proj conv.
+static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& proj, float* out, const char* proj_name, int B, int T) {
+  const vits_hparams& hp = s->m->hp;
+  const int D = hp.dp_filter_channels, K = hp.dp_kernel_size;
+  static const bool no_c16 = getenv("VITS_NO_DDS_C16") != nullptr;  // A/B switch for tools/ and tests
+  static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
+  {
+    ConvParams P = conv_params(proj, h, out, B, T, 1, 0);
+    P.len = s->len_x;
+    if (!no_c16 && (g_force_tile == 0 || g_force_tile == 3) && (long)B * T <= c16_cols && c16_dds_ok(P, K) && W.pw.size() >= 1 && W.pw[0].w16) {
+      const int n = (int)W.pw.size();
+      float* X[2] = {s->dy, s->dq1};
+      float* Y[2] = {s->dy2, s->dq2};
+      const float* xin = h;
+      int dil = 1;
+      for (int i = 0; i <= n; ++i) {
+        const bool fin = i == n;
+        P = conv_params(fin ? proj : W.pw[i], xin, fin ? out : Y[i & 1], B, T, 1, 0);
+        P.len = s->len_x;
+        if (fin) P.out_mask = 1;
+        mark_masked(s, P, s->len_x);
+        if (i > 0) {
+          P.dds_y2 = Y[(i - 1) & 1]; P.dds_g2 = W.g2[i - 1]; P.dds_b2 = W.b2[i - 1];
+          if (!fin) P.dds_xout = X[(i - 1) & 1];
+        }
+        if (!fin) { P.dds_sw = W.sw[i]; P.dds_sb = W.sb[i]; P.dds_g1 = W.g1[i]; P.dds_b1 = W.b1[i]; P.dds_dil = dil; }
+        launch_c16_dds(s, P, fin ? proj_name : "dp.dds_layer", 2.0 * B * T * ((double)P.Cout * D + (fin ? 0.0 : (double)D * K)));
+        if (i > 0 && !fin) xin = X[(i - 1) & 1];
+        dil *= K;
+      }
+      return;
+    }
+  }
+  const float* hd = run_dds(s, W, h, B, T);
+  ConvParams P = conv_params(proj, hd, out, B, T, 1, 0);
+  P.out_mask = 1; P.len = s->len_x;
+  mark_masked(s, P, s->len_x);
+  launch_conv(s, P, EPI_STORE, proj_name);
+}
+
 // ---- a6: StochasticDurationPredictor.forward(reverse=True) (models.py:56-63,93-101) -> s->logw
 static void run_duration(vits_session* s, const float* x, const float* d_noise, float nsw, uint64_t seed, int B, int Tx) {
   vits_model* m = s->m;
@@ -1047,11 +1194,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dp_off; }
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.pre");
-  const float* hd = run_dds(s, m->dp_dds, s->dh, B, Tx);
-  P = conv_params(m->dp_proj, hd, s->dc, B, Tx, 1, 0);
-  P.out_mask = 1; P.len = s->len_x;
-  mark_masked(s, P, s->len_x);
-  launch_conv(s, P, EPI_STORE, "dp.proj");
+  run_dds_proj(s, m->dp_dds, s->dh, m->dp_proj, s->dc, "dp.proj", B, Tx);
   hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx, s->solo ? 1 : 0, s->dv);
   int swap = 0;
   const float cst = (float)log(exp(1.0 - 1e-3) - 1.0);
@@ -1061,11 +1204,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
     const ConvFlowW& c = m->cf[k];
     hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(Tx, 64), D, B), dim3(64), 0, s->stream, s->dz, swap, c.pre_w, c.pre_b,
                        s->dc, s->dfh, D, Tx);
-    const float* hf = run_dds(s, c.dds, s->dfh, B, Tx);
-    P = conv_params(c.proj, hf, s->dpr, B, Tx, 1, 0);
-    P.out_mask = 1; P.len = s->len_x;
-    mark_masked(s, P, s->len_x);
-    launch_conv(s, P, EPI_STORE, "dp.cfproj");
+    run_dds_proj(s, c.dds, s->dfh, c.proj, s->dpr, "dp.cfproj", B, Tx);
     hipLaunchKernelGGL(spline_inverse_kernel, dim3(cdiv(Tx, 64), B), dim3(64), 0, s->stream, s->dz, swap, s->dpr, c.proj.M,
                        s->len_x, Tx, hp.dp_num_bins, hp.dp_tail_bound, 1.0f / sqrtf((float)D));
   }
@@ -1230,7 +1369,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
       ProfScope ps(s, "istft_pqmf", 0, "istft_pqmf_kernel");
       TailParams tp{post, m->istft_basis, m->pqmf, mb, d_audio, S, N, hop, Tp, Tm, hp.pqmf_taps, audio_bstride, rag, rate * hop};
       const int HM = (hp.pqmf_taps / 2 + S - 1) / S + 1, nsub = TAIL_MB + 2 * HM, FR = (nsub + N) / hop + 2;
-      const size_t lds = ((size_t)2 * S * (N / 2 + 1) * FR + (size_t)S * nsub) * sizeof(float);
+      const size_t lds = ((size_t)2 * S * (N / 2 + 1) * FR + (size_t)S * nsub + (size_t)(N + 2) * N + (size_t)S * (hp.pqmf_taps + 1)) * sizeof(float);
       hipLaunchKernelGGL(istft_pqmf_kernel, dim3(cdiv(Tm, TAIL_MB), B), dim3(256), lds, s->stream, tp);
     } else {
       {

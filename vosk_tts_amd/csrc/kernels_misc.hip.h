@@ -967,7 +967,7 @@ __global__ void pqmf_synthesis_kernel(const float* mb, const float* filt, float*
 //   2. the sub-band samples [m0 - HM, m0 + TAIL_MB + HM) by the same windowed-basis sum as istft_kernel -> LDS (and -> mb),
 //   3. the polyphase PQMF FIR over LDS -> audio.
 // Same operand order as the separate kernels, so results agree to rounding of the re-used products.
-#define TAIL_MB 256
+#define TAIL_MB 64
 struct TailParams {
   const float* post; const float* basis; const float* filt; float* mb; float* audio;
   int S, N, hop, Tp, Tm, taps;
@@ -990,9 +990,13 @@ __global__ void __launch_bounds__(256) istft_pqmf_kernel(const TailParams P) {
   int f_hi = (n_lo + nsub - 1 + N / 2) / hop;
   f_hi = f_hi < f_hi_lim ? f_hi : f_hi_lim;
   const int nfr = f_hi - f_lo + 1;
-  float* re = sm;
-  float* im = sm + S * cut * FR;
-  float* sub = im + S * cut * FR;
+  float* re = sm;                       // [S*cut][FR]
+  float* im = re + S * cut * FR;
+  float* sub = im + S * cut * FR;       // [S][nsub]
+  float* bas = sub + S * nsub;          // [(N+2)][N]   windowed inverse basis
+  float* flt = bas + (N + 2) * N;       // [S][L]       PQMF synthesis filters
+  for (int i = tid; i < (N + 2) * N; i += 256) bas[i] = P.basis[i];
+  for (int i = tid; i < S * L; i += 256) flt[i] = P.filt[i];
   for (int i = tid; i < S * cut * nfr; i += 256) {
     const int fr = i % nfr, sk = i / nfr, s = sk / cut, k = sk - s * cut;
     const float* pb = P.post + ((long long)b * C + (long long)s * (N + 2)) * Tp + f_lo + fr;
@@ -1017,7 +1021,7 @@ __global__ void __launch_bounds__(256) istft_pqmf_kernel(const TailParams P) {
         const int j = np - t * hop;
         const float* rp = re + (s * cut) * FR + (t - f_lo);
         const float* ip = im + (s * cut) * FR + (t - f_lo);
-        for (int k = 0; k < cut; ++k) a += rp[k * FR] * P.basis[k * N + j] + ip[k * FR] * P.basis[(cut + k) * N + j];
+        for (int k = 0; k < cut; ++k) a += rp[k * FR] * bas[k * N + j] + ip[k * FR] * bas[(cut + k) * N + j];
       }
       a *= (float)N / (float)hop;
       if (P.mb && q >= HM && q < HM + TAIL_MB) P.mb[((long long)b * S + s) * Tm + n] = a;
@@ -1026,9 +1030,10 @@ __global__ void __launch_bounds__(256) istft_pqmf_kernel(const TailParams P) {
   }
   __syncthreads();
   const int To = Tm * S;
-  for (int r = 0; r < S; ++r) {
-    const int t = m0 * S + r * 256 + tid;
-    if (t >= To) continue;
+  for (int r = 0; r * 256 < TAIL_MB * S; ++r) {
+    const int o = r * 256 + tid;
+    const int t = m0 * S + o;
+    if (o >= TAIL_MB * S || t >= To) continue;
     float a = 0.f;
     if (t < n_valid * S) {
       const int j0 = ((padl - t) % S + S) % S;
@@ -1037,7 +1042,7 @@ __global__ void __launch_bounds__(256) istft_pqmf_kernel(const TailParams P) {
         for (int j = j0; j < L; j += S) {
           const int u = t + j - padl;  // a multiple of S by construction of j0
           const int m = u >= 0 ? u / S : -((-u) / S);
-          a += P.filt[s * L + j] * (xb[m] * (float)S);
+          a += flt[s * L + j] * (xb[m] * (float)S);
         }
       }
     }
