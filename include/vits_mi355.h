@@ -269,7 +269,8 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
  * 2 = always the K-split small-N kernel, 3 = the small-tile (16x16x4 MFMA, LDS-staged) kernel wherever a launch is
  * eligible for it.  Process-wide. */
 void vits_debug_force_tile(int mode);
-/* Test hook: 0 = fp32-MFMA flash attention (default), 1 = the scalar-VALU attention kernel. */
+/* Test hook: 0 = by sequence length (default: 16-query MFMA kernel up to T = 512, 32-query MFMA flash kernel beyond),
+ * 1 = the scalar-VALU attention kernel, 2 = always the 32-query kernel, 3 = always the 16-query kernel. */
 void vits_debug_attention_impl(int impl);
 /* Test hook: 1 (default) = vits_synthesize replays captured hipGraphs over bucketed shapes when no noise tensor is
  * injected; 0 = always the eager path (one launch per kernel, exact-size workspace).  Both give the same samples. */

@@ -216,9 +216,10 @@ def test_every_epilogue_on_both_conv_kernels(hip_lib, hip_default, hip_tiny, ora
 
 
 def test_both_attention_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny):
-    """Default = fp32-MFMA flash attention; the scalar-VALU kernel is an independent implementation of the same
-    banded relative-position math.  Both must match the oracle, incl. a flow long enough (T_y = 400) that
-    every wave of the MFMA kernel merges several key tiles and the band straddles tile borders."""
+    """Three implementations of the same banded relative-position attention: the scalar-VALU kernel (1), the 32-query
+    MFMA flash kernel (2, long sequences) and the 16-query MFMA kernel (3, short sequences; 0 = chosen by length).  All must
+    match the oracle, incl. a flow long enough (T_y = 400) that every wave merges several key tiles and the band straddles
+    tile borders, ragged lengths, and the T = 1..9 window-edge fixtures."""
     rng = np.random.default_rng(21)
     B, Ty = 2, 400
     z_p = rng.standard_normal((B, 192, Ty)).astype(np.float32)
@@ -227,7 +228,7 @@ def test_both_attention_kernels(hip_lib, hip_default, hip_tiny, oracle_default, 
     want = oracle_default.flow(z_p, ylen, sid)
     mask = (np.arange(Ty)[None, :] < ylen[:, None])[:, None, :]
     try:
-        for impl in (1, 0):
+        for impl in (1, 2, 3, 0):
             hip_lib.lib.vits_debug_attention_impl(impl)
             got = hip_default.flow(z_p, ylen, sid)
             assert_close(f"flow (attention impl {impl})", want * mask, got * mask, STAGE_TOL)

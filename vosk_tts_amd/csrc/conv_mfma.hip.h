@@ -107,6 +107,13 @@ struct ConvParams {
   const float* dds_sw; const float* dds_sb; const float* dds_g1; const float* dds_b1;
   float* dds_xout;
   int dds_dil;
+  // LayerNorm prologue of the small-tile kernel (PRO == 2): the staged tile holds the RAW tensor y (all channels of the tile's
+  // columns); before the MFMAs it is replaced by  ((LN_c(y; ln_g, ln_b) + ln_vec[b][c] + ln_base[c][t]) * [valid column])
+  // -- modules.LayerNorm (modules.py:29-32) folded into its consumer; ln_out (optional) receives the normalised tensor for
+  // the tile's own 16 columns (written once per column tile, by the workgroups of M-tile 0) since the residual path needs it.
+  const float* ln_g; const float* ln_b; const float* ln_base; const float* ln_vec;
+  int ln_vec_stride, ln_vec_off;
+  float* ln_out;
   int row_len;        // LDS row = N_T + halo
   long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
   // Ragged batches: item b only needs columns up to rag[b] frames (its length + a halo wider than the

@@ -68,7 +68,7 @@ __device__ __forceinline__ float c16_gelu(float v) { return 0.5f * v * (1.0f + e
 __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGroup& G, int b, int mt, int n0, float* tile, float* red) {
   const int tid = threadIdx.x, j = tid & 15, cg = tid >> 4;
   const int D = P.Cin, T = P.Tin, nci = D >> 4;
-  const int L = P.len[b] < T ? P.len[b] : T;
+  const int len_raw = P.len[b];  // requested here, first USED after the tensor loads below are in flight
   const float invD = 1.0f / (float)D;
   const bool dw = P.dds_sw != nullptr;
   const int dil = P.dds_dil;
@@ -76,11 +76,9 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
   const float* xb = G.x + bo;
   const float* yb = P.dds_y2 ? P.dds_y2 + bo : nullptr;
   int tk[3], tkc[3];
-  bool tin[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     tk[k] = n0 + j + (dw ? (k - 1) * dil : 0);
-    tin[k] = tk[k] >= 0 && tk[k] < L;
     tkc[k] = tk[k] < 0 ? 0 : (tk[k] >= T ? T - 1 : tk[k]);
   }
   // x_in at the three tap columns (finish mode: only k == 1 matters, the other two repeat it)
@@ -92,8 +90,8 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
       const int c = cg + 16 * i, cc = c < D ? c : D - 1;
       xin[k][i] = xb[(long long)cc * T + tkc[k]];
     }
+  float yv[3][DDS_MAXI];
   if (yb) {
-    float yv[3][DDS_MAXI];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -101,6 +99,13 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
         const int c = cg + 16 * i, cc = c < D ? c : D - 1;
         yv[k][i] = yb[(long long)cc * T + tkc[k]];
       }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // every tensor load above is issued before anything waits for len[b]
+  const int L = len_raw < T ? len_raw : T;
+  bool tin[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tin[k] = tk[k] >= 0 && tk[k] < L;
+  if (yb) {
     float g2[DDS_MAXI], b2[DDS_MAXI];
 #pragma unroll
     for (int i = 0; i < DDS_MAXI; ++i) {
@@ -176,6 +181,78 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
   }
 }
 
+// ---- LayerNorm prologue (PRO == 2): in-place over the staged tile [C_in][ROWP] (ROW <= 32 columns).
+// thread = (column j = tid & 31, channel group cg = tid >> 5) keeps its <= LN_MAXC channel values in registers between the two
+// statistics passes (two-pass like F.layer_norm) and the write-back; gamma / beta were requested before the staging barrier.
+#define C16_LN_MAXC 24
+template <int NW>
+struct C16LnRegs { float g[C16_LN_MAXC], b[C16_LN_MAXC]; };
+template <int NW>
+__device__ __forceinline__ void c16_ln_prefetch(const ConvParams& P, C16LnRegs<NW>& R) {
+  constexpr int NG = NW * 2;
+  const int cg = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < C16_LN_MAXC; ++i) {
+    const int c = cg + NG * i, cc = c < P.Cin ? c : P.Cin - 1;
+    R.g[i] = P.ln_g[cc]; R.b[i] = P.ln_b[cc];
+  }
+}
+template <int NW>
+__device__ __forceinline__ void c16_ln_tile(const ConvParams& P, const ConvGroup& G, int b, int mt, int n0, int ROW, int ROWP, int t_lim,
+                                             int lenb, float* tile, float* red, const C16LnRegs<NW>& R) {
+  constexpr int NG = NW * 2;  // channel groups
+  const int tid = threadIdx.x, j = tid & 31, cg = tid >> 5;
+  const int Cin = P.Cin, T = P.Tin;
+  const bool jok = j < ROW;
+  const int jc = jok ? j : 0;
+  const float invC = 1.0f / (float)Cin;
+  float v[C16_LN_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < C16_LN_MAXC; ++i) {
+    const int c = cg + NG * i;
+    v[i] = c < Cin ? tile[c * ROWP + jc] : 0.f;
+    s += v[i];
+  }
+  red[cg * 32 + j] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) mean += red[g * 32 + j];
+  mean *= invC;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < C16_LN_MAXC; ++i) { const float d = v[i] - mean; q += (cg + NG * i) < Cin ? d * d : 0.f; }
+  red[cg * 32 + j] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) var += red[g * 32 + j];
+  const float rstd = 1.0f / sqrtf(var * invC + 1e-5f);
+  const int t = n0 - G.pad_l + j;
+  // conv zero padding, the mask when the consumer masks its input, and -- masked stages of a ragged batch / padded bucket --
+  // columns beyond the item's length, whose raw values were never written by the (tile-skipping) producer
+  const bool valid = jok && t >= 0 && t < t_lim && (!P.skip_len || t < lenb);
+  const bool center = jok && t >= n0 && t < n0 + 16 && t < T;
+  const float* vec = P.ln_vec ? P.ln_vec + (long long)b * P.ln_vec_stride + P.ln_vec_off : nullptr;
+  const float* base = P.ln_base ? P.ln_base + (long long)b * P.x_bstride : nullptr;
+  float* out = (P.ln_out && mt == 0) ? P.ln_out + (long long)b * P.x_bstride : nullptr;
+  const int tcl = t < 0 ? 0 : (t >= T ? T - 1 : t);
+#pragma unroll
+  for (int i = 0; i < C16_LN_MAXC; ++i) {
+    const int c = cg + NG * i;
+    if (c < Cin) {
+      float o = (v[i] - mean) * rstd * R.g[i] + R.b[i];
+      if (vec) o += vec[c];
+      if (base) o += base[(long long)c * T + tcl];
+      o = valid ? o : 0.f;
+      if (jok) tile[c * ROWP + j] = o;
+      if (out && center) out[(long long)c * T + t] = o;
+    }
+  }
+}
+
 template <int EPI, int NW, int MAXU, int PRO = 0>
 __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   extern __shared__ float lds[];
@@ -191,11 +268,13 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   const ConvGroup& G = P.g[0];
   const int n0 = nt * 16, m0 = mt * 16;
   const int K = G.K, dil = G.dil;
-  int t_lim = P.Tin;
-  int lenb = 0x7fffffff;
-  if (P.in_mask || P.out_mask || P.skip_len || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) lenb = P.len[b];
-  if (P.in_mask) t_lim = lenb < t_lim ? lenb : t_lim;
-  if (P.skip_len && n0 >= lenb) return;  // masked stage of a ragged batch / padded bucket: the tile is all padding
+  // A kernel of this regime is a chain of dependent COLD memory accesses (~0.8 us each: kernel arguments -> len[b] ->
+  // operands -> epilogue operands -> stores), not arithmetic.  So every load whose address is known from the arguments alone
+  // is requested up front -- len[b], the weight fragments, the epilogue's bias / conditioning / residual values, then the
+  // staging loads (addresses clamped by T only) -- and len[b] is first USED when the staged values are written to LDS.
+  constexpr bool kNeedLen = EPI == EPI_RESSKIP || EPI == EPI_COUPLE || PRO == 1;
+  int len_raw = 0x7fffffff;
+  if (kNeedLen || P.in_mask || P.out_mask || P.skip_len) len_raw = P.len[b];
   const int ROW = 16 + (K - 1) * dil, ROWP = P.row_len;
   const int total_u = P.Cin / CONV_CI_T * K;
   const int my_units = wave < total_u ? (total_u - wave + NW - 1) / NW : 0;
@@ -211,6 +290,41 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     a[i] = wp[(size_t)(u < total_u ? u : total_u - 1) * 64];
   }
 
+  // ---- 1b. epilogue operands of this thread's output element (row = tid >> 4, column = tid & 15), clamped addresses
+  float ep0 = 0.f, ep1 = 0.f, ep2 = 0.f, ep3 = 0.f;
+  {
+    const int erow = tid >> 4, ecol = n0 + (tid & 15);
+    const int colc = ecol < P.Tout ? ecol : P.Tout - 1;
+    if (EPI == EPI_STORE) {
+      const int r = m0 + (erow & 15), rc = r < P.Cout ? r : P.Cout - 1;
+      if (G.bias) ep0 = G.bias[rc];
+      if (P.bias_b) ep1 = P.bias_b[(long long)b * P.bias_b_stride + P.bias_b_off + rc];
+      ep2 = P.scale_b ? P.scale_b[(long long)b * P.scale_b_stride + P.scale_b_off + rc] : 1.f;
+      if (G.res) ep3 = G.res[(long long)b * P.y_bstride + (long long)rc * P.Tout_stride + colc];
+    } else if (EPI == EPI_GATE) {
+      const int c = mt * 8 + (erow & 7), cc = c < P.H ? c : P.H - 1;
+      ep0 = G.bias[cc]; ep1 = G.bias[P.H + cc];
+      if (P.bias_b) {
+        const float* bb = P.bias_b + (long long)b * P.bias_b_stride + P.bias_b_off;
+        ep2 = bb[cc]; ep3 = bb[P.H + cc];
+      }
+    } else if (EPI == EPI_RESSKIP) {
+      const int r = m0 + (erow & 15), rc = r < P.Cout ? r : P.Cout - 1;
+      const bool to_skip = P.last || rc >= P.H;
+      const int sr = (P.last || rc < P.H) ? rc : rc - P.H;
+      ep0 = G.bias[rc];
+      const float* src = to_skip ? P.skip : P.io;
+      if (!(to_skip && P.first)) ep1 = src[(long long)b * P.y_bstride + (long long)sr * P.Tout_stride + colc];
+    } else {  // EPI_COUPLE
+      const int r = m0 + (erow & 15), rc = r < P.Cout ? r : P.Cout - 1;
+      const long long bo = (long long)b * P.y_bstride + colc;
+      ep0 = G.bias[rc];
+      ep1 = P.u[bo + (long long)(P.H - 1 - rc) * P.Tout_stride];      // x1 (before the Flip that precedes this layer)
+      ep2 = P.u[bo + (long long)(2 * P.H - 1 - rc) * P.Tout_stride];  // x0
+    }
+  }
+  C16LnRegs<NW> lnr;
+  if (PRO == 2) c16_ln_prefetch<NW>(P, lnr);
   // ---- 2. stage the B operand: all C_in channels x ROW columns, rpi rows per wave-instruction
   if (PRO == 1) {
     c16_stage_dds(P, G, b, mt, n0, lds, lds + P.Cin * 16);
@@ -220,7 +334,6 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     const int rsub = lane / seg, j = lane - rsub * seg;
     const bool jok = j < ROW && rsub < rpi;
     const int t = n0 - G.pad_l + j;
-    const bool tok = jok && t >= 0 && t < t_lim;
     const int tc = t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t);
     const float* xb = G.x + (long long)b * P.x_bstride;
     const float* xb2 = G.x2 ? G.x2 + (long long)b * P.x_bstride : xb;
@@ -250,6 +363,9 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
           v[k] = ks_ld(second ? xb2 : xb, (unsigned)(ch0 + (second ? cc - split : cc) * chs) * 4u);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);  // the batch's loads are issued before anything below waits for len[b]
+      const int t_lim_ = (P.in_mask && len_raw < P.Tin) ? len_raw : P.Tin;
+      const bool tok = jok && t >= 0 && t < t_lim_;
 #pragma unroll
       for (int k = 0; k < C16_SB; ++k) {
         const int c = cb + k * step + rsub;
@@ -258,7 +374,16 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
       }
     }
   }
+  const int lenb = len_raw;
+  const int t_lim = (P.in_mask && lenb < P.Tin) ? lenb : P.Tin;
+  // masked stage of a ragged batch / padded bucket: the tile is all padding (block-uniform; decided only now so that the
+  // loads above did not wait for len[b] -- a skipped tile has merely prefetched for nothing)
+  if (P.skip_len && n0 >= lenb) return;
   __syncthreads();
+  if (PRO == 2) {
+    c16_ln_tile<NW>(P, G, b, mt, n0, ROW, ROWP, t_lim, lenb, lds, lds + P.Cin * ROWP, lnr);
+    __syncthreads();
+  }
 
   // ---- 3. MFMAs: unit u = (chunk c, tap kk); k4-step q covers channels 16c + 4q + (lane>>4)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -298,23 +423,55 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
   __syncthreads();
+  // (operands ep0..ep3 were requested at the top of the kernel; semantics identical to conv_epilogue_frag / conv_epilogue_gate)
   if (EPI == EPI_GATE) {
-    // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8*mt .. 8*mt + 7
+    // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8*mt .. 8*mt + 7 (commons.py:100-107)
     if (tid >= 128) return;
-    const int ch = tid >> 4, col = tid & 15;
-    float at[1] = {0.f}, as[1] = {0.f};
+    const int ch = tid >> 4, col = n0 + (tid & 15);
+    float at = 0.f, as = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      at[0] += red[(w * 4 + (ch & 3)) * 64 + (ch >> 2) * 16 + col];
-      as[0] += red[(w * 4 + (ch & 3)) * 64 + ((ch >> 2) + 2) * 16 + col];
+      at += red[(w * 4 + (ch & 3)) * 64 + (ch >> 2) * 16 + (tid & 15)];
+      as += red[(w * 4 + (ch & 3)) * 64 + ((ch >> 2) + 2) * 16 + (tid & 15)];
     }
-    conv_epilogue_gate<1>(P, G, b, mt * 8 + ch, 0, n0 + col, at, as);
+    const int c = mt * 8 + ch;
+    const float tv = tanhf(at + ep0 + ep2);
+    const float sv = 1.0f / (1.0f + __expf(-(as + ep1 + ep3)));
+    if (col < P.Tout && c < P.H) G.y[(long long)b * P.y_bstride + (long long)c * P.Tout_stride + col] = tv * sv;
     return;
   }
   if (tid >= 256) return;
-  const int row = tid >> 4, col = tid & 15;
-  float v[1] = {0.f};
+  const int row = tid >> 4, col = n0 + (tid & 15);
+  float v = 0.f;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) v[0] += red[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + col];
-  conv_epilogue_frag<EPI, 1>(P, G, b, lenb, m0 + row, 0, n0 + col, v);
+  for (int w = 0; w < NW; ++w) v += red[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + (tid & 15)];
+  const int r = m0 + row;
+  if (col >= P.Tout || r >= P.Cout) return;
+  if (EPI == EPI_STORE) {
+    v += ep0;
+    v += ep1;
+    if (P.relu == 1) v = v > 0.f ? v : 0.f;
+    else if (P.relu == 2) v = v / (1.0f + __expf(-v));
+    else if (P.relu == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (P.out_mask && col >= lenb) v = 0.f;
+    v *= ep2;
+    v += ep3;
+    const long long o = (long long)b * P.y_bstride + (long long)r * P.Tout_stride + col;
+    G.y[o] = v;
+    if (G.y2) G.y2[o] = v;
+  } else if (EPI == EPI_RESSKIP) {
+    // rows < H update x in place (modules.py:171); rows >= H (or every row of the last layer) feed the skip accumulator
+    const bool to_skip = P.last || r >= P.H;
+    const int sr = (P.last || r < P.H) ? r : r - P.H;
+    const bool valid = col < lenb;
+    float o = ep1 + v + ep0;
+    if (to_skip) { if (P.last && !valid) o = 0.f; }
+    else if (!valid) o = 0.f;
+    float* dst = to_skip ? P.skip : P.io;
+    dst[(long long)b * P.y_bstride + (long long)sr * P.Tout_stride + col] = o;
+  } else {  // EPI_COUPLE: new z = cat(x0, (x1 - m) * mask) with the following Flip folded in (models.py:390-392)
+    const long long bo = (long long)b * P.y_bstride + col;
+    P.io[bo + (long long)(P.H + r) * P.Tout_stride] = col < lenb ? (ep1 - (v + ep0)) : 0.f;
+    P.io[bo + (long long)r * P.Tout_stride] = ep2;
+  }
 }

@@ -540,6 +540,7 @@ struct vits_session {
   std::vector<std::tuple<const int*, int, int, int, int>> tile_keys;
   int64_t* ylen64 = nullptr;
   float *x = nullptr, *qkv = nullptr, *att = nullptr, *y1 = nullptr, *ffh = nullptr, *stats = nullptr;
+  float *xb = nullptr, *y1b = nullptr;  // second x / y pair of the LayerNorm-folded encoder schedule
   float *condv = nullptr;
   float *dh = nullptr, *dy = nullptr, *dy2 = nullptr, *dc = nullptr, *dz = nullptr, *dpr = nullptr, *logw = nullptr, *dfh = nullptr;
   float *dq1 = nullptr, *dq2 = nullptr;  // second x / y pair of the per-layer DDSConv launches (ping-pong with dy / dy2)
@@ -596,6 +597,8 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->qkv = bump<float>(s, B * 3 * H * Tm);
   s->att = bump<float>(s, B * H * Tm);
   s->y1 = bump<float>(s, B * H * Tm);
+  s->xb = bump<float>(s, B * H * Tm);
+  s->y1b = bump<float>(s, B * H * Tm);
   s->ffh = bump<float>(s, B * Fm * Tm);
   s->stats = bump<float>(s, B * 2 * I * Tx);
   s->dh = bump<float>(s, B * D * Tx); s->dy = bump<float>(s, B * D * Tx); s->dy2 = bump<float>(s, B * D * Tx);
@@ -817,9 +820,9 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo, ProfScope* ps = 
 }
 
 // ---- small-tile kernel (conv_small.hip.h): eligibility + launch
-template <int EPI, int NW, int MAXU>
+template <int EPI, int NW, int MAXU, int PRO = 0>
 static void launch_c16_inst(hipStream_t st, const ConvParams& P, dim3 grid, size_t lds) {
-  auto kern = conv16_kernel<EPI, NW, MAXU>;
+  auto kern = conv16_kernel<EPI, NW, MAXU, PRO>;
   if (lds > 64 * 1024) {
     static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)once;
@@ -833,7 +836,9 @@ static int c16_waves(const ConvParams& P, int epi) {
   if (epi == EPI_GATE && (P.H % 8)) return 0;
   const int halo = (G.K - 1) * G.dil;
   if (halo > 48) return 0;
-  const size_t lds = (size_t)P.Cin * c16_row_pitch(16 + halo) * sizeof(float);
+  if (P.ln_g && P.Cin > 8 * C16_LN_MAXC) return 0;
+  if (P.ln_g && (halo > 16 || P.in_slope != 1.f || P.in_scale != 1.f || P.x_split || P.x_ch_sign != 1 || P.x_ch_off || epi != EPI_STORE)) return 0;
+  const size_t lds = ((size_t)P.Cin * c16_row_pitch(16 + halo) + 16 * 32) * sizeof(float);
   if (lds > 150 * 1024) return 0;
   const int units = P.Cin / CONV_CI_T * G.K;
   if (units <= 4 * C16_MAXU) return 4;
@@ -846,7 +851,7 @@ static void launch_c16(vits_session* s, ConvParams& P, int epi, int nw) {
   P.ntiles_m = cdiv(epi == EPI_GATE ? 2 * P.H : P.Cout, 16);
   P.ntiles_n = cdiv(P.Tout, 16);
   P.row_len = c16_row_pitch(16 + (G.K - 1) * G.dil);
-  size_t lds = (size_t)P.Cin * P.row_len * sizeof(float);
+  size_t lds = ((size_t)P.Cin * P.row_len + (P.ln_g ? (size_t)nw * 2 * 32 : 0)) * sizeof(float);
   const size_t red = (size_t)nw * 4 * 64 * sizeof(float);
   if (lds < red) lds = red;
   const dim3 grid(8 * cdiv(P.ntiles_m, 8) * P.ntiles_n * P.B);
@@ -862,7 +867,15 @@ static void launch_c16(vits_session* s, ConvParams& P, int epi, int nw) {
       else launch_c16_inst<EPI_, 4, C16_MAXU>(st, P, grid, lds);                      \
     }                                                                                 \
   } while (0)
-  if (epi == EPI_GATE) C16_GO(EPI_GATE);
+  if (P.ln_g) {  // LayerNorm-on-load (EPI_STORE only)
+    if (nw == 8) {
+      if (few) launch_c16_inst<EPI_STORE, 8, 8, 2>(st, P, grid, lds);
+      else launch_c16_inst<EPI_STORE, 8, C16_MAXU, 2>(st, P, grid, lds);
+    } else {
+      if (few) launch_c16_inst<EPI_STORE, 4, 8, 2>(st, P, grid, lds);
+      else launch_c16_inst<EPI_STORE, 4, C16_MAXU, 2>(st, P, grid, lds);
+    }
+  } else if (epi == EPI_GATE) C16_GO(EPI_GATE);
   else if (epi == EPI_RESSKIP) C16_GO(EPI_RESSKIP);
   else if (epi == EPI_COUPLE) C16_GO(EPI_COUPLE);
   else C16_GO(EPI_STORE);
@@ -883,6 +896,14 @@ static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, dou
   const dim3 grid(8 * cdiv(P.ntiles_m, 8) * P.ntiles_n * P.B);
   if (P.Cin / CONV_CI_T <= 4 * 8) hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, 8, 1>), grid, dim3(256), lds, s->stream, P);
   else hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, C16_MAXU, 1>), grid, dim3(256), lds, s->stream, P);
+}
+
+// would launch_conv route this launch to the small-tile kernel?  (callers that fold a LayerNorm into the consumer's staging
+// must know before they drop the LayerNorm launch: only that kernel has the prologue)
+static bool conv_takes_c16(const ConvParams& P, int epi) {
+  static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
+  if (!(g_force_tile == 3 || (g_force_tile == 0 && (long)P.B * P.Tout <= c16_cols))) return false;
+  return c16_waves(P, epi) != 0;
 }
 
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
@@ -939,7 +960,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     const int nw16 = c16_waves(P, epi);
     if (nw16) {
       static const char* names[4] = {"conv16_kernel<STORE>", "conv16_kernel<GATE>", "conv16_kernel<RESSKIP>", "conv16_kernel<COUPLE>"};
-      ps.set_kernel(names[epi]);
+      ps.set_kernel(P.ln_g ? "conv16_kernel<STORE,ln>" : names[epi]);
       ps.add_template_arg(nw16);
       launch_c16(s, P, epi, nw16);
       return;
@@ -1015,8 +1036,28 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
                              int H, int T) {
   const vits_hparams& hp = s->m->hp;
   const int nh = hp.n_heads, dk = H / nh, W = hp.window_size;
-  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T, g_attn_impl == 0 ? "relpos_attention_mfma_kernel" : "relpos_attention_kernel");
-  if (g_attn_impl == 0) {  // fp32-MFMA flash kernel (default)
+  static const int t16_max = getenv("VITS_ATT16_MAXT") ? atoi(getenv("VITS_ATT16_MAXT")) : 512;
+  const bool use16 = g_attn_impl == 3 || (g_attn_impl == 0 && T <= t16_max);
+  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T,
+               use16 ? "relpos_attention16_kernel" : (g_attn_impl == 1 ? "relpos_attention_kernel" : "relpos_attention_mfma_kernel"));
+  if (use16) {  // short sequences: 16-query tiles, more and smaller workgroups
+    dim3 grid(cdiv(T, 16), nh, B);
+    const bool w8 = T > 64;
+    const int nwv = w8 ? 8 : 4;
+    const int wreg = 16 * (dk + 4) + 12 * 16 + 12 * 16, nv = (dk / 16) * 4 + 2;
+    const size_t lds = (size_t)nwv * (wreg > nv * 64 ? wreg : nv * 64) * sizeof(float);
+#define ATT16_GO(DK_)                                                                                                                  \
+  do {                                                                                                                                 \
+    if (w8) hipLaunchKernelGGL((relpos_attention16_kernel<DK_, 8>), grid, dim3(512), lds, s->stream, qkv, L.ek, L.ev, len, out, H, T, W); \
+    else hipLaunchKernelGGL((relpos_attention16_kernel<DK_, 4>), grid, dim3(256), lds, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);   \
+  } while (0)
+    if (dk == 96) ATT16_GO(96);
+    else if (dk == 64) ATT16_GO(64);
+    else ATT16_GO(32);
+#undef ATT16_GO
+    return;
+  }
+  if (g_attn_impl != 1) {  // fp32-MFMA flash kernel (32-query tiles)
     dim3 grid(cdiv(T, 32), nh, B);
     const int wreg = dk * 33 + 10 * 32 + 9 * 32;
     const size_t lds = (size_t)4 * wreg * sizeof(float);
@@ -1033,17 +1074,46 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
 
 // attentions.Encoder.forward (attentions.py:48-65).  x in place [B,H,T]; final_base (optional):
 // out = final_base + encoder(x) (the VITS2 residual at models.py:377), written to final_out.
+//
+// Few-column regime (every conv of the layer runs on the small-tile kernel): no LayerNorm launches.  norm_layers_1 is folded
+// into the staging of conv_1 of the FFN, norm_layers_2 (and the speaker-embedding add before layer `cond_layer`,
+// attentions.py:52-56) into the staging of the next layer's fused q/k/v conv; each writes the normalised tensor once (the
+// residual path needs it).  The last norm_layers_2 is handed to the caller's consumer through `pend` when it has one
+// (TextEncoder.proj), otherwise it runs as the LayerNorm kernel (flow: + final_base, masked).
+struct PendingLN { const float* raw = nullptr; const float* g = nullptr; const float* b = nullptr; };
+
+static bool enc_fold_ok(vits_session* s, const EncoderW& E, int B, int T) {
+  static const bool no_fold = getenv("VITS_NO_LN_FOLD") != nullptr;  // A/B switch for tools/ and tests
+  if (no_fold || E.layers.empty() || !s->xb || !s->y1b) return false;
+  const EncLayerW& L = E.layers[0];
+  static const float dummy = 0.f;
+  ConvParams P = conv_params(L.qkv, s->x, s->qkv, B, T, 1, 0);
+  P.ln_g = &dummy;
+  if (!conv_takes_c16(P, EPI_STORE)) return false;
+  P = conv_params(L.f1, s->x, s->ffh, B, T, 1, (E.K - 1) / 2);
+  P.ln_g = &dummy;
+  if (!conv_takes_c16(P, EPI_STORE)) return false;
+  return true;
+}
+
 static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int* len, int B, int T, int cond_layer,
-                        int cond_off, const float* final_base, float* final_out) {
+                        int cond_off, const float* final_base, float* final_out, PendingLN* pend = nullptr) {
   vits_model* m = s->m;
   const int H = E.H, F = E.F, K = E.K;
   const int n = (int)E.layers.size();
+  const bool fold = enc_fold_ok(s, E, B, T);
+  PendingLN prev;  // norm_layers_2 of the previous layer, not yet applied (fold only)
   for (int i = 0; i < n; ++i) {
     const EncLayerW& L = E.layers[i];
-    if (i == cond_layer && cond_off >= 0)
+    const bool cond_here = i == cond_layer && cond_off >= 0;
+    if (cond_here && !prev.raw)
       hipLaunchKernelGGL(add_vec_mask_kernel, dim3(cdiv(T, 64), H, B), dim3(64), 0, s->stream, x, s->condv, m->cond_rows,
                          cond_off, len, H, T);
-    ConvParams P = conv_params(L.qkv, x, s->qkv, B, T, 1, 0);
+    ConvParams P = conv_params(L.qkv, prev.raw ? prev.raw : x, s->qkv, B, T, 1, 0);
+    if (prev.raw) {
+      P.ln_g = prev.g; P.ln_b = prev.b; P.ln_out = x; P.len = len;
+      if (cond_here) { P.ln_vec = s->condv; P.ln_vec_stride = m->cond_rows; P.ln_vec_off = cond_off; }
+    }
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.qkv");
     launch_attention(s, s->qkv, L, len, s->att, B, H, T);
@@ -1051,18 +1121,23 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
     P.g[0].res = x;
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.o");
-    launch_ln(s, s->y1, nullptr, nullptr, x, L.g1, L.b1, len, B, H, T, 0, 0);
+    const float* xf = x;  // input of the FFN (after norm_layers_1)
+    if (!fold) launch_ln(s, s->y1, nullptr, nullptr, x, L.g1, L.b1, len, B, H, T, 0, 0);
     // FFN (attentions.py:308-317): conv_1(pad(x*mask)) -> relu -> *mask -> conv_2(pad(.)) -> *mask
-    P = conv_params(L.f1, x, s->ffh, B, T, 1, (K - 1) / 2);
+    P = conv_params(L.f1, fold ? s->y1 : x, s->ffh, B, T, 1, (K - 1) / 2);
     P.in_mask = 1; P.len = len; P.relu = 1; P.out_mask = 1;
+    if (fold) { P.ln_g = L.g1; P.ln_b = L.b1; P.ln_out = s->xb; xf = s->xb; }
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.ffn1");
-    P = conv_params(L.f2, s->ffh, s->y1, B, T, 1, (K - 1) / 2);
-    P.in_mask = 1; P.len = len; P.out_mask = 1; P.g[0].res = x;  // y1 = x + ffn(x)
+    float* y2 = fold ? s->y1b : s->y1;
+    P = conv_params(L.f2, s->ffh, y2, B, T, 1, (K - 1) / 2);
+    P.in_mask = 1; P.len = len; P.out_mask = 1; P.g[0].res = xf;  // y = x + ffn(x)
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.ffn2");
     const bool lastl = i == n - 1;
-    launch_ln(s, s->y1, nullptr, lastl ? final_base : nullptr, (lastl && final_out) ? final_out : x, L.g2, L.b2, len, B, H,
+    if (fold && !lastl) { prev.raw = y2; prev.g = L.g2; prev.b = L.b2; continue; }
+    if (fold && lastl && pend) { pend->raw = y2; pend->g = L.g2; pend->b = L.b2; return; }
+    launch_ln(s, y2, nullptr, lastl ? final_base : nullptr, (lastl && final_out) ? final_out : x, L.g2, L.b2, len, B, H,
               T, 0, lastl ? 1 : 0);
   }
   (void)F;
@@ -1098,9 +1173,18 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   const int H = hp.hidden_channels;
   hipLaunchKernelGGL(embed_kernel, dim3(cdiv(Tx, 64), 8, B), dim3(64), 0, s->stream, d_ids, s->len_x, m->emb, s->x, H, Tx,
                      hp.n_vocab, sqrtf((float)H), s->d_err);
-  run_encoder(s, m->enc_p, s->x, s->len_x, B, Tx, m->use_g ? hp.enc_cond_layer : -1, m->cond_enc_off, nullptr, nullptr);
-  ConvParams P = conv_params(m->enc_proj, s->x, s->stats, B, Tx, 1, 0);
+  // the encoder's last LayerNorm is folded into proj's staging when both run on the small-tile kernel
+  PendingLN pend;
+  {
+    static const float dummy = 0.f;
+    ConvParams Pt = conv_params(m->enc_proj, s->x, s->stats, B, Tx, 1, 0);
+    Pt.ln_g = &dummy; Pt.in_mask = 1; Pt.out_mask = 1; Pt.len = s->len_x;
+    const bool can = conv_takes_c16(Pt, EPI_STORE);
+    run_encoder(s, m->enc_p, s->x, s->len_x, B, Tx, m->use_g ? hp.enc_cond_layer : -1, m->cond_enc_off, nullptr, nullptr, can ? &pend : nullptr);
+  }
+  ConvParams P = conv_params(m->enc_proj, pend.raw ? pend.raw : s->x, s->stats, B, Tx, 1, 0);
   P.out_mask = 1; P.len = s->len_x;
+  if (pend.raw) { P.ln_g = pend.g; P.ln_b = pend.b; P.ln_out = s->x; P.in_mask = 1; }  // x = encoder(...) * x_mask, also left in s->x
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "enc.proj");
 }

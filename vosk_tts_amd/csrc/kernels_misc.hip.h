@@ -1231,3 +1231,185 @@ __global__ void transpose_ct_kernel(const float* x, float* y, int C, int T) {  /
   const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
   if (c < C) y[(long long)t * C + c] = x[(long long)c * T + t];
 }
+
+// ----------------------------------------------------------------------------- attention, few-column form
+// Same math as relpos_attention_mfma_kernel (attentions.py:165-260, exact banded relative positions) for SHORT sequences
+// (a single utterance: T_x ~ 50 tokens, T_y ~ 150 frames), where that kernel's 32-query tiles leave 4..10 workgroups on
+// the chip.  Here a workgroup owns 16 queries of one (batch, head) on v_mfma_f32_16x16x4_f32 and its NW waves split the key
+// tiles of 16:  S^T[key][q] = K Q^T  (A = K fragment straight from global, B = pre-scaled Q^T kept in registers),
+// a lane owns one query column and 4 of the 16 keys, so P^T's accumulator registers ARE the B operand of the PV step when
+// k-step r is defined to cover keys {4g + r}; V goes through a wave-private LDS tile [key][d]; relative keys by one MFMA
+// pass (Q E_k^T -> LDS), relative values by 3 k-steps over a gathered band; waves merge (m, l, O) through LDS.
+// Every load address depends on T only (clamped), len[b] is first used after Q and the first K tile are in flight.
+template <int DK, int NW>
+__global__ void __launch_bounds__(NW * 64) relpos_attention16_kernel(const float* qkv, const float* ek, const float* ev,
+                                                                      const int* len, float* out, int H, int T, int W) {
+  constexpr int NS = DK / 4, ND = DK / 16, DS = DK + 4;
+  constexpr int WREG = 16 * DS + 12 * 16 + 12 * 16;  // per-wave LDS: V tile [16 keys][DS] | Prel [12][16] | QE [12][16]
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hd = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * 16;
+  const int len_raw = len[b];
+  const int i = i0 + l15;
+  const int ic = i < T ? i : T - 1;
+  const float* qb = qkv + ((long long)b * 3 * H + (long long)hd * DK) * T;
+  const float* kb = qb + (long long)H * T;
+  const float* vb = kb + (long long)H * T;
+  float* ob = out + ((long long)b * H + (long long)hd * DK) * T;
+  float* vt = lds + wave * WREG;
+  float* prel = vt + 16 * DS;
+  float* qes = prel + 12 * 16;
+  const float scale = 1.0f / sqrtf((float)DK);
+  const int NWR = 2 * W + 1;
+  const bool rel = ek != nullptr;
+
+  // Q^T[d = 4s + g][query], K fragments of this wave's first tile: requested before len[b] is needed
+  float qf[NS], kf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qf[s] = qb[(long long)(4 * s + g) * T + ic];
+  auto load_k = [&](int jt_) {
+    const int j = jt_ * 16 + l15;
+    const int jc = j < T ? j : T - 1;
+    const float* kp = kb + (long long)g * T + jc;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kf[s] = kp[(long long)(4 * s) * T];
+  };
+  load_k(wave);
+  float eka[NS];
+  if (rel) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) eka[s] = l15 < NWR ? ek[(l15 < NWR ? l15 : 0) * DK + 4 * s + g] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int L = len_raw < T ? len_raw : T;
+  if (i0 >= L) {  // whole query tile is padding: zeros (see "masked rows" in DESIGN.md)
+    if (i < T)
+      for (int d = (threadIdx.x >> 4); d < DK; d += NW * 4) ob[(long long)d * T + i] = 0.f;
+    return;
+  }
+  const bool active = i < L;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qf[s] *= scale;
+  if (rel) {  // QE^T[r][q] (attentions.py:175-177): A = E_k[r = l15][d = 4s + g]; rows r = 4g + e
+    f32x4 qe = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qe = __builtin_amdgcn_mfma_f32_16x16x4f32(eka[s], qf[s], qe, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * g + e < 12) qes[(4 * g + e) * 16 + l15] = qe[e];
+  }
+  f32x4 O[ND];
+#pragma unroll
+  for (int db = 0; db < ND; ++db) O[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;  // l: this lane's partial row sum (its 4 keys per tile); the 4 lane groups add up at the end
+  const int ntiles = (L + 15) >> 4;
+  for (int jt = wave; jt < ntiles; jt += NW) {
+    const int j0 = jt * 16;
+    // V tile: lane (key = l15, d = 4s + g); keys beyond L are written as 0 (select: stale memory may hold NaN)
+    float vst[NS];
+    const bool vok = j0 + l15 < L;
+    {
+      const int jc = j0 + l15 < T ? j0 + l15 : T - 1;
+      const float* vp = vb + (long long)g * T + jc;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vst[s] = vp[(long long)(4 * s) * T];
+    }
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[s], S, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vt[l15 * DS + 4 * s + g] = vok ? vst[s] : 0.f;
+    if (jt + NW < ntiles) load_k(jt + NW);
+    const bool near = rel && (j0 + 15 >= i0 - W) && (j0 <= i0 + 15 + W);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = j0 + 4 * g + e;
+      float sv = S[e];
+      if (near) {
+        const int r = key - i + W;
+        const int rc = r < 0 ? 0 : (r > 11 ? 11 : r);
+        const float bias = qes[rc * 16 + l15];
+        sv += (r >= 0 && r < NWR) ? bias : 0.f;
+      }
+      sv = key < L ? sv : -3.0e38f;
+      S[e] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = j0 + 4 * g + e;
+      const float pe = key < L ? __expf(S[e] - mn) : 0.f;
+      S[e] = pe;  // S now holds P^T
+      psum += pe;
+    }
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int db = 0; db < ND; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) O[db][e] *= alpha;
+    // O^T += V P^T: k-step r <-> keys {4g + r}: B fragment == S[r]; A = V[d = 16 db + l15][key 4g + r]
+#pragma unroll
+    for (int db = 0; db < ND; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        O[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[(4 * g + r) * DS + db * 16 + l15], S[r], O[db], 0, 0, 0);
+    if (near) {  // relative values (attentions.py:191-194): Prel^T[r][q] gathered through LDS, 3 k-steps of 4
+#pragma unroll
+      for (int r3 = 0; r3 < 3; ++r3) prel[(3 * g + r3) * 16 + l15] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = j0 + 4 * g + e;
+        const int r = key - i + W;
+        if (r >= 0 && r < NWR && key < L) prel[r * 16 + l15] = S[e];
+      }
+#pragma unroll
+      for (int db = 0; db < ND; ++db)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const int r = 4 * s3 + g;
+          const float a = r < NWR ? ev[(r < NWR ? r : 0) * DK + db * 16 + l15] : 0.f;
+          O[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, prel[r * 16 + l15], O[db], 0, 0, 0);
+        }
+    }
+  }
+  // ---- merge the waves' partial (m, l, O) through LDS; wave w finishes output registers idx == w (mod NW)
+  __syncthreads();
+  constexpr int NV = ND * 4 + 2;
+  float* comb = lds;  // [wave][NV][64]
+  {
+    float* c = comb + (wave * NV) * 64 + lane;
+    c[0] = m;
+    c[64] = l;
+#pragma unroll
+    for (int db = 0; db < ND; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[(2 + db * 4 + e) * 64] = O[db][e];
+  }
+  __syncthreads();
+  float sc[NW];
+  float ms = -3.0e38f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { sc[w] = comb[(w * NV) * 64 + lane]; ms = fmaxf(ms, sc[w]); }
+  float lt = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { sc[w] = __expf(sc[w] - ms); lt += comb[(w * NV + 1) * 64 + lane] * sc[w]; }
+  lt += __shfl_xor(lt, 16, 64);
+  lt += __shfl_xor(lt, 32, 64);
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  for (int idx = wave; idx < ND * 4; idx += NW) {
+    const int db = idx >> 2, e = idx & 3;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += comb[(w * NV + 2 + idx) * 64 + lane] * sc[w];
+    const int d = db * 16 + 4 * g + e;
+    if (i < T) ob[(long long)d * T + i] = active ? a * inv : 0.f;
+  }
+}
