@@ -277,6 +277,9 @@ void vits_debug_attention_impl(int impl);
 void vits_debug_fast_path(int on);
 /* Test hook: waves per workgroup of the K-split conv kernel: 0 = size heuristic (default), 4 / 8 / 16 forced. */
 void vits_debug_ks_waves(int nw);
+/* Test hook: LDS-staged 16-wave conv kernel of the single-utterance decoder: 0 = size heuristic (default), 1 = never,
+ * 2 = wherever a launch is eligible. */
+void vits_debug_conv_ls(int mode);
 /* Test hook: 0 = fused exp/sin + iSTFT + PQMF tail kernel (default), 1 = the separate istft / pqmf kernels. */
 void vits_debug_tail_impl(int impl);
 /* Test hook: fill every newly laid-out workspace with NaN bit patterns (stale-padding detector). */

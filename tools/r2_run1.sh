@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $O/r2_t1.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2_t1.log
 tail -15 $O/r2_t1.log
-for nw in 4 8 16 0; do
+for nw in 16 0; do
   VITS_KS_WAVES=$nw timeout 300 python bench.py --no-batch32 --no-cpu-baseline --no-host-api --steps 50 > $O/r2_c2_nw$nw.json 2> $O/r2_c2_nw$nw.err
   python - <<PY
 import json

@@ -475,3 +475,151 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     P.io[bo + (long long)r * P.Tout_stride] = ep2;
   }
 }
+
+// =============================================================================================================================
+// conv_ls_kernel — the single-utterance DECODER regime (T = 600..2400 columns, C = 128..512, 3..11 taps, up to 3 grouped convs):
+// 32 x 32 output tile per workgroup on v_mfma_f32_32x32x2_f32, the contraction split over 16 waves (4 per SIMD) by taps like
+// the K-split kernel, but with that kernel's two per-MFMA global loads gone:
+//   * B operand: the workgroup stages ALL input channels x (32 columns + halo) once in LDS, cooperatively and coalesced
+//     (leaky-relu, MRF mean of up to three inputs, mask / ragged limit, ReflectionPad applied once per element); every tap of
+//     every wave reads shifted columns of that tile (ds_read_b32, 32 consecutive columns per half-wave: conflict-free);
+//   * A operand: each wave requests ALL its weight fragments (<= MAXT taps x 2 dwordx4, same packing as the other 32x32
+//     kernels) before the staging barrier, so the weight stream flies under the staging phase and the MFMA loop touches no
+//     global memory at all.  The L1 / texture-address path, which the K-split kernel loads with 512 B per MFMA, carries only
+//     the 256 B of weights.
+// Partial tiles meet in LDS (the staged tile is dead by then), 1024 threads run the shared STORE epilogue one element each.
+// Serves (B = 1): conv_pre, polyphase ConvTranspose1d, ResBlock1 convs (grouped k = 3/7/11), subband_conv_post / conv_post
+// (models.py:983-1040, modules.py:210-223).
+template <int MAXT, int NIN>
+__global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
+  constexpr int NW = 16;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  // block -> (group, batch item, column tile, M tile): heaviest group first (the launcher sorts groups by taps)
+  int id = blockIdx.x;
+  const int mt = id % P.ntiles_m; id /= P.ntiles_m;
+  const int nt = id % P.ntiles_n; id /= P.ntiles_n;
+  const int b = id % P.B;
+  const int grp = id / P.B;
+  const ConvGroup& G = P.g[grp];
+  const int n0 = nt * 32, m0 = mt * 32;
+  const int K = G.K, dil = G.dil;
+  int tap_base = 0;
+  if (P.ups_u) tap_base = P.ups_shift[m0 / P.ups_cout];
+  int len_raw = 0x7fffffff, rag_raw = 0x7fffffff;
+  if (P.in_mask || P.out_mask) len_raw = P.len[b];
+  if (P.rag) rag_raw = P.rag[b];
+  const int ROW = P.row_len;  // 32 + the launch's largest halo
+  const int nchunks = P.Cin / CONV_CI_T;
+  const int total_taps = nchunks * K;
+  const int my_taps = wave < total_taps ? (total_taps - wave + NW - 1) / NW : 0;
+
+  // ---- 1. request the B tile [C_in][ROW] (element e = tid, tid + 1024, ... -> (channel, column) by an incremental cursor;
+  //         one batch of <= SB loads per thread), THEN all weight fragments of this wave (tap q = chunk*K + kk -> step-groups
+  //         2q, 2q + 1).  Loads return in order: the staging values arrive first and are written to LDS while the weight
+  //         stream is still in flight.
+  constexpr int SB = MAXT > 6 ? 8 : 12;
+  const int Cin = P.Cin, n_el = Cin * ROW;
+  int c = tid / ROW, j = tid - (tid / ROW) * ROW;
+  const int dc = 1024 / ROW, dj = 1024 - dc * ROW;
+  const float* xb = G.x + (long long)b * P.x_bstride;
+  const float* xb2 = (NIN > 1 && G.x2) ? G.x2 + (long long)b * P.x_bstride : xb;
+  const float* xb3 = (NIN > 1 && G.x3) ? G.x3 + (long long)b * P.x_bstride : xb2;
+  const float s3 = (NIN > 1 && G.x3) ? 1.f : 0.f;
+  const float slope = P.in_slope, scale = P.in_scale;
+  const int refl_t = P.reflect ? ((P.Tin > 1) ? 1 : 0) : -1;
+  const int t_base = n0 - G.pad_l;
+  auto stage_load = [&](float (&v)[SB]) {
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+      int t = t_base + j;
+      t = (t == -1 && refl_t >= 0) ? refl_t : t;
+      const int tcl = t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t);
+      const int cl = c < Cin ? c : Cin - 1;
+      const unsigned off = (unsigned)(cl * P.Tin_stride + tcl) * 4u;
+      float x = ks_ld(xb, off);
+      if (NIN > 1) x = (x + ks_ld(xb2, off) + s3 * ks_ld(xb3, off));
+      v[k] = x;
+      j += dj; c += dc;
+      if (j >= ROW) { j -= ROW; ++c; }
+    }
+  };
+  auto stage_store = [&](const float (&v)[SB], int c2, int j2) {
+    int t_lim = P.Tin;
+    if (P.in_mask) t_lim = len_raw < t_lim ? len_raw : t_lim;
+    if (P.rag) { const int il = rag_raw * P.rag_in_mul + P.rag_in_add; t_lim = il < t_lim ? il : t_lim; }
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+      int t = t_base + j2;
+      t = (t == -1 && refl_t >= 0) ? refl_t : t;
+      const bool ok = t >= 0 && t < t_lim;
+      const float o = ok ? conv_act_in(v[k], scale, slope) : 0.f;  // select: stale padding may hold NaN
+      if (c2 < Cin) lds[c2 * ROW + j2] = o;
+      j2 += dj; c2 += dc;
+      if (j2 >= ROW) { j2 -= ROW; ++c2; }
+    }
+  };
+  float sv[SB];
+  const int c_s = c, j_s = j;
+  stage_load(sv);
+  int mb = m0 >> 5;
+  if (mb >= (P.M >> 5)) mb = 0;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
+  f32x4 a[MAXT][2];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int q = wave + NW * i;
+    const int qc = q < total_taps ? q : total_taps - 1;
+    a[i][0] = wp[(size_t)(2 * qc) * 64];
+    a[i][1] = wp[(size_t)(2 * qc + 1) * 64];
+  }
+  __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything waits for len[b] / rag[b]
+  stage_store(sv, c_s, j_s);
+  for (int e0 = tid + 1024 * SB; e0 < n_el; e0 += 1024 * SB) {  // tiles beyond 12 K elements: further batches
+    const int c_t = c, j_t = j;
+    stage_load(sv);
+    stage_store(sv, c_t, j_t);
+  }
+  // ragged batch: the whole tile is padding of this item (block-uniform; decided after the loads were issued)
+  if (P.rag && n0 >= rag_raw * P.rag_out_mul + P.rag_out_add) return;
+  __syncthreads();
+
+  // ---- 3. MFMAs: tap q = (chunk, kk): 8 k-steps p over channel pairs 16*chunk + 2p + h, B read one tap ahead
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  {
+    const float* bl = lds + h * ROW + l31 + tap_base;
+    int uc = wave / K, uk = wave - (wave / K) * K;
+    const int step_c = NW / K, step_k = NW - step_c * K;
+    // (4 waves per SIMD cover each other's LDS latency; no per-wave double buffering: the register file is full of weights)
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      if (i < my_taps) {
+        const float* bp = bl + uc * (CONV_CI_T * ROW) + uk * dil;
+        float bc[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) bc[p] = bp[2 * p * ROW];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][p >> 2][p & 3], bc[p], acc, 0, 0, 0);
+        uk += step_k;
+        uc += step_c + (uk >= K ? 1 : 0);
+        uk -= uk >= K ? K : 0;
+      }
+    }
+  }
+
+  // ---- 4. cross-wave reduction through LDS (the staged tile is dead) + one element per thread through the shared epilogue
+  __syncthreads();
+  float* red = lds;  // [wave][e][lane]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+  float v[1] = {0.f};
+#pragma unroll
+  for (int w = 0; w < NW; ++w) v[0] += red[(w * 16 + wave) * 64 + lane];
+  const int lenb = P.out_mask ? len_raw : 0x7fffffff;
+  conv_epilogue_frag<EPI_STORE, 1>(P, G, b, lenb, m0 + 4 * h, wave, n0 + l31, v);
+}

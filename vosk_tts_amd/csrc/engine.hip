@@ -131,6 +131,7 @@ struct vits_model {
   std::vector<ResBlockW> rb;
   float *istft_basis = nullptr, *pqmf = nullptr;
   bool use_g = false;
+  int rag_halo = 32;  // frames decoded beyond an item's end in ragged batches / streaming windows: >= the decoder's receptive field
 
   std::mutex pool_mu;
   std::vector<vits_session*> pool;
@@ -316,6 +317,47 @@ static int load_decoder(vits_model* m) {
   char nm[200];
   int C = hp.dec_initial_channel;
   m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true, false);
+  // Geometry checks before anything divides by a rate or sizes a buffer from hop_length: the decoder writes
+  // T_y * prod(up_rates) [* istft_hop * subbands] samples per item while every output buffer is T_y * hop_length.
+  {
+    long long rate = 1;
+    for (int i = 0; i < hp.n_ups; ++i) {
+      const int u = hp.up_rates[i], Ku = hp.up_kernels[i];
+      if (u <= 0 || Ku < u) return fail(VITS_ERR_BLOB, "decoder stage %d: upsample rate %d / kernel %d invalid", i, u, Ku);
+      rate *= u;
+    }
+    if (hp.dec_type == 0) {
+      if (hp.subbands <= 0 || hp.istft_hop <= 0 || hp.istft_n_fft <= 0 || hp.istft_n_fft % hp.istft_hop || hp.pqmf_taps <= 0)
+        return fail(VITS_ERR_BLOB, "iSTFT / PQMF parameters invalid (subbands %d, n_fft %d, hop %d, taps %d)", hp.subbands, hp.istft_n_fft, hp.istft_hop, hp.pqmf_taps);
+      rate *= (long long)hp.istft_hop * hp.subbands;
+    }
+    if (hp.hop_length <= 0 || rate != hp.hop_length)
+      return fail(VITS_ERR_BLOB, "decoder produces %lld samples per frame but hop_length is %d", rate, hp.hop_length);
+    for (int j = 0; j < hp.n_resk; ++j)
+      if (hp.res_kernels[j] <= 0 || hp.res_kernels[j] % 2 == 0) return fail(VITS_ERR_BLOB, "resblock kernel %d invalid", hp.res_kernels[j]);
+  }
+  {
+    // One-sided receptive field of the decoder in frames (24.9 for the default config): ragged batches and
+    // streaming windows reproduce the dense result only if the halo they keep is at least this wide.
+    double rf = 3.0, rate = 1.0;  // conv_pre k = 7
+    for (int i = 0; i < hp.n_ups; ++i) {
+      const int u = hp.up_rates[i], Ku = hp.up_kernels[i];
+      rf += (double)((Ku + u - 1) / u / 2 + 1) / rate;
+      rate *= u;
+      double worst = 0;
+      for (int j = 0; j < hp.n_resk; ++j) {
+        double span = 0;
+        for (int d = 0; d < hp.n_resd; ++d) span += (hp.res_kernels[j] - 1) * hp.res_dilations[j][d] / 2.0 + (hp.res_kernels[j] - 1) / 2.0;
+        if (span > worst) worst = span;
+      }
+      rf += worst / rate;
+    }
+    rf += 4.0 / rate;  // conv_post k = 7 (+ reflection pad)
+    if (hp.dec_type == 0) rf += ((double)hp.istft_n_fft / hp.istft_hop + (hp.pqmf_taps / 2.0) / hp.subbands / hp.istft_hop) / rate;
+    m->rag_halo = (int)ceil(rf) + 2;
+    if (m->rag_halo < 32) m->rag_halo = 32;
+    if (m->rag_halo > 4096) return fail(VITS_ERR_UNSUPPORTED, "decoder receptive field of %d frames is not supported", m->rag_halo);
+  }
   m->ups.resize(hp.n_ups);
   m->rb.resize((size_t)hp.n_ups * hp.n_resk);
   for (int i = 0; i < hp.n_ups && !m->missing; ++i) {
@@ -776,8 +818,10 @@ static int ks_pick_waves(const ConvParams& P, long nblk) {
   for (int g = 0; g < P.n_groups; ++g) { const int t = P.Cin / CONV_CI_T * P.g[g].K; if (t > taps) taps = t; }
   // few workgroups (less than one per CU): 16 waves each, i.e. 4 per SIMD, as long as every wave still gets >= 2 taps;
   // up to two workgroups per CU: 8 waves (the register file holds 2 x 8 waves of <= 128 registers)
-  if (nblk <= 256 && taps >= 32) return 16;
-  if (nblk <= 512 && taps >= 16) return 8;
+  // measured on the c2 forward (profiles/r2_c2_nw*_bench.json.txt): 16 waves win wherever a wave still gets >= 2 taps, also
+  // for the grouped decoder launches of ~450 workgroups; 8 waves only pay for launches of a few rounds of the chip
+  if (nblk <= 1024 && taps >= 32) return 16;
+  if (nblk <= 2048 && taps >= 16) return 8;
   return 4;
 }
 
@@ -803,14 +847,12 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo, ProfScope* ps = 
   P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
   const dim3 grid(nblk);
-  const int nw = NI == 1 ? ks_pick_waves(P, nblk) : 4;  // the 32x64 tile is only chosen for launches with thousands of workgroups
+  const int nw = ks_pick_waves(P, nblk);
   if (ps) ps->add_template_arg(nw);
 #define KS_GO(MI_, NI_, EPI_, NIN_)                                                            \
   do {                                                                                         \
-    if constexpr ((NI_) == 1) {                                                                \
-      if (nw == 16) { launch_ks_inst<MI_, NI_, EPI_, NIN_, 16>(st, P, grid); break; }          \
-      if (nw == 8) { launch_ks_inst<MI_, NI_, EPI_, NIN_, 8>(st, P, grid); break; }            \
-    }                                                                                          \
+    if (nw == 16) { launch_ks_inst<MI_, NI_, EPI_, NIN_, 16>(st, P, grid); break; }            \
+    if (nw == 8) { launch_ks_inst<MI_, NI_, EPI_, NIN_, 8>(st, P, grid); break; }              \
     launch_ks_inst<MI_, NI_, EPI_, NIN_, 4>(st, P, grid);                                      \
   } while (0)
   if (EPI == EPI_STORE && MI * NI == 1 && P.x_split) KS_GO(1, 1, EPI_STORE, 2);
@@ -898,6 +940,53 @@ static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, dou
   else hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, C16_MAXU, 1>), grid, dim3(256), lds, s->stream, P);
 }
 
+// ---- LDS-staged 16-wave kernel for the single-utterance decoder (conv_small.hip.h conv_ls_kernel)
+static int g_ls_mode = 0;  // 0 = heuristic, 1 = never, 2 = whenever eligible (tests)
+static bool conv_ls_ok(const ConvParams& P, int epi, int halo, long nblk32) {
+  static const int env_mode = getenv("VITS_CONV_LS") ? atoi(getenv("VITS_CONV_LS")) : 0;
+  const int mode = g_ls_mode ? g_ls_mode : env_mode;
+  if (mode == 1 || epi != EPI_STORE) return false;
+  if (P.x_split || P.x_ch_sign != 1 || P.x_ch_off || P.skip_len || P.tile_start || P.scale_b) return false;
+  if (P.ups_u && (P.ups_cout % 32)) return false;
+  int taps = 0;
+  for (int g = 0; g < P.n_groups; ++g) {
+    const int t = P.Cin / CONV_CI_T * P.g[g].K;
+    if (t > taps) taps = t;
+    if (P.g[g].x2 && !P.g[0].x2) return false;
+  }
+  if (cdiv(taps, 16) > (P.g[0].x2 ? 6 : 11)) return false;
+  const size_t lds = (size_t)P.Cin * (32 + halo) * sizeof(float);
+  if (lds > 156 * 1024) return false;
+  // Measured on the single-utterance decoder (tools/convdbg.py): 24.7 us vs 24.2 us for the 16-wave K-split kernel on
+  // the k = 11 ResBlock conv and 3..10 % slower on the grouped launches -- removing both per-MFMA global loads from the loop
+  // does not help, so the kernel is kept as a tested alternative (VITS_CONV_LS=2 / vits_debug_conv_ls) and not dispatched.
+  (void)nblk32;
+  return mode == 2;
+}
+static void launch_conv_ls(vits_session* s, ConvParams& P, int halo, ProfScope& ps) {
+  P.tile_start = nullptr;
+  P.ntiles_m = cdiv(P.M, 32);
+  P.ntiles_n = cdiv(P.Tout, 32);
+  P.row_len = 32 + halo;
+  int taps = 0;
+  for (int g = 0; g < P.n_groups; ++g) { const int t = P.Cin / CONV_CI_T * P.g[g].K; if (t > taps) taps = t; }
+  const bool few = cdiv(taps, 16) <= 6;
+  const bool multi = P.g[0].x2 != nullptr;
+  size_t lds = (size_t)P.Cin * P.row_len * sizeof(float);
+  if (lds < (size_t)16 * 16 * 64 * sizeof(float)) lds = (size_t)16 * 16 * 64 * sizeof(float);
+  const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
+#define LS_GO(MAXT_, NIN_)                                                                                           \
+  do {                                                                                                               \
+    auto kern = conv_ls_kernel<MAXT_, NIN_>;                                                                         \
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)once;                                                                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s->stream, P);                                                   \
+  } while (0)
+  if (multi) { ps.set_kernel("conv_ls_kernel<6,3>"); LS_GO(6, 3); }
+  else { ps.set_kernel(few ? "conv_ls_kernel<6,1>" : "conv_ls_kernel<11,1>"); if (few) LS_GO(6, 1); else LS_GO(11, 1); }
+#undef LS_GO
+}
+
 // would launch_conv route this launch to the small-tile kernel?  (callers that fold a LayerNorm into the consumer's staging
 // must know before they drop the LayerNorm launch: only that kernel has the prologue)
 static bool conv_takes_c16(const ConvParams& P, int epi) {
@@ -928,15 +1017,15 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   static long long* dbg_buf = nullptr;
   const bool dbg_this = (dbg_counter++ == dbg_want);
   if (dbg_this) {
-    if (!dbg_buf) hipMalloc((void**)&dbg_buf, 64 * sizeof(long long));
-    hipMemsetAsync(dbg_buf, 0, 64 * sizeof(long long), st);
+    if (!dbg_buf) hipMalloc((void**)&dbg_buf, 128 * sizeof(long long));
+    hipMemsetAsync(dbg_buf, 0, 128 * sizeof(long long), st);
     P.dbg = dbg_buf;
   }
   struct DbgPrint {
     bool on; hipStream_t st; long long* buf; const char* name; int M, Cin, K, T, B;
     ~DbgPrint() {
       if (!on) return;
-      long long h[64];
+      long long h[128];
       hipStreamSynchronize(st);
       hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost);
       fprintf(stderr, "[in-forward conv dbg] %s M=%d Cin=%d K=%d T=%d B=%d\n", name, M, Cin, K, T, B);
@@ -980,6 +1069,10 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(s, P, halo, &ps); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(s, P, halo); }
     return;
+  }
+  if (small || g_ls_mode == 2) {
+    const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
+    if (conv_ls_ok(P, epi, halo, blocks32)) { launch_conv_ls(s, P, halo, ps); return; }
   }
   if (small) {
     const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
@@ -1369,8 +1462,9 @@ static void set_rag(ConvParams& P, const int* rag, int in_mul, int in_add, int o
 // padded-batch result on every valid sample; 0 decodes every item as if it were alone (zeros beyond its own end at every
 // stage), which is what a batch of independent utterances of the StableTTS path wants.
 static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, int Ty, float* d_audio, long long audio_bstride,
-                        float* d_mb, bool ragged = false, int rag_halo = VITS_RAGGED_HALO) {
+                        float* d_mb, bool ragged = false, int rag_halo = -1) {
   vits_model* m = s->m;
+  if (rag_halo < 0) rag_halo = m->rag_halo;  // default: the reference's padded-batch continuation over the receptive field
   const vits_hparams& hp = m->hp;
   int C = hp.dec_initial_channel, T = Ty;
   const int* rag = nullptr;
@@ -1576,8 +1670,10 @@ int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
   memcpy(&m->n_entries, p + 12 + hb, 4);
   m->entries = reinterpret_cast<const vits_blob_entry*>(p + 16 + hb);
   if (16 + hb + (size_t)m->n_entries * sizeof(vits_blob_entry) > bytes) { delete m; return fail(VITS_ERR_BLOB, "truncated table"); }
-  for (uint32_t i = 0; i < m->n_entries; ++i)
-    if (m->entries[i].offset + m->entries[i].nelem * 4 > bytes) { delete m; return fail(VITS_ERR_BLOB, "truncated data"); }
+  for (uint32_t i = 0; i < m->n_entries; ++i) {  // overflow-safe: nelem and offset are 64-bit values from the file
+    const uint64_t off = m->entries[i].offset, ne = m->entries[i].nelem;
+    if (off > bytes || ne > (bytes - off) / 4) { delete m; return fail(VITS_ERR_BLOB, "truncated data"); }
+  }
   int rc = load_model(m);
   m->blob = nullptr; m->entries = nullptr;
   if (rc != VITS_OK) { for (void* a : m->allocs) hipFree(a); delete m; return rc; }
@@ -1982,7 +2078,7 @@ static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm)
     float* z = run_flow(Bk, B, TyB);
     // a lone utterance decodes as the exact-size run does (zeros beyond its end); batches keep the reference's padded-batch
     // continuation over the halo unless the caller asked for independent items
-    run_decoder(Bk, z, true, B, TyB, Bk->out_d, stride, nullptr, true, (solo || B == 1) ? 0 : VITS_RAGGED_HALO);
+    run_decoder(Bk, z, true, B, TyB, Bk->out_d, stride, nullptr, true, (solo || B == 1) ? 0 : F->m->rag_halo);
     if (pcm) {
       hipLaunchKernelGGL(pcm16_kernel, dim3(cdiv((int)stride, 256), B), dim3(256), 0, F->stream, Bk->out_d, stride, Bk->pcm_d, stride, stride, 1.f, Bk->dv);
       hipMemcpyAsync(Bk->out_h, Bk->pcm_d, Bk->out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, F->stream);
@@ -2082,7 +2178,7 @@ static int synth_eager(vits_model* m, const int64_t* ids, const int64_t* lengths
   const int64_t S = Ty * hp.hop_length;
   float* d_audio = hs.dev_alloc<float>((size_t)B * S);
   if (!d_audio) return fail(VITS_ERR_NOMEM, "device alloc failed");
-  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr, true, s->solo ? 0 : VITS_RAGGED_HALO);
+  run_decoder(s, z, true, B, (int)Ty, d_audio, S, nullptr, true, s->solo ? 0 : m->rag_halo);
   const size_t esz = pcm ? sizeof(int16_t) : sizeof(float);
   const void* d_src = d_audio;
   if (pcm) {
@@ -2142,7 +2238,7 @@ struct vits_stream {
   vits_model* m = nullptr;
   HostStage* hs = nullptr;          // acoustic session + temporaries; z lives in its workspace
   const float* z = nullptr;
-  int Ty = 0, chunk = 0, W = 0, halo = VITS_RAGGED_HALO;
+  int Ty = 0, chunk = 0, W = 0, halo = VITS_RAGGED_HALO;  // halo is set from the model's receptive field at open
   int pos = 0;                      // first frame not yet handed to the caller
   int win_start = -1;               // frame window currently decoded (or in flight) in d_aud
   float *d_win = nullptr, *d_aud = nullptr, *h_pin = nullptr;
@@ -2201,6 +2297,7 @@ int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float*
   const vits_hparams& hp = m->hp;
   st->z = z;
   st->Ty = (int)Ty;
+  st->halo = m->rag_halo;
   st->chunk = chunk_frames;
   st->W = chunk_frames + 2 * st->halo;
   if (st->W > st->Ty) st->W = st->Ty;
@@ -2327,6 +2424,7 @@ void vits_debug_force_tile(int mode) { g_force_tile = mode; }
 void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
 void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
+void vits_debug_conv_ls(int mode) { g_ls_mode = mode; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
 
 int vits_session_sync(vits_session* s) {
@@ -2395,10 +2493,11 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
     P.in_slope = slope;
     const char* dbg_env = getenv("VITS_CONV_DBG");
     long long* d_dbg = nullptr;
-    if (dbg_env) { hipMalloc((void**)&d_dbg, 32 * sizeof(long long)); hipMemset(d_dbg, 0, 32 * sizeof(long long)); P.dbg = d_dbg; }
+    if (dbg_env) { hipMalloc((void**)&d_dbg, 128 * sizeof(long long)); hipMemset(d_dbg, 0, 128 * sizeof(long long)); P.dbg = d_dbg; }
     const int reps = dbg_env ? atoi(dbg_env) : 1;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0, e1, ea; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&ea);
     for (int r = 0; r < reps; ++r) {
+      if (r == 1 || reps == 1) hipEventRecord(ea, 0);  // all launches after the first (steady state, operands cache-warm)
       if (r == reps - 1) hipEventRecord(e0, 0);
       launch_conv(&s, P, EPI_STORE, "op.conv1d");
     }
@@ -2407,10 +2506,13 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
     if (e != hipSuccess) rc = fail(VITS_ERR_DEVICE, "conv kernel failed: %s", hipGetErrorString(e));
     else hipMemcpy(y, dy, sizeof(float) * (size_t)B * Cout * T, hipMemcpyDeviceToHost);
     if (dbg_env && rc == VITS_OK) {
-      long long h[32]; float ms = 0;
+      long long h[128]; float ms = 0, msa = 0;
       hipMemcpy(h, d_dbg, sizeof h, hipMemcpyDeviceToHost);
       hipEventElapsedTime(&ms, e0, e1);
-      fprintf(stderr, "[conv dbg] B=%d Cin=%d Cout=%d T=%d K=%d dil=%d: last launch %.2f us (event); block 0 cycles since kernel start:\n", B, Cin, Cout, T, K, dil, ms * 1e3);
+      hipEventElapsedTime(&msa, ea, e1);
+      fprintf(stderr, "[conv dbg] B=%d Cin=%d Cout=%d T=%d K=%d dil=%d: last launch %.2f us (event), %.2f us/launch over the last %d back-to-back launches = %.1f TFLOP/s; block 0 cycles since kernel start:\n",
+              B, Cin, Cout, T, K, dil, ms * 1e3, msa * 1e3 / (reps > 1 ? reps - 1 : 1), reps > 1 ? reps - 1 : 1,
+              2.0 * B * Cin * Cout * (double)T * K / (msa * 1e-3 / (reps > 1 ? reps - 1 : 1)) / 1e12);
       const long blocks64 = (long)cdiv(W.Mpad, 64) * cdiv(T, 64) * B;
       {
         int nb = -1, nb2 = -1, nb3 = -1;
@@ -2426,12 +2528,12 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
           fprintf(stderr, "   [big-tile] wave %d: prologue %lld  taps %lld  store+barrier %lld  mainloop_end %lld  end %lld  (MFMA floor %lld)\n", w, h[w * 8], h[w * 8 + 1],
                   h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], (long long)(Cin / 2) * K * 4 * 64);
       } else
-      for (int w = 0; w < 4; ++w)
-        fprintf(stderr, "   wave %d: staged0 %lld  loop_done %lld  barrier %lld  reduced %lld  end %lld\n", w, h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8],
+      for (int w = 0; w < 16; w += 5)
+        if (h[w * 8]) fprintf(stderr, "   wave %d: staged0 %lld  loop_done %lld  barrier %lld  reduced %lld  end %lld\n", w, h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8],
                 h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8]);
     }
     if (d_dbg) hipFree(d_dbg);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ea);
   }
   if (dx) hipFree(dx);
   if (dy) hipFree(dy);

@@ -462,7 +462,7 @@ int stts_create(const void* blob, size_t bytes, vits_model* vocoder, int device,
   int rc = VITS_OK;
   if (16 + hb + (size_t)b->n_entries * sizeof(vits_blob_entry) > bytes) rc = fail(VITS_ERR_BLOB, "truncated table");
   for (uint32_t i = 0; rc == VITS_OK && i < b->n_entries; ++i)
-    if (b->entries[i].offset + b->entries[i].nelem * 4 > bytes) rc = fail(VITS_ERR_BLOB, "truncated data");
+    if (b->entries[i].offset > bytes || b->entries[i].nelem > (bytes - b->entries[i].offset) / 4) rc = fail(VITS_ERR_BLOB, "truncated data");  // overflow-safe
   if (rc == VITS_OK) rc = stts_load(m);
   b->blob = nullptr; b->entries = nullptr;
   if (rc != VITS_OK) { for (void* a : b->allocs) hipFree(a); delete m; return rc; }
@@ -855,7 +855,7 @@ int stts_bert_create(const void* blob, size_t bytes, int device, bert_model** ou
   int rc = VITS_OK;
   if (16 + hb + (size_t)b->n_entries * sizeof(vits_blob_entry) > bytes) rc = fail(VITS_ERR_BLOB, "truncated table");
   for (uint32_t i = 0; rc == VITS_OK && i < b->n_entries; ++i)
-    if (b->entries[i].offset + b->entries[i].nelem * 4 > bytes) rc = fail(VITS_ERR_BLOB, "truncated data");
+    if (b->entries[i].offset > bytes || b->entries[i].nelem > (bytes - b->entries[i].offset) / 4) rc = fail(VITS_ERR_BLOB, "truncated data");  // overflow-safe
   if (rc == VITS_OK) rc = bert_load(m);
   b->blob = nullptr; b->entries = nullptr;
   if (rc != VITS_OK) { for (void* a : b->allocs) hipFree(a); delete m; return rc; }

@@ -14,7 +14,7 @@ This path could not be validated against a real vosk model here (none is availab
 wire parser and the name/shape mapping are covered by tests/test_onnx_import.py with a synthetic file.
 
 ONNX protobuf fields used (onnx.proto3): ModelProto.graph = 7; GraphProto.node = 1, .initializer = 5;
-NodeProto.output = 2, .op_type = 4, .attribute = 5; AttributeProto.name = 1, .t = 5;
+NodeProto.output = 2, .op_type = 4, .attribute = 5; AttributeProto.name = 1, .i = 3, .t = 5, .ints = 8;
 TensorProto.dims = 1, .data_type = 2, .float_data = 4, .int64_data = 7, .name = 8, .raw_data = 9,
 .double_data = 10, .data_location = 14.
 """
@@ -136,6 +136,7 @@ class OnnxGraph:
         data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
         self.inits = {}
         self.nodes = []  # (name, op_type, inputs, outputs)
+        self.attrs = {}  # node name -> {attribute name: [ints]}  (strides / dilations / kernel_shape of the conv nodes)
         self.alias = {}  # Identity output -> input
         for fno, wt, v in _fields(memoryview(data)):
             if fno != 7 or wt != 2:  # ModelProto.graph
@@ -146,7 +147,7 @@ class OnnxGraph:
                     if arr is not None:
                         self.inits[name] = arr
                 elif gno == 1 and gwt == 2:  # node
-                    ins, outs, name, op, tens = [], [], "", "", None
+                    ins, outs, name, op, tens, attrs = [], [], "", "", None, {}
                     for nno, nwt, nv in _fields(gv):
                         if nno == 1:
                             ins.append(bytes(nv).decode("utf-8", "replace"))
@@ -157,10 +158,21 @@ class OnnxGraph:
                         elif nno == 4:
                             op = bytes(nv).decode("utf-8", "replace")
                         elif nno == 5 and nwt == 2:
+                            aname, ints = "", []
                             for ano, awt, av in _fields(nv):
                                 if ano == 5 and awt == 2:
                                     tens = _tensor(av)[1]
+                                elif ano == 1 and awt == 2:
+                                    aname = bytes(av).decode("utf-8", "replace")
+                                elif ano == 8:  # repeated int64 ints (packed or one varint per element)
+                                    ints.extend(_packed_varints(av) if awt == 2 else [int(av)])
+                                elif ano == 3 and awt == 0:  # single int
+                                    ints.append(int(av))
+                            if aname and ints:
+                                attrs[aname] = ints
                     self.nodes.append((name, op, ins, outs))
+                    if name and attrs:
+                        self.attrs[name] = attrs
                     if op == "Constant" and tens is not None and outs:  # Constant tensors count as initializers
                         self.inits.setdefault(outs[0], tens)
                     elif op == "Identity" and len(ins) == 1 and len(outs) == 1:
@@ -337,6 +349,26 @@ def import_onnx(path_or_bytes, config=None):
         raise NotImplementedError("BERT-conditioned flavour: not part of the VITS2 hot path (SURVEY.md §8f rank 2)")
     hp = infer_hparams(t)
     config = config or {}
+    # Geometry that tensor shapes cannot reveal comes from the graph itself: the `strides` attribute of every
+    # /dec/ups.N/ConvTranspose node, the `dilations` of the ResBlock convs, the stride of the iSTFT's ConvTranspose.
+    # (A runtime vosk model's config.json normally has no "model"/"data" sections; config values, when present, win.)
+    for i in range(hp.n_ups):
+        st = g.attrs.get(f"/dec/ups.{i}/ConvTranspose", {}).get("strides")
+        if st:
+            hp.up_rates[i] = int(st[0])
+        elif hp.up_rates[i] <= 0:  # no attribute and no in-repo default for this stage: HiFi-GAN convention kernel = 2 * rate
+            hp.up_rates[i] = max(1, hp.up_kernels[i] // 2)
+    for i in range(hp.n_ups, len(hp.up_rates)):
+        hp.up_rates[i] = 0
+    for j in range(hp.n_resk):
+        for d in range(hp.n_resd):
+            dl = g.attrs.get(f"/dec/resblocks.{j}/convs1.{d}/Conv", {}).get("dilations")
+            if dl:
+                hp.res_dilations[j][d] = int(dl[0])
+    if hp.dec_type == 0:
+        for nm, at in g.attrs.items():
+            if nm.startswith("/dec/") and "stft" in nm.lower() and nm.endswith("ConvTranspose") and at.get("strides"):
+                hp.istft_hop = int(at["strides"][0])
     for i, r in enumerate(config.get("upsample_rates", [])):
         hp.up_rates[i] = int(r)
     for j, dl in enumerate(config.get("resblock_dilation_sizes", [])):
@@ -346,6 +378,10 @@ def import_onnx(path_or_bytes, config=None):
                        ("hop_length", "hop_length")):
         if key in config:
             setattr(hp, field, int(config[key]))
+    rate = int(np.prod([hp.up_rates[i] for i in range(hp.n_ups)])) * (hp.istft_hop * hp.subbands if hp.dec_type == 0 else 1)
+    if "hop_length" not in config:
+        hp.hop_length = rate  # samples per frame are a property of the decoder, not an independent setting
+    W.validate_hparams(hp)
     tensors, missing, bad = {}, [], []
     for name, shape, _kind, _fan, _gain in W.tensor_specs(hp):
         a = t.get(name)

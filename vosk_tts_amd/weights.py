@@ -347,7 +347,28 @@ def synthetic_from_specs(specs, seed=1234):
 # blob I/O
 # --------------------------------------------------------------------------- #
 
+def validate_hparams(hp):
+    """The checks vits_create makes before it divides by a rate or sizes a buffer from hop_length (engine.hip load_decoder):
+    the decoder writes T_y * prod(up_rates) [* istft_hop * subbands] samples per item into buffers of T_y * hop_length."""
+    if not isinstance(hp, HParams):
+        return
+    rate = 1
+    for i in range(hp.n_ups):
+        u, k = hp.up_rates[i], hp.up_kernels[i]
+        if u <= 0 or k < u:
+            raise ValueError(f"decoder stage {i}: upsample rate {u} / kernel {k} invalid")
+        rate *= u
+    if hp.dec_type == 0:
+        if hp.subbands <= 0 or hp.istft_hop <= 0 or hp.istft_n_fft <= 0 or hp.istft_n_fft % hp.istft_hop:
+            raise ValueError("iSTFT / PQMF parameters invalid")
+        rate *= hp.istft_hop * hp.subbands
+    if rate != hp.hop_length:
+        raise ValueError(f"decoder produces {rate} samples per frame but hop_length is {hp.hop_length}: upsample_rates / "
+                         "gen_istft_hop_size / subbands / hop_length are inconsistent")
+
+
 def pack_blob(hp, tensors, magic=MAGIC):
+    validate_hparams(hp)
     names = list(tensors.keys())
     n = len(names)
     head = magic + struct.pack("<I", ctypes.sizeof(type(hp))) + bytes(hp) + struct.pack("<I", n)
