@@ -248,3 +248,35 @@ def test_wire_reader_roundtrips_random_tensors():
             assert got[k].shape == tens[k].shape and np.array_equal(got[k], tens[k]), k
 
     check()
+
+
+def test_decoder_geometry_comes_from_the_graph_and_is_validated(tmp_path):
+    """A runtime model's config.json has no "model" section: upsample rates must come from the ConvTranspose `strides`, ResBlock
+    dilations from the Conv `dilations`, hop_length from their product; inconsistent geometry is rejected before a blob exists
+    (engine.hip makes the same checks at vits_create: a zero rate would otherwise divide by zero, a wrong hop_length overrun)."""
+    from vosk_tts_amd import onnx_import as O
+    from vosk_tts_amd import weights as W
+
+    hp = W.plain_hparams()  # plain HiFi-GAN generator: rates other than the in-repo default [4, 4]
+    rates = [hp.up_rates[i] for i in range(hp.n_ups)]
+    t = W.make_synthetic_weights(hp, 5)
+    nodes = [(f"/dec/ups.{i}/ConvTranspose", "ConvTranspose", ["x", f"dec.ups.{i}.weight"], ["y"], {"strides": [r], "kernel_shape": [hp.up_kernels[i]]})
+             for i, r in enumerate(rates)]
+    nodes += [(f"/dec/resblocks.{j}/convs1.{d}/Conv", "Conv", ["x", f"dec.resblocks.{j}.convs1.{d}.weight"], ["y"], {"dilations": [hp.res_dilations[j][d]]})
+              for j in range(hp.n_resk) for d in range(hp.n_resd)]
+    p = O.write_minimal_onnx(str(tmp_path / "m.onnx"), t, nodes=nodes)
+    got, _ = O.import_onnx(p)  # no config at all
+    assert [got.up_rates[i] for i in range(got.n_ups)] == rates
+    assert got.hop_length == int(np.prod(rates)) == hp.hop_length
+    assert [[got.res_dilations[j][d] for d in range(got.n_resd)] for j in range(got.n_resk)] == \
+           [[hp.res_dilations[j][d] for d in range(hp.n_resd)] for j in range(hp.n_resk)]
+    with pytest.raises(ValueError, match="hop_length"):
+        O.import_onnx(p, {"hop_length": 2 * hp.hop_length, "upsample_rates": rates})  # contradicts the graph
+    bad = W.default_hparams()
+    bad.up_rates[1] = 0
+    with pytest.raises(ValueError, match="upsample rate"):
+        W.pack_blob(bad, {})
+    bad = W.default_hparams()
+    bad.hop_length = 512
+    with pytest.raises(ValueError, match="hop_length"):
+        W.pack_blob(bad, {})

@@ -630,11 +630,16 @@ def _enc_field(fno, wt, payload):
 
 def write_minimal_onnx(path, tensors, use_float_data=(), nodes=()):
     """ModelProto{ir_version, graph{node..., initializer...}} with raw_data (or float_data for names in use_float_data);
-    nodes: (name, op_type, inputs, outputs) tuples."""
+    nodes: (name, op_type, inputs, outputs[, {attribute: [ints]}]) tuples."""
     graph = bytearray()
-    for name, op, ins, outs in nodes:
+    for node in nodes:
+        name, op, ins, outs = node[:4]
+        attrs = node[4] if len(node) > 4 else {}
+        ab = b""
+        for an, ints in attrs.items():  # AttributeProto{name = 1, ints = 8 (one varint per element), type = 20 (INTS = 7)}
+            ab += _enc_field(5, 2, _enc_field(1, 2, an.encode()) + b"".join(_enc_field(8, 0, int(v)) for v in ints) + _enc_field(20, 0, 7))
         graph += _enc_field(1, 2, b"".join(_enc_field(1, 2, i.encode()) for i in ins) + b"".join(_enc_field(2, 2, o.encode()) for o in outs)
-                            + _enc_field(3, 2, name.encode()) + _enc_field(4, 2, op.encode()))
+                            + _enc_field(3, 2, name.encode()) + _enc_field(4, 2, op.encode()) + ab)
     for name, a in tensors.items():
         a = np.asarray(a, dtype="<f4")  # (ascontiguousarray would turn a 0-d tensor into [1])
         tp = b"".join(_enc_field(1, 0, int(d)) for d in a.shape) + _enc_field(2, 0, 1) + _enc_field(8, 2, name.encode())
