@@ -129,6 +129,8 @@ const char* vits_last_error(void);
 int vits_get_hparams(const vits_model* m, vits_hparams* out);
 /* Returns 1 for the HIP library, 0 for the CPU oracle. */
 int vits_is_device_backend(void);
+/* Number of HIP devices visible to the process (replicas-only multi-GPU: one vits_model per device). */
+int vits_device_count(void);
 
 /* ---- the hot path: one .run() --------------------------------------------- */
 
@@ -143,6 +145,8 @@ typedef struct vits_synth_opts {
   uint64_t       seed;             /* Philox seed when noise_* are NULL */
   int32_t        max_frames;       /* 0 = unlimited; capacity bound on T_y per item (error if exceeded) */
   int32_t        flags;            /* VITS_FLAG_* */
+  const uint64_t* item_seeds;      /* [B] or NULL; with VITS_FLAG_SOLO_BATCH: item b uses item_seeds[b] instead of seed + b, so a
+                                      request keeps its own noise draw however a server groups requests into batches */
 } vits_synth_opts;
 
 #define VITS_FLAG_NONE 0

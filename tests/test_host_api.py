@@ -175,6 +175,44 @@ def test_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_multi_device_synth_is_independent_of_sharding(tmp_path):
+    """MultiDeviceSynth (one Model replica + worker thread per device, plan_shards -> pad_batch -> vits_synthesize_pcm16 ->
+    scatter_results): results come back in request order, and a request's samples do not depend on the number of replicas or on
+    what shared its batch -- two replicas on device 0, one replica, batches of 2, and one-request-at-a-time calls through
+    Synth's own session all agree (int16, at most one LSB apart: batch composition changes which conv kernel runs)."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.batching import MultiDeviceSynth
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), W.default_hparams(n_vocab=len(PHONEMES)))
+    texts = ["прив+ет, м+ир!", "м+ир", "прив+ет прив+ет прив+ет м+ир, м+ир.", "м+ир прив+ет?", "прив+ет", "м+ир, м+ир, м+ир; прив+ет!", "прив+ет м+ир"]
+    sids = [2, 0, 5, 2, 7, 1, 3]
+    seeds = [101, 7, 33, 58, 4, 90, 12]
+    two = MultiDeviceSynth(d, devices=[0, 0], max_batch=32)
+    one = MultiDeviceSynth(d, devices=[0], max_batch=2)
+    try:
+        a = two.synth_batch(texts, speaker_ids=sids, seeds=seeds)
+        b = one.synth_batch(texts, speaker_ids=sids, seeds=seeds)
+        assert len(a) == len(b) == len(texts)
+        synth = one.synths[0]
+        for i, t in enumerate(texts):
+            ids = np.array([synth.g2p_noembed(t)], np.int64)
+            feed = {"input": ids, "input_lengths": np.array([ids.shape[1]], np.int64), "scales": np.array([0.8, 1.0, 0.8], np.float32),
+                    "sid": np.array([sids[i]], np.int64), "bert": None, "phone_duration_extra": None, "vits.seed": seeds[i]}
+            solo = synth.model.onnx.run_pcm16(feed, 1.0)[0]
+            assert a[i].dtype == np.int16 and a[i].shape == b[i].shape == solo.shape and a[i].size % 256 == 0 and a[i].size > 0
+            for name, got in (("2 replicas", a[i]), ("1 replica, batches of 2", b[i])):
+                assert np.abs(got.astype(np.int32) - solo.astype(np.int32)).max() <= 1, (name, i)
+        # a second call draws fresh seeds; explicit speaker broadcast; empty request list
+        c = two.synth_batch(texts[:3], speaker_ids=2)
+        assert len(c) == 3 and all(x.size > 0 for x in c)
+        assert two.synth_batch([]) == []
+    finally:
+        two.close()
+        one.close()
+
+
+@pytest.mark.gpu
 def test_session_is_reentrant_from_threads(hip_tiny, oracle_tiny):
     """gRPC server shares one Synth across a thread pool (server/tts_server.py:39-40,57)."""
     import threading

@@ -7,6 +7,9 @@ with the least predicted work, so padded batches stay tight and ranks finish tog
 No collective is needed on the data path: each rank reads the same request list and keeps its
 own shard; only the small int16 PCM results travel back (over the launcher's channel of choice).
 """
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 
@@ -54,3 +57,88 @@ def scatter_results(n_requests, shards, shard_outputs):
     if any(o is None for o in out):
         raise ValueError("some requests were not assigned to any shard")
     return out
+
+
+class MultiDeviceSynth:
+    """Batched multi-utterance synthesis over N device replicas in ONE process (BASELINE north_star: "Batched multi-utterance
+    synthesis shards across the 8 GPUs of one node as embarrassingly-parallel data replicas"; SURVEY.md 8e: "one host thread
+    per device; results gathered on host in original order").  The seam is where the reference's gRPC server shares one Synth
+    across a thread pool (server/tts_server.py:37-40,56-63): here each device holds its own `Model` replica (weights resident
+    once per device) and a worker thread; a list of requests is front-ended on the host (the same g2p as `Synth`), sharded by
+    predicted cost (`plan_shards`), every shard runs as padded batches of at most `max_batch` through the C ABI
+    (vits_synthesize_pcm16, int16 conversion on the device) and the results come back in request order.
+
+    Every request is synthesized as an independent utterance (VITS_FLAG_SOLO_BATCH) with its own noise seed, so the samples a
+    request gets do not depend on how many devices there are or on what else was in its batch.  No collective anywhere: ctypes
+    drops the GIL during the call, the devices run concurrently.
+
+        mds = MultiDeviceSynth(model_path, devices=[0, 1, 2, 3, 4, 5, 6, 7])
+        pcm = mds.synth_batch(["...", "..."], speaker_ids=2)        # list of int16 arrays, request order
+    """
+
+    def __init__(self, model_path=None, devices=None, model_name=None, lang=None, max_batch=32):
+        from .model import Model
+        from .synth import Synth
+
+        if devices is None:
+            from .capi import VitsLib
+
+            n = VitsLib().device_count()
+            devices = list(range(max(n, 1)))
+        if not devices:
+            raise ValueError("no devices")
+        self.devices = list(devices)
+        self.max_batch = int(max_batch)
+        self.models = [Model(model_path=model_path, model_name=model_name, lang=lang, device=d) for d in self.devices]
+        for m in self.models:
+            if not hasattr(m.onnx, "run_pcm16"):
+                raise NotImplementedError("MultiDeviceSynth drives VITS voices (batched C ABI); multistream voices batch through "
+                                          "SttsModel.synthesize_batch")
+        self.synths = [Synth(m) for m in self.models]
+        self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="vits-dev")
+        self._seed = 0
+        self._lock = threading.Lock()
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for m in self.models:
+            m.onnx.close()
+
+    def _run_shard(self, r, token_lists, idx, sids, scales, scale, seeds):
+        """the requests `idx` on replica r, in batches of <= max_batch (already sorted by descending length) -> list of int16 arrays"""
+        out = []
+        sess = self.models[r].onnx
+        for k in range(0, len(idx), self.max_batch):
+            part = idx[k:k + self.max_batch]
+            ids, lens = pad_batch(token_lists, part)
+            feed = {"input": ids, "input_lengths": lens, "scales": scales, "sid": np.array([sids[i] for i in part], np.int64),
+                    "bert": None, "phone_duration_extra": None, "vits.solo": True,
+                    "vits.item_seeds": np.array([seeds[i] for i in part], np.uint64)}
+            pcm = sess.run_pcm16(feed, scale)
+            out.extend(pcm[j, :int(sess.last_lengths[j])].copy() for j in range(len(part)))
+        return out
+
+    def synth_batch(self, texts, speaker_ids=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None, seeds=None):
+        """texts: list of str -> list of int16 PCM arrays (22.05 kHz), one per request, in request order.  `seeds`: optional
+        per-request noise seeds (default: a running counter), `speaker_ids`: one id or one per request."""
+        n = len(texts)
+        if n == 0:
+            return []
+        s0 = self.synths[0]
+        inf = s0.model.config.get("inference", {})
+        noise_level = inf.get("noise_level", 0.8) if noise_level is None else noise_level
+        speech_rate = inf.get("speech_rate", 1.0) if speech_rate is None else speech_rate
+        duration_noise_level = inf.get("duration_noise_level", 0.8) if duration_noise_level is None else duration_noise_level
+        scale = inf.get("scale", 1.0) if scale is None else scale
+        scales = np.array([noise_level, 1.0 / speech_rate, duration_noise_level], np.float32)  # synth.py:106
+        token_lists = [s0.g2p_noembed(s0.normalize(t)) for t in texts]
+        sids = [speaker_ids] * n if np.isscalar(speaker_ids) or speaker_ids is None else list(speaker_ids)
+        sids = [0 if v is None else int(v) for v in sids]
+        if seeds is None:
+            with self._lock:
+                seeds = [self._seed + 1 + i for i in range(n)]
+                self._seed += n
+        shards = plan_shards([len(t) for t in token_lists], len(self.devices))
+        futs = [self._pool.submit(self._run_shard, r, token_lists, idx, sids, scales, scale, seeds) if idx else None
+                for r, idx in enumerate(shards)]
+        return scatter_results(n, [idx for idx in shards if idx], [f.result() for f in futs if f is not None])

@@ -32,6 +32,7 @@ class SynthOpts(ctypes.Structure):
         ("seed", ctypes.c_uint64),
         ("max_frames", ctypes.c_int32),
         ("flags", ctypes.c_int32),
+        ("item_seeds", ctypes.POINTER(ctypes.c_uint64)),
     ]
 
 
@@ -128,6 +129,13 @@ class VitsLib:
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
 
+    def device_count(self):
+        """HIP devices visible to this process (0 for the CPU oracle)"""
+        if not self.is_device or not self.has("device_count"):
+            return 0
+        self._fn("device_count").restype = ctypes.c_int
+        return int(self._fn("device_count")())
+
     def has(self, name):
         return hasattr(self.lib, self.prefix + name)
 
@@ -176,9 +184,14 @@ class VitsModel:
         except Exception:
             pass
 
-    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo=False):
+    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo=False, item_seeds=None):
         opts = SynthOpts()
         keep = []
+        if item_seeds is not None:
+            a = np.ascontiguousarray(item_seeds, dtype=np.uint64); keep.append(a)
+            if a.shape != (B,) or not solo:
+                raise ValueError("item_seeds must be [B] and needs solo=True")
+            opts.item_seeds = a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
         if noise_dp is not None:
             a = _f32(noise_dp); keep.append(a)
             if a.shape != (B, 2, Tx):
@@ -202,7 +215,7 @@ class VitsModel:
 
     # ---- the hot path -----------------------------------------------------
     def synthesize(self, ids, lengths, scales, sid, noise_dp=None, noise_prior=None, forced_durations=None, seed=0,
-                   max_frames=0, solo=False):
+                   max_frames=0, solo=False, item_seeds=None):
         """One .run(): returns (audio float32 [B,S], out_lengths int64 [B]).  solo=True (VITS_FLAG_SOLO_BATCH): every
         item equals its own single-utterance call with seed + b instead of the reference's padded-batch result."""
         ids = _i64(ids)
@@ -212,7 +225,7 @@ class VitsModel:
         scales = _f32(scales)
         if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
             raise ValueError("bad feed shapes")
-        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo)
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo, item_seeds)
         out = c_f32p()
         ns = ctypes.c_int64()
         olen = np.zeros(B, dtype=np.int64)
@@ -226,7 +239,7 @@ class VitsModel:
         return audio, olen
 
     def synthesize_pcm16(self, ids, lengths, scales, sid, pcm_scale=1.0, noise_dp=None, noise_prior=None, forced_durations=None,
-                         seed=0, max_frames=0, solo=False):
+                         seed=0, max_frames=0, solo=False, item_seeds=None):
         """synthesize() with Synth.synth_audio's `* scale` and audio_float_to_int16 (vosk_tts/synth.py:127-130) done on the
         device: returns (pcm int16 [B,S], out_lengths int64 [B])."""
         ids = _i64(ids)
@@ -234,7 +247,7 @@ class VitsModel:
         lengths = _i64(lengths); sid = _i64(sid); scales = _f32(scales)
         if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
             raise ValueError("bad feed shapes")
-        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo)
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo, item_seeds)
         out = ctypes.POINTER(ctypes.c_int16)()
         ns = ctypes.c_int64()
         olen = np.zeros(B, dtype=np.int64)

@@ -569,6 +569,7 @@ struct vits_session {
   std::map<GKey, hipGraphExec_t> graphs;
   bool use_graph = true;
   const SynthDev* dv = nullptr;  // device parameter block of the graph-replayed fast path (null: scalars by value)
+  const unsigned long long* item_seeds = nullptr;  // device [B]: per-item Philox seeds of a solo batch (null: seed + b)
   bool ragged = false;  // full-path calls with B > 1: skip padding tiles of masked stages (set per call)
   bool solo = false;    // VITS_FLAG_SOLO_BATCH: every item as if synthesized alone (noise streams, decoder halo 0)
 
@@ -599,7 +600,7 @@ struct vits_session {
   bool rag_b1 = false;             // single utterance in a frame bucket: decoder sees zeros beyond the item's own end
   bool sdp_always = false;         // device-session option: run the duration predictor even when durations are forced
   char *io_h = nullptr, *io_d = nullptr;  // per-call inputs: pinned host mirror and device copy (SynthDev | lengths | sid | ids | forced)
-  size_t io_bytes = 0, io_len = 0, io_sid = 0, io_ids = 0, io_forced = 0;
+  size_t io_bytes = 0, io_len = 0, io_sid = 0, io_ids = 0, io_forced = 0, io_seeds = 0;
   int64_t* h_ylen = nullptr;       // pinned [B] + one int error word behind it
   hipGraphExec_t g1[4] = {nullptr, nullptr, nullptr, nullptr};  // [forced*2 + solo]
   std::map<int, vits_session*> backs;
@@ -1372,7 +1373,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "dp.pre");
   run_dds_proj(s, m->dp_dds, s->dh, m->dp_proj, s->dc, "dp.proj", B, Tx);
-  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx, s->solo ? 1 : 0, s->dv);
+  hipLaunchKernelGGL(dp_init_z_kernel, dim3(cdiv(Tx, 64), 2, B), dim3(64), 0, s->stream, s->dz, d_noise, nsw, seed, Tx, s->solo ? 1 : 0, s->dv, s->item_seeds);
   int swap = 0;
   const float cst = (float)log(exp(1.0 - 1e-3) - 1.0);
   (void)cst;
@@ -1401,7 +1402,7 @@ static void run_expand(vits_session* s, const float* d_noise, long long noise_st
                        float* z_p, int B, int Tx, int Ty) {
   const int I = s->m->hp.inter_channels;
   hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(Ty, 64), cdiv(I, EXPAND_CPB), B), dim3(256), 0, s->stream, s->stats, s->cum, s->len_y,
-                     d_noise, noise_stride, noise_scale, seed, z_p, I, Tx, Ty, s->solo ? 1 : 0, s->dv);
+                     d_noise, noise_stride, noise_scale, seed, z_p, I, Tx, Ty, s->solo ? 1 : 0, s->dv, s->item_seeds);
 }
 
 // ---- a12-a14: ResidualCouplingTransformersBlock.forward(reverse=True) (models.py:750-757).
@@ -1649,6 +1650,10 @@ static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t*
 extern "C" {
 
 int vits_is_device_backend(void) { return 1; }
+int vits_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 const char* vits_last_error(void) { return g_err; }
 
 int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
@@ -1865,6 +1870,11 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   if (!d_ids || !d_len) return fail(VITS_ERR_NOMEM, "device alloc failed");
   s->ragged = B > 1;
   s->solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
+  s->item_seeds = nullptr;
+  if (s->solo && opts->item_seeds) {
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "seed width");
+    s->item_seeds = hs.to_dev(reinterpret_cast<const unsigned long long*>(opts->item_seeds), (size_t)B);
+  }
   s->tile_keys.clear();
   struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->solo = false; } } ragged_off{s};
   set_lengths(s, d_len, s->len_x, B, Tx);
@@ -1964,7 +1974,8 @@ static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
   s->io_sid = s->io_len + align_up(sizeof(int64_t) * B, 64);
   s->io_ids = s->io_sid + align_up(sizeof(int64_t) * B, 64);
   s->io_forced = s->io_ids + align_up(sizeof(int64_t) * (size_t)B * TxB, 64);
-  s->io_bytes = s->io_forced + align_up(sizeof(int32_t) * (size_t)B * TxB, 64);
+  s->io_seeds = s->io_forced + align_up(sizeof(int32_t) * (size_t)B * TxB, 64);
+  s->io_bytes = s->io_seeds + align_up(sizeof(unsigned long long) * B, 64);
   if (hipHostMalloc((void**)&s->io_h, s->io_bytes) != hipSuccess || hipMalloc((void**)&s->io_d, s->io_bytes) != hipSuccess ||
       hipHostMalloc((void**)&s->h_ylen, sizeof(int64_t) * (B + 1)) != hipSuccess) {
     session_free(s);
@@ -2026,6 +2037,7 @@ static int back_get(vits_session* F, int TyB, vits_session** out) {
   // phase 2 reads the front's phase-1 results in place
   s->stats = F->stats; s->cum = F->cum; s->condv = F->condv; s->len_y = F->len_y; s->len_x = F->len_x; s->ylen64 = F->ylen64;
   s->dv = reinterpret_cast<const SynthDev*>(F->io_d);
+  s->item_seeds = reinterpret_cast<const unsigned long long*>(F->io_d + F->io_seeds);
   s->last_use = ++F->last_use;
   F->backs[TyB] = s;
   *out = s;
@@ -2049,6 +2061,7 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
     hipMemcpyAsync(F->io_d, F->io_h, F->io_bytes, hipMemcpyHostToDevice, F->stream);
     F->ragged = true; F->solo = solo; F->tile_keys.clear();
     F->dv = reinterpret_cast<const SynthDev*>(F->io_d);
+    F->item_seeds = reinterpret_cast<const unsigned long long*>(F->io_d + F->io_seeds);
     const int64_t* d_len = reinterpret_cast<const int64_t*>(F->io_d + F->io_len);
     const int64_t* d_sid = reinterpret_cast<const int64_t*>(F->io_d + F->io_sid);
     const int64_t* d_ids = reinterpret_cast<const int64_t*>(F->io_d + F->io_ids);
@@ -2118,7 +2131,9 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   int64_t* h_sid = reinterpret_cast<int64_t*>(F->io_h + F->io_sid);
   int64_t* h_ids = reinterpret_cast<int64_t*>(F->io_h + F->io_ids);
   int32_t* h_forced = reinterpret_cast<int32_t*>(F->io_h + F->io_forced);
+  unsigned long long* h_seeds = reinterpret_cast<unsigned long long*>(F->io_h + F->io_seeds);
   for (int b = 0; b < B; ++b) {
+    h_seeds[b] = (opts && opts->item_seeds) ? opts->item_seeds[b] : hv->seed + (uint64_t)b;
     h_len[b] = lengths[b];
     h_sid[b] = sid ? sid[b] : 0;
     memcpy(h_ids + (size_t)b * TxB, ids + (size_t)b * Tx, sizeof(int64_t) * Tx);

@@ -697,12 +697,14 @@ __global__ void __launch_bounds__(256, 2) relpos_attention_mfma_kernel(const flo
 // ----------------------------------------------------------------------------- duration predictor
 // z[b,c,t] = noise * noise_scale_w  (models.py:96)
 // solo != 0 (VITS_FLAG_SOLO_BATCH): item b draws what a single-utterance call with seed + b would draw
-__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T, int solo, const SynthDev* dv) {
+// item_seeds (optional, solo batches): per-item seeds instead of seed + b (requests batched by a server keep their own draw)
+__global__ void dp_init_z_kernel(float* z, const float* noise, float nsw, uint64_t seed, int T, int solo, const SynthDev* dv,
+                                 const unsigned long long* item_seeds) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   if (dv) { nsw = dv->scales[2]; seed = dv->seed; }
   const long long o = ((long long)b * 2 + c) * T + t;
-  const float e = noise ? noise[o] : (solo ? philox_normal(seed + (uint64_t)b, 1, (uint32_t)c, (uint32_t)t)
+  const float e = noise ? noise[o] : (solo ? philox_normal(item_seeds ? item_seeds[b] : seed + (uint64_t)b, 1, (uint32_t)c, (uint32_t)t)
                                             : philox_normal(seed, 1, (uint32_t)(b * 2 + c), (uint32_t)t));
   z[o] = e * nsw;
 }
@@ -835,7 +837,8 @@ __global__ void durations_kernel(const float* logw, const int* forced, const int
 #define EXPAND_CPB 16  // channels per block (4 lanes x 4 channels)
 __global__ void __launch_bounds__(256) expand_prior_kernel(const float* stats, const int* cum, const int* ylen, const float* noise,
                                                            long long noise_stride, float noise_scale, uint64_t seed, float* z_p,
-                                                           int I, int Tx, int Ty, int solo, const SynthDev* dv) {
+                                                           int I, int Tx, int Ty, int solo, const SynthDev* dv,
+                                                           const unsigned long long* item_seeds) {
   const int f = blockIdx.x * 64 + (threadIdx.x & 63), cl = threadIdx.x >> 6, b = blockIdx.z;
   if (f >= Ty) return;
   if (dv) { noise_scale = dv->scales[0]; seed = dv->seed; }  // device parameter block (graph replay) instead of by value
@@ -855,7 +858,7 @@ __global__ void __launch_bounds__(256) expand_prior_kernel(const float* stats, c
     const float ls_ = stats[((long long)b * 2 * I + I + c) * Tx + tk];
     const float mu = tok >= 0 ? mu_ : 0.f, ls = tok >= 0 ? ls_ : 0.f;
     const float e = noise ? noise[((long long)b * I + c) * noise_stride + f]
-                          : (solo ? philox_normal(seed + (uint64_t)b, 2, (uint32_t)c, (uint32_t)f)
+                          : (solo ? philox_normal(item_seeds ? item_seeds[b] : seed + (uint64_t)b, 2, (uint32_t)c, (uint32_t)f)
                                   : philox_normal(seed, 2, (uint32_t)(b * I + c), (uint32_t)f));
     z_p[((long long)b * I + c) * Ty + f] = mu + e * expf(ls) * noise_scale;
   }

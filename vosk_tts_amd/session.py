@@ -21,7 +21,7 @@ from .capi import VitsLib
 _GRAPH_INPUTS = ("input", "input_lengths", "scales", "sid")
 _OPTIONAL_NONE = ("bert", "phone_duration_extra")
 # extension feeds (not part of the ONNX graph) used by parity tests
-_EXT = ("vits.noise_dp", "vits.noise_prior", "vits.forced_durations", "vits.seed", "vits.solo")
+_EXT = ("vits.noise_dp", "vits.noise_prior", "vits.forced_durations", "vits.seed", "vits.solo", "vits.item_seeds")
 
 
 class _Arg:
@@ -82,7 +82,8 @@ class VitsSession:
         audio, lengths = self._model.synthesize(
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
-            forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)))
+            forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)),
+            item_seeds=feed.get("vits.item_seeds"))
         self.last_lengths = lengths
         return [audio[:, None, None, :]]
 
@@ -94,7 +95,8 @@ class VitsSession:
         pcm, lengths = self._model.synthesize_pcm16(
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             pcm_scale=float(scale), noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
-            forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)))
+            forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)),
+            item_seeds=feed.get("vits.item_seeds"))
         self.last_lengths = lengths
         return pcm
 

@@ -23,6 +23,11 @@ class Synth:
         audio_norm = np.clip(audio * max_wav_value, -max_wav_value, max_wav_value)
         return audio_norm.astype("int16")
 
+    @staticmethod
+    def normalize(text):
+        """the two text fix-ups synth_audio applies before any front-end (synth.py:58-59)"""
+        return re.sub("—", "-", text.strip())
+
     def _feed(self, text, speaker_id, noise_level, speech_rate, duration_noise_level, scale):
         """Runtime defaults and the six-key feed of synth.py:50-56,100-120."""
         inf = self.model.config.get("inference", {})
@@ -35,7 +40,7 @@ class Synth:
         if scale is None:
             scale = inf.get("scale", 1.0)
 
-        text = re.sub("—", "-", text.strip())
+        text = self.normalize(text)
         model_type = self.model.config.get("model_type") or ""
         bert_embs = None
         phone_duration_extra = None
