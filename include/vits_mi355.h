@@ -93,7 +93,10 @@ typedef struct vits_hparams {
   float   dp_tail_bound;     /* modules.py:347 5.0 */
   int32_t sampling_rate;     /* json:29 22050 */
   int32_t hop_length;        /* json:31 256 */
-  int32_t reserved[8];
+  int32_t bert_dim;          /* 0 = plain VITS2 (the in-repo TextEncoder).  > 0: BERT-conditioned flavour (vosk_tts/synth.py:88-99 feeds
+                                "bert" [B, bert_dim, T_x]): tensors enc_p.bert_proj.{weight [hidden, bert_dim, 1], bias} exist and the
+                                text encoder input is (emb(ids)*sqrt(hidden) + bert_proj(bert)) * mask -- see vits_synth_opts.bert */
+  int32_t reserved[7];
 } vits_hparams;
 
 /*
@@ -147,6 +150,9 @@ typedef struct vits_synth_opts {
   int32_t        flags;            /* VITS_FLAG_* */
   const uint64_t* item_seeds;      /* [B] or NULL; with VITS_FLAG_SOLO_BATCH: item b uses item_seeds[b] instead of seed + b, so a
                                       request keeps its own noise draw however a server groups requests into batches */
+  const float*   bert;             /* [B, bert_dim, T_x] or NULL: the "bert" feed of the BERT-conditioned flavours (synth.py:113-120);
+                                      required when hparams.bert_dim > 0.  The shipped graphs' text encoder is not in the reference tree
+                                      (SURVEY.md 8f rank 2); the wiring implemented is a 1x1 projection added to the scaled embedding. */
 } vits_synth_opts;
 
 #define VITS_FLAG_NONE 0

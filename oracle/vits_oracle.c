@@ -328,8 +328,17 @@ static int speaker_g(vits_model* m, const int64_t* sid, int B, float* g) {
 
 /* ------------------------------------------------------------ a2 TextEncoder */
 
+/* bert (optional, [B, bert_dim, T]): the "bert" feed of the BERT-conditioned flavours (vosk_tts/synth.py:88-99,113-120).  Their
+ * text encoder is not in the reference tree; the build defines the wiring as a 1x1 projection added to the
+ * scaled embedding, x = (emb(ids) * sqrt(H) + bert_proj(bert)) * mask, and this function is its CPU statement. */
+static int text_encoder_impl(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t T,
+                             const int64_t* sid, const float* bert, float* x, float* m_p, float* logs_p);
 int API(stage_text_encoder)(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t T,
                             const int64_t* sid, float* x, float* m_p, float* logs_p) {
+  return text_encoder_impl(m, ids, lengths, B, T, sid, NULL, x, m_p, logs_p);
+}
+static int text_encoder_impl(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t T,
+                             const int64_t* sid, const float* bert, float* x, float* m_p, float* logs_p) {
   if (!m || !ids || !lengths || !x || !m_p || !logs_p || B <= 0 || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
   const vits_hparams* hp = &m->hp;
   int H = hp->hidden_channels, I = hp->inter_channels, G = hp->gin_channels;
@@ -345,6 +354,19 @@ int API(stage_text_encoder)(vits_model* m, const int64_t* ids, const int64_t* le
       float sc = sqrtf((float)H); /* models.py:318 */
       for (int c = 0; c < H; ++c) x[((size_t)b * H + c) * T + t] = emb[(size_t)id * H + c] * sc;
     }
+  }
+  if (hp->bert_dim > 0) {
+    if (!bert) return fail(VITS_ERR_ARG, "this voice is BERT-conditioned: the bert feed is required");
+    const float* bw = tget(m, 3, H, hp->bert_dim, 1, "enc_p.bert_proj.weight");
+    const float* bb = tget(m, 1, H, -1, -1, "enc_p.bert_proj.bias");
+    if (m->missing) return VITS_ERR_BLOB;
+    float* pr = falloc((size_t)B * H * T);
+    conv1d(bert, B, hp->bert_dim, T, bw, bb, H, 1, 1, 0, T, pr);
+    mul_mask(pr, B, H, T, lengths);
+    for (size_t i = 0; i < (size_t)B * H * T; ++i) x[i] += pr[i];
+    free(pr);
+  } else if (bert) {
+    return fail(VITS_ERR_ARG, "the bert feed was given but this voice has no BERT projection");
   }
   float* g = falloc((size_t)B * G);
   int rc = speaker_g(m, sid, B, g);
@@ -1035,7 +1057,7 @@ int API(synthesize)(vits_model* m, const int64_t* ids, const int64_t* lengths, i
   int32_t* dur = (int32_t*)calloc((size_t)B * T, sizeof(int32_t));
   int64_t* ylen = (int64_t*)calloc((size_t)B, sizeof(int64_t));
   float *ndp = NULL, *npr = NULL, *z_p = NULL, *z = NULL, *audio = NULL;
-  rc = API(stage_text_encoder)(m, ids, lengths, B, T, sid, x, m_p, logs_p);
+  rc = text_encoder_impl(m, ids, lengths, B, T, sid, opts ? opts->bert : NULL, x, m_p, logs_p);
   if (rc) goto done;
   if (!(opts && opts->forced_durations)) {
     ndp = falloc((size_t)B * 2 * T);

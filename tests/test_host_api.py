@@ -138,7 +138,61 @@ def test_blob_roundtrip_and_determinism():
     assert g["x"].shape == (1, 192, 10)
 
 
+def test_bert_conditioned_vits_frontends_match_reference_functions():
+    """Synth.g2p (blank-interspersed) and Synth.g2p_noblank (vosk_tts/synth.py:152-220) against outputs of the reference's own
+    functions on fixed sentences (tests/golden/g2p_bert.npz, oracle/gen_golden_g2p_bert.py): phoneme ids and, per position, which
+    row of get_word_bert's output it receives (spaces do not advance the word count, '$' takes the last row)."""
+    import types
+
+    from vosk_tts_amd import Synth
+    from vosk_tts_amd.toymodel import phoneme_id_map
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g2p_bert.npz"))
+    model = types.SimpleNamespace(dic={"привет": "p rj i0 vj e1 t", "мир": "mj i1 r"}, config={"phoneme_id_map": phoneme_id_map()}, tokenizer=None)
+    synth = Synth(model)
+    emb = list(range(200))
+    for fn in ("g2p", "g2p_noblank"):
+        for k, sent in enumerate(g["sentences"]):
+            ids, rows = getattr(synth, fn)(str(sent), emb)
+            a, b = g[fn + "_offsets"][k], g[fn + "_offsets"][k + 1]
+            assert ids == list(g[fn + "_ids"][a:b]) and rows == list(g[fn + "_rows"][a:b]), (fn, sent)
+    # consistent with g2p_noembed: same ids, blanks included
+    assert synth.g2p("прив+ет, м+ир!", emb)[0] == synth.g2p_noembed("прив+ет, м+ир!")
+
+
 # ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_blank", [0, 1])
+def test_bert_conditioned_vits_voice_end_to_end_on_gpu(tmp_path, oracle_lib, no_blank):
+    """A BERT-conditioned VITS voice (vosk_tts/synth.py:88-99): bert/ next to the model -> tokenizer + encoder loaded, synth_audio
+    runs get_word_bert -> g2p / g2p_noblank -> feed with "bert" [1,768,T] -> int16; the same feed through run() equals the
+    oracle's statement of the wiring (x = (emb * sqrt(H) + bert_proj(bert)) * mask); the graph now declares the input."""
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd.toymodel import write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), bert=True, no_blank=no_blank)
+    model = Model(model_path=d, device=0)
+    assert model.tokenizer is not None and model.onnx.hp.bert_dim == 768
+    assert [a.name for a in model.onnx.get_inputs()][-1] == "bert"
+    synth = Synth(model)
+    pcm = synth.synth_audio("прив+ет, м+ир!", speaker_id=3)
+    assert pcm.dtype == np.int16 and pcm.size > 0 and pcm.size % 256 == 0
+    feed, _ = synth._feed("прив+ет, м+ир!", 3, None, None, None, None)
+    T = feed["input"].shape[1]
+    assert feed["bert"].shape == (1, 768, T) and feed["phone_duration_extra"] is None
+    assert (T == len(synth.phonemize("прив+ет, м+ир!"))) == bool(no_blank)
+    dur = np.full((1, T), 2, np.int32)
+    got = model.onnx.run(None, dict(feed, **{"vits.forced_durations": dur, "vits.seed": 5}))[0]
+    ref = oracle_lib.create(open(os.path.join(d, "model.vitsw"), "rb").read())
+    want, _ = ref.synthesize(feed["input"], [T], feed["scales"], [3], forced_durations=dur, seed=5, bert=feed["bert"])
+    assert_close("BERT-conditioned VITS vs oracle", want, got.reshape(want.shape), 5e-4)
+    # the projection matters, and the feed is required
+    other = model.onnx.run(None, dict(feed, bert=np.zeros_like(feed["bert"]), **{"vits.forced_durations": dur, "vits.seed": 5}))[0]
+    assert np.abs(other - got).max() > 1e-3
+    with pytest.raises(ValueError, match="bert"):
+        model.onnx.run(None, dict(feed, bert=None))
+
+
 @pytest.mark.gpu
 def test_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
     from vosk_tts_amd import Model, Synth

@@ -280,3 +280,25 @@ def test_decoder_geometry_comes_from_the_graph_and_is_validated(tmp_path):
     bad.hop_length = 512
     with pytest.raises(ValueError, match="hop_length"):
         W.pack_blob(bad, {})
+
+
+def test_bert_conditioned_vits_graph_surfaces_its_projection(tmp_path):
+    """A BERT-conditioned VITS export (vosk_tts/synth.py:88-99) carries one extra projection; whatever the exporter called it,
+    a [hidden, D] / [hidden, D, 1] weight and a [hidden] bias with "bert" in their names map onto enc_p.bert_proj and set
+    bert_dim; an unidentifiable set of BERT-like tensors is reported with names and shapes."""
+    from vosk_tts_amd import onnx_import as O
+    from vosk_tts_amd import weights as W
+
+    hp = W.tiny_hparams()
+    hp.bert_dim = 32
+    t = W.make_synthetic_weights(hp, 3)
+    w, b = t.pop("enc_p.bert_proj.weight"), t.pop("enc_p.bert_proj.bias")
+    g = dict(t)
+    g["enc_p.bert_linear.weight"] = w[:, :, 0]  # nn.Linear layout
+    g["enc_p.bert_linear.bias"] = b
+    got_hp, got = O.import_onnx(O.write_minimal_onnx(str(tmp_path / "a.onnx"), g))
+    assert got_hp.bert_dim == 32 and np.array_equal(got["enc_p.bert_proj.weight"], w) and np.array_equal(got["enc_p.bert_proj.bias"], b)
+    assert any("bert_linear" in n for n in O.import_onnx.notes)
+    g["enc_p.bert_gate.weight"] = w[:, :, 0]  # a second candidate: refuse to guess
+    with pytest.raises(NotImplementedError, match="bert_gate"):
+        O.import_onnx(O.write_minimal_onnx(str(tmp_path / "b.onnx"), g))

@@ -33,6 +33,7 @@ class SynthOpts(ctypes.Structure):
         ("max_frames", ctypes.c_int32),
         ("flags", ctypes.c_int32),
         ("item_seeds", ctypes.POINTER(ctypes.c_uint64)),
+        ("bert", c_f32p),
     ]
 
 
@@ -184,9 +185,14 @@ class VitsModel:
         except Exception:
             pass
 
-    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo=False, item_seeds=None):
+    def _opts(self, B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo=False, item_seeds=None, bert=None):
         opts = SynthOpts()
         keep = []
+        if bert is not None:
+            a = _f32(bert); keep.append(a)
+            if a.shape != (B, self.hp.bert_dim, Tx):
+                raise ValueError(f"bert must be [B, {self.hp.bert_dim}, T_x] (got {a.shape})")
+            opts.bert = _p(a, c_f32p)
         if item_seeds is not None:
             a = np.ascontiguousarray(item_seeds, dtype=np.uint64); keep.append(a)
             if a.shape != (B,) or not solo:
@@ -215,7 +221,7 @@ class VitsModel:
 
     # ---- the hot path -----------------------------------------------------
     def synthesize(self, ids, lengths, scales, sid, noise_dp=None, noise_prior=None, forced_durations=None, seed=0,
-                   max_frames=0, solo=False, item_seeds=None):
+                   max_frames=0, solo=False, item_seeds=None, bert=None):
         """One .run(): returns (audio float32 [B,S], out_lengths int64 [B]).  solo=True (VITS_FLAG_SOLO_BATCH): every
         item equals its own single-utterance call with seed + b instead of the reference's padded-batch result."""
         ids = _i64(ids)
@@ -225,7 +231,7 @@ class VitsModel:
         scales = _f32(scales)
         if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
             raise ValueError("bad feed shapes")
-        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo, item_seeds)
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo, item_seeds, bert)
         out = c_f32p()
         ns = ctypes.c_int64()
         olen = np.zeros(B, dtype=np.int64)
@@ -239,7 +245,7 @@ class VitsModel:
         return audio, olen
 
     def synthesize_pcm16(self, ids, lengths, scales, sid, pcm_scale=1.0, noise_dp=None, noise_prior=None, forced_durations=None,
-                         seed=0, max_frames=0, solo=False, item_seeds=None):
+                         seed=0, max_frames=0, solo=False, item_seeds=None, bert=None):
         """synthesize() with Synth.synth_audio's `* scale` and audio_float_to_int16 (vosk_tts/synth.py:127-130) done on the
         device: returns (pcm int16 [B,S], out_lengths int64 [B])."""
         ids = _i64(ids)
@@ -247,7 +253,7 @@ class VitsModel:
         lengths = _i64(lengths); sid = _i64(sid); scales = _f32(scales)
         if lengths.shape != (B,) or sid.shape != (B,) or scales.shape != (3,):
             raise ValueError("bad feed shapes")
-        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo, item_seeds)
+        opts, keep = self._opts(B, Tx, noise_dp, noise_prior, forced_durations, seed, max_frames, solo, item_seeds, bert)
         out = ctypes.POINTER(ctypes.c_int16)()
         ns = ctypes.c_int64()
         olen = np.zeros(B, dtype=np.int64)

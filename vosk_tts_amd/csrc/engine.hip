@@ -120,6 +120,7 @@ struct vits_model {
   int cond_rows = 0, cond_enc_off = -1, cond_dp_off = -1, cond_dec_off = -1;
   EncoderW enc_p;
   ConvW enc_proj;
+  ConvW bert_proj;  // BERT-conditioned flavour (hparams.bert_dim > 0): 1x1 projection of the "bert" feed onto the embedding
   ConvW dp_pre, dp_proj;
   DDSW dp_dds;
   std::vector<ConvFlowW> cf;  // index k -> dp.flows.(2k+1), k = 1..n-1 (k = 0 unused)
@@ -463,6 +464,8 @@ static int load_model(vits_model* m) {
   m->emb = upload(m, tget(m, 2, hp.n_vocab, H, -1, "enc_p.emb.weight"), (size_t)hp.n_vocab * H);
   load_encoder(m, m->enc_p, "enc_p.encoder", hp.n_layers, H, F, hp.kernel_size);
   m->enc_proj = conv_from(m, "enc_p.proj", 2 * I, H, 1, true);
+  if (hp.bert_dim < 0 || hp.bert_dim % CONV_CI_T) return fail(VITS_ERR_UNSUPPORTED, "bert_dim %d must be a multiple of %d", hp.bert_dim, CONV_CI_T);
+  if (hp.bert_dim > 0) m->bert_proj = conv_from(m, "enc_p.bert_proj", H, hp.bert_dim, 1, true);
   if (m->missing) return VITS_ERR_BLOB;
 
   // ---- all speaker-conditioning matrices in one GEMV table
@@ -1261,12 +1264,20 @@ static void run_cond(vits_session* s, const int64_t* d_sid, int B) {
 }
 
 // ---- a2: TextEncoder.forward (models.py:317-326) -> s->x [B,H,Tx], s->stats [B,2I,Tx]
-static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int Tx) {
+static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int Tx, const float* d_bert = nullptr) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels;
   hipLaunchKernelGGL(embed_kernel, dim3(cdiv(Tx, 64), 8, B), dim3(64), 0, s->stream, d_ids, s->len_x, m->emb, s->x, H, Tx,
                      hp.n_vocab, sqrtf((float)H), s->d_err);
+  if (d_bert && m->bert_proj.w) {  // x = (emb * sqrt(H) + bert_proj(bert)) * mask   (BERT-conditioned flavour, synth.py:88-99)
+    ConvParams Pb = conv_params(m->bert_proj, d_bert, s->x, B, Tx, 1, 0);
+    Pb.g[0].res = s->x;  // every output element is read (residual) and written by the same thread: in place is safe
+    Pb.out_mask = 1; Pb.len = s->len_x;
+    // out_mask zeroes the projection beyond len; the embedding there is already 0
+    mark_masked(s, Pb, s->len_x);
+    launch_conv(s, Pb, EPI_STORE, "enc.bert_proj");
+  }
   // the encoder's last LayerNorm is folded into proj's staging when both run on the small-tile kernel
   PendingLN pend;
   {
@@ -1877,9 +1888,17 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   }
   s->tile_keys.clear();
   struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->solo = false; } } ragged_off{s};
+  float* d_bert = nullptr;
+  if (hp.bert_dim > 0) {
+    if (!opts || !opts->bert) return fail(VITS_ERR_ARG, "this voice is BERT-conditioned: the bert feed [B,%d,T_x] is required", hp.bert_dim);
+    d_bert = hs.to_dev(opts->bert, (size_t)B * hp.bert_dim * Tx);
+    if (!d_bert) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  } else if (opts && opts->bert) {
+    return fail(VITS_ERR_ARG, "the bert feed was given but this voice has no BERT projection (hparams.bert_dim == 0)");
+  }
   set_lengths(s, d_len, s->len_x, B, Tx);
   run_cond(s, d_sid, B);
-  run_text_encoder(s, d_ids, B, Tx);
+  run_text_encoder(s, d_ids, B, Tx, d_bert);
   int* d_forced = nullptr;
   if (opts && opts->forced_durations) {
     d_forced = hs.to_dev(opts->forced_durations, (size_t)B * Tx);
@@ -2221,7 +2240,7 @@ static int synth_dispatch(vits_model* m, const int64_t* ids, const int64_t* leng
   if (!m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
   static const bool env_off = getenv("VITS_NO_FASTPATH") != nullptr;
-  const bool injected = opts && (opts->noise_dp || opts->noise_prior);
+  const bool injected = (opts && (opts->noise_dp || opts->noise_prior || opts->bert)) || m->hp.bert_dim > 0;
   if (g_fast_path && !env_off && !injected) return synth_fast(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
   return synth_eager(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
 }

@@ -337,7 +337,7 @@ def infer_hparams(t):
     return hp
 
 
-def import_onnx(path_or_bytes, config=None):
+def import_onnx(path_or_bytes, config=None):  # noqa: C901
     """-> (HParams, {name: float32 ndarray}) restricted to the tensors the engine needs.
 
     `config`: optional dict with the values that shapes cannot reveal — "upsample_rates",
@@ -345,10 +345,29 @@ def import_onnx(path_or_bytes, config=None):
     (keys of training/vits2/configs/*.json "model"/"data")."""
     g = OnnxGraph(path_or_bytes)
     t = g.tensors()
-    if any(k.startswith(("bert", "enc_p.bert")) for k in t):
-        raise NotImplementedError("BERT-conditioned flavour: not part of the VITS2 hot path (SURVEY.md §8f rank 2)")
     hp = infer_hparams(t)
     config = config or {}
+    # BERT-conditioned flavours (vosk_tts/synth.py:88-99): their text encoder is not in the reference tree, so the extra tensors are
+    # found by name and shape -- a [hidden, D(, 1)] weight with "bert" in its name and a [hidden] bias next to it -- and mapped onto
+    # the engine's enc_p.bert_proj (1x1 projection of the bert feed added to the scaled embedding).  Anything else BERT-like is
+    # reported with names and shapes instead of being guessed at.
+    bertish = {k: a for k, a in t.items() if "bert" in k.lower() and not k.startswith("enc_p.bert_proj.")}
+    if "enc_p.bert_proj.weight" in t:
+        hp.bert_dim = int(t["enc_p.bert_proj.weight"].shape[1])
+    elif bertish:
+        H = hp.hidden_channels
+        ws = [(k, a) for k, a in bertish.items() if a.ndim in (2, 3) and a.shape[0] == H and a.shape[1] >= 16 and (a.ndim == 2 or a.shape[2] == 1)]
+        bs = [(k, a) for k, a in bertish.items() if a.ndim == 1 and a.shape[0] == H]
+        if len(ws) == 1 and len(bs) == 1:
+            (wk, w), (bk, b) = ws[0], bs[0]
+            hp.bert_dim = int(w.shape[1])
+            t = dict(t)
+            t["enc_p.bert_proj.weight"] = np.ascontiguousarray(np.asarray(w, np.float32).reshape(H, hp.bert_dim, 1))
+            t["enc_p.bert_proj.bias"] = np.asarray(b, np.float32)
+            import_onnx.notes = [f"bert projection: {wk} {tuple(w.shape)} + {bk} -> enc_p.bert_proj (bert_dim {hp.bert_dim})"]
+        else:
+            raise NotImplementedError("BERT-conditioned graph whose projection could not be identified; BERT-like tensors: "
+                                      + ", ".join(f"{k} {tuple(a.shape)}" for k, a in sorted(bertish.items())[:12]))
     # Geometry that tensor shapes cannot reveal comes from the graph itself: the `strides` attribute of every
     # /dec/ups.N/ConvTranspose node, the `dilations` of the ResBlock convs, the stride of the iSTFT's ConvTranspose.
     # (A runtime vosk model's config.json normally has no "model"/"data" sections; config values, when present, win.)

@@ -39,10 +39,13 @@ class VitsSession:
 
     # -- onnxruntime.InferenceSession surface used by the reference ------------------------
     def get_inputs(self):
-        return [_Arg("input", "tensor(int64)", ["batch_size", "phonemes"]),
+        args = [_Arg("input", "tensor(int64)", ["batch_size", "phonemes"]),
                 _Arg("input_lengths", "tensor(int64)", ["batch_size"]),
                 _Arg("scales", "tensor(float)", [3]),
                 _Arg("sid", "tensor(int64)", ["batch_size"])]
+        if self.hp.bert_dim > 0:  # BERT-conditioned flavour (vosk_tts/synth.py:88-99)
+            args.append(_Arg("bert", "tensor(float)", ["batch_size", self.hp.bert_dim, "phonemes"]))
+        return args
 
     def get_outputs(self):
         return [_Arg("output", "tensor(float)", ["batch_size", 1, 1, "time"])]
@@ -55,13 +58,15 @@ class VitsSession:
             raise ValueError(f"unknown output names {output_names}")
         feed = {k: v for k, v in input_feed.items() if v is not None}  # ORT ignores None feeds
         for k in feed:
+            if k == "bert" and self.hp.bert_dim > 0:
+                continue  # this graph declares the input (BERT-conditioned VITS flavour)
             if k in _OPTIONAL_NONE:
                 raise NotImplementedError(
-                    f"feed '{k}': BERT / duration-extra conditioned flavours are not part of the VITS2 hot path "
-                    "(SURVEY.md §8f rank 2-3)")
+                    f"feed '{k}': this VITS graph declares no such input (bert: voices whose blob carries enc_p.bert_proj; "
+                    "phone_duration_extra: multistream voices only, SURVEY.md §8f rank 2-3)")
             if k not in _GRAPH_INPUTS and k not in _EXT:
                 raise ValueError(f"Invalid input name: {k}")
-        for k in _GRAPH_INPUTS:
+        for k in _GRAPH_INPUTS + (("bert",) if self.hp.bert_dim > 0 else ()):
             if k not in feed and not (k == "sid" and self.hp.n_speakers <= 1):
                 raise ValueError(f"Required input {k} is missing")
         ids = np.asarray(feed["input"])
@@ -83,7 +88,7 @@ class VitsSession:
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
             forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)),
-            item_seeds=feed.get("vits.item_seeds"))
+            item_seeds=feed.get("vits.item_seeds"), bert=feed.get("bert"))
         self.last_lengths = lengths
         return [audio[:, None, None, :]]
 
@@ -96,7 +101,7 @@ class VitsSession:
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             pcm_scale=float(scale), noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
             forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)),
-            item_seeds=feed.get("vits.item_seeds"))
+            item_seeds=feed.get("vits.item_seeds"), bert=feed.get("bert"))
         self.last_lengths = lengths
         return pcm
 

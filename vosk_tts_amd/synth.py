@@ -72,8 +72,14 @@ class Synth:
                 bert_embs = np.expand_dims(np.transpose(np.array(per_symbol, dtype=np.float32)), 0)  # [1, 768, T]
             lengths = np.array([ids.shape[2]], dtype=np.int64)
         elif have_bert:
-            raise NotImplementedError("BERT-conditioned VITS flavours (synth.py:88-99): the text encoder of those graphs is not in "
-                                      "the reference tree (SURVEY.md §8f rank 2)")
+            # BERT-conditioned VITS flavours (synth.py:88-99): per-word vectors fanned out to the phonemes of each word,
+            # with (g2p) or without (g2p_noblank, config "no_blank") the interspersed blank
+            bert = self.get_word_bert(text)
+            fe = self.g2p_noblank if self.model.config.get("no_blank", 0) != 0 else self.g2p
+            phoneme_ids, emb = fe(text, bert)
+            bert_embs = np.expand_dims(np.transpose(np.array(emb, dtype=np.float32)), 0)
+            ids = np.expand_dims(np.array(phoneme_ids, dtype=np.int64), 0)
+            lengths = np.array([ids.shape[1]], dtype=np.int64)
         else:
             phoneme_ids = self.g2p_noembed(text)
             ids = np.expand_dims(np.array(phoneme_ids, dtype=np.int64), 0)
@@ -135,20 +141,51 @@ class Synth:
             f.setframerate(22050)
             f.writeframes(audio.tobytes())
 
+    def _phonemes_and_words(self, text):
+        """One pass over the split text: the phoneme string ('^' ... '$', punctuation kept, dictionary or rule G2P per word) and,
+        per phoneme, the index of the token it belongs to in get_word_bert's row order: 0 = '^' ([CLS]), tokens counted from 1,
+        spaces emit a phoneme but do not advance the count, -1 = '$' ([SEP])  (synth.py:152-171 / 190-209 / 224-236)."""
+        phonemes, words = ["^"], [0]
+        w = 1
+        for token in re.split(_SPLIT, text.lower()):
+            if token == "":
+                continue
+            if re.match(_SPLIT, token) or token == "-":
+                ps = [token]
+            elif token in self.model.dic:
+                ps = self.model.dic[token].split()
+            else:
+                ps = convert(token).split()
+            phonemes.extend(ps)
+            words.extend([w] * len(ps))
+            if token != " ":
+                w += 1
+        phonemes.append("$")
+        words.append(-1)
+        return phonemes, words
+
     def phonemize(self, text):
         """Words -> dictionary lookup or rule G2P, punctuation kept, '^' ... '$' (synth.py:224-236)."""
-        phonemes = ["^"]
-        for word in re.split(_SPLIT, text.lower()):
-            if word == "":
-                continue
-            if re.match(_SPLIT, word) or word == "-":
-                phonemes.append(word)
-            elif word in self.model.dic:
-                phonemes.extend(self.model.dic[word].split())
-            else:
-                phonemes.extend(convert(word).split())
-        phonemes.append("$")
-        return phonemes
+        return self._phonemes_and_words(text)[0]
+
+    def g2p_noblank(self, text, embeddings):
+        """BERT-conditioned front-end without blanks (synth.py:190-220): ids of the phoneme string and, per phoneme, the BERT row
+        of its word (embeddings[0] for '^', embeddings[-1] for '$')."""
+        phonemes, words = self._phonemes_and_words(text)
+        id_map = self.model.config["phoneme_id_map"]
+        logging.info(f"Text: {text}")
+        logging.info(f"Phonemes: {phonemes}")
+        return [id_map[p] for p in phonemes], [embeddings[w] for w in words]
+
+    def g2p(self, text, embeddings):
+        """BERT-conditioned front-end with the interspersed blank 0 (synth.py:152-188): every blank carries the BERT row of the
+        phoneme that FOLLOWS it."""
+        ids, emb = self.g2p_noblank(text, embeddings)
+        out_ids, out_emb = [ids[0]], [emb[0]]
+        for i, e in zip(ids[1:], emb[1:]):
+            out_ids += [0, i]
+            out_emb += [e, e]
+        return out_ids, out_emb
 
     def g2p_noembed(self, text):
         phonemes = self.phonemize(text)

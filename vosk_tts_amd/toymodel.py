@@ -15,9 +15,14 @@ def phoneme_id_map():
     return {p: i for i, p in enumerate(PHONEMES)}
 
 
-def write_toy_model(path, hp=None, seed=1234, dictionary=None, inference=None):
+def write_toy_model(path, hp=None, seed=1234, dictionary=None, inference=None, bert=False, no_blank=0):
+    """bert=True: a BERT-conditioned VITS voice (vosk_tts/synth.py:88-99): hp.bert_dim = 768, enc_p.bert_proj in the blob,
+    bert/vocab.txt + bert/model.bertw next to it; no_blank selects g2p_noblank (config "no_blank")."""
     os.makedirs(path, exist_ok=True)
     hp = hp or W.default_hparams(n_vocab=len(PHONEMES))
+    if bert:
+        hp.bert_dim = 768
+        write_bert_dir(os.path.join(path, "bert"), seed)
     if hp.n_vocab < len(PHONEMES):
         raise ValueError("n_vocab too small for the phoneme inventory")
     W.save_blob(os.path.join(path, "model.vitsw"), hp, W.make_synthetic_weights(hp, seed))
@@ -28,7 +33,7 @@ def write_toy_model(path, hp=None, seed=1234, dictionary=None, inference=None):
                 f.write(f"{word} {prob} {ph}\n")
     cfg = {"audio": {"sample_rate": hp.sampling_rate},
            "inference": inference or {"noise_level": 0.8, "speech_rate": 1.0, "duration_noise_level": 0.8, "scale": 1.0},
-           "phoneme_id_map": phoneme_id_map(), "num_speakers": hp.n_speakers, "model_type": "vits"}
+           "phoneme_id_map": phoneme_id_map(), "num_speakers": hp.n_speakers, "model_type": "vits", "no_blank": no_blank}
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, ensure_ascii=False)
     return path

@@ -67,7 +67,8 @@ class HParams(ctypes.Structure):
         ("dp_tail_bound", ctypes.c_float),
         ("sampling_rate", ctypes.c_int32),
         ("hop_length", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 8),
+        ("bert_dim", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 7),
     ]
 
     def total_upsample(self):
@@ -242,6 +243,8 @@ def tensor_specs(hp):
             specs.append(("enc_p.encoder.spk_emb_linear.weight", (H, G), "w", G, 1.0))
             specs.append(("enc_p.encoder.spk_emb_linear.bias", (H,), "b", 0, 1.0))
         conv("enc_p.proj", 2 * I, H, 1, gain=0.5)
+        if hp.bert_dim > 0:  # BERT-conditioned flavour (vosk_tts/synth.py:88-99): 1x1 projection of the "bert" feed
+            conv("enc_p.bert_proj", H, hp.bert_dim, 1, gain=0.5)
 
     # decoder (models.py:974-1014 / 845-871)
     C0 = hp.dec_initial_channel
