@@ -112,6 +112,8 @@ class VitsSession:
         feed, ids, sid, seed = self._validated(output_names, input_feed)
         if ids.shape[0] != 1:
             raise ValueError("run_stream takes one utterance")
+        if "bert" in feed:
+            raise NotImplementedError("streaming of BERT-conditioned voices: vits_stream_open takes no bert feed yet")
         n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
         fd = feed.get("vits.forced_durations")
         nd = feed.get("vits.noise_dp")

@@ -130,6 +130,9 @@ class Synth:
         `SynthesizeStream` handler would put into successive AudioChunk messages (tts_service.proto:46-54) instead
         of the single whole-utterance chunk of tts_server.py:54.  Same conversion as synth_audio per chunk."""
         args, scale = self._feed(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
+        if not hasattr(self.model.onnx, "run_stream"):
+            raise NotImplementedError("streaming synthesis is implemented for VITS voices (vits_stream_*: the decoder is replayed over "
+                                      "frame windows); multistream (StableTTS) voices synthesize one utterance per call")
         for chunk in self.model.onnx.run_stream(None, args, chunk_frames=chunk_frames):
             yield self.audio_float_to_int16(chunk * scale)
 
