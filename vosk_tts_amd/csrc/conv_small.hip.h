@@ -45,139 +45,144 @@ static void pack_conv_weights16(float* dst, int Mpad16, int Cin, int K, F src) {
 // LDS row pitch for a staged row of `row` floats: == 16 (mod 32) so that B-fragment reads are bank-conflict free
 static inline int c16_row_pitch(int row) { return row <= 16 ? 16 : (row <= 48 ? 48 : 80); }
 
-// ---- DDSConv prologue (PRO == 1; 256 threads, C_in <= 256, 3-tap depthwise conv) ---------------------------------------
-// thread = (column j = tid & 15, channel group cg = tid >> 4), channels cg + 16 i.  Channel LayerNorms are two-pass
-// (mean, then centred second moment) like modules.LayerNorm / F.layer_norm; the 16 channel groups meet in LDS.
-#define DDS_MAXI 16  // channels per thread (C_in <= 256)
-template <int NT>
-__device__ __forceinline__ void c16_colsum(float (&v)[NT], float* red, int cg, int j) {
-#pragma unroll
-  for (int k = 0; k < NT; ++k) red[(cg * NT + k) * 16 + j] = v[k];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) s += red[(g * NT + k) * 16 + j];
-    v[k] = s;
-  }
-  __syncthreads();
-}
+// ---- DDSConv prologue (PRO == 1; 512 threads, C_in <= 256, 3-tap depthwise conv) ---------------------------------------
+// Phase A: the finished input x_in = (x + gelu(LN2(y2))) * mask of this layer over the CONTIGUOUS column range the tile's
+//          depthwise taps touch, [n0 - dil, n0 + 16 + dil), once per column -> LDS xs[c][DDS_XP] (and -> dds_xout for the tile's
+//          own columns).  thread = (column slot tid & 31, channel group tid >> 5), channels cg + 16 i.
+// Phase B: y1 = conv_sep(x_in) from LDS, LN1, GELU -> the B tile [c][16].  thread = (column tid & 15, group tid >> 4),
+//          channels cg + 32 i.
+// Channel LayerNorms are two-pass (mean, then centred second moment) like modules.LayerNorm / F.layer_norm.
+#define DDS_MAXI 16  // channels per thread in phase A (C_in <= 256)
+#define DDS_XP 36    // LDS pitch of xs rows: 16 + 2 * 9 columns, padded
+// GELU, erf form (F.gelu default).  (A branch-free Abramowitz-Stegun erf was measured here: no change -- the prologue is bound by
+// its memory round trips and barriers, not by the 24 erf evaluations per thread -- so the library erff stays.)
 __device__ __forceinline__ float c16_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// sum over the NG channel groups of one value per thread; red is [NG][NC] floats
+template <int NG, int NC>
+__device__ __forceinline__ float c16_groupsum(float v, float* red, int cg, int j) {
+  red[cg * NC + j] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) s += red[g * NC + j];
+  __syncthreads();
+  return s;
+}
 
-__device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGroup& G, int b, int mt, int n0, float* tile, float* red) {
-  const int tid = threadIdx.x, j = tid & 15, cg = tid >> 4;
-  const int D = P.Cin, T = P.Tin, nci = D >> 4;
-  const int len_raw = P.len[b];  // requested here, first USED after the tensor loads below are in flight
+// tile: [D][16] B operand; xs: [D][DDS_XP]; red: 16 * 32 floats; par: [8][D] per-channel parameters of both phases
+// (g2, b2, sb, sw0, sw1, sw2, g1, b1), fetched ONCE per workgroup by the first D threads together with the tensor loads
+// -- read per thread they would be a third cold round trip in front of phase B
+__device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGroup& G, int b, int mt, int n0, float* tile, float* xs, float* red,
+                                              float* par) {
+  const int tid = threadIdx.x;
+  CONV_DBG_DO(const int lane = tid & 63; const int wave = tid >> 6;)
+  const int D = P.Cin, T = P.Tin;
+  int bi_ = b;
+  asm volatile("" : "+v"(bi_));   // vector load: keeps the cold len[b] line off the scalar-load counter (see conv16_kernel)
+  const int len_raw = P.len[bi_];  // requested here, first USED after the tensor loads below are in flight
   const float invD = 1.0f / (float)D;
   const bool dw = P.dds_sw != nullptr;
-  const int dil = P.dds_dil;
+  const int dil = dw ? P.dds_dil : 0;
+  const int Wc = 16 + 2 * dil;  // columns of x_in this tile needs: t = n0 - dil + j
   const long long bo = (long long)b * P.x_bstride;
   const float* xb = G.x + bo;
   const float* yb = P.dds_y2 ? P.dds_y2 + bo : nullptr;
-  int tk[3], tkc[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    tk[k] = n0 + j + (dw ? (k - 1) * dil : 0);
-    tkc[k] = tk[k] < 0 ? 0 : (tk[k] >= T ? T - 1 : tk[k]);
-  }
-  // x_in at the three tap columns (finish mode: only k == 1 matters, the other two repeat it)
-  float xin[3][DDS_MAXI];
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int i = 0; i < DDS_MAXI; ++i) {
-      const int c = cg + 16 * i, cc = c < D ? c : D - 1;
-      xin[k][i] = xb[(long long)cc * T + tkc[k]];
+  float pv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < D) {
+    if (yb) { pv[0] = P.dds_g2[tid]; pv[1] = P.dds_b2[tid]; }
+    if (dw) {
+      pv[2] = P.dds_sb[tid]; pv[3] = P.dds_sw[tid * 3]; pv[4] = P.dds_sw[tid * 3 + 1]; pv[5] = P.dds_sw[tid * 3 + 2];
+      pv[6] = P.dds_g1[tid]; pv[7] = P.dds_b1[tid];
     }
-  float yv[3][DDS_MAXI];
-  if (yb) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
+  }
+  bool par_stored = false;
+  // ---------------- phase A
+  {
+    const int jl = tid & 31, cg = tid >> 5, nci = D >> 4;
+    for (int jb = 0; jb < Wc; jb += 32) {
+      const int j = jb + jl;
+      const bool jok = j < Wc;
+      const int t = n0 - dil + j;
+      const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+      float xv[DDS_MAXI], yv[DDS_MAXI];
 #pragma unroll
       for (int i = 0; i < DDS_MAXI; ++i) {
         const int c = cg + 16 * i, cc = c < D ? c : D - 1;
-        yv[k][i] = yb[(long long)cc * T + tkc[k]];
+        xv[i] = xb[(long long)cc * T + tc];
+        yv[i] = yb ? yb[(long long)cc * T + tc] : 0.f;
       }
-  }
-  __builtin_amdgcn_sched_barrier(0);  // every tensor load above is issued before anything waits for len[b]
-  const int L = len_raw < T ? len_raw : T;
-  bool tin[3];
+      __builtin_amdgcn_sched_barrier(0);  // every tensor load above is issued before anything waits for len[b]
+      if (!par_stored) {  // (block-uniform) the parameters land with the first batch of tensor loads
+        if (tid < D) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) tin[k] = tk[k] >= 0 && tk[k] < L;
-  if (yb) {
-    float g2[DDS_MAXI], b2[DDS_MAXI];
+          for (int k = 0; k < 8; ++k) par[k * D + tid] = pv[k];
+        }
+        par_stored = true;
+        __syncthreads();
+      }
+      const int len_u = __builtin_amdgcn_readfirstlane(len_raw);
+      const int L = len_u < T ? len_u : T;
+      const bool tin = jok && t >= 0 && t < L;
+      if (yb) {
+        float m = 0.f;
 #pragma unroll
-    for (int i = 0; i < DDS_MAXI; ++i) {
-      const int c = cg + 16 * i, cc = c < D ? c : D - 1;
-      g2[i] = P.dds_g2[cc]; b2[i] = P.dds_b2[cc];
-    }
-    float mean[3], var[3];
+        for (int i = 0; i < DDS_MAXI; ++i) m += i < nci ? yv[i] : 0.f;
+        m = c16_groupsum<16, 32>(m, red, cg, jl) * invD;
+        float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      mean[k] = 0.f;
+        for (int i = 0; i < DDS_MAXI; ++i) { const float d = yv[i] - m; q += i < nci ? d * d : 0.f; }
+        q = c16_groupsum<16, 32>(q, red, cg, jl);
+        const float rstd = 1.0f / sqrtf(q * invD + 1e-5f);
 #pragma unroll
-      for (int i = 0; i < DDS_MAXI; ++i) mean[k] += i < nci ? yv[k][i] : 0.f;
-    }
-    c16_colsum<3>(mean, red, cg, j);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      mean[k] *= invD;
-      var[k] = 0.f;
-#pragma unroll
-      for (int i = 0; i < DDS_MAXI; ++i) { const float d = yv[k][i] - mean[k]; var[k] += i < nci ? d * d : 0.f; }
-    }
-    c16_colsum<3>(var, red, cg, j);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float rstd = 1.0f / sqrtf(var[k] * invD + 1e-5f);
+        for (int i = 0; i < DDS_MAXI; ++i) {
+          const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+          xv[i] += c16_gelu((yv[i] - m) * rstd * par[cc] + par[D + cc]);
+        }
+      }
+      float* xo = (P.dds_xout && mt == 0 && jok && t >= n0 && t < n0 + 16 && t < T) ? P.dds_xout + bo : nullptr;
 #pragma unroll
       for (int i = 0; i < DDS_MAXI; ++i) {
-        const float y = c16_gelu((yv[k][i] - mean[k]) * rstd * g2[i] + b2[i]);
-        xin[k][i] = tin[k] ? xin[k][i] + y : 0.f;  // x = (x + y) * mask, masked every layer (every read of x is masked)
+        const int c = cg + 16 * i;
+        const float v = tin ? xv[i] : 0.f;  // x = (x + y) * mask, masked every layer (every read of x is masked)
+        if (i < nci && jok) xs[c * DDS_XP + j] = v;
+        if (i < nci && xo) xo[(long long)c * T + t] = v;
       }
     }
-    if (P.dds_xout && mt == 0 && tk[1] < T) {
-      float* xo = P.dds_xout + bo;
-#pragma unroll
-      for (int i = 0; i < DDS_MAXI; ++i)
-        if (i < nci) xo[(long long)(cg + 16 * i) * T + tk[1]] = xin[1][i];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int i = 0; i < DDS_MAXI; ++i) xin[k][i] = tin[k] ? xin[k][i] : 0.f;
   }
+  __syncthreads();
+  CONV_DBG(6);
+  // ---------------- phase B
+  const int j = tid & 15, cg = tid >> 4, ncj = D >> 5;  // 32 groups, channels cg + 32 i
   if (!dw) {
 #pragma unroll
-    for (int i = 0; i < DDS_MAXI; ++i)
-      if (i < nci) tile[(cg + 16 * i) * 16 + j] = xin[1][i];
+    for (int i = 0; i < DDS_MAXI / 2; ++i) {
+      const int c = cg + 32 * i;
+      if (i < ncj) tile[c * 16 + j] = xs[c * DDS_XP + j];
+    }
     return;
   }
-  // y = conv_sep(x * mask) -> LN1 -> GELU
-  float y1[DDS_MAXI];
-  float m1[1] = {0.f};
+  float y1[DDS_MAXI / 2];
+  float m1 = 0.f;
 #pragma unroll
-  for (int i = 0; i < DDS_MAXI; ++i) {
-    const int c = cg + 16 * i, cc = c < D ? c : D - 1;
-    float a = P.dds_sb[cc];
+  for (int i = 0; i < DDS_MAXI / 2; ++i) {
+    const int c = cg + 32 * i, cc = c < D ? c : D - 1;
+    float a = par[2 * D + cc];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a += P.dds_sw[cc * 3 + k] * xin[k][i];
+    for (int k = 0; k < 3; ++k) a += par[(3 + k) * D + cc] * xs[cc * DDS_XP + j + k * dil];
     y1[i] = a;
-    m1[0] += i < nci ? a : 0.f;
+    m1 += i < ncj ? a : 0.f;
   }
-  c16_colsum<1>(m1, red, cg, j);
-  m1[0] *= invD;
-  float v1[1] = {0.f};
+  CONV_DBG(7);
+  m1 = c16_groupsum<32, 16>(m1, red, cg, j) * invD;
+  float v1 = 0.f;
 #pragma unroll
-  for (int i = 0; i < DDS_MAXI; ++i) { const float d = y1[i] - m1[0]; v1[0] += i < nci ? d * d : 0.f; }
-  c16_colsum<1>(v1, red, cg, j);
-  const float rstd1 = 1.0f / sqrtf(v1[0] * invD + 1e-5f);
+  for (int i = 0; i < DDS_MAXI / 2; ++i) { const float d = y1[i] - m1; v1 += i < ncj ? d * d : 0.f; }
+  v1 = c16_groupsum<32, 16>(v1, red, cg, j);
+  const float rstd1 = 1.0f / sqrtf(v1 * invD + 1e-5f);
 #pragma unroll
-  for (int i = 0; i < DDS_MAXI; ++i) {
-    const int c = cg + 16 * i, cc = c < D ? c : D - 1;
-    if (i < nci) tile[c * 16 + j] = c16_gelu((y1[i] - m1[0]) * rstd1 * P.dds_g1[cc] + P.dds_b1[cc]);
+  for (int i = 0; i < DDS_MAXI / 2; ++i) {
+    const int c = cg + 32 * i, cc = c < D ? c : D - 1;
+    if (i < ncj) tile[c * 16 + j] = c16_gelu((y1[i] - m1) * rstd1 * par[6 * D + cc] + par[7 * D + cc]);
   }
 }
 
@@ -256,9 +261,11 @@ __device__ __forceinline__ void c16_ln_tile(const ConvParams& P, const ConvGroup
 template <int EPI, int NW, int MAXU, int PRO = 0>
 __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   extern __shared__ float lds[];
+  kernarg_warm<sizeof(ConvParams)>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block -> (M-tile, batch item, column tile): every column tile of an M-tile on the XCD mt % 8
+  CONV_DBG(0);
   const int Lb = blockIdx.x, xcd = Lb & 7, slot = Lb >> 3;
   const int per = P.ntiles_n * P.B;
   const int mt = xcd + 8 * (slot / per);
@@ -273,8 +280,14 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   // is requested up front -- len[b], the weight fragments, the epilogue's bias / conditioning / residual values, then the
   // staging loads (addresses clamped by T only) -- and len[b] is first USED when the staged values are written to LDS.
   constexpr bool kNeedLen = EPI == EPI_RESSKIP || EPI == EPI_COUPLE || PRO == 1;
+  // (a VECTOR load: a scalar load would share the lgkm counter with the kernel-argument loads, and the first
+  //  s_waitcnt lgkmcnt(0) hipcc places before ANY later argument use would wait for this cold line too)
   int len_raw = 0x7fffffff;
-  if (kNeedLen || P.in_mask || P.out_mask || P.skip_len) len_raw = P.len[b];
+  if (kNeedLen || P.in_mask || P.out_mask || P.skip_len) {
+    int bi = b;
+    asm volatile("" : "+v"(bi));
+    len_raw = P.len[bi];
+  }
   const int ROW = 16 + (K - 1) * dil, ROWP = P.row_len;
   const int total_u = P.Cin / CONV_CI_T * K;
   const int my_units = wave < total_u ? (total_u - wave + NW - 1) / NW : 0;
@@ -325,9 +338,10 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   }
   C16LnRegs<NW> lnr;
   if (PRO == 2) c16_ln_prefetch<NW>(P, lnr);
+  CONV_DBG(1);
   // ---- 2. stage the B operand: all C_in channels x ROW columns, rpi rows per wave-instruction
   if (PRO == 1) {
-    c16_stage_dds(P, G, b, mt, n0, lds, lds + P.Cin * 16);
+    c16_stage_dds(P, G, b, mt, n0, lds, lds + P.Cin * 16, lds + P.Cin * (16 + DDS_XP), lds + P.Cin * (16 + DDS_XP) + 16 * 32);
   } else {
     const int rpi = ROW <= 16 ? 4 : (ROW <= 21 ? 3 : (ROW <= 32 ? 2 : 1));
     const int seg = 64 / rpi;
@@ -364,6 +378,7 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // the batch's loads are issued before anything below waits for len[b]
+      len_raw = __builtin_amdgcn_readfirstlane(len_raw);
       const int t_lim_ = (P.in_mask && len_raw < P.Tin) ? len_raw : P.Tin;
       const bool tok = jok && t >= 0 && t < t_lim_;
 #pragma unroll
@@ -374,12 +389,13 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
       }
     }
   }
-  const int lenb = len_raw;
+  const int lenb = __builtin_amdgcn_readfirstlane(len_raw);
   const int t_lim = (P.in_mask && lenb < P.Tin) ? lenb : P.Tin;
   // masked stage of a ragged batch / padded bucket: the tile is all padding (block-uniform; decided only now so that the
   // loads above did not wait for len[b] -- a skipped tile has merely prefetched for nothing)
   if (P.skip_len && n0 >= lenb) return;
   __syncthreads();
+  CONV_DBG(2);
   if (PRO == 2) {
     c16_ln_tile<NW>(P, G, b, mt, n0, ROW, ROWP, t_lim, lenb, lds, lds + P.Cin * ROWP, lnr);
     __syncthreads();
@@ -418,6 +434,7 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   }
 
   // ---- 4. cross-wave reduction (the staged tile is dead: reuse its LDS) and one-element-per-thread epilogue
+  CONV_DBG(3);
   __syncthreads();
   float* red = lds;  // [wave][r][lane]
 #pragma unroll
@@ -459,6 +476,7 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     const long long o = (long long)b * P.y_bstride + (long long)r * P.Tout_stride + col;
     G.y[o] = v;
     if (G.y2) G.y2[o] = v;
+    CONV_DBG(5);
   } else if (EPI == EPI_RESSKIP) {
     // rows < H update x in place (modules.py:171); rows >= H (or every row of the last layer) feed the skip accumulator
     const bool to_skip = P.last || r >= P.H;
@@ -494,6 +512,7 @@ template <int MAXT, int NIN>
 __global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
   constexpr int NW = 16;
   extern __shared__ float lds[];
+  kernarg_warm<sizeof(ConvParams)>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;

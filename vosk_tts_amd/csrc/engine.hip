@@ -930,7 +930,8 @@ static void launch_c16(vits_session* s, ConvParams& P, int epi, int nw) {
 
 // 1x1 conv whose B operand is produced by the DDSConv prologue (conv_small.hip.h PRO == 1); P.dds_* set by the caller
 static bool c16_dds_ok(const ConvParams& P, int dds_K) {
-  return P.g[0].w16 && P.g[0].K == 1 && P.Cin % 16 == 0 && P.Cin <= 16 * DDS_MAXI && dds_K == 3 && P.Cin / CONV_CI_T <= 4 * C16_MAXU && P.len;
+  return P.g[0].w16 && P.g[0].K == 1 && P.Cin % 32 == 0 && P.Cin <= 16 * DDS_MAXI && dds_K == 3 && P.Cin / CONV_CI_T <= 8 * 8 && P.len &&
+         (!P.dds_sw || P.dds_dil <= 9);
 }
 static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, double flops) {
   ProfScope ps(s, name, flops, "conv16_kernel<STORE,dds>");
@@ -938,10 +939,32 @@ static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, dou
   P.ntiles_m = cdiv(P.Cout, 16);
   P.ntiles_n = cdiv(P.Tout, 16);
   P.row_len = 16;
-  const size_t lds = ((size_t)P.Cin * 16 + 16 * 3 * 16) * sizeof(float);
+  const size_t lds = ((size_t)P.Cin * (16 + DDS_XP + 8) + 16 * 32) * sizeof(float);  // B tile | x_in over the tap range | reductions | parameters
   const dim3 grid(8 * cdiv(P.ntiles_m, 8) * P.ntiles_n * P.B);
-  if (P.Cin / CONV_CI_T <= 4 * 8) hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, 8, 1>), grid, dim3(256), lds, s->stream, P);
-  else hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 4, C16_MAXU, 1>), grid, dim3(256), lds, s->stream, P);
+#ifdef CONV_TIMING
+  // timing build: VITS_DBG_DDS=<i> prints the phase stamps (cycles since kernel start, block 0, wave 0) of the i-th DDS launch
+  static long dds_counter = 0;
+  static const long dds_want = getenv("VITS_DBG_DDS") ? atol(getenv("VITS_DBG_DDS")) : -1;
+  static long long* dds_buf = nullptr;
+  const bool dds_this = (dds_counter++ == dds_want);
+  if (dds_this) {
+    if (!dds_buf) hipMalloc((void**)&dds_buf, 128 * sizeof(long long));
+    hipMemsetAsync(dds_buf, 0, 128 * sizeof(long long), s->stream);
+    P.dbg = dds_buf;
+  }
+  struct DdsPrint {
+    bool on; hipStream_t st; long long* buf; const char* name;
+    ~DdsPrint() {
+      if (!on) return;
+      long long h[128];
+      hipStreamSynchronize(st);
+      hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[dds dbg] %s: wave 0 cycles since start: prefetch-issued %lld | phaseA-done %lld | dw+sum1 %lld | staged %lld | mfma-done %lld | end %lld\n", name,
+              h[1] - h[0], h[6] - h[0], h[7] - h[0], h[2] - h[0], h[3] - h[0], h[5] - h[0]);
+    }
+  } dds_print{dds_this, s->stream, dds_buf, name};
+#endif
+  hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 8, 8, 1>), grid, dim3(512), lds, s->stream, P);
 }
 
 // ---- LDS-staged 16-wave kernel for the single-utterance decoder (conv_small.hip.h conv_ls_kernel)
@@ -1343,7 +1366,10 @@ static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& 
   {
     ConvParams P = conv_params(proj, h, out, B, T, 1, 0);
     P.len = s->len_x;
-    if (!no_c16 && (g_force_tile == 0 || g_force_tile == 3) && (long)B * T <= c16_cols && c16_dds_ok(P, K) && W.pw.size() >= 1 && W.pw[0].w16) {
+    int max_dil = 1;
+    for (size_t i = 1; i < W.pw.size(); ++i) max_dil *= K;
+    if (!no_c16 && (g_force_tile == 0 || g_force_tile == 3) && (long)B * T <= c16_cols && c16_dds_ok(P, K) && max_dil <= 9 && W.pw.size() >= 1 &&
+        W.pw[0].w16) {
       const int n = (int)W.pw.size();
       float* X[2] = {s->dy, s->dq1};
       float* Y[2] = {s->dy2, s->dq2};

@@ -122,6 +122,7 @@ __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int c
 template <int MAXV>
 __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   __shared__ float red[LN_CG * LN_TL];
+  kernarg_warm<sizeof(LNParams)>();
   const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
   if (P.skip_len && (int)(blockIdx.x * LN_TL) >= P.len[b]) return;  // block-uniform
   const int t = blockIdx.x * LN_TL + tl;
@@ -979,6 +980,7 @@ struct TailParams {
 };
 __global__ void __launch_bounds__(256) istft_pqmf_kernel(const TailParams P) {
   extern __shared__ float sm[];
+  kernarg_warm<sizeof(TailParams)>();
   const int tid = threadIdx.x, b = blockIdx.y, m0 = blockIdx.x * TAIL_MB;
   const int S = P.S, N = P.N, hop = P.hop, Tp = P.Tp, Tm = P.Tm;
   const int cut = N / 2 + 1, C = S * (N + 2), L = P.taps + 1, padl = P.taps / 2;
