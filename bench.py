@@ -328,6 +328,7 @@ def main():
             blocks.append(timed_block())
         elapsed = float(np.median(blocks))
         timed_region_s = float(sum(blocks))
+        graph_nodes = sess.graph_nodes()
         assert torch.isfinite(d_audio).all().item(), "non-finite audio"
 
         ms_per_step = elapsed / steps * 1e3
@@ -436,7 +437,7 @@ def main():
         sess.close()
         return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
                     ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales,
-                    timed_region_s=timed_region_s, blocks=len(blocks), launches=sum(v[0] for v in rep.values()) // nprof)
+                    timed_region_s=timed_region_s, blocks=len(blocks), launches=graph_nodes or sum(v[0] for v in rep.values()) // nprof)
 
     R = measure(args.workload, args.steps, args.warmup, args.min_seconds)
     B, Tx, Ty, lengths, ids, dur = R["B"], R["Tx"], R["Ty"], R["lengths"], R["ids"], R["dur"]

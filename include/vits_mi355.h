@@ -237,6 +237,8 @@ int vits_session_sync(vits_session* s);
 /* use_graph: replay the forward as a cached hipGraph (default 1).  profile: run eagerly and
  * bracket every kernel launch with HIP events (for vits_session_profile_report). */
 int vits_session_set_options(vits_session* s, int use_graph, int profile);
+/* Nodes of the most recently captured forward graph of this session = kernel launches (+ copies) per forward; 0 before a capture. */
+int vits_session_graph_nodes(vits_session* s);
 /* on != 0: run the stochastic duration predictor even when durations are forced (its logw is then unused): lets a
  * fixed-work benchmark time the whole of SynthesizerTrn.infer instead of skipping rows a6-a9. */
 int vits_session_set_sdp_always(vits_session* s, int on);

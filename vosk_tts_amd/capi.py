@@ -408,6 +408,12 @@ class VitsDeviceSession:
     def set_options(self, use_graph=True, profile=False):
         self.lib.check(self.lib._fn("session_set_options")(self._h, int(use_graph), int(profile)))
 
+    def graph_nodes(self):
+        """kernel launches (graph nodes) of the captured forward, 0 before the first graph capture"""
+        fn = self.lib._fn("session_graph_nodes")
+        fn.argtypes = [ctypes.c_void_p]
+        return int(fn(self._h))
+
     def set_sdp_always(self, on=True):
         """run the duration predictor even when durations are forced (fixed-work benchmark of the whole infer())"""
         self.lib.check(self.lib._fn("session_set_sdp_always")(self._h, int(on)))

@@ -107,6 +107,10 @@ struct ConvParams {
   const float* dds_sw; const float* dds_sb; const float* dds_g1; const float* dds_b1;
   float* dds_xout;
   int dds_dil;
+  // first layer of a ConvFlow's DDSConv (dds_y2 == null): x is the conditioning tensor and the layer input is
+  // x_in = dds_pw[c] * dds_z[b][t] + dds_pb[c] + x[c][t]   (ConvFlow.pre, a Conv1d(1, C, 1), + g: modules.py:365-366,97-98)
+  const float* dds_z; const float* dds_pw; const float* dds_pb;
+  long long dds_z_bstride;
   // LayerNorm prologue of the small-tile kernel (PRO == 2): the staged tile holds the RAW tensor y (all channels of the tile's
   // columns); before the MFMAs it is replaced by  ((LN_c(y; ln_g, ln_b) + ln_vec[b][c] + ln_base[c][t]) * [valid column])
   // -- modules.LayerNorm (modules.py:29-32) folded into its consumer; ln_out (optional) receives the normalised tensor for

@@ -90,6 +90,7 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
   float pv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (tid < D) {
     if (yb) { pv[0] = P.dds_g2[tid]; pv[1] = P.dds_b2[tid]; }
+    else if (P.dds_pw) { pv[0] = P.dds_pw[tid]; pv[1] = P.dds_pb[tid]; }
     if (dw) {
       pv[2] = P.dds_sb[tid]; pv[3] = P.dds_sw[tid * 3]; pv[4] = P.dds_sw[tid * 3 + 1]; pv[5] = P.dds_sw[tid * 3 + 2];
       pv[6] = P.dds_g1[tid]; pv[7] = P.dds_b1[tid];
@@ -105,6 +106,7 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
       const int t = n0 - dil + j;
       const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
       float xv[DDS_MAXI], yv[DDS_MAXI];
+      const float zv = (!yb && P.dds_pw) ? P.dds_z[(long long)b * P.dds_z_bstride + tc] : 0.f;
 #pragma unroll
       for (int i = 0; i < DDS_MAXI; ++i) {
         const int c = cg + 16 * i, cc = c < D ? c : D - 1;
@@ -123,6 +125,13 @@ __device__ __forceinline__ void c16_stage_dds(const ConvParams& P, const ConvGro
       const int len_u = __builtin_amdgcn_readfirstlane(len_raw);
       const int L = len_u < T ? len_u : T;
       const bool tin = jok && t >= 0 && t < L;
+      if (!yb && P.dds_pw) {
+#pragma unroll
+        for (int i = 0; i < DDS_MAXI; ++i) {
+          const int c = cg + 16 * i, cc = c < D ? c : D - 1;
+          xv[i] = par[cc] * zv + par[D + cc] + xv[i];
+        }
+      }
       if (yb) {
         float m = 0.f;
 #pragma unroll

@@ -600,6 +600,9 @@ struct vits_session {
   // ---- graph-replayed fast path of vits_synthesize (see "fast path" below).  A FRONT session is laid out for
   // (B, T_x bucket) and owns phase 1 (text encoder .. durations); its BACK sessions, one per frame bucket, own phase 2
   // (prior .. decoder) and read the front's phase-1 results in place.
+  int graph_nodes = 0;             // nodes (= launches) of the most recently captured forward graph
+  bool ea_pending = false;         // run_duration left the final ElementwiseAffine to durations_kernel (row of z in ea_row)
+  int ea_row = 0;
   bool rag_b1 = false;             // single utterance in a frame bucket: decoder sees zeros beyond the item's own end
   bool sdp_always = false;         // device-session option: run the duration predictor even when durations are forced
   char *io_h = nullptr, *io_d = nullptr;  // per-call inputs: pinned host mirror and device copy (SynthDev | lengths | sid | ids | forced)
@@ -1278,12 +1281,17 @@ static int check_err(vits_session* s) {
   return VITS_OK;
 }
 
+static void set_lengths(vits_session* s, const int64_t* d_len64, int* d_len32, int B, int clamp);
 // ---- speaker conditioning vectors for the whole forward (one GEMV launch)
-static void run_cond(vits_session* s, const int64_t* d_sid, int B) {
+// d_len64 (optional): also converts the feed's int64 lengths to the clamped int32 array the kernels read (set_lengths folded in)
+static void run_cond(vits_session* s, const int64_t* d_sid, int B, const int64_t* d_len64 = nullptr, int* d_len32 = nullptr, int clamp = 0) {
   vits_model* m = s->m;
-  if (!m->use_g || !m->cond_rows) return;
+  if (!m->use_g || !m->cond_rows) {
+    if (d_len64) set_lengths(s, d_len64, d_len32, B, clamp);
+    return;
+  }
   hipLaunchKernelGGL(cond_gemv_kernel, dim3(cdiv(m->cond_rows, 4), B), dim3(256), 0, s->stream, m->cond_W, m->cond_b, m->emb_g,
-                     d_sid, s->condv, m->cond_rows, m->hp.gin_channels, m->hp.n_speakers, s->d_err);
+                     d_sid, s->condv, m->cond_rows, m->hp.gin_channels, m->hp.n_speakers, s->d_err, d_len64, d_len32, clamp);
 }
 
 // ---- a2: TextEncoder.forward (models.py:317-326) -> s->x [B,H,Tx], s->stats [B,2I,Tx]
@@ -1358,7 +1366,11 @@ static float* run_dds(vits_session* s, const DDSW& W, float* h, int B, int T) {
 // the previous layer's raw tensors (finish LN2 + GELU + residual, depthwise conv, LN1, GELU: conv_small.hip.h), and `proj`
 // finishes the last layer the same way -- n_layers + 1 launches of ~16 x T/16 small workgroups.  Larger problems keep one
 // workgroup-per-8-columns fused layer kernel or the three-launch form, then the plain proj conv.
-static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& proj, float* out, const char* proj_name, int B, int T) {
+// pre (optional, ConvFlow): the layer input is pre->pw[c] * z[x0 row] + pre->pb[c] + cond -- folded into the first layer's
+// prologue on the small-tile path, the convflow_pre_kernel launch into `h` otherwise
+struct DdsPre { const float* z; int row; const float* pw; const float* pb; const float* cond; };
+static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& proj, float* out, const char* proj_name, int B, int T,
+                         const DdsPre* pre = nullptr) {
   const vits_hparams& hp = s->m->hp;
   const int D = hp.dp_filter_channels, K = hp.dp_kernel_size;
   static const bool no_c16 = getenv("VITS_NO_DDS_C16") != nullptr;  // A/B switch for tools/ and tests
@@ -1373,7 +1385,7 @@ static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& 
       const int n = (int)W.pw.size();
       float* X[2] = {s->dy, s->dq1};
       float* Y[2] = {s->dy2, s->dq2};
-      const float* xin = h;
+      const float* xin = pre ? pre->cond : h;
       int dil = 1;
       for (int i = 0; i <= n; ++i) {
         const bool fin = i == n;
@@ -1381,17 +1393,26 @@ static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& 
         P.len = s->len_x;
         if (fin) P.out_mask = 1;
         mark_masked(s, P, s->len_x);
+        if (i == 0 && pre) {
+          P.dds_z = pre->z + (long long)pre->row * T; P.dds_z_bstride = 2LL * T; P.dds_pw = pre->pw; P.dds_pb = pre->pb;
+          P.dds_xout = X[1];  // layer 1 reads the materialised layer input (x_in of layer 0) as its residual stream
+        }
         if (i > 0) {
           P.dds_y2 = Y[(i - 1) & 1]; P.dds_g2 = W.g2[i - 1]; P.dds_b2 = W.b2[i - 1];
           if (!fin) P.dds_xout = X[(i - 1) & 1];
         }
         if (!fin) { P.dds_sw = W.sw[i]; P.dds_sb = W.sb[i]; P.dds_g1 = W.g1[i]; P.dds_b1 = W.b1[i]; P.dds_dil = dil; }
         launch_c16_dds(s, P, fin ? proj_name : "dp.dds_layer", 2.0 * B * T * ((double)P.Cout * D + (fin ? 0.0 : (double)D * K)));
+        if (i == 0 && pre) xin = X[1];
         if (i > 0 && !fin) xin = X[(i - 1) & 1];
         dil *= K;
       }
       return;
     }
+  }
+  if (pre) {
+    const int D2 = hp.dp_filter_channels;
+    hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(T, 64), D2, B), dim3(64), 0, s->stream, pre->z, pre->row, pre->pw, pre->pb, pre->cond, h, D2, T);
   }
   const float* hd = run_dds(s, W, h, B, T);
   ConvParams P = conv_params(proj, hd, out, B, T, 1, 0);
@@ -1401,7 +1422,9 @@ static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& 
 }
 
 // ---- a6: StochasticDurationPredictor.forward(reverse=True) (models.py:56-63,93-101) -> s->logw
-static void run_duration(vits_session* s, const float* x, const float* d_noise, float nsw, uint64_t seed, int B, int Tx) {
+// defer_ea: the caller runs run_durations next on this session; the final ElementwiseAffine (logw from z) is then folded into
+// durations_kernel instead of being its own launch (stage-level callers need logw itself and keep the launch)
+static void run_duration(vits_session* s, const float* x, const float* d_noise, float nsw, uint64_t seed, int B, int Tx, bool defer_ea = false) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int D = hp.dp_filter_channels;
@@ -1417,21 +1440,24 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   for (int k = hp.dp_n_flows - 1; k >= 1; --k) {
     swap ^= 1;  // Flip (modules.py:270-277) is a row relabel on the 2-channel z
     const ConvFlowW& c = m->cf[k];
-    hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(Tx, 64), D, B), dim3(64), 0, s->stream, s->dz, swap, c.pre_w, c.pre_b,
-                       s->dc, s->dfh, D, Tx);
-    run_dds_proj(s, c.dds, s->dfh, c.proj, s->dpr, "dp.cfproj", B, Tx);
+    const DdsPre pre{s->dz, swap, c.pre_w, c.pre_b, s->dc};
+    run_dds_proj(s, c.dds, s->dfh, c.proj, s->dpr, "dp.cfproj", B, Tx, &pre);
     hipLaunchKernelGGL(spline_inverse_kernel, dim3(cdiv(Tx, 64), B), dim3(64), 0, s->stream, s->dz, swap, s->dpr, c.proj.M,
                        s->len_x, Tx, hp.dp_num_bins, hp.dp_tail_bound, 1.0f / sqrtf((float)D));
   }
   swap ^= 1;
+  if (defer_ea) { s->ea_pending = true; s->ea_row = swap; return; }
   hipLaunchKernelGGL(ea_logw_kernel, dim3(cdiv(Tx, 64), B), dim3(64), 0, s->stream, s->dz, swap, m->ea_m, m->ea_logs, s->len_x,
                      s->logw, Tx);
 }
 
 // ---- a10: durations / cumsum / y_lengths
 static void run_durations(vits_session* s, const int* d_forced, float length_scale, int B, int Tx, int Tcap) {
+  const bool ea = s->ea_pending && !d_forced;
+  s->ea_pending = false;
   hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s->stream, s->logw, d_forced, s->len_x, length_scale, Tx, s->dur,
-                     s->cum, s->len_y, s->ylen64, Tcap, s->d_err, s->dv);
+                     s->cum, s->len_y, s->ylen64, Tcap, s->d_err, s->dv, ea ? s->dz : (const float*)nullptr, s->ea_row,
+                     (const float*)s->m->ea_m, (const float*)s->m->ea_logs);
 }
 
 // ---- a10/a11: expand prior + sample -> z_p [B,I,Ty]
@@ -1671,10 +1697,9 @@ static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t*
   static const bool no_ragged = getenv("VITS_NO_RAGGED") != nullptr;  // A/B switch for tools/
   s->ragged = B > 1 && !no_ragged;
   s->tile_keys.clear();
-  set_lengths(s, d_len, s->len_x, B, Tx);
-  run_cond(s, d_sid, B);
+  run_cond(s, d_sid, B, d_len, s->len_x, Tx);
   run_text_encoder(s, d_ids, B, Tx);
-  if (!d_forced || s->sdp_always) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx);  // logw unused when durations are pinned
+  if (!d_forced || s->sdp_always) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx, true);  // logw unused when durations are pinned
   run_durations(s, d_forced, scales[1], B, Tx, Ty);
   run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
   float* z = run_flow(s, B, Ty);
@@ -1922,15 +1947,14 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   } else if (opts && opts->bert) {
     return fail(VITS_ERR_ARG, "the bert feed was given but this voice has no BERT projection (hparams.bert_dim == 0)");
   }
-  set_lengths(s, d_len, s->len_x, B, Tx);
-  run_cond(s, d_sid, B);
+  run_cond(s, d_sid, B, d_len, s->len_x, Tx);
   run_text_encoder(s, d_ids, B, Tx, d_bert);
   int* d_forced = nullptr;
   if (opts && opts->forced_durations) {
     d_forced = hs.to_dev(opts->forced_durations, (size_t)B * Tx);
   } else {
     float* d_ndp = (opts && opts->noise_dp) ? hs.to_dev(opts->noise_dp, (size_t)B * 2 * Tx) : nullptr;
-    run_duration(s, s->x, d_ndp, noise_scale_w, seed, B, Tx);
+    run_duration(s, s->x, d_ndp, noise_scale_w, seed, B, Tx, true);
   }
   run_durations(s, d_forced, length_scale, B, Tx, 0);
   // the one host round trip of the free-running path: T_y sizes everything downstream
@@ -2111,10 +2135,9 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
     const int64_t* d_sid = reinterpret_cast<const int64_t*>(F->io_d + F->io_sid);
     const int64_t* d_ids = reinterpret_cast<const int64_t*>(F->io_d + F->io_ids);
     const int32_t* d_forced = reinterpret_cast<const int32_t*>(F->io_d + F->io_forced);
-    set_lengths(F, d_len, F->len_x, B, TxB);
-    run_cond(F, d_sid, B);
+    run_cond(F, d_sid, B, d_len, F->len_x, TxB);
     run_text_encoder(F, d_ids, B, TxB);
-    if (!forced) run_duration(F, F->x, nullptr, 0.f, 0, B, TxB);
+    if (!forced) run_duration(F, F->x, nullptr, 0.f, 0, B, TxB, true);
     run_durations(F, forced ? d_forced : nullptr, 1.f, B, TxB, 0);
     hipMemcpyAsync(F->h_ylen, F->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, F->stream);
     hipMemcpyAsync(F->h_ylen + B, F->d_err, sizeof(int), hipMemcpyDeviceToHost, F->stream);
@@ -2457,6 +2480,7 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
       HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
       forward_device(s, d_ids, d_lengths, B, Tx, scales, d_sid, d_forced, Ty, seed, d_audio, cap);
       HIP_TRY(hipStreamEndCapture(s->stream, &g));
+      { size_t nn = 0; if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) s->graph_nodes = (int)nn; }
       hipGraphExec_t ge = nullptr;
       HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       hipGraphDestroy(g);
@@ -2498,6 +2522,8 @@ int vits_session_set_options(vits_session* s, int use_graph, int profile) {
   s->profile = profile != 0;
   return VITS_OK;
 }
+
+int vits_session_graph_nodes(vits_session* s) { return s ? s->graph_nodes : 0; }
 
 int vits_session_set_sdp_always(vits_session* s, int on) {
   if (!s) return fail(VITS_ERR_ARG, "null session");

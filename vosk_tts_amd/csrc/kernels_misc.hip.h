@@ -66,9 +66,15 @@ __global__ void embed_kernel(const int64_t* ids, const int* len, const float* em
 // out[b][r] = bias[r] + sum_j W[r][j] * emb_g[sid[b]][j]   — every cond(g) / Linear(g) on the path
 // in one launch: enc spk_emb_linear (attentions.py:52-56), dp.cond (models.py:60), WN cond_layer
 // (modules.py:152-153).  W is the row-concatenation built at load time.  One wave per row.
+// len64 / len32 (optional): the int64 -> clamped int32 conversion of the feed's lengths rides along (one launch less)
 __global__ void cond_gemv_kernel(const float* W, const float* bias, const float* emb_g, const int64_t* sid, float* out,
-                                 int rows, int G, int n_speakers, int* err) {
+                                 int rows, int G, int n_speakers, int* err, const int64_t* len64, int* len32, int clamp_max) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), b = blockIdx.y;
+  if (len64 && blockIdx.x == 0 && threadIdx.x == 0) {
+    long long v = len64[b];
+    v = v < 0 ? 0 : (v > clamp_max ? clamp_max : v);
+    len32[b] = (int)v;
+  }
   if (row >= rows) return;
   long long s = sid ? sid[b] : 0;
   if (s < 0 || s >= n_speakers) { if (lane == 0) atomicOr(err, 2); s = 0; }
@@ -796,10 +802,14 @@ __global__ void ea_logw_kernel(const float* z, int row, const float* m, const fl
 // ----------------------------------------------------------------------------- length regulator
 // w = exp(logw)*mask*length_scale; w_ceil; y_len = max(1, sum) (models.py:1689-1691); inclusive
 // cumsum for generate_path (commons.py:128-143).  One block per batch item.
+// ea_z (optional): logw is not read but computed here from the duration flow's z, i.e. ea_logw_kernel folded in
+// (ElementwiseAffine reverse, modules.py:293-295: logw = (z[row] - m) * exp(-logs), masked)
 __global__ void durations_kernel(const float* logw, const int* forced, const int* len, float length_scale, int T,
-                                 int* dur, int* cum, int* ylen32, int64_t* ylen64, int Tcap, int* err, const SynthDev* dv) {
+                                 int* dur, int* cum, int* ylen32, int64_t* ylen64, int Tcap, int* err, const SynthDev* dv,
+                                 const float* ea_z, int ea_row, const float* ea_m, const float* ea_logs) {
   __shared__ int part[256];
   if (dv) length_scale = dv->scales[1];
+  const float ea_mu = ea_z ? ea_m[0] : 0.f, ea_sc = ea_z ? expf(-ea_logs[0]) : 0.f;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int L = len[b];
   const int per = (T + 255) / 256;
@@ -807,7 +817,13 @@ __global__ void durations_kernel(const float* logw, const int* forced, const int
   int s = 0;
   for (int t = t0; t < t0 + per && t < T; ++t) {
     int d = 0;
-    if (t < L) d = forced ? forced[(long long)b * T + t] : (int)ceilf(expf(logw[(long long)b * T + t]) * length_scale);
+    if (t < L) {
+      if (forced) d = forced[(long long)b * T + t];
+      else {
+        const float lw = ea_z ? (ea_z[((long long)b * 2 + ea_row) * T + t] - ea_mu) * ea_sc : logw[(long long)b * T + t];
+        d = (int)ceilf(expf(lw) * length_scale);
+      }
+    }
     if (d < 0) d = 0;
     dur[(long long)b * T + t] = d;
     s += d;
