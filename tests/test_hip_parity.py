@@ -252,6 +252,32 @@ def test_every_epilogue_on_both_conv_kernels(hip_lib, hip_default, hip_tiny, ora
         hip_lib.lib.vits_debug_force_tile(0)
 
 
+def test_wn_folded_and_unfolded_tail(hip_lib, hip_default, oracle_default):
+    """The coupling layers' WaveNet tail in its folded form (default: one conv = post o sum of the skip halves over the stacked gate
+    outputs, residual halves only per layer) and as the reference executes it (res/skip epilogue per layer, then post): both match
+    the oracle and each other, ragged batch included, on all three conv kernels."""
+    rng = np.random.default_rng(17)
+    B, Ty = 2, 150
+    z_p = rng.standard_normal((B, 192, Ty)).astype(np.float32)
+    ylen = np.array([150, 97], np.int64)
+    sid = np.array([1, 7], np.int64)
+    want = oracle_default.flow(z_p, ylen, sid)
+    mask = (np.arange(Ty)[None, :] < ylen[:, None])[:, None, :]
+    try:
+        for mode in (0, 1, 2, 3):
+            hip_lib.lib.vits_debug_force_tile(mode)
+            got = []
+            for fold in (1, 0):
+                hip_lib.lib.vits_debug_wn_fold(fold)
+                z = hip_default.flow(z_p, ylen, sid)
+                assert_close(f"flow, conv kernel mode {mode}, wn fold {fold}", want * mask, z * mask, STAGE_TOL)
+                got.append(z * mask)
+            assert_close("folded vs unfolded", got[1], got[0], 2e-5)
+    finally:
+        hip_lib.lib.vits_debug_force_tile(0)
+        hip_lib.lib.vits_debug_wn_fold(1)
+
+
 def test_both_attention_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny):
     """Three implementations of the same banded relative-position attention: the scalar-VALU kernel (1), the 32-query
     MFMA flash kernel (2, long sequences) and the 16-query MFMA kernel (3, short sequences; 0 = chosen by length).  All must

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x --timeout 600 -k "stages or epilogue or encoder or c2_single or fast_path or poisoned or attention or free_running or ksplit or c3_full or long_form" > $O/r2_t4.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2_t4.log
+timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x --timeout 600 -k "stages or epilogue or wn_folded or c2_single or fast_path or poisoned or free_running or c3_full or long_form" > $O/r2_t4.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2_t4.log
 tail -25 $O/r2_t4.log
 VITS_KS_WAVES=16 timeout 300 python bench.py --no-batch32 --no-cpu-baseline --no-host-api --steps 50 > $O/r2_c2_v4.json 2> $O/r2_c2_v4.err
 python - <<PY

@@ -525,6 +525,7 @@ __global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
+  CONV_DBG(0);
   // block -> (group, batch item, column tile, M tile): heaviest group first (the launcher sorts groups by taps)
   int id = blockIdx.x;
   const int mt = id % P.ntiles_m; id /= P.ntiles_m;
@@ -539,80 +540,146 @@ __global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
   int len_raw = 0x7fffffff, rag_raw = 0x7fffffff;
   if (P.in_mask || P.out_mask) len_raw = P.len[b];
   if (P.rag) rag_raw = P.rag[b];
-  const int ROW = P.row_len;  // 32 + the launch's largest halo
+  const int ROWC = P.row_len;            // columns a tile needs: 32 + the launch's largest halo
+  const int ROW = (ROWC + 3) & ~3;       // LDS row pitch (multiple of 4: rows are written with ds_write_b128 on the fast path)
   const int nchunks = P.Cin / CONV_CI_T;
   const int total_taps = nchunks * K;
   const int my_taps = wave < total_taps ? (total_taps - wave + NW - 1) / NW : 0;
 
-  // ---- 1. request the B tile [C_in][ROW] (element e = tid, tid + 1024, ... -> (channel, column) by an incremental cursor;
-  //         one batch of <= SB loads per thread), THEN all weight fragments of this wave (tap q = chunk*K + kk -> step-groups
-  //         2q, 2q + 1).  Loads return in order: the staging values arrive first and are written to LDS while the weight
-  //         stream is still in flight.
-  constexpr int SB = MAXT > 6 ? 8 : 12;
-  const int Cin = P.Cin, n_el = Cin * ROW;
-  int c = tid / ROW, j = tid - (tid / ROW) * ROW;
-  const int dc = 1024 / ROW, dj = 1024 - dc * ROW;
+  // ---- 1. load order (phase stamps of the first version, tools/convdbg.py: with all 22 KB of a wave's weights queued ahead of
+  //         the staging loads of the other waves, the B tile was complete only after 19 k cycles and the MFMA phase -- which
+  //         then runs at ~100 % of the matrix pipe -- started 8 us into a 20 us kernel):
+  //           a. the weight fragments of this wave's FIRST TWO taps,
+  //           b. the whole B tile [C_in][ROW] in ONE batch (element e = tid, tid + 1024, ... -> (channel, column) by an
+  //              incremental cursor; registers are free, the bulk of the weights is not live yet),
+  //           c. staging values -> LDS (loads return in order, so a. has landed too),
+  //           d. the rest of the weight stream, which then arrives while the MFMA loop is already consuming taps in order.
+  //         Staging geometry: wave w owns channels w, w + 16, ...; a lane owns column lane (and lane + 64 when the row is wider):
+  //         the per-column work (reflection, clamping, validity) is done ONCE per lane, a row costs one uniform base + one load
+  //         per 64 columns.  (The first version walked a flat element index with ~25 VALU instructions per element: with 4 waves
+  //         per SIMD the load ISSUE alone took 11 k cycles.)
+  constexpr int RB = 16;  // rows per register batch
+  constexpr int NA0 = MAXT < 2 ? MAXT : 2;
+  const int Cin = P.Cin;
   const float* xb = G.x + (long long)b * P.x_bstride;
   const float* xb2 = (NIN > 1 && G.x2) ? G.x2 + (long long)b * P.x_bstride : xb;
   const float* xb3 = (NIN > 1 && G.x3) ? G.x3 + (long long)b * P.x_bstride : xb2;
   const float s3 = (NIN > 1 && G.x3) ? 1.f : 0.f;
   const float slope = P.in_slope, scale = P.in_scale;
-  const int refl_t = P.reflect ? ((P.Tin > 1) ? 1 : 0) : -1;
   const int t_base = n0 - G.pad_l;
-  auto stage_load = [&](float (&v)[SB]) {
+  const bool wide = ROW > 64;  // block-uniform
+  unsigned toff[2];
+  int tt[2];
 #pragma unroll
-    for (int k = 0; k < SB; ++k) {
-      int t = t_base + j;
-      t = (t == -1 && refl_t >= 0) ? refl_t : t;
-      const int tcl = t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t);
-      const int cl = c < Cin ? c : Cin - 1;
-      const unsigned off = (unsigned)(cl * P.Tin_stride + tcl) * 4u;
-      float x = ks_ld(xb, off);
-      if (NIN > 1) x = (x + ks_ld(xb2, off) + s3 * ks_ld(xb3, off));
-      v[k] = x;
-      j += dj; c += dc;
-      if (j >= ROW) { j -= ROW; ++c; }
-    }
-  };
-  auto stage_store = [&](const float (&v)[SB], int c2, int j2) {
-    int t_lim = P.Tin;
-    if (P.in_mask) t_lim = len_raw < t_lim ? len_raw : t_lim;
-    if (P.rag) { const int il = rag_raw * P.rag_in_mul + P.rag_in_add; t_lim = il < t_lim ? il : t_lim; }
-#pragma unroll
-    for (int k = 0; k < SB; ++k) {
-      int t = t_base + j2;
-      t = (t == -1 && refl_t >= 0) ? refl_t : t;
-      const bool ok = t >= 0 && t < t_lim;
-      const float o = ok ? conv_act_in(v[k], scale, slope) : 0.f;  // select: stale padding may hold NaN
-      if (c2 < Cin) lds[c2 * ROW + j2] = o;
-      j2 += dj; c2 += dc;
-      if (j2 >= ROW) { j2 -= ROW; ++c2; }
-    }
-  };
-  float sv[SB];
-  const int c_s = c, j_s = j;
-  stage_load(sv);
+  for (int q = 0; q < 2; ++q) {
+    int t = t_base + lane + 64 * q;
+    if (P.reflect && t == -1) t = (P.Tin > 1) ? 1 : 0;
+    tt[q] = t;
+    toff[q] = (unsigned)(t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t)) * 4u;
+  }
   int mb = m0 >> 5;
   if (mb >= (P.M >> 5)) mb = 0;
   const f32x4* wp = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
   f32x4 a[MAXT][2];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
+  for (int i = 0; i < NA0; ++i) {
     const int q = wave + NW * i;
     const int qc = q < total_taps ? q : total_taps - 1;
     a[i][0] = wp[(size_t)(2 * qc) * 64];
     a[i][1] = wp[(size_t)(2 * qc + 1) * 64];
   }
-  __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything waits for len[b] / rag[b]
-  stage_store(sv, c_s, j_s);
-  for (int e0 = tid + 1024 * SB; e0 < n_el; e0 += 1024 * SB) {  // tiles beyond 12 K elements: further batches
-    const int c_t = c, j_t = j;
-    stage_load(sv);
-    stage_store(sv, c_t, j_t);
+  // Interior tiles (no edge, mask or ragged limit inside the window -- all but the first and last column tile of a conv): rows are
+  // fetched with UNALIGNED dwordx4 loads, 64 / nvec rows per wave-instruction.  The texture-address path of a CU retires about
+  // one vector memory instruction per ~14 cycles whatever its width (measured: 16 waves x 36 dword loads kept the B tile of a
+  // k = 11 conv incomplete for 19 k cycles), so a staged row should be ONE wide instruction, not two narrow ones.
+  bool fast = false;
+  {
+    int t_lim = P.Tin;
+    if (P.in_mask) t_lim = __builtin_amdgcn_readfirstlane(len_raw) < t_lim ? __builtin_amdgcn_readfirstlane(len_raw) : t_lim;
+    if (P.rag) { const int il = __builtin_amdgcn_readfirstlane(rag_raw) * P.rag_in_mul + P.rag_in_add; t_lim = il < t_lim ? il : t_lim; }
+    fast = t_base >= 0 && t_base + ROW <= t_lim && ROW <= 256;
+  }
+  if (fast) {
+    const int nvec = ROW >> 2, rpi = 64 / nvec;            // vectors per row, rows per wave-instruction
+    const int rsub = lane / nvec, jv = lane - rsub * nvec;  // per-lane constants
+    const bool lok = rsub < rpi;
+    const int ngroups = (Cin + rpi - 1) / rpi;              // groups of rpi consecutive channels; wave w owns groups w, w + 16, ...
+    constexpr int GB = 8;                                   // groups per register batch
+    for (int g0 = wave; g0 < ngroups; g0 += NW * GB) {
+      f32x4 v[GB];
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int cch = (g0 + NW * k) * rpi + rsub;
+        const int cl = (cch < Cin && lok) ? cch : Cin - 1;
+        const unsigned off = (unsigned)(cl * P.Tin_stride + t_base + 4 * jv) * 4u;
+        f32x4 x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) + off);
+        if (NIN > 1) {
+          const f32x4 x2 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb2) + off);
+          const f32x4 x3 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb3) + off);
+          x = x + x2 + s3 * x3;
+        }
+        v[k] = x;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g0 == wave) CONV_DBG(1);
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int cch = (g0 + NW * k) * rpi + rsub;
+        if (cch < Cin && lok) {
+          f32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = conv_act_in(v[k][q], scale, slope);
+          *reinterpret_cast<f32x4*>(lds + cch * ROW + 4 * jv) = o;
+        }
+      }
+    }
+  } else
+  for (int r0 = 0; r0 * NW < Cin; r0 += RB) {
+    float v0[RB], v1[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int cch = wave + NW * (r0 + r);
+      const int cl = cch < Cin ? cch : Cin - 1;  // wave-uniform
+      const long long ro = (long long)cl * P.Tin_stride;
+      float x0 = ks_ld(xb + ro, toff[0]);
+      if (NIN > 1) x0 = x0 + ks_ld(xb2 + ro, toff[0]) + s3 * ks_ld(xb3 + ro, toff[0]);
+      v0[r] = x0;
+      float x1 = 0.f;
+      if (wide) {
+        x1 = ks_ld(xb + ro, toff[1]);
+        if (NIN > 1) x1 = x1 + ks_ld(xb2 + ro, toff[1]) + s3 * ks_ld(xb3 + ro, toff[1]);
+      }
+      v1[r] = x1;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything waits for len[b] / rag[b]
+    if (r0 == 0) CONV_DBG(1);
+    int t_lim = P.Tin;
+    if (P.in_mask) t_lim = len_raw < t_lim ? len_raw : t_lim;
+    if (P.rag) { const int il = rag_raw * P.rag_in_mul + P.rag_in_add; t_lim = il < t_lim ? il : t_lim; }
+    const bool ok0 = lane < ROW && tt[0] >= 0 && tt[0] < t_lim;
+    const bool ok1 = lane + 64 < ROW && tt[1] >= 0 && tt[1] < t_lim;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int cch = wave + NW * (r0 + r);
+      if (cch < Cin) {  // wave-uniform
+        if (lane < ROW) lds[cch * ROW + lane] = ok0 ? conv_act_in(v0[r], scale, slope) : 0.f;  // select: stale padding may hold NaN
+        if (wide && lane + 64 < ROW) lds[cch * ROW + lane + 64] = ok1 ? conv_act_in(v1[r], scale, slope) : 0.f;
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // the bulk of the weight stream is requested only now
+#pragma unroll
+  for (int i = NA0; i < MAXT; ++i) {
+    const int q = wave + NW * i;
+    const int qc = q < total_taps ? q : total_taps - 1;
+    a[i][0] = wp[(size_t)(2 * qc) * 64];
+    a[i][1] = wp[(size_t)(2 * qc + 1) * 64];
   }
   // ragged batch: the whole tile is padding of this item (block-uniform; decided after the loads were issued)
   if (P.rag && n0 >= rag_raw * P.rag_out_mul + P.rag_out_add) return;
+  CONV_DBG(2);
   __syncthreads();
+  CONV_DBG(3);
 
   // ---- 3. MFMAs: tap q = (chunk, kk): 8 k-steps p over channel pairs 16*chunk + 2p + h, B read one tap ahead
   f32x16 acc;
@@ -640,6 +707,7 @@ __global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
   }
 
   // ---- 4. cross-wave reduction through LDS (the staged tile is dead) + one element per thread through the shared epilogue
+  CONV_DBG(4);
   __syncthreads();
   float* red = lds;  // [wave][e][lane]
 #pragma unroll
@@ -649,5 +717,7 @@ __global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
 #pragma unroll
   for (int w = 0; w < NW; ++w) v[0] += red[(w * 16 + wave) * 64 + lane];
   const int lenb = P.out_mask ? len_raw : 0x7fffffff;
+  CONV_DBG(5);
   conv_epilogue_frag<EPI_STORE, 1>(P, G, b, lenb, m0 + 4 * h, wave, n0 + l31, v);
+  CONV_DBG(6);
 }

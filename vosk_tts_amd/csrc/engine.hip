@@ -57,6 +57,8 @@ static int g_attn_impl = 0;
 static int g_poison = 0;
 // 0 = fused exp/sin + iSTFT + PQMF kernel (default), 1 = the two separate kernels (independent cross-check in tests)
 static int g_tail_impl = 0;
+// 1 = folded WN tail (stacked gate outputs, one skip+post conv; default), 0 = per-layer res/skip epilogue + post
+static int g_wn_fold = 1;
 
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
@@ -87,6 +89,13 @@ struct CouplingW {
   ConvW pre, post;
   EncoderW enc;
   std::vector<ConvW> in_layers, rs_layers;
+  // Folded form of the WN tail (modules.py:168-176 + models.py:379-380): the skip halves of all res_skip layers and the
+  // coupling's `post` conv are linear maps with nothing between them, so
+  //   post((sum_i W_skip_i acts_i + b_skip_i) * mask) = [W_post W_skip_0 | ... | W_post W_skip_{L-1}] [acts_0; ...; acts_{L-1}] + b'
+  // on every valid column: ONE [I/2 x L*H] 1x1 conv over the stacked gate outputs replaces L skip accumulations and `post`;
+  // rsx[i] (i < L-1) keeps only the residual half of res_skip layer i.
+  std::vector<ConvW> rsx;
+  ConvW skip_post;
   int cond_off = 0;
 };
 struct ResBlockW {
@@ -539,6 +548,39 @@ static int load_model(vits_model* m) {
                             tget(m, 1, 2 * H * L, -1, -1, "flow.flows.%d.enc.cond_layer.bias", 2 * f), 2 * H * L);
     snprintf(nm, sizeof nm, "flow.flows.%d.post", 2 * f);
     c.post = conv_from(m, nm, I / 2, H, 1, true);
+    if (!m->missing) {
+      const float* pw = tget(m, 3, I / 2, H, 1, "%s.weight", nm);
+      const float* pb = tget(m, 1, I / 2, -1, -1, "%s.bias", nm);
+      std::vector<const float*> rw(L), rb(L);
+      for (int i = 0; i < L; ++i) {
+        const int rows = i < L - 1 ? 2 * H : H;
+        rw[i] = tget(m, 3, rows, H, 1, "flow.flows.%d.enc.res_skip_layers.%d.weight", 2 * f, i);
+        rb[i] = tget(m, 1, rows, -1, -1, "flow.flows.%d.enc.res_skip_layers.%d.bias", 2 * f, i);
+      }
+      if (!m->missing) {
+        for (int i = 0; i < L - 1; ++i)  // residual half: rows [0, H)
+          c.rsx.push_back(make_conv(m, H, H, 1, rb[i], [&](int r, int ci, int) { return rw[i][(size_t)r * H + ci]; }));
+        const int half = I / 2;
+        std::vector<double> Wf((size_t)half * L * H, 0.0), bf(half, 0.0);
+        for (int o = 0; o < half; ++o) {
+          double bacc = pb[o];
+          for (int i = 0; i < L; ++i) {
+            const int off = i < L - 1 ? H : 0;  // skip rows of layer i (the last layer is all skip)
+            for (int k = 0; k < H; ++k) {
+              const double pwk = pw[(size_t)o * H + k];
+              bacc += pwk * rb[i][off + k];
+              const float* wr = rw[i] + (size_t)(off + k) * H;
+              double* dst = &Wf[((size_t)o * L + i) * H];
+              for (int ci = 0; ci < H; ++ci) dst[ci] += pwk * wr[ci];
+            }
+          }
+          bf[o] = bacc;
+        }
+        std::vector<float> bff(half);
+        for (int o = 0; o < half; ++o) bff[o] = (float)bf[o];
+        c.skip_post = make_conv(m, half, L * H, 1, bff.data(), [&](int r, int ci, int) { return (float)Wf[(size_t)r * L * H + ci]; });
+      }
+    }
   }
   if (m->use_g && hp.dec_type == 1)  // Generator.cond (models.py:869-870, 873-875)
     m->cond_dec_off = add_cond(tget(m, 3, hp.dec_initial_channel, G, 1, "dec.cond.weight"),
@@ -656,7 +698,8 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->dz = bump<float>(s, (size_t)B * 2 * Tx); s->dpr = bump<float>(s, (size_t)B * 32 * Tx); s->logw = bump<float>(s, (size_t)B * Tx);
   s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
   s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
-  s->facts = bump<float>(s, B * H * Ty); s->fskip = bump<float>(s, B * H * Ty);
+  s->facts = bump<float>(s, B * H * Ty * (size_t)(hp.flow_wn_layers > 0 ? hp.flow_wn_layers : 1));  // gate outputs of all WN layers, stacked
+  s->fskip = bump<float>(s, B * H * Ty);
   // decoder: conv_pre out, then per stage: ups out + 3 tmp + 3 res-chain (models.py:1026-1036)
   s->dec_bufs.clear();
   size_t C = hp.dec_initial_channel, T = Ty;
@@ -985,7 +1028,7 @@ static bool conv_ls_ok(const ConvParams& P, int epi, int halo, long nblk32) {
     if (P.g[g].x2 && !P.g[0].x2) return false;
   }
   if (cdiv(taps, 16) > (P.g[0].x2 ? 6 : 11)) return false;
-  const size_t lds = (size_t)P.Cin * (32 + halo) * sizeof(float);
+  const size_t lds = (size_t)P.Cin * ((32 + halo + 3) & ~3) * sizeof(float);
   if (lds > 156 * 1024) return false;
   // Measured on the single-utterance decoder (tools/convdbg.py): 24.7 us vs 24.2 us for the 16-wave K-split kernel on
   // the k = 11 ResBlock conv and 3..10 % slower on the grouped launches -- removing both per-MFMA global loads from the loop
@@ -1002,7 +1045,7 @@ static void launch_conv_ls(vits_session* s, ConvParams& P, int halo, ProfScope& 
   for (int g = 0; g < P.n_groups; ++g) { const int t = P.Cin / CONV_CI_T * P.g[g].K; if (t > taps) taps = t; }
   const bool few = cdiv(taps, 16) <= 6;
   const bool multi = P.g[0].x2 != nullptr;
-  size_t lds = (size_t)P.Cin * P.row_len * sizeof(float);
+  size_t lds = (size_t)P.Cin * ((P.row_len + 3) & ~3) * sizeof(float);
   if (lds < (size_t)16 * 16 * 64 * sizeof(float)) lds = (size_t)16 * 16 * 64 * sizeof(float);
   const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
 #define LS_GO(MAXT_, NIN_)                                                                                           \
@@ -1155,10 +1198,11 @@ static void launch_ln(vits_session* s, const float* a, const float* b, const flo
   launch_layernorm(s->stream, P, B);
 }
 
-static void launch_attention(vits_session* s, const float* qkv, const EncLayerW& L, const int* len, float* out, int B,
-                             int H, int T) {
-  const vits_hparams& hp = s->m->hp;
-  const int nh = hp.n_heads, dk = H / nh, W = hp.window_size;
+// ek / ev: relative-position tables [2W+1][dk] or null (plain scaled-dot-product attention: StableTTS DiT blocks, BERT)
+static void launch_attention_raw(vits_session* s, const float* qkv, const float* ek, const float* ev, const int* len, float* out, int B,
+                                 int H, int T, int nh, int W) {
+  const int dk = H / nh;
+  struct { const float* ek; const float* ev; } L{ek, ev};
   static const int t16_max = getenv("VITS_ATT16_MAXT") ? atoi(getenv("VITS_ATT16_MAXT")) : 512;
   const bool use16 = g_attn_impl == 3 || (g_attn_impl == 0 && T <= t16_max);
   ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T,
@@ -1193,6 +1237,10 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
   if (dk == 96) hipLaunchKernelGGL((relpos_attention_kernel<96>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
   else if (dk == 64) hipLaunchKernelGGL((relpos_attention_kernel<64>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
   else hipLaunchKernelGGL((relpos_attention_kernel<32>), grid, dim3(256), 0, s->stream, qkv, L.ek, L.ev, len, out, H, T, W);
+}
+
+static void launch_attention(vits_session* s, const float* qkv, const EncLayerW& L, const int* len, float* out, int B, int H, int T) {
+  launch_attention_raw(s, qkv, L.ek, L.ev, len, out, B, H, T, s->m->hp.n_heads, s->m->hp.window_size);
 }
 
 // attentions.Encoder.forward (attentions.py:48-65).  x in place [B,H,T]; final_base (optional):
@@ -1488,16 +1536,30 @@ static float* run_flow(vits_session* s, int B, int Ty) {
     launch_conv(s, P, EPI_STORE, "flow.pre");
     // h = h + pre_transformer(h * mask)  (models.py:377)
     run_encoder(s, C.enc, s->x, s->len_y, B, Ty, -1, -1, s->fh, s->fx);
-    // WN (modules.py:148-176): fx is the running x, fskip the output accumulator
+    // WN (modules.py:148-176): fx is the running x.  Folded form (default): the gate outputs of all layers are kept, stacked
+    // [L*H, T]; res_skip layer i < L-1 only updates x (its residual half); one [I/2 x L*H] conv = post o (sum of skip halves)
+    // feeds the coupling tail.  Unfolded form (vits_debug_wn_fold(0)): res/skip epilogue per layer + post, as the reference runs it.
+    const bool fold = g_wn_fold && !C.rsx.empty() && C.skip_post.w;
+    const long long acts_b = (long long)(fold ? L : 1) * H * Ty;
     for (int i = 0; i < L; ++i) {
-      P = conv_params(C.in_layers[i], s->fx, s->facts, B, Ty, 1, (K5 - 1) / 2);
-      P.Cout = H; P.H = H; P.y_bstride = (long long)H * Ty;
+      float* acts = s->facts + (fold ? (size_t)i * H * Ty : 0);
+      P = conv_params(C.in_layers[i], s->fx, acts, B, Ty, 1, (K5 - 1) / 2);
+      P.Cout = H; P.H = H; P.y_bstride = acts_b;
       if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = C.cond_off + i * 2 * H; }
       // x is masked in the reference (modules.py:171); reading it through the mask makes the K=5 window
       // independent of whatever a skipped padding tile left behind
       P.in_mask = 1; P.len = s->len_y;
       mark_masked(s, P, s->len_y);
       launch_conv(s, P, EPI_GATE, "flow.wn_in");
+      if (fold) {
+        if (i == L - 1) break;
+        P = conv_params(C.rsx[i], acts, s->fx, B, Ty, 1, 0);  // x = (x + res_acts) * mask, in place (x is masked on entry)
+        P.x_bstride = acts_b;
+        P.g[0].res = s->fx; P.out_mask = 1; P.len = s->len_y;
+        mark_masked(s, P, s->len_y);
+        launch_conv(s, P, EPI_STORE, "flow.wn_rs");
+        continue;
+      }
       P = conv_params(C.rs_layers[i], s->facts, nullptr, B, Ty, 1, 0);
       P.io = s->fx; P.skip = s->fskip; P.H = H; P.first = i == 0; P.last = i == L - 1; P.len = s->len_y;
       P.y_bstride = (long long)H * Ty;
@@ -1505,7 +1567,7 @@ static float* run_flow(vits_session* s, int B, int Ty) {
       launch_conv(s, P, EPI_RESSKIP, "flow.wn_rs");
     }
     // m = post(h) * mask ; x1 = (x1 - m) * mask ; cat (models.py:379-392)
-    P = conv_params(C.post, s->fskip, nullptr, B, Ty, 1, 0);
+    P = fold ? conv_params(C.skip_post, s->facts, nullptr, B, Ty, 1, 0) : conv_params(C.post, s->fskip, nullptr, B, Ty, 1, 0);
     P.u = u; P.io = v; P.H = half; P.len = s->len_y; P.y_bstride = (long long)I * Ty;
     mark_masked(s, P, s->len_y);
     launch_conv(s, P, EPI_COUPLE, "flow.post");
@@ -2508,6 +2570,7 @@ void vits_debug_force_tile(int mode) { g_force_tile = mode; }
 void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
 void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
+void vits_debug_wn_fold(int on) { g_wn_fold = on; }
 void vits_debug_conv_ls(int mode) { g_ls_mode = mode; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
 
@@ -2615,8 +2678,8 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
                   h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], (long long)(Cin / 2) * K * 4 * 64);
       } else
       for (int w = 0; w < 16; w += 5)
-        if (h[w * 8]) fprintf(stderr, "   wave %d: staged0 %lld  loop_done %lld  barrier %lld  reduced %lld  end %lld\n", w, h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8],
-                h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8]);
+        if (h[w * 8]) fprintf(stderr, "   wave %d: +%lld  +%lld  +%lld  +%lld  +%lld  +%lld  (K-split: loads-issued, loop, barrier, reduced, end | LDS-staged: loads-issued, stored, barrier, mfma, reduced-sync.., end)\n", w,
+                h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8], h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8], h[w * 8 + 6] - h[w * 8]);
     }
     if (d_dbg) hipFree(d_dbg);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ea);

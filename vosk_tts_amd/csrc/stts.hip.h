@@ -121,13 +121,9 @@ static int stts_arena(vits_session* s, size_t bytes) {
 static void stts_attention(vits_session* s, const stts_model* m, const float* qkv, const int* len, float* out, int B, int H, int T, int nh) {
   const int dk = H / nh;
   hipLaunchKernelGGL(rope_kernel, dim3(cdiv(T, 64), nh * (dk / 4), B * 2), dim3(64), 0, s->stream, const_cast<float*>(qkv), H, T, nh, dk);
-  ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T, "relpos_attention_mfma_kernel");
-  dim3 grid(cdiv(T, 32), nh, B);
-  const size_t lds = (size_t)4 * (dk * 33 + 10 * 32 + 9 * 32) * sizeof(float);
-  // null relative tables: the kernel skips the banded relative-position terms (F.scaled_dot_product_attention has none)
-  if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), grid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, len, out, H, T, 4);
-  else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), grid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, len, out, H, T, 4);
-  else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), grid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, len, out, H, T, 4);
+  // null relative tables: the kernels skip the banded relative-position terms (F.scaled_dot_product_attention has none);
+  // short sequences take the 16-query kernel like the VITS encoders (engine.hip launch_attention_raw)
+  launch_attention_raw(s, qkv, nullptr, nullptr, len, out, B, H, T, nh, 4);
 }
 
 struct DitScratch { float *hn, *qkv, *att, *ffh; };
@@ -905,14 +901,10 @@ int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, in
     LNParams P{y, nullptr, nullptr, x, m->eg, m->eb, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr};
     launch_layernorm(s->stream, P, 1);
   }
-  const dim3 agrid(cdiv(T, 32), nh, 1);
-  const size_t lds = (size_t)4 * (dk * 33 + 10 * 32 + 9 * 32) * sizeof(float);
   for (const BertLayerW& L : m->layers) {
     ConvParams P = conv_params(L.qkv, x, qkv, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.qkv");
-    if (dk == 96) hipLaunchKernelGGL((relpos_attention_mfma_kernel<96>), agrid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, d_len, att, H, T, 4);
-    else if (dk == 64) hipLaunchKernelGGL((relpos_attention_mfma_kernel<64>), agrid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, d_len, att, H, T, 4);
-    else hipLaunchKernelGGL((relpos_attention_mfma_kernel<32>), agrid, dim3(256), lds, s->stream, qkv, nullptr, nullptr, d_len, att, H, T, 4);
+    launch_attention_raw(s, qkv, nullptr, nullptr, d_len, att, 1, H, T, nh, 4);
     P = conv_params(L.o, att, y, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.o");
     { LNParams Q{y, x, nullptr, x, L.g1, L.b1, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr}; launch_layernorm(s->stream, Q, 1); }  // LayerNorm(dense(ctx) + x)
