@@ -292,9 +292,8 @@ void vits_debug_ks_waves(int nw);
 /* Test hook: 1 (default) = WaveNet tail of the coupling layers in folded form (gate outputs of all layers kept, one conv =
  * post o sum of skip halves), 0 = per-layer res/skip accumulation + post as the reference executes it.  Same results to rounding. */
 void vits_debug_wn_fold(int on);
-/* Test hook: LDS-staged 16-wave conv kernel of the single-utterance decoder: 0 = size heuristic (default), 1 = never,
- * 2 = wherever a launch is eligible. */
-void vits_debug_conv_ls(int mode);
+/* Test hook: wave-pipelined decoder conv kernel (conv_wp_kernel): 0 = by size (default), 1 = never, 2 = whenever eligible. */
+void vits_debug_conv_wp(int mode);
 /* Test hook: 0 = fused exp/sin + iSTFT + PQMF tail kernel (default), 1 = the separate istft / pqmf kernels. */
 void vits_debug_tail_impl(int impl);
 /* Test hook: fill every newly laid-out workspace with NaN bit patterns (stale-padding detector). */

@@ -116,41 +116,42 @@ def test_ksplit_kernel_wave_counts(hip_lib, hip_default, hip_tiny, oracle_lib, o
         hip_lib.lib.vits_debug_ks_waves(0)
 
 
-def test_lds_staged_decoder_conv_kernel(hip_lib, hip_default, oracle_lib, oracle_default):
-    """conv_ls_kernel (32x32 tiles, 16 waves, B operand staged once in LDS, all weights requested up front) is picked by size
-    for the single-utterance decoder; force it wherever eligible: random conv shapes (1..11 taps, dilation up to the halo
-    limit, odd lengths, C_out not a multiple of 32), the whole decoder (polyphase upsamplers, grouped ResBlock convs, MRF
-    mean of three inputs, reflection pad) against golden + oracle, and with the kernel disabled (mode 1) the same results."""
+def test_wave_pipelined_decoder_conv_kernel(hip_lib, hip_default, oracle_lib, oracle_default):
+    """conv_wp_kernel (32x32 tiles, 8 waves splitting the contraction by 16-channel chunk, wave-private LDS slabs) is picked by size
+    for the single-utterance decoder's ResBlock convs; force it wherever eligible: random conv shapes (1..11 taps, dilations up
+    to the slab width, odd lengths with edge tiles on both sides, C_in from one chunk to more chunks than waves, C_out not a
+    multiple of 32), the whole decoder against golden + oracle, a bucketed single utterance (ragged limit inside a tile) and a
+    ragged batch; with the kernel disabled (mode 1) the same results."""
     from vosk_tts_amd.capi import op_conv1d
 
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(777)
     try:
-        hip_lib.lib.vits_debug_conv_ls(2)
-        for _ in range(16):
-            K = int(rng.choice([1, 3, 5, 7, 11]))
-            dil = min(int(rng.integers(1, max(1, 50 // max(K - 1, 1)) + 1)) if K > 1 else 1, 9)
-            Cin = 16 * int(rng.integers(1, 17))
+        hip_lib.lib.vits_debug_conv_wp(2)
+        for it in range(20):
+            K = int(rng.choice([1, 2, 3, 5, 7, 11]))
+            dil = min(int(rng.integers(1, max(1, 64 // max(K - 1, 1)) + 1)) if K > 1 else 1, 9)
+            Cin = 16 * int(rng.choice([1, 3, 8, 12, 16, 20]))
             Cout = int(rng.choice([1, 29, 32, 72, 96, 128, 256]))
-            T = int(rng.choice([1, 31, 33, 150, 600, 601]))
+            T = int(rng.choice([4, 5, 31, 33, 64, 150, 600, 601]))
             slope = float(rng.choice([1.0, 0.1]))
-            x = rng.standard_normal((1, Cin, T)).astype(np.float32)
+            x = rng.standard_normal((1 + it % 2, Cin, T)).astype(np.float32)
             w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
             bias = rng.standard_normal(Cout).astype(np.float32)
             want = op_conv1d(oracle_lib, x, w, bias, dil, slope)
             got = op_conv1d(hip_lib, x, w, bias, dil, slope)
-            assert_close(f"conv_ls Cin={Cin} Cout={Cout} T={T} K={K} dil={dil}", want, got, 2e-5)
+            assert_close(f"conv_wp Cin={Cin} Cout={Cout} T={T} K={K} dil={dil}", want, got, 2e-5)
         z = rng.standard_normal((1, 192, 47)).astype(np.float32)
         a_ref, mb_ref = oracle_default.decoder(z)
-        outs = []
         for mode in (2, 1, 0):
-            hip_lib.lib.vits_debug_conv_ls(mode)
+            hip_lib.lib.vits_debug_conv_wp(mode)
             a, mb = hip_default.decoder(z)
-            assert_close(f"decoder audio, conv_ls mode {mode}", a_ref, a, STAGE_TOL)
-            assert_close(f"decoder audio_mb, conv_ls mode {mode}", mb_ref, mb, STAGE_TOL)
-        hip_lib.lib.vits_debug_conv_ls(2)
+            assert_close(f"decoder audio, conv_wp mode {mode}", a_ref, a, STAGE_TOL)
+            assert_close(f"decoder audio_mb, conv_wp mode {mode}", mb_ref, mb, STAGE_TOL)
+        hip_lib.lib.vits_debug_conv_wp(2)
         _stages_vs(hip_default, oracle_default, golden("full_c1"), STAGE_TOL)
+        _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)
     finally:
-        hip_lib.lib.vits_debug_conv_ls(0)
+        hip_lib.lib.vits_debug_conv_wp(0)
 
 
 def test_fused_tail_kernel_equals_separate_istft_and_pqmf(hip_lib, hip_default, oracle_default):

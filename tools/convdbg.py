@@ -1,5 +1,5 @@
 """Single conv launches through vits_op_conv1d with the timing build (phase stamps of block 0 + steady-state time per launch):
-   VITS_CONV_DBG=20 [VITS_KS_WAVES=..] [VITS_CONV_LS=..] python tools/convdbg.py [decoder|small]"""
+   VITS_CONV_DBG=20 [VITS_KS_WAVES=..] [VITS_CONV_WP=..] python tools/convdbg.py [decoder|small]"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
@@ -13,4 +13,4 @@ shapes = {"decoder": [(1,256,256,600,3,1), (1,256,256,600,7,3), (1,256,256,600,1
           "small": [(1,192,192,50,1,1), (1,768,192,50,3,1), (1,192,384,150,5,1), (1,192,576,150,1,1)]}[which]
 for (B, Cin, Cout, T, K, dil) in shapes:
     x = rng.standard_normal((B,Cin,T)).astype(np.float32); w = rng.standard_normal((Cout,Cin,K)).astype(np.float32)
-    op_conv1d(lib, x, w, np.zeros(Cout, np.float32), dil, 0.1)
+    op_conv1d(lib, x, w, np.zeros(Cout, np.float32), dil, float(os.environ.get('CONVDBG_SLOPE', '0.1')))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# round-2 evidence run: full GPU test suite, default bench line, rocprofv3 kernel stats (c2-only and default), PMC passes (c2, c3).
+# Outputs land in gpurun_out/final/ under the names profiles/ expects; copy them to profiles/ afterwards.
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; mkdir -p $O
+cd $R
+if [ "$1" != "noprof_tests" ]; then
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $O/r2_gpu_tests.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2_gpu_tests.log
+tail -5 $O/r2_gpu_tests.log
+fi
+timeout 600 python bench.py > $O/r2_default_bench.json.txt 2> $O/bench_default.err; echo "bench rc=$?"
+tail -c 600 $O/bench_default.err
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c2 -o trace -- python $R/bench.py --no-batch32 --no-cpu-baseline --no-host-api --steps 50 > $O/r2_c2_only_bench_under_rocprof.json.txt 2> $O/prof_c2.err
+cp $(find $O/prof/c2 -name '*kernel_stats.csv' | head -1) $O/r2_c2_only_bench_rocprofv3_kernel_stats.csv
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/def -o trace -- python $R/bench.py --no-cpu-baseline > $O/r2_default_bench_under_rocprof.json.txt 2> $O/prof_def.err
+cp $(find $O/prof/def -name '*kernel_stats.csv' | head -1) $O/r2_default_bench_rocprofv3_kernel_stats.csv
+rm -rf $O/prof
+cd $R
+for w in c2 c3; do
+  timeout 900 bash tools/pmc_passes.sh $w > $O/pmc_$w.log 2>&1
+  cp $R/gpurun_out/pmc_$w/pmc_$w.json $O/r2_pmc_$w.json
+  rm -rf $R/gpurun_out/pmc_$w
+done
+ls -la $O
+head -c 1500 $O/r2_default_bench.json.txt

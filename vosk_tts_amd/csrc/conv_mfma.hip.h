@@ -205,7 +205,7 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
   return true;
 }
 #ifdef CONV_TIMING
-#define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) { P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); if ((k) == 0) P.dbg[wave * 8 + 7] = __builtin_amdgcn_s_getreg(63492); } } while (0)
 #define CONV_DBG_DO(x) x
 #else
 #define CONV_DBG(k) do { } while (0)

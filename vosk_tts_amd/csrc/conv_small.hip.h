@@ -503,221 +503,271 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
   }
 }
 
-// =============================================================================================================================
-// conv_ls_kernel — the single-utterance DECODER regime (T = 600..2400 columns, C = 128..512, 3..11 taps, up to 3 grouped convs):
-// 32 x 32 output tile per workgroup on v_mfma_f32_32x32x2_f32, the contraction split over 16 waves (4 per SIMD) by taps like
-// the K-split kernel, but with that kernel's two per-MFMA global loads gone:
-//   * B operand: the workgroup stages ALL input channels x (32 columns + halo) once in LDS, cooperatively and coalesced
-//     (leaky-relu, MRF mean of up to three inputs, mask / ragged limit, ReflectionPad applied once per element); every tap of
-//     every wave reads shifted columns of that tile (ds_read_b32, 32 consecutive columns per half-wave: conflict-free);
-//   * A operand: each wave requests ALL its weight fragments (<= MAXT taps x 2 dwordx4, same packing as the other 32x32
-//     kernels) before the staging barrier, so the weight stream flies under the staging phase and the MFMA loop touches no
-//     global memory at all.  The L1 / texture-address path, which the K-split kernel loads with 512 B per MFMA, carries only
-//     the 256 B of weights.
-// Partial tiles meet in LDS (the staged tile is dead by then), 1024 threads run the shared STORE epilogue one element each.
-// Serves (B = 1): conv_pre, polyphase ConvTranspose1d, ResBlock1 convs (grouped k = 3/7/11), subband_conv_post / conv_post
-// (models.py:983-1040, modules.py:210-223).
-template <int MAXT, int NIN>
-__global__ void __launch_bounds__(1024) conv_ls_kernel(const ConvParams P) {
-  constexpr int NW = 16;
+// ---------------------------------------------------------------------------------------------
+// conv_wp_kernel — single-utterance decoder ResBlock convs (T = 600..2400 columns, C = 128..256, 3..11 taps, 3 grouped convs).
+// What the older kernels showed on these launches (tools/convdbg.py phase stamps, PMC): the K-split kernel issues one global load
+// per MFMA and its matrix pipe is ~43 % busy from start to end; a first LDS version (whole workgroup stages the full B tile, barrier,
+// then MFMAs; removed) ran its MFMA phase at ~100 % -- but only after a staging phase nothing overlapped (one workgroup per CU).
+// Here every wave is its own pipeline: the contraction is split over the NW waves by 16-CHANNEL CHUNK, a wave stages ITS chunk
+// (16 rows x (32 + halo) columns, leaky-relu applied once) into a wave-private LDS slab with 4..8 unaligned dwordx4 loads, and then
+// issues 8 K MFMAs on it with B fragments read from LDS at shifted columns one tap ahead and weight fragments requested two taps
+// ahead.  No workgroup barrier before the final reduction, 48 KB of LDS and <= 128 registers per wave: 2 workgroups per CU overlap
+// each other's start-up, reduction and epilogue.  Measured (K = 11, C = 128, T = 2400): the first wave of a SIMD runs at 76 cycles
+// per MFMA (64 = peak); what is left is the start-up -- every launch begins with cold L2s, and the last waves of a workgroup get
+// their slab ~5 k cycles after the first ones (outstanding-miss limited fetch from the Infinity Cache).
+// ---------------------------------------------------------------------------------------------
+#define WP_PITCH 96  // slab row pitch in floats: == 32 mod 64 (rows 2p / 2p + 1 of a B fragment land in different bank halves)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int V> struct wp_int { static constexpr int value = V; };
+// KT = compile-time tap count (3 / 7 / 11: the decoder's ResBlock kernels, fully unrolled so that every register of the weight
+// and B-fragment rings is named statically -- a rolled loop makes hipcc rotate the rings with v_mov behind s_waitcnt vmcnt(0)),
+// 0 = run-time tap count (any other conv; same arithmetic, rolled loop).
+template <int NW, int KT>
+__device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b, int wave, int lane) {
+  constexpr int NE = 16 / NW;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int n0 = nt * 32, m0 = mt * 32;
+  const int K = KT ? KT : G.K, dil = G.dil;
+  const int nchunks = P.Cin / CONV_CI_T;
+  const int my_chunks = wave < nchunks ? (nchunks - wave + NW - 1) / NW : 0;
+  const int last_c = wave + NW * (my_chunks > 0 ? my_chunks - 1 : 0);
+  // ---- request order: weight fragments of the first two taps (no geometry needed), len[b] / rag[b] (vector loads: needed only
+  //      after the slab loads have been issued), then the first slab
+  int mb = m0 >> 5;
+  if (mb >= (P.M >> 5)) mb = 0;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
+  f32x4 a[2][2];        // weight fragments of two consecutive taps; a slot is re-requested right after its last MFMA, two taps ahead
+  int lci = 0, lk = 0;  // load cursor of the weight stream (this wave's chunk index, tap)
+  auto load_a_half = [&](f32x4 (&d)[2], int half) {  // half 1 advances the cursor
+    const int c = wave + NW * lci;
+    const bool live = c <= last_c && my_chunks > 0;
+    const size_t sg = 2 * ((size_t)(live ? c : last_c) * K + (live ? lk : K - 1));
+    d[half] = wp[(sg + half) * 64];
+    if (half) {
+      ++lk;
+      if (lk == K) { lk = 0; ++lci; }
+    }
+  };
+  auto load_a = [&](f32x4 (&d)[2]) { load_a_half(d, 0); load_a_half(d, 1); };
+  load_a(a[0]);
+  load_a(a[1]);
+  int bi = b;
+  asm volatile("" : "+v"(bi));
+  int len_raw = 0x7fffffff, rag_raw = 0x7fffffff;
+  if (P.in_mask || P.out_mask) len_raw = P.len[bi];
+  if (P.rag) rag_raw = P.rag[bi];
+
+  // slab geometry of this group: one load instruction = vector v16 (+ 16 in the second pass) of rows 4 j + r4: 4 instructions stage a
+  // 16-row slab of up to 64 columns, 8 one of up to 96
+  const int row_len = 32 + (K - 1) * dil;
+  const int nvec = (row_len + 3) >> 2;
+  const bool two = nvec > 16;  // block-uniform
+  const int t_base = n0 - G.pad_l;
+  const int r4 = lane >> 4, v16 = lane & 15;
+  int tvp[2], tcp[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    tvp[ps] = t_base + 4 * (v16 + 16 * ps);
+    const int tc = tvp[ps] < 0 ? 0 : tvp[ps];
+    tcp[ps] = tc > P.Tin - 4 ? P.Tin - 4 : tc;  // clamped (always valid) vector start; exact for interior tiles
+  }
+  const unsigned lrow = (unsigned)(r4 * P.Tin_stride);
+  float* sl = lds + wave * (CONV_CI_T * WP_PITCH);
+  float* sw = sl + r4 * WP_PITCH + 4 * v16;  // + 4 j rows, + 64 columns in the second pass
+  const float* xb = G.x + (long long)b * P.x_bstride;
+  const float slope = P.in_slope;
+  f32x4 v0[4], v1[4];
+  auto load_slab = [&](int ci) {
+    const float* xc = xb + (long long)(wave + NW * ci) * CONV_CI_T * P.Tin_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      v0[j] = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(xc + 4 * j * P.Tin_stride) + (lrow + (unsigned)tcp[0]) * 4u);
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v1[j] = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(xc + 4 * j * P.Tin_stride) + (lrow + (unsigned)tcp[1]) * 4u);
+    }
+  };
+  if (my_chunks > 0) load_slab(0);
+  // epilogue operands (bias, residual) of the NE accumulator elements this wave finishes: requested now, consumed after the reduction
+  // (their cold misses would otherwise sit on the critical path of the tail: ~1 us per launch)
+  const int ecol = n0 + l31;
+  const int ecolc = ecol < P.Tout ? ecol : P.Tout - 1;
+  long long eoff[NE];
+  bool eok[NE];
+  float ebias[NE], eres[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = NE * wave + i;
+    const int r = m0 + 4 * h + (e & 3) + 8 * (e >> 2);
+    const int rc = r < P.Cout ? r : P.Cout - 1;
+    eok[i] = ecol < P.Tout && r < P.Cout;
+    eoff[i] = (long long)b * P.y_bstride + (long long)rc * P.Tout_stride + ecolc;
+    ebias[i] = G.bias ? G.bias[rc] : 0.f;
+    eres[i] = G.res ? G.res[eoff[i]] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  CONV_DBG(1);
+  int t_lim = P.Tin;
+  if (P.in_mask) { const int l = __builtin_amdgcn_readfirstlane(len_raw); t_lim = l < t_lim ? l : t_lim; }
+  if (P.rag) {
+    const int rl = __builtin_amdgcn_readfirstlane(rag_raw);
+    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
+    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    t_lim = il < t_lim ? il : t_lim;
+  }
+  const bool interior = t_base >= 0 && t_base + 4 * nvec <= t_lim;
+  // leaky-relu (0 <= slope <= 1) once per element, then the slab.  Edge tiles (first / last columns, mask or ragged limit inside
+  // the window): every element they need lies inside the clamped vector, shifted by sh = wanted - loaded start (|sh| <= 3)
+  auto put = [&](f32x4 (&v)[4], int ps) {
+    if (v16 + 16 * ps >= nvec) return;
+    if (interior && slope == 1.f) {  // (block-uniform) plain copy: no VALU work between the load and the slab
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(sw + 4 * j * WP_PITCH + 64 * ps) = v[j];
+    } else if (interior) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = fmaxf(v[j][q], v[j][q] * slope);
+        *reinterpret_cast<f32x4*>(sw + 4 * j * WP_PITCH + 64 * ps) = o;
+      }
+    } else {
+      const int sh = tvp[ps] - tcp[ps];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = tvp[ps] + q, idx = q + sh;
+          const float x = idx <= 0 ? v[j][0] : (idx == 1 ? v[j][1] : (idx == 2 ? v[j][2] : v[j][3]));
+          o[q] = (t >= 0 && t < t_lim) ? fmaxf(x, x * slope) : 0.f;  // select: stale padding may hold NaN
+        }
+        *reinterpret_cast<f32x4*>(sw + 4 * j * WP_PITCH + 64 * ps) = o;
+      }
+    }
+  };
+  auto stage = [&]() {
+    put(v0, 0);
+    if (two) put(v1, 1);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // ---- 8 K MFMAs on the slab: B fragment of (tap, channel pair p) = rows 2p + h at columns l31 + tap * dil, read one tap ahead.
+  //      PAR = which weight slot holds the chunk's first tap (flips per chunk when the tap count is odd).
+  const float* bl = sl + h * WP_PITCH + l31;
+  auto read_b = [&](float (&d)[8], int tap) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) d[p] = bl[2 * p * WP_PITCH + tap * dil];
+  };
+  auto mfma8 = [&](const f32x4 (&w)[2], const float (&d)[8]) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[p >> 2][p & 3], d[p], acc, 0, 0, 0);
+  };
+  auto taps = [&](auto par) {
+    constexpr int PAR = decltype(par)::value;
+    float bb[2][8];
+    read_b(bb[0], 0);
+    if (KT) {
+      // program order pinned per tap (hipcc otherwise sinks every load to its use: B fragments one MFMA pair ahead, weights one
+      // tap ahead): [B of tap + 1] | 4 MFMAs, first weight vector of tap + 2, 4 MFMAs, second weight vector |
+#pragma unroll
+      for (int tap = 0; tap < (KT ? KT : 1); ++tap) {
+        f32x4 (&w)[2] = a[(tap + PAR) & 1];
+        const float (&d)[8] = bb[tap & 1];
+        if (tap + 1 < KT) read_b(bb[(tap + 1) & 1], tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0][p], d[p], acc, 0, 0, 0);
+        load_a_half(w, 0);
+#pragma unroll
+        for (int p = 4; p < 8; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1][p & 3], d[p], acc, 0, 0, 0);
+        load_a_half(w, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 1
+      for (int tap = 0; tap < K; tap += 2) {
+        read_b(bb[1], tap + 1 < K ? tap + 1 : tap);
+        mfma8(a[PAR], bb[0]);
+        load_a(a[PAR]);
+        if (tap + 1 < K) {
+          read_b(bb[0], tap + 2 < K ? tap + 2 : tap + 1);
+          mfma8(a[PAR ^ 1], bb[1]);
+          load_a(a[PAR ^ 1]);
+        }
+      }
+    }
+  };
+  constexpr bool FLIP = KT & 1;  // static tap counts: the odd ones alternate the slot parity per chunk
+#pragma unroll 1
+  for (int ci = 0; ci < my_chunks; ci += 2) {
+    stage();
+    if (ci + 1 < my_chunks) load_slab(ci + 1);
+    if (ci == 0) CONV_DBG(2);
+    taps(wp_int<0>{});
+    if (!KT && (K & 1)) {  // run-time odd tap count: the next chunk's first tap sits in slot 1 -> swap once per chunk
+      const f32x4 t0 = a[0][0], t1 = a[0][1];
+      a[0][0] = a[1][0]; a[0][1] = a[1][1];
+      a[1][0] = t0; a[1][1] = t1;
+    }
+    if (ci + 1 < my_chunks) {
+      stage();
+      if (ci + 2 < my_chunks) load_slab(ci + 2);
+      taps(wp_int<FLIP ? 1 : 0>{});
+      if (!KT && (K & 1)) {
+        const f32x4 t0 = a[0][0], t1 = a[0][1];
+        a[0][0] = a[1][0]; a[0][1] = a[1][1];
+        a[1][0] = t0; a[1][1] = t1;
+      }
+    }
+  }
+  CONV_DBG(3);
+  // ---- cross-wave reduction: the partial tile goes into this wave's own (dead) slab, one barrier, NE elements per wave
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sl[e * 64 + lane] = acc[e];
+  __syncthreads();
+  CONV_DBG(4);
+  float sum[NE];
+#pragma unroll
+  for (int ee = 0; ee < NE; ++ee) {
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r += lds[w * (CONV_CI_T * WP_PITCH) + (NE * wave + ee) * 64 + lane];
+    sum[ee] = r;
+  }
+  // epilogue of this kernel's launches (the launcher rejects per-item bias / scale and output activations): bias, mask, residual
+  const bool masked = P.out_mask && ecol >= len_raw;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    float r = sum[i] + ebias[i];
+    if (masked) r = 0.f;
+    r += eres[i];
+    if (eok[i]) {
+      G.y[eoff[i]] = r;
+      if (G.y2) G.y2[eoff[i]] = r;
+    }
+  }
+  CONV_DBG(5);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) conv_wp_kernel(const ConvParams P) {
   extern __shared__ float lds[];
   kernarg_warm<sizeof(ConvParams)>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, l31 = lane & 31;
   CONV_DBG(0);
-  // block -> (group, batch item, column tile, M tile): heaviest group first (the launcher sorts groups by taps)
-  int id = blockIdx.x;
-  const int mt = id % P.ntiles_m; id /= P.ntiles_m;
-  const int nt = id % P.ntiles_n; id /= P.ntiles_n;
-  const int b = id % P.B;
-  const int grp = id / P.B;
+  int mt, grp, nt, b;
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
   const ConvGroup& G = P.g[grp];
-  const int n0 = nt * 32, m0 = mt * 32;
-  const int K = G.K, dil = G.dil;
-  int tap_base = 0;
-  if (P.ups_u) tap_base = P.ups_shift[m0 / P.ups_cout];
-  int len_raw = 0x7fffffff, rag_raw = 0x7fffffff;
-  if (P.in_mask || P.out_mask) len_raw = P.len[b];
-  if (P.rag) rag_raw = P.rag[b];
-  const int ROWC = P.row_len;            // columns a tile needs: 32 + the launch's largest halo
-  const int ROW = (ROWC + 3) & ~3;       // LDS row pitch (multiple of 4: rows are written with ds_write_b128 on the fast path)
-  const int nchunks = P.Cin / CONV_CI_T;
-  const int total_taps = nchunks * K;
-  const int my_taps = wave < total_taps ? (total_taps - wave + NW - 1) / NW : 0;
-
-  // ---- 1. load order (phase stamps of the first version, tools/convdbg.py: with all 22 KB of a wave's weights queued ahead of
-  //         the staging loads of the other waves, the B tile was complete only after 19 k cycles and the MFMA phase -- which
-  //         then runs at ~100 % of the matrix pipe -- started 8 us into a 20 us kernel):
-  //           a. the weight fragments of this wave's FIRST TWO taps,
-  //           b. the whole B tile [C_in][ROW] in ONE batch (element e = tid, tid + 1024, ... -> (channel, column) by an
-  //              incremental cursor; registers are free, the bulk of the weights is not live yet),
-  //           c. staging values -> LDS (loads return in order, so a. has landed too),
-  //           d. the rest of the weight stream, which then arrives while the MFMA loop is already consuming taps in order.
-  //         Staging geometry: wave w owns channels w, w + 16, ...; a lane owns column lane (and lane + 64 when the row is wider):
-  //         the per-column work (reflection, clamping, validity) is done ONCE per lane, a row costs one uniform base + one load
-  //         per 64 columns.  (The first version walked a flat element index with ~25 VALU instructions per element: with 4 waves
-  //         per SIMD the load ISSUE alone took 11 k cycles.)
-  constexpr int RB = 16;  // rows per register batch
-  constexpr int NA0 = MAXT < 2 ? MAXT : 2;
-  const int Cin = P.Cin;
-  const float* xb = G.x + (long long)b * P.x_bstride;
-  const float* xb2 = (NIN > 1 && G.x2) ? G.x2 + (long long)b * P.x_bstride : xb;
-  const float* xb3 = (NIN > 1 && G.x3) ? G.x3 + (long long)b * P.x_bstride : xb2;
-  const float s3 = (NIN > 1 && G.x3) ? 1.f : 0.f;
-  const float slope = P.in_slope, scale = P.in_scale;
-  const int t_base = n0 - G.pad_l;
-  const bool wide = ROW > 64;  // block-uniform
-  unsigned toff[2];
-  int tt[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int t = t_base + lane + 64 * q;
-    if (P.reflect && t == -1) t = (P.Tin > 1) ? 1 : 0;
-    tt[q] = t;
-    toff[q] = (unsigned)(t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t)) * 4u;
+  switch (G.K) {  // block-uniform
+    case 3: conv_wp_body<NW, 3>(P, G, lds, mt, nt, b, wave, lane); break;
+    case 7: conv_wp_body<NW, 7>(P, G, lds, mt, nt, b, wave, lane); break;
+    case 11: conv_wp_body<NW, 11>(P, G, lds, mt, nt, b, wave, lane); break;
+    default: conv_wp_body<NW, 0>(P, G, lds, mt, nt, b, wave, lane); break;
   }
-  int mb = m0 >> 5;
-  if (mb >= (P.M >> 5)) mb = 0;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
-  f32x4 a[MAXT][2];
-#pragma unroll
-  for (int i = 0; i < NA0; ++i) {
-    const int q = wave + NW * i;
-    const int qc = q < total_taps ? q : total_taps - 1;
-    a[i][0] = wp[(size_t)(2 * qc) * 64];
-    a[i][1] = wp[(size_t)(2 * qc + 1) * 64];
-  }
-  // Interior tiles (no edge, mask or ragged limit inside the window -- all but the first and last column tile of a conv): rows are
-  // fetched with UNALIGNED dwordx4 loads, 64 / nvec rows per wave-instruction.  The texture-address path of a CU retires about
-  // one vector memory instruction per ~14 cycles whatever its width (measured: 16 waves x 36 dword loads kept the B tile of a
-  // k = 11 conv incomplete for 19 k cycles), so a staged row should be ONE wide instruction, not two narrow ones.
-  bool fast = false;
-  {
-    int t_lim = P.Tin;
-    if (P.in_mask) t_lim = __builtin_amdgcn_readfirstlane(len_raw) < t_lim ? __builtin_amdgcn_readfirstlane(len_raw) : t_lim;
-    if (P.rag) { const int il = __builtin_amdgcn_readfirstlane(rag_raw) * P.rag_in_mul + P.rag_in_add; t_lim = il < t_lim ? il : t_lim; }
-    fast = t_base >= 0 && t_base + ROW <= t_lim && ROW <= 256;
-  }
-  if (fast) {
-    const int nvec = ROW >> 2, rpi = 64 / nvec;            // vectors per row, rows per wave-instruction
-    const int rsub = lane / nvec, jv = lane - rsub * nvec;  // per-lane constants
-    const bool lok = rsub < rpi;
-    const int ngroups = (Cin + rpi - 1) / rpi;              // groups of rpi consecutive channels; wave w owns groups w, w + 16, ...
-    constexpr int GB = 8;                                   // groups per register batch
-    for (int g0 = wave; g0 < ngroups; g0 += NW * GB) {
-      f32x4 v[GB];
-#pragma unroll
-      for (int k = 0; k < GB; ++k) {
-        const int cch = (g0 + NW * k) * rpi + rsub;
-        const int cl = (cch < Cin && lok) ? cch : Cin - 1;
-        const unsigned off = (unsigned)(cl * P.Tin_stride + t_base + 4 * jv) * 4u;
-        f32x4 x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) + off);
-        if (NIN > 1) {
-          const f32x4 x2 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb2) + off);
-          const f32x4 x3 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb3) + off);
-          x = x + x2 + s3 * x3;
-        }
-        v[k] = x;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (g0 == wave) CONV_DBG(1);
-#pragma unroll
-      for (int k = 0; k < GB; ++k) {
-        const int cch = (g0 + NW * k) * rpi + rsub;
-        if (cch < Cin && lok) {
-          f32x4 o;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = conv_act_in(v[k][q], scale, slope);
-          *reinterpret_cast<f32x4*>(lds + cch * ROW + 4 * jv) = o;
-        }
-      }
-    }
-  } else
-  for (int r0 = 0; r0 * NW < Cin; r0 += RB) {
-    float v0[RB], v1[RB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int cch = wave + NW * (r0 + r);
-      const int cl = cch < Cin ? cch : Cin - 1;  // wave-uniform
-      const long long ro = (long long)cl * P.Tin_stride;
-      float x0 = ks_ld(xb + ro, toff[0]);
-      if (NIN > 1) x0 = x0 + ks_ld(xb2 + ro, toff[0]) + s3 * ks_ld(xb3 + ro, toff[0]);
-      v0[r] = x0;
-      float x1 = 0.f;
-      if (wide) {
-        x1 = ks_ld(xb + ro, toff[1]);
-        if (NIN > 1) x1 = x1 + ks_ld(xb2 + ro, toff[1]) + s3 * ks_ld(xb3 + ro, toff[1]);
-      }
-      v1[r] = x1;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything waits for len[b] / rag[b]
-    if (r0 == 0) CONV_DBG(1);
-    int t_lim = P.Tin;
-    if (P.in_mask) t_lim = len_raw < t_lim ? len_raw : t_lim;
-    if (P.rag) { const int il = rag_raw * P.rag_in_mul + P.rag_in_add; t_lim = il < t_lim ? il : t_lim; }
-    const bool ok0 = lane < ROW && tt[0] >= 0 && tt[0] < t_lim;
-    const bool ok1 = lane + 64 < ROW && tt[1] >= 0 && tt[1] < t_lim;
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int cch = wave + NW * (r0 + r);
-      if (cch < Cin) {  // wave-uniform
-        if (lane < ROW) lds[cch * ROW + lane] = ok0 ? conv_act_in(v0[r], scale, slope) : 0.f;  // select: stale padding may hold NaN
-        if (wide && lane + 64 < ROW) lds[cch * ROW + lane + 64] = ok1 ? conv_act_in(v1[r], scale, slope) : 0.f;
-      }
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);  // the bulk of the weight stream is requested only now
-#pragma unroll
-  for (int i = NA0; i < MAXT; ++i) {
-    const int q = wave + NW * i;
-    const int qc = q < total_taps ? q : total_taps - 1;
-    a[i][0] = wp[(size_t)(2 * qc) * 64];
-    a[i][1] = wp[(size_t)(2 * qc + 1) * 64];
-  }
-  // ragged batch: the whole tile is padding of this item (block-uniform; decided after the loads were issued)
-  if (P.rag && n0 >= rag_raw * P.rag_out_mul + P.rag_out_add) return;
-  CONV_DBG(2);
-  __syncthreads();
-  CONV_DBG(3);
-
-  // ---- 3. MFMAs: tap q = (chunk, kk): 8 k-steps p over channel pairs 16*chunk + 2p + h, B read one tap ahead
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  {
-    const float* bl = lds + h * ROW + l31 + tap_base;
-    int uc = wave / K, uk = wave - (wave / K) * K;
-    const int step_c = NW / K, step_k = NW - step_c * K;
-    // (4 waves per SIMD cover each other's LDS latency; no per-wave double buffering: the register file is full of weights)
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      if (i < my_taps) {
-        const float* bp = bl + uc * (CONV_CI_T * ROW) + uk * dil;
-        float bc[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) bc[p] = bp[2 * p * ROW];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][p >> 2][p & 3], bc[p], acc, 0, 0, 0);
-        uk += step_k;
-        uc += step_c + (uk >= K ? 1 : 0);
-        uk -= uk >= K ? K : 0;
-      }
-    }
-  }
-
-  // ---- 4. cross-wave reduction through LDS (the staged tile is dead) + one element per thread through the shared epilogue
-  CONV_DBG(4);
-  __syncthreads();
-  float* red = lds;  // [wave][e][lane]
-#pragma unroll
-  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
-  __syncthreads();
-  float v[1] = {0.f};
-#pragma unroll
-  for (int w = 0; w < NW; ++w) v[0] += red[(w * 16 + wave) * 64 + lane];
-  const int lenb = P.out_mask ? len_raw : 0x7fffffff;
-  CONV_DBG(5);
-  conv_epilogue_frag<EPI_STORE, 1>(P, G, b, lenb, m0 + 4 * h, wave, n0 + l31, v);
-  CONV_DBG(6);
 }
+

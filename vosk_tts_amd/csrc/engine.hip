@@ -1013,51 +1013,29 @@ static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, dou
   hipLaunchKernelGGL((conv16_kernel<EPI_STORE, 8, 8, 1>), grid, dim3(512), lds, s->stream, P);
 }
 
-// ---- LDS-staged 16-wave kernel for the single-utterance decoder (conv_small.hip.h conv_ls_kernel)
-static int g_ls_mode = 0;  // 0 = heuristic, 1 = never, 2 = whenever eligible (tests)
-static bool conv_ls_ok(const ConvParams& P, int epi, int halo, long nblk32) {
-  static const int env_mode = getenv("VITS_CONV_LS") ? atoi(getenv("VITS_CONV_LS")) : 0;
-  const int mode = g_ls_mode ? g_ls_mode : env_mode;
+// ---- wave-pipelined kernel for the single-utterance decoder's ResBlock convs (conv_small.hip.h conv_wp_kernel)
+static int g_wp_mode = 0;  // 0 = heuristic, 1 = never, 2 = whenever eligible (tests)
+static bool conv_wp_ok(const ConvParams& P, int epi, int halo, bool small) {
+  static const int env_mode = getenv("VITS_CONV_WP") ? atoi(getenv("VITS_CONV_WP")) : 0;
+  const int mode = g_wp_mode ? g_wp_mode : env_mode;
   if (mode == 1 || epi != EPI_STORE) return false;
-  if (P.x_split || P.x_ch_sign != 1 || P.x_ch_off || P.skip_len || P.tile_start || P.scale_b) return false;
-  if (P.ups_u && (P.ups_cout % 32)) return false;
-  int taps = 0;
-  for (int g = 0; g < P.n_groups; ++g) {
-    const int t = P.Cin / CONV_CI_T * P.g[g].K;
-    if (t > taps) taps = t;
-    if (P.g[g].x2 && !P.g[0].x2) return false;
-  }
-  if (cdiv(taps, 16) > (P.g[0].x2 ? 6 : 11)) return false;
-  const size_t lds = (size_t)P.Cin * ((32 + halo + 3) & ~3) * sizeof(float);
-  if (lds > 156 * 1024) return false;
-  // Measured on the single-utterance decoder (tools/convdbg.py): 24.7 us vs 24.2 us for the 16-wave K-split kernel on
-  // the k = 11 ResBlock conv and 3..10 % slower on the grouped launches -- removing both per-MFMA global loads from the loop
-  // does not help, so the kernel is kept as a tested alternative (VITS_CONV_LS=2 / vits_debug_conv_ls) and not dispatched.
-  (void)nblk32;
-  return mode == 2;
+  if (P.x_split || P.x_ch_sign != 1 || P.x_ch_off || P.skip_len || P.tile_start || P.ups_u || P.reflect || P.in_scale != 1.f || P.ln_g || P.bias_b || P.scale_b || P.relu) return false;
+  if (P.Cin % CONV_CI_T || P.Tin < 4 || 32 + halo > WP_PITCH || P.in_slope < 0.f || P.in_slope > 1.f) return false;
+  for (int g = 0; g < P.n_groups; ++g)
+    if (P.g[g].x2 || P.g[g].x3) return false;
+  if (mode == 2) return true;
+  // the decoder ResBlock regime: every wave gets at least one 16-channel chunk and a chunk carries >= 24 MFMAs
+  return small && P.Cin >= 8 * CONV_CI_T && (long)P.B * P.Tout >= 256;
 }
-static void launch_conv_ls(vits_session* s, ConvParams& P, int halo, ProfScope& ps) {
+static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
+  constexpr int NW = 8;
   P.tile_start = nullptr;
   P.ntiles_m = cdiv(P.M, 32);
   P.ntiles_n = cdiv(P.Tout, 32);
-  P.row_len = 32 + halo;
-  int taps = 0;
-  for (int g = 0; g < P.n_groups; ++g) { const int t = P.Cin / CONV_CI_T * P.g[g].K; if (t > taps) taps = t; }
-  const bool few = cdiv(taps, 16) <= 6;
-  const bool multi = P.g[0].x2 != nullptr;
-  size_t lds = (size_t)P.Cin * ((P.row_len + 3) & ~3) * sizeof(float);
-  if (lds < (size_t)16 * 16 * 64 * sizeof(float)) lds = (size_t)16 * 16 * 64 * sizeof(float);
+  const size_t lds = (size_t)NW * CONV_CI_T * WP_PITCH * sizeof(float);
   const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
-#define LS_GO(MAXT_, NIN_)                                                                                           \
-  do {                                                                                                               \
-    auto kern = conv_ls_kernel<MAXT_, NIN_>;                                                                         \
-    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)once;                                                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s->stream, P);                                                   \
-  } while (0)
-  if (multi) { ps.set_kernel("conv_ls_kernel<6,3>"); LS_GO(6, 3); }
-  else { ps.set_kernel(few ? "conv_ls_kernel<6,1>" : "conv_ls_kernel<11,1>"); if (few) LS_GO(6, 1); else LS_GO(11, 1); }
-#undef LS_GO
+  ps.set_kernel("conv_wp_kernel<8>");
+  hipLaunchKernelGGL(conv_wp_kernel<NW>, grid, dim3(NW * 64), lds, s->stream, P);
 }
 
 // would launch_conv route this launch to the small-tile kernel?  (callers that fold a LayerNorm into the consumer's staging
@@ -1143,10 +1121,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(s, P, halo); }
     return;
   }
-  if (small || g_ls_mode == 2) {
-    const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
-    if (conv_ls_ok(P, epi, halo, blocks32)) { launch_conv_ls(s, P, halo, ps); return; }
-  }
+  if (conv_wp_ok(P, epi, halo, small)) { launch_conv_wp(s, P, ps); return; }
   if (small) {
     const long blocks32 = (long)cdiv(P.M, 32) * cdiv(P.Tout, 32) * P.B * P.n_groups;
     const bool multi = P.g[0].x2 != nullptr;
@@ -2571,7 +2546,7 @@ void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
 void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
-void vits_debug_conv_ls(int mode) { g_ls_mode = mode; }
+void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
 
 int vits_session_sync(vits_session* s) {
@@ -2677,9 +2652,9 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
           fprintf(stderr, "   [big-tile] wave %d: prologue %lld  taps %lld  store+barrier %lld  mainloop_end %lld  end %lld  (MFMA floor %lld)\n", w, h[w * 8], h[w * 8 + 1],
                   h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], (long long)(Cin / 2) * K * 4 * 64);
       } else
-      for (int w = 0; w < 16; w += 5)
-        if (h[w * 8]) fprintf(stderr, "   wave %d: +%lld  +%lld  +%lld  +%lld  +%lld  +%lld  (K-split: loads-issued, loop, barrier, reduced, end | LDS-staged: loads-issued, stored, barrier, mfma, reduced-sync.., end)\n", w,
-                h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8], h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8], h[w * 8 + 6] - h[w * 8]);
+      for (int w = 0; w < 16; ++w)  // stamps relative to wave 0's start; HW_ID: simd = bits 5:4, cu = bits 11:8, se = bits 15:13
+        if (h[w * 8]) fprintf(stderr, "   wave %2d simd %lld cu %lld: start %+lld | +%lld  +%lld  +%lld  +%lld  +%lld  +%lld\n", w, (h[w * 8 + 7] >> 4) & 3, (h[w * 8 + 7] >> 8) & 15,
+                h[w * 8] - h[0], h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8], h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8], h[w * 8 + 6] - h[w * 8]);
     }
     if (d_dbg) hipFree(d_dbg);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ea);
