@@ -140,6 +140,7 @@ def test_wave_pipelined_decoder_conv_kernel(hip_lib, hip_default, oracle_lib, or
             want = op_conv1d(oracle_lib, x, w, bias, dil, slope)
             got = op_conv1d(hip_lib, x, w, bias, dil, slope)
             assert_close(f"conv_wp Cin={Cin} Cout={Cout} T={T} K={K} dil={dil}", want, got, 2e-5)
+        _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)  # per-item conditioning bias, masks, ragged tile skipping
         z = rng.standard_normal((1, 192, 47)).astype(np.float32)
         a_ref, mb_ref = oracle_default.decoder(z)
         for mode in (2, 1, 0):

@@ -120,6 +120,50 @@ def test_stts_medium_utterance_vs_oracle_and_long_form_properties(stts_pair):
     assert np.array_equal(m1, m3)
 
 
+def test_stts_fast_path_equals_eager(hip_lib, stts_pair):
+    """stts_synthesize replays two captured graphs per call (shape buckets: T_x to 8, frames to 32; scalars and inputs through
+    a device block) -- against the eager path (vits_debug_fast_path(0)) on the same seeds: lengths inside and on bucket borders,
+    with / without BERT rows and forced pauses, different seeds / temperatures / speakers / step counts on a cached bucket,
+    mel-only and audio-only calls, and an invalid token id (error, then the next call is clean)."""
+    hip, _ = stts_pair
+    rng = np.random.default_rng(101)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    cases = []
+    for Tx, use_bert, use_pde, seed, sid, n in [(13, True, True, 5, 2, 2), (16, False, True, 6, 0, 2), (11, True, False, 7, 3, 3),
+                                                (13, False, True, 8, 1, 2), (40, True, True, 9, 6, 2)]:
+        ids = rng.integers(1, 40, size=(5, Tx)).astype(np.int64)
+        bert = rng.standard_normal((768, Tx)).astype(np.float32) if use_bert else None
+        pde = rng.integers(2, 7, size=Tx).astype(np.float32) if use_pde else None
+        s2 = sc.copy()
+        s2[0] = 0.5 + 0.1 * (seed % 4)
+        cases.append((ids, s2, sid, bert, pde, seed, n))
+    try:
+        outs = {}
+        for on in (1, 0, 1):  # the second fast pass runs entirely on cached graphs
+            hip_lib.lib.vits_debug_fast_path(on)
+            outs[on] = [hip.synthesize(i, s2, sid, b, p, seed=sd, n_timesteps=n) for (i, s2, sid, b, p, sd, n) in cases]
+        for k, ((a1, m1), (a0, m0)) in enumerate(zip(outs[1], outs[0])):
+            assert a1.shape == a0.shape and m1.shape == m0.shape
+            assert_close(f"mel, case {k}", m0, m1, 2e-5)
+            assert_close(f"audio, case {k}", a0, a1, 5e-5)
+        hip_lib.lib.vits_debug_fast_path(1)
+        i, s2, sid, b, p, sd, n = cases[0]
+        a, m = outs[1][0]
+        _, m_only = hip.synthesize(i, s2, sid, b, p, seed=sd, n_timesteps=n, want_audio=False)
+        a_only, _ = hip.synthesize(i, s2, sid, b, p, seed=sd, n_timesteps=n, want_mel=False)
+        assert np.array_equal(m_only, m) and np.array_equal(a_only, a)
+        a_other, _ = hip.synthesize(i, s2, sid, b, p, seed=sd + 1, n_timesteps=n)
+        assert a_other.shape == a.shape and not np.array_equal(a_other, a)
+        bad = i.copy()
+        bad[0, 3] = 10 ** 6
+        with pytest.raises(Exception):
+            hip.synthesize(bad, s2, sid, b, p, seed=sd, n_timesteps=n)
+        a_again, _ = hip.synthesize(i, s2, sid, b, p, seed=sd, n_timesteps=n)
+        assert np.array_equal(a_again, a)
+    finally:
+        hip_lib.lib.vits_debug_fast_path(1)
+
+
 @pytest.mark.parametrize("name,hidden", [("bert_small", 128), ("bert_768", 768)])
 def test_bert_encoder_vs_transformers_golden(hip_lib, name, hidden):
     from vosk_tts_amd import weights_bert as BW

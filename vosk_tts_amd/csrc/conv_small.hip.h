@@ -554,7 +554,7 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   int bi = b;
   asm volatile("" : "+v"(bi));
   int len_raw = 0x7fffffff, rag_raw = 0x7fffffff;
-  if (P.in_mask || P.out_mask) len_raw = P.len[bi];
+  if (P.in_mask || P.out_mask || P.skip_len) len_raw = P.len[bi];
   if (P.rag) rag_raw = P.rag[bi];
 
   // slab geometry of this group: one load instruction = vector v16 (+ 16 in the second pass) of rows 4 j + r4: 4 instructions stage a
@@ -577,8 +577,11 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   const float* xb = G.x + (long long)b * P.x_bstride;
   const float slope = P.in_slope;
   f32x4 v0[4], v1[4];
+  const float* xb2 = G.x2 ? G.x2 + (long long)b * P.x_bstride : xb;  // channel-concatenated second input (x_split): chunks at or beyond the split
+  const int split_chunk = P.x_split ? P.x_split / CONV_CI_T : 0x7fffffff;
   auto load_slab = [&](int ci) {
-    const float* xc = xb + (long long)(wave + NW * ci) * CONV_CI_T * P.Tin_stride;
+    const int c = wave + NW * ci;
+    const float* xc = c >= split_chunk ? xb2 + (long long)(c - split_chunk) * CONV_CI_T * P.Tin_stride : xb + (long long)c * CONV_CI_T * P.Tin_stride;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       v0[j] = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(xc + 4 * j * P.Tin_stride) + (lrow + (unsigned)tcp[0]) * 4u);
@@ -610,6 +613,7 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   CONV_DBG(1);
   int t_lim = P.Tin;
   if (P.in_mask) { const int l = __builtin_amdgcn_readfirstlane(len_raw); t_lim = l < t_lim ? l : t_lim; }
+  if (P.skip_len && n0 >= __builtin_amdgcn_readfirstlane(len_raw)) return;  // masked stage: the whole tile lies in this item's padding
   if (P.rag) {
     const int rl = __builtin_amdgcn_readfirstlane(rag_raw);
     if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
@@ -738,7 +742,13 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
     for (int w = 0; w < NW; ++w) r += lds[w * (CONV_CI_T * WP_PITCH) + (NE * wave + ee) * 64 + lane];
     sum[ee] = r;
   }
-  // epilogue of this kernel's launches (the launcher rejects per-item bias / scale and output activations): bias, mask, residual
+  if (P.bias_b || P.scale_b || P.relu) {  // (kernel-uniform) per-item bias / gate, output activation: the shared epilogue
+    const int lenb = P.out_mask ? len_raw : 0x7fffffff;
+    conv_epilogue_frag<EPI_STORE, NE>(P, G, b, lenb, m0 + 4 * h, NE * wave, ecol, sum);
+    CONV_DBG(5);
+    return;
+  }
+  // plain epilogue on the prefetched operands: bias, mask, residual
   const bool masked = P.out_mask && ecol >= len_raw;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {

@@ -1019,12 +1019,13 @@ static bool conv_wp_ok(const ConvParams& P, int epi, int halo, bool small) {
   static const int env_mode = getenv("VITS_CONV_WP") ? atoi(getenv("VITS_CONV_WP")) : 0;
   const int mode = g_wp_mode ? g_wp_mode : env_mode;
   if (mode == 1 || epi != EPI_STORE) return false;
-  if (P.x_split || P.x_ch_sign != 1 || P.x_ch_off || P.skip_len || P.tile_start || P.ups_u || P.reflect || P.in_scale != 1.f || P.ln_g || P.bias_b || P.scale_b || P.relu) return false;
+  if (P.x_ch_sign != 1 || P.x_ch_off || P.tile_start || P.ups_u || P.reflect || P.in_scale != 1.f || P.ln_g || P.dds_y2) return false;
   if (P.Cin % CONV_CI_T || P.Tin < 4 || 32 + halo > WP_PITCH || P.in_slope < 0.f || P.in_slope > 1.f) return false;
+  if (P.x_split && (P.n_groups != 1 || P.x_split % CONV_CI_T || !P.g[0].x2)) return false;
   for (int g = 0; g < P.n_groups; ++g)
-    if (P.g[g].x2 || P.g[g].x3) return false;
+    if (P.g[g].x3 || (P.g[g].x2 && !P.x_split)) return false;
   if (mode == 2) return true;
-  // the decoder ResBlock regime: every wave gets at least one 16-channel chunk and a chunk carries >= 24 MFMAs
+  // every wave gets at least one 16-channel chunk; enough columns that 32-column tiles pay (the few-column regime belongs to conv16)
   return small && P.Cin >= 8 * CONV_CI_T && (long)P.B * P.Tout >= 256;
 }
 static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
@@ -1096,7 +1097,10 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   // few-column regime (a single utterance's encoder / duration predictor / flow): many small workgroups, LDS-staged B
   static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
-  if (g_force_tile == 3 || (g_force_tile == 0 && (long)P.B * P.Tout <= c16_cols)) {
+  // between ~200 and ~1000 columns the 16-column tiles re-read every weight once per column tile (19 times at 304 columns: the
+  // StableTTS estimator, 20 us per conv): the wave-pipelined 32x32 kernel takes those when it can
+  const bool wp_first = g_force_tile == 0 && (long)P.B * P.Tout > 192 && P.Cin >= 256 && !P.ln_g && !P.dds_y2 && conv_wp_ok(P, epi, halo, small);
+  if (!wp_first && (g_force_tile == 3 || (g_force_tile == 0 && (long)P.B * P.Tout <= c16_cols))) {
     const int nw16 = c16_waves(P, epi);
     if (nw16) {
       static const char* names[4] = {"conv16_kernel<STORE>", "conv16_kernel<GATE>", "conv16_kernel<RESSKIP>", "conv16_kernel<COUPLE>"};

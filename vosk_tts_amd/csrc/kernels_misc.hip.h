@@ -1187,10 +1187,14 @@ __global__ void copy_rows_kernel(const float* src, long long sb, float* dst, lon
 // z = randn * temperature (flow_matching.py:52) into the state rows of both CFG batch items
 // Batch of B utterances (blockIdx.z): item b's state also lives in CFG item B + b when cfg != 0; its library noise uses
 // the Philox stream of seed + b, i.e. exactly what a single-utterance call with that seed draws.
+// per-call scalars of the graph-replayed single-utterance path (stts.hip.h "fast path"): read from device memory so that one captured
+// graph serves every request of its shape bucket
+struct SttsDev { float temperature; float pad; unsigned long long seed; };
 __global__ void cfm_init_kernel(float* cat, long long cat_b, const float* noise, long long nstride, float temperature, uint64_t seed,
-                                int NF, int T, int B, int cfg) {
+                                int NF, int T, int B, int cfg, const SttsDev* dv) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
+  if (dv) { temperature = dv->temperature; seed = dv->seed; }
   const float v = (noise ? noise[(long long)c * nstride + t] : philox_normal(seed + (uint64_t)b, 3u, (uint32_t)c, (uint32_t)t)) * temperature;
   cat[(long long)b * cat_b + (long long)c * T + t] = v;
   if (cfg) cat[(long long)(B + b) * cat_b + (long long)c * T + t] = v;
@@ -1228,6 +1232,14 @@ __global__ void stts_mel_kernel(const float* cat, long long cat_b, int T, const 
   float v = 0.f;
   if (t < len[b]) v = (pau[(long long)b * T + t] > 0.f ? cb[(long long)c * T] : cb[(long long)c * T + t]) * mel_std + mel_mean;
   mel[((long long)b * NF + c) * Tm + t] = v;
+}
+// dst[b][0..G) = table[idx[b]][0..G)  (speaker embedding lookup with the id in device memory; out-of-range ids raise bit 2 of *err)
+__global__ void gather_rows_kernel(float* dst, const float* table, const int64_t* idx, int G, int n_rows, int* err) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= G) return;
+  long long r = idx[b];
+  if (r < 0 || r >= n_rows) { if (j == 0) atomicOr(err, 2); r = 0; }
+  dst[(long long)b * G + j] = table[r * G + j];
 }
 // dst[r][t] = vec[r % C]  (fake_content.repeat over frames and batch items, flow_matching.py:183-184)
 __global__ void fill_rows_kernel(float* dst, const float* vec, int T, int C) {

@@ -10,6 +10,8 @@ struct DitW {  // DiTConVBlock (models/components/diffusion_transformer.py:82-11
   float *a0w = nullptr, *a0b = nullptr, *a2w = nullptr, *a2b = nullptr;  // adaLN_modulation Linear(G,H), Linear(H,6H)
 };
 
+struct SttsFront;
+static void stts_front_free(SttsFront* f);
 struct stts_model {
   vits_model base;  // blob table, device allocations and the session pool (tget / upload / make_conv / pool_acquire)
   stts_hparams hp;
@@ -21,6 +23,8 @@ struct stts_model {
   std::vector<ConvW> lsc;
   float *t0w = nullptr, *t0b = nullptr, *t2w = nullptr, *t2b = nullptr;
   std::vector<float*> film_w, film_b;
+  std::map<int, SttsFront*> fronts;  // graph-replayed fast path of stts_synthesize: cached contexts by T_x bucket (under base.pool_mu)
+  uint64_t use_clock = 0;
 };
 
 static DitW load_dit(vits_model* b, const char* p, int H, int F, int K, int G) {
@@ -190,8 +194,9 @@ static size_t stts_enc_bytes(const stts_hparams& hp, int B, int T) {
   const size_t H = hp.enc_hidden, F = hp.enc_filter;
   return ((size_t)B * T * (H * 2 + 3 * H + H + F) + (size_t)B * (hp.spk_emb_dim + H + hp.enc_layers * 6 * H)) * sizeof(float) + 64 * 1024;
 }
+// speaker ids: sid_host (eager calls: one D2D copy per item) or d_sid (graph capture: gathered on the device)
 static void stts_run_encoder(vits_session* s, const stts_model* m, const int64_t* d_ids, const int* d_len, const int64_t* sid_host, int B,
-                             int T, const float* d_bert, float* d_x, float* d_mu) {
+                             int T, const float* d_bert, float* d_x, float* d_mu, const int64_t* d_sid = nullptr) {
   const stts_hparams& hp = m->hp;
   const int H = hp.enc_hidden, F = hp.enc_filter, G = hp.spk_emb_dim, E = hp.emb_dim, Pd = hp.punc_dim, NE = E + 4 * Pd;
   SttsEncBufs w;
@@ -205,8 +210,11 @@ static void stts_run_encoder(vits_session* s, const stts_model* m, const int64_t
   launch_conv(s, P, EPI_STORE, "enc.bert_proj");
   hipMemcpyAsync(w.h, d_x, sizeof(float) * (size_t)B * H * T, hipMemcpyDeviceToDevice, s->stream);
   hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(T, 64), H, B), dim3(64), 0, s->stream, w.h, d_len, H, T);
+  if (d_sid && hp.n_spks > 1)
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(G, 64), B), dim3(64), 0, s->stream, w.cvec, m->dur_spk_emb, d_sid, G, hp.n_spks, s->d_err);
+  else
   for (int b = 0; b < B; ++b)  // dur_spks = dur_spk_emb(sid) (matcha_tts.py:139)
-    hipMemcpyAsync(w.cvec + (size_t)b * G, hp.n_spks > 1 ? m->dur_spk_emb + (size_t)sid_host[b] * G : m->zero_vec, sizeof(float) * G,
+    hipMemcpyAsync(w.cvec + (size_t)b * G, (hp.n_spks > 1 && sid_host) ? m->dur_spk_emb + (size_t)sid_host[b] * G : m->zero_vec, sizeof(float) * G,
                    hipMemcpyDeviceToDevice, s->stream);
   stts_modulations(s, m->enc, w.cvec, B, H, G, w.tmp, w.mods);
   for (int i = 0; i < hp.enc_layers; ++i)
@@ -225,6 +233,7 @@ struct SttsEst {
   int* lenT;  // [nb] frames per item rounded up to a multiple of 4: where a single-utterance run's tensors END, i.e. where the
               // unmasked convs (cond_proj, long-skip) see zero padding; equals T for one utterance
   std::vector<float> host_sinus;
+  bool tables_ready = false;  // the per-step time tables (sinus, t1, temb, film: functions of n_steps only) are already resident
 };
 static size_t stts_est_bytes(const stts_hparams& hp, int nb, int T, int n_steps) {
   const size_t H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers;
@@ -250,7 +259,7 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
   // and the FiLM projections of all blocks as GEMVs over the n_steps columns (components/decoder.py:35-62,15-33)
   float* sinus = bump<float>(s, (size_t)n * H); float* t1 = bump<float>(s, (size_t)n * F); float* temb = bump<float>(s, (size_t)n * H);
   E.film = bump<float>(s, (size_t)NL * n * 2 * H);
-  {
+  if (!E.tables_ready) {
     std::vector<float>& hs = E.host_sinus;  // must outlive the asynchronous copy below: owned by the call's SttsEst
     hs.resize((size_t)n * H);
     const int half = H / 2;
@@ -261,10 +270,10 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
         hs[(size_t)k * H + j] = sinf(a); hs[(size_t)k * H + half + j] = cosf(a);
       }
     hipMemcpyAsync(sinus, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice, s->stream);
+    stts_gemv(s, m->t0w, m->t0b, sinus, H, t1, F, F, H, n, 1);
+    stts_gemv(s, m->t2w, m->t2b, t1, F, temb, H, H, F, n, 0);
+    for (int i = 0; i < NL; ++i) stts_gemv(s, m->film_w[i], m->film_b[i], temb, H, E.film + (size_t)i * n * 2 * H, 2 * H, 2 * H, H, n, 0);
   }
-  stts_gemv(s, m->t0w, m->t0b, sinus, H, t1, F, F, H, n, 1);
-  stts_gemv(s, m->t2w, m->t2b, t1, F, temb, H, H, F, n, 0);
-  for (int i = 0; i < NL; ++i) stts_gemv(s, m->film_w[i], m->film_b[i], temb, H, E.film + (size_t)i * n * 2 * H, 2 * H, 2 * H, H, n, 0);
   float* tmp = bump<float>(s, (size_t)nb * H);
   E.mods = bump<float>(s, (size_t)NL * nb * 6 * H);
   stts_modulations(s, m->dec, d_c, nb, H, G, tmp, E.mods);
@@ -417,13 +426,15 @@ static void stts_durations_host(const stts_hparams& hp, const float* mu_dp, int 
 // d_mu2 [nb][enc_hidden][T] (item 1 pre-filled with fake_content), result: state rows of E.cat item 0
 // B utterances; E.nb = B (no guidance) or 2B (items [B,2B) = the unconditional branch of items [0,B))
 static void stts_run_cfm(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu2, const int* d_len, const float* d_noise,
-                         long long nstride, float temperature, uint64_t seed, int B = 1, const int* d_lenT = nullptr) {
+                         long long nstride, float temperature, uint64_t seed, int B = 1, const int* d_lenT = nullptr, const SttsDev* dv = nullptr,
+                         bool setup_only = false) {
   const stts_hparams& hp = m->hp;
   const int NF = hp.n_feats, H = hp.dec_hidden, T = E.T, cfg = E.nb > B ? 1 : 0;
   std::vector<float> tv, dtv;
   stts_time_grid(E.n_steps, tv, dtv);
   stts_est_setup(s, m, E, d_c, d_mu2, d_len, tv.data(), d_lenT);
-  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, B, cfg);
+  if (setup_only) return;
+  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, B, cfg, dv);
   for (int k = 0; k < E.n_steps; ++k) {
     stts_est_step(s, m, E, k);
     hipLaunchKernelGGL(cfm_euler_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, E.dphi, dtv[k], hp.guidance_scale, NF, T, B, cfg);
@@ -471,6 +482,7 @@ int stts_create(const void* blob, size_t bytes, vits_model* vocoder, int device,
 void stts_destroy(stts_model* m) {
   if (!m) return;
   hipSetDevice(m->base.device);
+  for (auto& kv : m->fronts) stts_front_free(kv.second);
   for (vits_session* s : m->base.pool) session_free(s);
   for (void* a : m->base.allocs) hipFree(a);
   delete m;
@@ -565,11 +577,331 @@ int stts_stage_cfm(stts_model* m, const float* mu_y, int64_t y_length, int32_t T
   return check_err(s);
 }
 
+}  // extern "C"
+
+// ---- fast path of stts_synthesize -----------------------------------------------------------------------------------
+// One utterance costs ~310 launches; issued eagerly the host needs longer than the GPU (m2: 5.6 ms wall for ~3 ms of kernels, and
+// 8 ms on a slower host).  Same recipe as the VITS entry point (engine.hip "fast path"): per-call scalars in a device block
+// (SttsDev), inputs through a pinned block copied by a memcpy node, shapes bucketed (T_x to a multiple of 8, frames to a
+// multiple of 32) and two captured graphs around the one host round trip the path needs (durations -> T_y):
+//   FRONT (T_x bucket): H2D, text encoder, duration logits D2H.       BACK (frame bucket, n_steps): H2D, expand, speaker
+//   vectors, cond_proj, n Euler steps of the estimator (CFG twins as a batch of 2), mel, vocoder (bucketed single utterance:
+//   zeros beyond the item's own end at every stage), clamp, D2H.
+// Bucketing is exact by the argument of stts_synthesize_batch: a padded item equals its own exact-size call because every
+// masked op masks per item and the unmasked convs read zeros beyond the item's own length rounded up to 4 (lenT).  The time
+// tables of the estimator (functions of n_steps only) are computed once when a BACK context is created.  Calls that inject a
+// noise tensor (parity tests) and VITS_NO_FASTPATH / vits_debug_fast_path(0) take the eager path.
+struct SttsBack {
+  vits_session* s = nullptr;   // estimator workspace (arena, error word); launches go onto the front's stream
+  vits_session* sv = nullptr;  // vocoder workspace (a session of the vocoder model owned by this context)
+  int TB = 0, n = 0, nb = 0;
+  SttsEst E;
+  char* buf = nullptr;         // d_mu2 | d_pau | d_c | d_mel | d_audio
+  float *d_mu2 = nullptr, *d_pau = nullptr, *d_c = nullptr, *d_mel = nullptr, *d_audio = nullptr;
+  float* out_h = nullptr;      // pinned: audio [TB * hop] | mel [NF * TB]
+  size_t audio_elems = 0;
+  hipGraphExec_t g[2] = {nullptr, nullptr};  // [with vocoder]
+  uint64_t last_use = 0;
+};
+struct SttsFront {
+  vits_session* s = nullptr;   // stream + encoder workspace
+  int TxB = 0;
+  char *io_h = nullptr, *io_d = nullptr;  // pinned host mirror / device copy of the per-call inputs (region A: phase 1, region B: phase 2)
+  size_t io_bytes = 0, a_bytes = 0, o_len = 0, o_sid = 0, o_bert = 0, o_dev = 0, o_cum = 0, o_pde = 0, o_len2 = 0, o_lenT = 0;
+  float *d_x = nullptr, *d_mu = nullptr;
+  float* mu_h = nullptr;       // pinned [dp_out * TxB] + one int error word behind it
+  hipGraphExec_t g1 = nullptr;
+  std::map<std::pair<int, int>, SttsBack*> backs;  // (frame bucket, n_steps)
+  uint64_t last_use = 0, clock = 0;
+};
+
+static void stts_back_free(SttsBack* b) {
+  if (!b) return;
+  for (int i = 0; i < 2; ++i) if (b->g[i]) hipGraphExecDestroy(b->g[i]);
+  if (b->buf) hipFree(b->buf);
+  if (b->out_h) hipHostFree(b->out_h);
+  if (b->sv) session_free(b->sv);
+  if (b->s) { b->s->stream = nullptr; session_free(b->s); }
+  delete b;
+}
+static void stts_front_free(SttsFront* f) {
+  if (!f) return;
+  if (f->s && f->s->stream) hipStreamSynchronize(f->s->stream);
+  for (auto& kv : f->backs) stts_back_free(kv.second);
+  if (f->g1) hipGraphExecDestroy(f->g1);
+  if (f->io_h) hipHostFree(f->io_h);
+  if (f->io_d) hipFree(f->io_d);
+  if (f->d_x) hipFree(f->d_x);
+  if (f->d_mu) hipFree(f->d_mu);
+  if (f->mu_h) hipHostFree(f->mu_h);
+  if (f->s) session_free(f->s);
+  delete f;
+}
+
+static int stts_front_acquire(stts_model* m, int TxB, SttsFront** out) {
+  {
+    std::lock_guard<std::mutex> g(m->base.pool_mu);
+    auto it = m->fronts.find(TxB);
+    if (it != m->fronts.end()) { *out = it->second; m->fronts.erase(it); return VITS_OK; }
+  }
+  const stts_hparams& hp = m->hp;
+  SttsFront* f = new SttsFront();
+  f->TxB = TxB;
+  int rc = session_new(&m->base, &f->s);
+  if (rc == VITS_OK) rc = stts_arena(f->s, stts_enc_bytes(hp, 1, TxB));
+  // region A: [ids int64 [5, TxB] | len int | sid int64 | bert float [bert_dim, TxB]]   region B: [SttsDev | cum int [TxB] | pde float [TxB] | len [2] | lenT [2]]
+  f->o_len = align_up(sizeof(int64_t) * 5 * (size_t)TxB, 64);
+  f->o_sid = f->o_len + 64;
+  f->o_bert = f->o_sid + 64;
+  f->a_bytes = f->o_bert + align_up(sizeof(float) * (size_t)hp.bert_dim * TxB, 256);
+  f->o_dev = f->a_bytes;
+  f->o_cum = f->o_dev + align_up(sizeof(SttsDev), 64);
+  f->o_pde = f->o_cum + align_up(sizeof(int) * (size_t)TxB, 64);
+  f->o_len2 = f->o_pde + align_up(sizeof(float) * (size_t)TxB, 64);
+  f->o_lenT = f->o_len2 + 64;
+  f->io_bytes = f->o_lenT + 64;
+  const size_t nmu = (size_t)hp.dp_out * TxB;
+  if (rc == VITS_OK && (hipHostMalloc((void**)&f->io_h, f->io_bytes) != hipSuccess || hipMalloc((void**)&f->io_d, f->io_bytes) != hipSuccess ||
+                        hipMalloc((void**)&f->d_x, sizeof(float) * (size_t)hp.enc_hidden * TxB) != hipSuccess ||
+                        hipMalloc((void**)&f->d_mu, sizeof(float) * nmu) != hipSuccess ||
+                        hipHostMalloc((void**)&f->mu_h, sizeof(float) * nmu + 64) != hipSuccess))
+    rc = fail(VITS_ERR_NOMEM, "fast-path staging buffers");
+  if (rc == VITS_OK) {
+    memset(f->io_h, 0, f->io_bytes);
+    if (hipMemsetAsync(f->io_d, 0, f->io_bytes, f->s->stream) != hipSuccess) rc = fail(VITS_ERR_DEVICE, "memset failed");
+  }
+  if (rc != VITS_OK) { stts_front_free(f); return rc; }
+  *out = f;
+  return VITS_OK;
+}
+static void stts_front_release(stts_model* m, SttsFront* f) {
+  std::vector<SttsFront*> evict;
+  {
+    std::lock_guard<std::mutex> g(m->base.pool_mu);
+    f->last_use = ++m->use_clock;
+    auto it = m->fronts.find(f->TxB);
+    if (it != m->fronts.end()) { evict.push_back(it->second); m->fronts.erase(it); }  // a concurrent call built the same bucket: keep the newer
+    m->fronts[f->TxB] = f;
+    while (m->fronts.size() > 16) {
+      auto lru = m->fronts.begin();
+      for (auto jt = m->fronts.begin(); jt != m->fronts.end(); ++jt) if (jt->second->last_use < lru->second->last_use) lru = jt;
+      evict.push_back(lru->second);
+      m->fronts.erase(lru);
+    }
+  }
+  for (SttsFront* e : evict) stts_front_free(e);
+}
+
+static int stts_back_get(stts_model* m, SttsFront* F, int TB, int n, SttsBack** out) {
+  const auto key = std::make_pair(TB, n);
+  auto it = F->backs.find(key);
+  if (it != F->backs.end()) { it->second->last_use = ++F->clock; *out = it->second; return VITS_OK; }
+  if (F->backs.size() >= 4) {
+    auto lru = F->backs.begin();
+    for (auto jt = F->backs.begin(); jt != F->backs.end(); ++jt) if (jt->second->last_use < lru->second->last_use) lru = jt;
+    hipStreamSynchronize(F->s->stream);
+    stts_back_free(lru->second);
+    F->backs.erase(lru);
+  }
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats, CC = hp.enc_hidden, G = hp.spk_emb_dim;
+  SttsBack* b = new SttsBack();
+  b->TB = TB; b->n = n; b->nb = hp.guidance_scale > 0.f ? 2 : 1;
+  b->s = new vits_session();
+  b->s->m = &m->base; b->s->stream = F->s->stream; b->s->own_stream = false;
+  int rc = VITS_OK;
+  if (hipMalloc((void**)&b->s->d_err, sizeof(int)) != hipSuccess || hipMemsetAsync(b->s->d_err, 0, sizeof(int), F->s->stream) != hipSuccess)
+    rc = fail(VITS_ERR_NOMEM, "back context");
+  if (rc == VITS_OK) rc = stts_arena(b->s, stts_est_bytes(hp, b->nb, TB, n));
+  const int hop = m->vocoder ? m->vocoder->hp.hop_length : 0;
+  b->audio_elems = (size_t)TB * hop;
+  const size_t o_pau = align_up(sizeof(float) * (size_t)b->nb * CC * TB, 256), o_c = o_pau + align_up(sizeof(float) * (size_t)TB, 256),
+               o_mel = o_c + align_up(sizeof(float) * (size_t)b->nb * G, 256), o_audio = o_mel + align_up(sizeof(float) * (size_t)NF * TB, 256),
+               total = o_audio + align_up(sizeof(float) * (b->audio_elems + 1), 256);
+  if (rc == VITS_OK && (hipMalloc((void**)&b->buf, total) != hipSuccess || hipMemsetAsync(b->buf, 0, total, F->s->stream) != hipSuccess ||
+                        hipHostMalloc((void**)&b->out_h, sizeof(float) * (b->audio_elems + (size_t)NF * TB + 1)) != hipSuccess))
+    rc = fail(VITS_ERR_NOMEM, "fast-path buffers of frame bucket %d", TB);
+  if (rc == VITS_OK) {
+    b->d_mu2 = reinterpret_cast<float*>(b->buf); b->d_pau = reinterpret_cast<float*>(b->buf + o_pau); b->d_c = reinterpret_cast<float*>(b->buf + o_c);
+    b->d_mel = reinterpret_cast<float*>(b->buf + o_mel); b->d_audio = reinterpret_cast<float*>(b->buf + o_audio);
+    if (m->vocoder) {
+      rc = session_new(m->vocoder, &b->sv);
+      if (rc == VITS_OK) rc = session_reserve(b->sv, 1, 1, TB);
+    }
+  }
+  if (rc == VITS_OK) {
+    // time tables of the estimator on the final arena layout (the captured run finds them resident)
+    b->E.nb = b->nb; b->E.T = TB; b->E.n_steps = n; b->E.tables_ready = false;
+    b->s->arena_used = 0;
+    stts_run_cfm(b->s, m, b->E, b->d_c, b->d_mu2, reinterpret_cast<const int*>(F->io_d + F->o_len2), nullptr, TB, 0.f, 0, 1,
+                 reinterpret_cast<const int*>(F->io_d + F->o_lenT), nullptr, true);
+    if (hipStreamSynchronize(F->s->stream) != hipSuccess) rc = fail(VITS_ERR_DEVICE, "estimator table setup failed");
+    b->E.tables_ready = true;
+  }
+  if (rc != VITS_OK) { stts_back_free(b); return rc; }
+  b->last_use = ++F->clock;
+  F->backs[key] = b;
+  *out = b;
+  return VITS_OK;
+}
+
+static int stts_phase1(stts_model* m, SttsFront* F) {
+  vits_session* s = F->s;
+  if (!F->g1) {
+    const stts_hparams& hp = m->hp;
+    const size_t nmu = (size_t)hp.dp_out * F->TxB;
+    s->arena_used = 0;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    hipMemcpyAsync(F->io_d, F->io_h, F->a_bytes, hipMemcpyHostToDevice, s->stream);
+    stts_run_encoder(s, m, reinterpret_cast<const int64_t*>(F->io_d), reinterpret_cast<const int*>(F->io_d + F->o_len), nullptr, 1, F->TxB,
+                     reinterpret_cast<const float*>(F->io_d + F->o_bert), F->d_x, F->d_mu, reinterpret_cast<const int64_t*>(F->io_d + F->o_sid));
+    hipMemcpyAsync(F->mu_h, F->d_mu, sizeof(float) * nmu, hipMemcpyDeviceToHost, s->stream);
+    hipMemcpyAsync(F->mu_h + nmu, s->d_err, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+    TRY(capture_end(s, &F->g1));
+  }
+  HIP_TRY(hipGraphLaunch(F->g1, s->stream));
+  return VITS_OK;
+}
+
+static int stts_phase2(stts_model* m, SttsFront* F, SttsBack* Bk, bool audio) {
+  const int gi = audio ? 1 : 0;
+  hipStream_t st = F->s->stream;
+  if (!Bk->g[gi]) {
+    const stts_hparams& hp = m->hp;
+    const int NF = hp.n_feats, CC = hp.enc_hidden, G = hp.spk_emb_dim, H = hp.dec_hidden, TB = Bk->TB, nb = Bk->nb;
+    vits_session* s = Bk->s;
+    const int* d_cum = reinterpret_cast<const int*>(F->io_d + F->o_cum);
+    const float* d_pde = reinterpret_cast<const float*>(F->io_d + F->o_pde);
+    const int* d_len = reinterpret_cast<const int*>(F->io_d + F->o_len2);
+    const int* d_lenT = reinterpret_cast<const int*>(F->io_d + F->o_lenT);
+    const int64_t* d_sid = reinterpret_cast<const int64_t*>(F->io_d + F->o_sid);
+    const SttsDev* dv = reinterpret_cast<const SttsDev*>(F->io_d + F->o_dev);
+    s->arena_used = 0;
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    hipMemcpyAsync(F->io_d + F->a_bytes, F->io_h + F->a_bytes, F->io_bytes - F->a_bytes, hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(stts_expand_kernel, dim3(cdiv(TB, 64), CC, 1), dim3(64), 0, st, F->d_x, d_cum, F->TxB, Bk->d_mu2, CC, TB, d_pde, Bk->d_pau);
+    if (hp.n_spks > 1) hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(G, 64), 1), dim3(64), 0, st, Bk->d_c, m->spk_emb, d_sid, G, hp.n_spks, s->d_err);
+    else hipMemcpyAsync(Bk->d_c, m->zero_vec, sizeof(float) * G, hipMemcpyDeviceToDevice, st);
+    if (nb == 2) {
+      hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(TB, 64), CC), dim3(64), 0, st, Bk->d_mu2 + (size_t)CC * TB, m->fake_content, TB, CC);
+      hipMemcpyAsync(Bk->d_c + G, m->fake_speaker, sizeof(float) * G, hipMemcpyDeviceToDevice, st);
+    }
+    stts_run_cfm(s, m, Bk->E, Bk->d_c, Bk->d_mu2, d_len, nullptr, TB, 0.f, 0, 1, d_lenT, dv);
+    hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv(TB, 64), NF, 1), dim3(64), 0, st, Bk->E.cat, (long long)(NF + H) * TB, TB, Bk->d_pau, Bk->d_mel, NF, TB, d_len,
+                       hp.mel_std, hp.mel_mean);
+    if (audio) {
+      vits_session* sv = Bk->sv;
+      hipStream_t own = sv->stream;
+      sv->stream = st;
+      sv->tile_keys.clear();
+      sv->ragged = true; sv->rag_b1 = true;
+      hipMemcpyAsync(sv->len_y, d_len, sizeof(int), hipMemcpyDeviceToDevice, st);
+      run_decoder(sv, Bk->d_mel, false, 1, TB, Bk->d_audio, (long long)Bk->audio_elems, nullptr, true, 0);
+      sv->ragged = false; sv->rag_b1 = false;
+      sv->stream = own;
+      hipLaunchKernelGGL(clamp_kernel, dim3(cdiv((int)Bk->audio_elems, 256)), dim3(256), 0, st, Bk->d_audio, (long long)Bk->audio_elems);
+      hipMemcpyAsync(Bk->out_h, Bk->d_audio, sizeof(float) * Bk->audio_elems, hipMemcpyDeviceToHost, st);
+    }
+    hipMemcpyAsync(Bk->out_h + Bk->audio_elems, Bk->d_mel, sizeof(float) * (size_t)NF * TB, hipMemcpyDeviceToHost, st);
+    TRY(capture_end(F->s, &Bk->g[gi]));
+  }
+  HIP_TRY(hipGraphLaunch(Bk->g[gi], st));
+  return VITS_OK;
+}
+
+static int stts_synth_fast(stts_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const float* bert, const float* pde,
+                           const stts_synth_opts* opts, float** out_audio, int64_t* out_samples, float** out_mel, int64_t* out_frames) {
+  const stts_hparams& hp = m->hp;
+  const int NF = hp.n_feats;
+  const int n = (opts && opts->n_timesteps > 0) ? opts->n_timesteps : hp.n_timesteps;
+  HIP_TRY(hipSetDevice(m->base.device));
+  const int TxB = (Tx + 7) / 8 * 8;
+  SttsFront* F = nullptr;
+  TRY(stts_front_acquire(m, TxB, &F));
+  struct Rel { stts_model* m; SttsFront* f; ~Rel() { stts_front_release(m, f); } } rel{m, F};
+  hipStream_t st = F->s->stream;
+  // ---- inputs -> pinned block (rows re-strided to the bucket, padding zero)
+  int64_t* h_ids = reinterpret_cast<int64_t*>(F->io_h);
+  for (int r = 0; r < 5; ++r) {
+    memcpy(h_ids + (size_t)r * TxB, ids + (size_t)r * Tx, sizeof(int64_t) * Tx);
+    for (int t = Tx; t < TxB; ++t) h_ids[(size_t)r * TxB + t] = 0;
+  }
+  *reinterpret_cast<int*>(F->io_h + F->o_len) = Tx;
+  *reinterpret_cast<int64_t*>(F->io_h + F->o_sid) = sid;
+  float* h_bert = reinterpret_cast<float*>(F->io_h + F->o_bert);
+  if (bert) {
+    for (int r = 0; r < hp.bert_dim; ++r) {
+      memcpy(h_bert + (size_t)r * TxB, bert + (size_t)r * Tx, sizeof(float) * Tx);
+      for (int t = Tx; t < TxB; ++t) h_bert[(size_t)r * TxB + t] = 0.f;
+    }
+  } else {
+    memset(h_bert, 0, sizeof(float) * (size_t)hp.bert_dim * TxB);
+  }
+  // ---- phase 1 and the one host round trip
+  TRY(stts_phase1(m, F));
+  HIP_TRY(hipStreamSynchronize(st));
+  const size_t nmu = (size_t)hp.dp_out * TxB;
+  {
+    int e = 0;
+    memcpy(&e, F->mu_h + nmu, sizeof(int));
+    if (e) {
+      hipMemsetAsync(F->s->d_err, 0, sizeof(int), st);
+      return fail(VITS_ERR_ARG, (e & 2) ? "speaker id out of range" : "token id out of range");
+    }
+  }
+  float* h_pde = reinterpret_cast<float*>(F->io_h + F->o_pde);
+  for (int t = 0; t < TxB; ++t) h_pde[t] = (pde && t < Tx) ? pde[t] : 0.f;
+  std::vector<int32_t> dur(TxB);
+  int64_t ytot = 0;
+  stts_durations_host(hp, F->mu_h, 1, TxB, scales[1], pde ? h_pde : nullptr, dur.data(), &ytot);
+  int* h_cum = reinterpret_cast<int*>(F->io_h + F->o_cum);
+  int ylen = 0;
+  for (int j = 0; j < TxB; ++j) { if (j < Tx) ylen += dur[j]; h_cum[j] = ylen; }  // only the utterance's own tokens count
+  if (ylen > (1 << 22)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  const int T4 = (ylen + 3) / 4 * 4;  // fix_len_compatibility (utils/model.py:14-20): where the exact-size run's tensors end
+  const int TB = (T4 + 31) / 32 * 32;
+  SttsDev* hv = reinterpret_cast<SttsDev*>(F->io_h + F->o_dev);
+  hv->temperature = scales[0]; hv->pad = 0.f; hv->seed = opts ? opts->seed : 0;
+  int* h_len2 = reinterpret_cast<int*>(F->io_h + F->o_len2);
+  int* h_lenT = reinterpret_cast<int*>(F->io_h + F->o_lenT);
+  h_len2[0] = h_len2[1] = ylen;
+  h_lenT[0] = h_lenT[1] = T4;
+  // ---- phase 2
+  SttsBack* Bk = nullptr;
+  TRY(stts_back_get(m, F, TB, n, &Bk));
+  const bool audio = out_audio != nullptr;
+  TRY(stts_phase2(m, F, Bk, audio));
+  const int64_t S = audio ? (int64_t)ylen * m->vocoder->hp.hop_length : 0;
+  float* h_audio = audio ? static_cast<float*>(malloc(sizeof(float) * (size_t)(S ? S : 1))) : nullptr;
+  float* h_mel = out_mel ? static_cast<float*>(malloc(sizeof(float) * (size_t)NF * (ylen ? ylen : 1))) : nullptr;
+  if ((audio && !h_audio) || (out_mel && !h_mel)) { hipStreamSynchronize(st); free(h_audio); free(h_mel); return fail(VITS_ERR_NOMEM, "host alloc failed"); }
+  hipError_t se = hipStreamSynchronize(st);
+  hipError_t le = hipGetLastError();
+  if (se != hipSuccess || le != hipSuccess) {
+    free(h_audio); free(h_mel);
+    return fail(VITS_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(se != hipSuccess ? se : le));
+  }
+  if (audio) { memcpy(h_audio, Bk->out_h, sizeof(float) * (size_t)S); *out_audio = h_audio; *out_samples = S; }
+  if (out_mel) {
+    const float* hm = Bk->out_h + Bk->audio_elems;
+    for (int c = 0; c < NF; ++c) memcpy(h_mel + (size_t)c * ylen, hm + (size_t)c * TB, sizeof(float) * (size_t)ylen);
+    *out_mel = h_mel; *out_frames = ylen;
+  }
+  return VITS_OK;
+}
+
+extern "C" {
+
 int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const float* bert, const float* pde,
                     const stts_synth_opts* opts, float** out_audio, int64_t* out_samples, float** out_mel, int64_t* out_frames) {
   if (!m || !ids || !scales || Tx <= 0 || (out_audio && !out_samples) || (out_mel && !out_frames)) return fail(VITS_ERR_ARG, "bad argument");
   if (out_audio && !m->vocoder) return fail(VITS_ERR_ARG, "no vocoder attached");
   TRY(stts_check_sid(m, &sid, 1));
+  {
+    static const bool env_off = getenv("VITS_NO_FASTPATH") != nullptr;
+    if (g_fast_path && !env_off && !(opts && opts->noise))
+      return stts_synth_fast(m, ids, Tx, scales, sid, bert, pde, opts, out_audio, out_samples, out_mel, out_frames);
+  }
   const stts_hparams& hp = m->hp;
   const int NF = hp.n_feats, CC = hp.enc_hidden, G = hp.spk_emb_dim, H = hp.dec_hidden;
   const float temperature = scales[0], length_scale = scales[1];
