@@ -460,6 +460,53 @@ def test_c3_full_size_batch_parity(hip_default, oracle_default):
     _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 4, seed=7)
 
 
+def test_bf16x3_decoder_variant(hip_lib, oracle_default):
+    """hparams.conv_precision = 1 (BASELINE configs[2]'s reduced-precision variant in its accuracy-preserving form): the decoder's
+    ResBlock convs at batch size run as 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulation, conv_bf3_kernel).
+    Stage level (dense batch of 8 x 400 frames: both decoder stages take the 128 x 128 kernel) and the full-size c3 batch of the
+    bench, against the same model's fp32 kernels (vits_debug_no_bf16x3) and against the oracle.  Tolerance: the north_star's 1e-3
+    end to end; the assertion is 20x tighter (a fragment-layout bug shows up as O(1))."""
+    from vosk_tts_amd import weights as W
+
+    hp = W.default_hparams()
+    hp.conv_precision = 1
+    model = hip_lib.create(W.synthetic_blob(hp, 1234), 0)
+    rng = np.random.default_rng(31)
+    try:
+        z = rng.standard_normal((8, 192, 400)).astype(np.float32)
+        a_bf, mb_bf = model.decoder(z)
+        hip_lib.lib.vits_debug_no_bf16x3(1)
+        a_fp, mb_fp = model.decoder(z)
+        hip_lib.lib.vits_debug_no_bf16x3(0)
+        assert not np.array_equal(a_bf, a_fp)  # the variant really ran
+        assert_close("decoder audio_mb: bf16x3 vs fp32 kernels", mb_fp, mb_bf, 5e-5)
+        assert_close("decoder audio: bf16x3 vs fp32 kernels", a_fp, a_bf, 5e-5)
+        a_ref, _ = oracle_default.decoder(z[:1])
+        assert_close("decoder audio: bf16x3 vs oracle", a_ref[0], a_bf[0], 5e-5)
+        # the bench's c3 batch through the full path
+        ids, lengths, dur = _bench_workload("c3")
+        B = ids.shape[0]
+        sid = np.full(B, 2, np.int64)
+        scales = np.array([0.8, 1.0, 0.8], np.float32)
+        ylens = dur.sum(1).astype(np.int64)
+        noise = rng.standard_normal((B, 192, int(ylens.max()))).astype(np.float32)
+        w_bf, l_bf = model.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+        hip_lib.lib.vits_debug_no_bf16x3(1)
+        w_fp, l_fp = model.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+        hip_lib.lib.vits_debug_no_bf16x3(0)
+        assert np.array_equal(l_bf, l_fp) and np.isfinite(w_bf).all() and not np.array_equal(w_bf, w_fp)
+        assert_close("c3 waveform: bf16x3 vs fp32 kernels", _valid(w_fp, l_fp), _valid(w_bf, l_bf), 5e-5)
+        for b in (int(np.argmin(ylens)), int(np.argmax(ylens))):
+            L, Ty = int(lengths[b]), int(ylens[b])
+            a_o, _ = oracle_default.synthesize(ids[b:b + 1, :L], lengths[b:b + 1], scales, sid[b:b + 1], noise_prior=noise[b:b + 1, :, :Ty],
+                                               forced_durations=dur[b:b + 1, :L])
+            n = Ty * 256 if Ty == int(ylens.max()) else max(Ty - 32, 0) * 256
+            assert_close(f"c3 item {b} vs oracle solo run (bf16x3)", a_o[0, :n], w_bf[b, :n], E2E_TOL)
+    finally:
+        hip_lib.lib.vits_debug_no_bf16x3(0)
+        model.close()
+
+
 def test_c4_shard_parity(hip_default, oracle_default):
     """BASELINE configs[3]: 256 requests sharded over 8 GPUs by plan_shards; rank 3's shard of 32 through the same path."""
     ids, lengths, dur = _bench_workload("c4", rank=3, world=8)

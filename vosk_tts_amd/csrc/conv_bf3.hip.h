@@ -1,0 +1,204 @@
+// Split-bf16 ("bf16x3") variant of the big-tile conv kernel: BASELINE configs[2] allows a reduced-precision acoustic path; this is
+// the form that keeps fp32-class accuracy.  Every fp32 operand is split once into two bf16 pieces, x = hi + lo with
+// hi = bf16(x), lo = bf16(x - hi), and a product is evaluated as  hi*hi + hi*lo + lo*hi  on the bf16 matrix core with fp32
+// accumulation (the dropped lo*lo term is 2^-16 relative; measured on one tile, K = 2304: 3.6e-6 of max|C| against fp64 vs 1.25e-6
+// for the fp32 MFMA, tools/bf16x3probe.hip) -- 3 v_mfma_f32_32x32x16_bf16 (16 channels x 1 tap each) instead of 8
+// v_mfma_f32_32x32x2_f32, ~7x the issue rate.
+//
+// Same implicit GEMM as conv_mfma_kernel<2,2,2,2> (128 x 128 tile, 4 waves of 64 x 64, 16-channel chunks staged once per chunk in
+// LDS and re-read for every tap at a shifted column, weights streamed from L2 in fragment order one tap ahead), with two changes:
+//   * weights are split and packed at load time: [m-block of 32][chunk][tap][piece][lane][8 bf16]  (pack_conv_weights_bf3);
+//   * the activation split is paid ONCE per element in the staging pass (not per fragment per wave: that costs more VALU than the
+//     MFMAs it feeds): the chunk is written channel-fastest, [piece][column][16 channels as bf16, pitch 48 B], so a lane's B
+//     fragment (8 consecutive channels of one column) is one ds_read_b128, bank-conflict free at any tap shift.
+// The k index inside a chunk is permuted so that the staging thread that holds channels {w, w+4, w+8, w+12} of a column (wave w: the
+// coalesced load pattern of the fp32 kernel) writes them as 4 consecutive bf16: position p = 4w + r  <->  channel w + 4r.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define BF3_PITCH 24  // bf16 elements per staged column (16 used): 48 B, 16 consecutive columns hit 16 distinct 16-byte bank groups
+
+static inline uint16_t bf3_rne(float x) {  // round-to-nearest-even fp32 -> bf16 bits (finite inputs)
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf3_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// dst: Mpad/32 * Cin/16 * K * 2 * 64 * 8 bf16 (= Mpad * Cin * K * 4 bytes, the size of the fp32 packing)
+template <typename F>
+static void pack_conv_weights_bf3(uint16_t* dst, int Mpad, int Cin, int K, F src /* float(int row,int ci,int kk) */) {
+  const int nch = Cin / CONV_CI_T;
+  for (int mb = 0; mb < Mpad / 32; ++mb)
+    for (int c = 0; c < nch; ++c)
+      for (int kk = 0; kk < K; ++kk)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int p = 8 * (lane >> 5) + e;
+            const int ci = c * CONV_CI_T + (p >> 2) + 4 * (p & 3);
+            const float w = src(mb * 32 + (lane & 31), ci, kk);
+            const uint16_t hi = bf3_rne(w), lo = bf3_rne(w - bf3_f32(hi));
+            const size_t base = (((size_t)mb * nch + c) * K + kk) * 2;
+            dst[((base + 0) * 64 + lane) * 8 + e] = hi;
+            dst[((base + 1) * 64 + lane) * 8 + e] = lo;
+          }
+}
+
+__global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
+  constexpr int N_T = 128, M_T = 128;
+  constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
+  extern __shared__ float lds[];
+  kernarg_warm<sizeof(ConvParams)>();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  int mt, grp, nt, b;
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
+  const ConvGroup& G = P.g[grp];
+  const int ROW = P.row_len;  // staged columns: 128 + the launch's largest halo
+  const int n0 = nt * N_T, m0 = mt * M_T;
+  const int K = G.K, dil = G.dil;
+  const int nchunks = P.Cin / CONV_CI_T;
+  int t_lim = P.Tin;
+  if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
+  if (P.rag) {
+    const int rl = P.rag[b];
+    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
+    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    t_lim = il < t_lim ? il : t_lim;
+  }
+  if (P.skip_len && n0 >= P.len[b]) return;
+
+  // ---- staging: wave w owns chunk rows w, w+4, w+8, w+12 (coalesced along time); lanes stride over columns
+  float stg[4][JT];
+  const float* xb = G.x + (long long)b * P.x_bstride;
+  const float in_scale = P.in_scale, in_slope = P.in_slope;
+  const int t_base = n0 - G.pad_l;
+  CONV_STAGE_COLS(JT)
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const long long ro = (long long)(c * CONV_CI_T + wave + 4 * rr) * P.Tin_stride;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) stg[rr][j] = xb[ro + toff[j]];
+    }
+    // (nothing here may consume the loaded values: they ride through the tap loop and are split only in store_chunk)
+  };
+  const int piece_bytes = ROW * (BF3_PITCH * 2);  // one piece (hi or lo) of one chunk buffer
+  auto store_chunk = [&](int buf) {
+    char* dst = reinterpret_cast<char*>(lds) + buf * (2 * piece_bytes) + 8 * wave;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int col = lane + 64 * j;
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float v = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;  // select: stale padding may hold NaN
+        hi[rr] = (__bf16)v;
+        lo[rr] = (__bf16)(v - (float)hi[rr]);
+      }
+      if (col < ROW) {
+        *reinterpret_cast<bf16x4*>(dst + col * (BF3_PITCH * 2)) = hi;
+        *reinterpret_cast<bf16x4*>(dst + piece_bytes + col * (BF3_PITCH * 2)) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // weight stream: step s = chunk * K + tap; per step and m-block: [hi | lo] x 64 lanes x 16 B
+  const int n_mblocks = P.M >> 5;
+  const int nsteps = nchunks * K;
+  const bf16x8* wp[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    int mb = (m0 >> 5) + wm * 2 + mi;
+    if (mb >= n_mblocks) mb = 0;  // padded tile: compute on valid memory, never stored
+    wp[mi] = reinterpret_cast<const bf16x8*>(G.wb) + (size_t)mb * nsteps * 128 + lane;
+  }
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  bf16x8 a_cur[2][2], a_nxt[2][2];  // [mi][piece]
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    a_cur[mi][0] = wp[mi][0];
+    a_cur[mi][1] = wp[mi][64];
+  }
+  int step = 1;  // next step to fetch
+
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const char* lb = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31) * (BF3_PITCH * 2) + 16 * h;
+#pragma unroll 1
+    for (int kk = 0; kk < K; ++kk) {
+      {
+        const int sc = step < nsteps ? step : nsteps - 1;  // unconditional (clamped) prefetch: counted s_waitcnt
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          a_nxt[mi][0] = wp[mi][(size_t)sc * 128];
+          a_nxt[mi][1] = wp[mi][(size_t)sc * 128 + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of this tap's MFMAs
+      }
+      ++step;
+      const char* lk = lb + kk * dil * (BF3_PITCH * 2);
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        bh[ni] = *reinterpret_cast<const bf16x8*>(lk + ni * 32 * (BF3_PITCH * 2));
+        bl[ni] = *reinterpret_cast<const bf16x8*>(lk + piece_bytes + ni * 32 * (BF3_PITCH * 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // all B-fragment reads of the tap in flight before its first MFMA
+      // hi*hi + hi*lo + lo*hi, the four accumulators interleaved (no back-to-back dependent MFMAs)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mi][1], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mi][0], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mi][0], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        a_cur[mi][0] = a_nxt[mi][0];
+        a_cur[mi][1] = a_nxt[mi][1];
+      }
+    }
+    if (c + 1 < nchunks) store_chunk((c + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (shared with the fp32 kernels).  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const int lenb = P.out_mask ? P.len[b] : 0x7fffffff;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e0 = 0; e0 < 16; e0 += 4) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][e0 + i];
+        conv_epilogue_frag<EPI_STORE, 4>(P, G, b, lenb, m0 + (wm * 2 + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
+      }
+}

@@ -48,6 +48,7 @@ struct ConvGroup {
   const float* x3;
   const float* w;     // packed weights (pack_conv_weights)
   const float* w16;   // the same weights in 16x16x4 fragment order (conv_small.hip.h) or null
+  const void* wb;     // the same weights split into bf16 (hi, lo) pieces in 32x32x16 fragment order (conv_bf3.hip.h) or null
   const float* bias;  // [Cout] or null
   float* y;           // output
   float* y2;          // optional second copy of the output (EPI_STORE, same layout): saves a device-to-device copy

@@ -24,6 +24,7 @@
 #include "../../include/vits_mi355.h"
 #include "conv_mfma.hip.h"
 #include "conv_small.hip.h"
+#include "conv_bf3.hip.h"
 #include "kernels_misc.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
@@ -64,6 +65,7 @@ static int g_wn_fold = 1;
 struct ConvW {
   float* w = nullptr;     // packed, MFMA fragment order
   float* w16 = nullptr;   // packed for the small-tile kernel (16x16x4 fragment order), null when not built
+  float* wb = nullptr;    // split-bf16 (hi, lo) pieces in 32x32x16 fragment order (conv_bf3.hip.h), null when not built
   float* bias = nullptr;  // original row order
   int M = 0, Mpad = 0, Cin = 0, K = 0, n_sg = 0;
 };
@@ -249,11 +251,23 @@ static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, 
 }
 
 // nn.Conv1d weight [Cout, Cin, K] (+ optional bias)
-static ConvW conv_from(vits_model* m, const char* name, int Cout, int Cin, int K, bool has_bias, bool small16 = true) {
+// third packing of a conv: bf16 (hi, lo) pieces for conv_bf3_kernel (hparams.conv_precision == 1, decoder ResBlock convs)
+template <typename F>
+static void add_bf3_packing(vits_model* m, ConvW& c, F src) {
+  if (!c.w || c.Mpad % 32 || c.Cin % CONV_CI_T) return;
+  std::vector<uint16_t> pk((size_t)c.Mpad * c.Cin * c.K * 2);
+  const int M = c.M;
+  pack_conv_weights_bf3(pk.data(), c.Mpad, c.Cin, c.K, [&](int row, int ci, int kk) -> float { return row < M ? src(row, ci, kk) : 0.f; });
+  c.wb = upload(m, reinterpret_cast<const float*>(pk.data()), pk.size() / 2);
+}
+static ConvW conv_from(vits_model* m, const char* name, int Cout, int Cin, int K, bool has_bias, bool small16 = true, bool bf3 = false) {
   const float* w = tget(m, 3, Cout, Cin, K, "%s.weight", name);
   const float* b = has_bias ? tget(m, 1, Cout, -1, -1, "%s.bias", name) : nullptr;
   if (m->missing) return ConvW();
-  return make_conv(m, Cout, Cin, K, b, [&](int r, int ci, int kk) { return w[((size_t)r * Cin + ci) * K + kk]; }, small16);
+  auto src = [&](int r, int ci, int kk) { return w[((size_t)r * Cin + ci) * K + kk]; };
+  ConvW c = make_conv(m, Cout, Cin, K, b, src, small16);
+  if (bf3) add_bf3_packing(m, c, src);
+  return c;
 }
 
 static void load_encoder(vits_model* m, EncoderW& E, const char* pfx, int n_layers, int H, int F, int K) {
@@ -404,9 +418,10 @@ static int load_decoder(vits_model* m) {
         R.dil[d] = hp.res_dilations[j][d];
         if ((R.K - 1) * R.dil[d] > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "resblock receptive field too wide");
         snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", i * hp.n_resk + j, d);
-        R.c1[d] = conv_from(m, nm, C, C, R.K, true, false);
+        const bool bf3 = hp.conv_precision == 1 && C % 128 == 0;  // split-bf16 variant of the batch-size kernel (128-row tiles)
+        R.c1[d] = conv_from(m, nm, C, C, R.K, true, false, bf3);
         snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", i * hp.n_resk + j, d);
-        R.c2[d] = conv_from(m, nm, C, C, R.K, true, false);
+        R.c2[d] = conv_from(m, nm, C, C, R.K, true, false, bf3);
       }
     }
   }
@@ -1015,6 +1030,7 @@ static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, dou
 
 // ---- wave-pipelined kernel for the single-utterance decoder's ResBlock convs (conv_small.hip.h conv_wp_kernel)
 static int g_wp_mode = 0;  // 0 = heuristic, 1 = never, 2 = whenever eligible (tests)
+static int g_no_bf3 = 0;   // test hook: 1 = a conv_precision == 1 model runs its fp32 kernels (A/B of the split-bf16 variant)
 static bool conv_wp_ok(const ConvParams& P, int epi, int halo, bool small) {
   static const int env_mode = getenv("VITS_CONV_WP") ? atoi(getenv("VITS_CONV_WP")) : 0;
   const int mode = g_wp_mode ? g_wp_mode : env_mode;
@@ -1146,7 +1162,21 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
-  if (m_fits && big_blocks >= 512) { ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return; }
+  if (m_fits && big_blocks >= 512) {
+    bool bf3 = !g_no_bf3 && !P.ups_u && !P.reflect && !P.x_split && P.x_ch_sign == 1 && !P.x_ch_off && !P.ln_g;
+    for (int g = 0; g < P.n_groups; ++g) bf3 = bf3 && P.g[g].wb && !P.g[g].x2 && !P.g[g].x3;
+    if (bf3) {  // split-bf16 variant (hparams.conv_precision == 1): same tile, same staging pattern, 3 bf16 MFMAs per 16 channels x tap
+      ps.set_kernel("conv_bf3_kernel");
+      attach_tile_table(s, P, 128);
+      P.ntiles_m = cdiv(P.M, 128);
+      P.ntiles_n = cdiv(P.Tout, 128);
+      P.row_len = 128 + halo;
+      const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
+      hipLaunchKernelGGL(conv_bf3_kernel, dim3(P.ntiles_m * P.ntiles_n * P.B * P.n_groups), dim3(256), lds, s->stream, P);
+      return;
+    }
+    ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return;
+  }
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
   launch_cfg<2, 2, 1, 1, EPI_STORE>(s, P, halo);
 }
@@ -1156,7 +1186,7 @@ static ConvParams conv_params(const ConvW& W, const float* x, float* y, int B, i
   ConvParams P;
   memset(&P, 0, sizeof P);
   P.n_groups = 1;
-  P.g[0].x = x; P.g[0].w = W.w; P.g[0].w16 = W.w16; P.g[0].bias = W.bias; P.g[0].y = y;
+  P.g[0].x = x; P.g[0].w = W.w; P.g[0].w16 = W.w16; P.g[0].wb = W.wb; P.g[0].bias = W.bias; P.g[0].y = y;
   P.g[0].K = W.K; P.g[0].dil = dil; P.g[0].pad_l = pad_l; P.g[0].n_sg = W.n_sg;
   P.B = B; P.Cin = W.Cin; P.x_ch_off = 0; P.x_ch_sign = 1;
   P.x_bstride = (long long)W.Cin * T; P.Tin = T; P.Tin_stride = T;
@@ -1613,7 +1643,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
       for (int j = 0; j < nk; ++j) {  // xt = c1(leaky_relu(x))
         const ResBlockW& R = m->rb[(size_t)i * nk + j];
         P.g[j].x = d == 0 ? y : set[4 + j];
-        P.g[j].w = R.c1[d].w; P.g[j].bias = R.c1[d].bias; P.g[j].y = set[1 + j];
+        P.g[j].w = R.c1[d].w; P.g[j].wb = R.c1[d].wb; P.g[j].bias = R.c1[d].bias; P.g[j].y = set[1 + j];
         P.g[j].K = R.K; P.g[j].dil = R.dil[d]; P.g[j].pad_l = (R.K - 1) * R.dil[d] / 2; P.g[j].n_sg = R.c1[d].n_sg;
       }
       P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
@@ -1624,7 +1654,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
       for (int j = 0; j < nk; ++j) {  // x = c2(leaky_relu(xt)) + x
         const ResBlockW& R = m->rb[(size_t)i * nk + j];
         P.g[j].x = set[1 + j];
-        P.g[j].w = R.c2[d].w; P.g[j].bias = R.c2[d].bias; P.g[j].y = set[4 + j];
+        P.g[j].w = R.c2[d].w; P.g[j].wb = R.c2[d].wb; P.g[j].bias = R.c2[d].bias; P.g[j].y = set[4 + j];
         P.g[j].res = d == 0 ? y : set[4 + j];
         P.g[j].K = R.K; P.g[j].dil = 1; P.g[j].pad_l = (R.K - 1) / 2; P.g[j].n_sg = R.c2[d].n_sg;
       }
@@ -2551,6 +2581,7 @@ void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
+void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
 
 int vits_session_sync(vits_session* s) {

@@ -68,7 +68,8 @@ class HParams(ctypes.Structure):
         ("sampling_rate", ctypes.c_int32),
         ("hop_length", ctypes.c_int32),
         ("bert_dim", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 7),
+        ("conv_precision", ctypes.c_int32),  # 0 fp32 (default), 1 split-bf16 decoder ResBlock convs at batch size ("bf16x3")
+        ("reserved", ctypes.c_int32 * 6),
     ]
 
     def total_upsample(self):
