@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd $R
-for prec in f32 bf16x3; do
+for prec in bf16x3; do
   timeout 300 python bench.py --workload c3 --precision $prec --no-cpu-baseline --no-host-api --steps 10 > $O/r2_c3_$prec.json 2> $O/r2_c3.err
   python - <<PY
 import json

@@ -50,18 +50,19 @@ static void pack_conv_weights_bf3(uint16_t* dst, int Mpad, int Cin, int K, F src
           }
 }
 
-__global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
+template <int V> struct bf3_int { static constexpr int value = V; };
+// At 32 cycles per MFMA a SIMD has ~8 issue slots per MFMA for ALL of its waves (MI355X_MICROARCH.md): a first version with the
+// fp32 kernel's rolled tap loop (16 v_mov per tap to rotate the weight registers, clamped 64-bit weight addresses, loop
+// bookkeeping) left the matrix pipe 47 % busy even with every load removed.  Here taps are processed in PAIRS so that the two
+// weight-fragment slots are named statically (slot = tap parity; an odd tap count costs one 16-register move per CHUNK instead of
+// one per tap), one pointer per m-block advances by a constant, and the B reads use
+// immediate offsets.  The weight stream is read one step past its end (add_bf3_packing pads the array).
+static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b) {
   constexpr int N_T = 128, M_T = 128;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
-  extern __shared__ float lds[];
-  kernarg_warm<sizeof(ConvParams)>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
-
-  int mt, grp, nt, b;
-  if (!conv_decode_block(P, mt, grp, nt, b)) return;
-  const ConvGroup& G = P.g[grp];
   const int ROW = P.row_len;  // staged columns: 128 + the launch's largest halo
   const int n0 = nt * N_T, m0 = mt * M_T;
   const int K = G.K, dil = G.dil;
@@ -77,17 +78,17 @@ __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   if (P.skip_len && n0 >= P.len[b]) return;
 
   // ---- staging: wave w owns chunk rows w, w+4, w+8, w+12 (coalesced along time); lanes stride over columns
-  float stg[4][JT];
+  float stg[4][JT], stn[4][JT];  // staged values of chunk c + 1 (loaded one chunk earlier) and in-flight loads of chunk c + 2
   const float* xb = G.x + (long long)b * P.x_bstride;
   const float in_scale = P.in_scale, in_slope = P.in_slope;
   const int t_base = n0 - G.pad_l;
   CONV_STAGE_COLS(JT)
-  auto load_chunk = [&](int c) {
+  auto load_chunk = [&](int c, float (&dst)[4][JT]) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const long long ro = (long long)(c * CONV_CI_T + wave + 4 * rr) * P.Tin_stride;
 #pragma unroll
-      for (int j = 0; j < JT; ++j) stg[rr][j] = xb[ro + toff[j]];
+      for (int j = 0; j < JT; ++j) dst[rr][j] = xb[ro + toff[j]];
     }
     // (nothing here may consume the loaded values: they ride through the tap loop and are split only in store_chunk)
   };
@@ -122,70 +123,85 @@ __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   // weight stream: step s = chunk * K + tap; per step and m-block: [hi | lo] x 64 lanes x 16 B
   const int n_mblocks = P.M >> 5;
   const int nsteps = nchunks * K;
-  const bf16x8* wp[2];
+  const bf16x8* wq[2];  // next step to fetch, per m-block
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     int mb = (m0 >> 5) + wm * 2 + mi;
     if (mb >= n_mblocks) mb = 0;  // padded tile: compute on valid memory, never stored
-    wp[mi] = reinterpret_cast<const bf16x8*>(G.wb) + (size_t)mb * nsteps * 128 + lane;
+    wq[mi] = reinterpret_cast<const bf16x8*>(G.wb) + (size_t)mb * nsteps * 128 + lane;
   }
 
-  load_chunk(0);
+  load_chunk(0, stg);
   store_chunk(0);
+  if (nchunks > 1) load_chunk(1, stg);
   __syncthreads();
 
-  bf16x8 a_cur[2][2], a_nxt[2][2];  // [mi][piece]
+  bf16x8 a[2][2][2];  // [slot][mi][piece]
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    a_cur[mi][0] = wp[mi][0];
-    a_cur[mi][1] = wp[mi][64];
+    a[0][mi][0] = wq[mi][0];
+    a[0][mi][1] = wq[mi][64];
+    wq[mi] += 128;
   }
-  int step = 1;  // next step to fetch
-
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    const char* lb = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31) * (BF3_PITCH * 2) + 16 * h;
+  // one tap: prefetch the next step into the other slot, read this tap's B fragments, 12 MFMAs
+  auto tap = [&](auto slot_, const char* lk0, const char* lk1) {
+    constexpr int S = decltype(slot_)::value;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      a[S ^ 1][mi][0] = wq[mi][0];
+      a[S ^ 1][mi][1] = wq[mi][64];
+      wq[mi] += 128;
+    }
+    bf16x8 bh[2], bl[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      bh[ni] = *reinterpret_cast<const bf16x8*>(lk0 + ni * 32 * (BF3_PITCH * 2));
+      bl[ni] = *reinterpret_cast<const bf16x8*>(lk1 + ni * 32 * (BF3_PITCH * 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // loads of the next step and this tap's B reads in flight before the first MFMA
+    // lo*hi + hi*lo + hi*hi, the four accumulators interleaved (no back-to-back dependent MFMAs)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][1], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][0], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][0], bh[ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
 #pragma unroll 1
-    for (int kk = 0; kk < K; ++kk) {
-      {
-        const int sc = step < nsteps ? step : nsteps - 1;  // unconditional (clamped) prefetch: counted s_waitcnt
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          a_nxt[mi][0] = wp[mi][(size_t)sc * 128];
-          a_nxt[mi][1] = wp[mi][(size_t)sc * 128 + 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of this tap's MFMAs
-      }
-      ++step;
-      const char* lk = lb + kk * dil * (BF3_PITCH * 2);
-      bf16x8 bh[2], bl[2];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        bh[ni] = *reinterpret_cast<const bf16x8*>(lk + ni * 32 * (BF3_PITCH * 2));
-        bl[ni] = *reinterpret_cast<const bf16x8*>(lk + piece_bytes + ni * 32 * (BF3_PITCH * 2));
-      }
-      __builtin_amdgcn_sched_barrier(0);  // all B-fragment reads of the tap in flight before its first MFMA
-      // hi*hi + hi*lo + lo*hi, the four accumulators interleaved (no back-to-back dependent MFMAs)
+  for (int c = 0; c < nchunks; ++c) {
+    // activations are requested TWO chunks ahead: a chunk's taps take 1.2 k (3 taps) .. 4.2 k (11 taps) MFMA cycles per wave, less
+    // than an HBM round trip under load -- with the fp32 kernel's one-chunk distance every chunk ended waiting for its successor
+    if (c + 2 < nchunks) load_chunk(c + 2, stn);
+    const int dstep = dil * (BF3_PITCH * 2);
+    const char* lk0 = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31) * (BF3_PITCH * 2) + 16 * h;
+    const char* lk1 = lk0 + piece_bytes;
+#pragma unroll 1
+    for (int kk = 0; kk + 1 < K; kk += 2) {
+      tap(bf3_int<0>{}, lk0, lk1);
+      tap(bf3_int<1>{}, lk0 + dstep, lk1 + dstep);
+      lk0 += 2 * dstep;
+      lk1 += 2 * dstep;
+    }
+    if (K & 1) {  // odd tap count: last tap from slot 0, then the next chunk's first tap (now in slot 1) moves to slot 0
+      tap(bf3_int<0>{}, lk0, lk1);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mi][1], bh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mi][0], bl[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mi][0], bh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        a_cur[mi][0] = a_nxt[mi][0];
-        a_cur[mi][1] = a_nxt[mi][1];
-      }
+        for (int pc = 0; pc < 2; ++pc) a[0][mi][pc] = a[1][mi][pc];
     }
     if (c + 1 < nchunks) store_chunk((c + 1) & 1);
     __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) stg[rr][j] = stn[rr][j];
   }
 
   // ---- epilogue (shared with the fp32 kernels).  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -201,4 +217,13 @@ __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
         for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][e0 + i];
         conv_epilogue_frag<EPI_STORE, 4>(P, G, b, lenb, m0 + (wm * 2 + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
       }
+}
+
+__global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
+  extern __shared__ float lds[];
+  kernarg_warm<sizeof(ConvParams)>();
+  int mt, grp, nt, b;
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
+  const ConvGroup& G = P.g[grp];
+  conv_bf3_body(P, G, lds, mt, nt, b);
 }

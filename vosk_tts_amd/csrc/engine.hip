@@ -255,7 +255,7 @@ static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, 
 template <typename F>
 static void add_bf3_packing(vits_model* m, ConvW& c, F src) {
   if (!c.w || c.Mpad % 32 || c.Cin % CONV_CI_T) return;
-  std::vector<uint16_t> pk((size_t)c.Mpad * c.Cin * c.K * 2);
+  std::vector<uint16_t> pk((size_t)c.Mpad * c.Cin * c.K * 2 + 128 * 8, 0);  // + one step: the kernel prefetches one step past the end
   const int M = c.M;
   pack_conv_weights_bf3(pk.data(), c.Mpad, c.Cin, c.K, [&](int row, int ci, int kk) -> float { return row < M ? src(row, ci, kk) : 0.f; });
   c.wb = upload(m, reinterpret_cast<const float*>(pk.data()), pk.size() / 2);
