@@ -538,7 +538,7 @@ def main():
         import copy
 
         a2 = copy.copy(args)
-        a2.steps, a2.warmup = max(5, min(args.steps, 20)), 3
+        a2.steps, a2.warmup = max(30, min(args.steps, 50)), 5  # (3 warm-up calls left the first timed requests on cold graphs / clocks)
         multistream = bench_multistream(a2, torch, rank, world, local_rank, dist, as_object=True)
 
     cpu_baseline = None

@@ -26,6 +26,14 @@ def label(name):
     m = re.match(r"void (conv_mfma_ks_kernel)<(\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return f"{m[1]}<{m[2]},{m[3]},{EPI[m[4]]},{m[5]}>"
+    m = re.match(r"void (conv16_kernel)<(\d+), (\d+), (\d+), (\d+)>", name)
+    if m:  # <EPI, NW, MAXU, PRO> -> the engine's label: PRO 1 = DDSConv prologue, 2 = LayerNorm prologue
+        if m[5] == "1":
+            return f"{m[1]}<{EPI[m[2]]},dds>"
+        return f"{m[1]}<{EPI[m[2]]},{'ln,' if m[5] == '2' else ''}{m[3]}>"
+    m = re.match(r"void (conv_wp_kernel)<(\d+)>", name)
+    if m:
+        return f"{m[1]}<{m[2]}>"
     m = re.match(r"(?:void )?(\w+)", name)
     return m[1] if m else name
 

@@ -17,6 +17,15 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/def 
 cp $(find $O/prof/def -name '*kernel_stats.csv' | head -1) $O/r2_default_bench_rocprofv3_kernel_stats.csv
 rm -rf $O/prof
 cd $R
+for w in c3 c4 c5 m2 m3; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline --no-host-api > $O/r2_${w}_bench.json.txt 2> $O/bench_$w.err; echo "bench $w rc=$?"
+done
+timeout 300 python bench.py --workload c3 --precision bf16x3 --no-cpu-baseline --no-host-api > $O/r2_c3_bf16x3_bench.json.txt 2> $O/bench_c3b.err; echo "bench c3 bf16x3 rc=$?"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/m2 -o trace -- python $R/bench.py --workload m2 --no-cpu-baseline --steps 30 > $O/r2_m2_bench_under_rocprof.json.txt 2> $O/prof_m2.err
+cp $(find $O/prof/m2 -name '*kernel_stats.csv' | head -1) $O/r2_m2_bench_rocprofv3_kernel_stats.csv
+rm -rf $O/prof
+cd $R
 for w in c2 c3; do
   timeout 900 bash tools/pmc_passes.sh $w > $O/pmc_$w.log 2>&1
   cp $R/gpurun_out/pmc_$w/pmc_$w.json $O/r2_pmc_$w.json
