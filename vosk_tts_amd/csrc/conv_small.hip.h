@@ -537,6 +537,8 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   if (mb >= (P.M >> 5)) mb = 0;
   const f32x4* wp = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
   f32x4 a[2][2];        // weight fragments of two consecutive taps; a slot is re-requested right after its last MFMA, two taps ahead
+  // (Tried: rotating the tap order per column tile so that the workgroups of an XCD that share an m-block do not pull the same
+  // weight stream through the fabric in lockstep -- no measurable change, dropped.)
   int lci = 0, lk = 0;  // load cursor of the weight stream (this wave's chunk index, tap)
   auto load_a_half = [&](f32x4 (&d)[2], int half) {  // half 1 advances the cursor
     const int c = wave + NW * lci;
@@ -606,8 +608,12 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
     const int rc = r < P.Cout ? r : P.Cout - 1;
     eok[i] = ecol < P.Tout && r < P.Cout;
     eoff[i] = (long long)b * P.y_bstride + (long long)rc * P.Tout_stride + ecolc;
-    ebias[i] = G.bias ? G.bias[rc] : 0.f;
-    eres[i] = G.res ? G.res[eoff[i]] : 0.f;
+    // UNCONDITIONAL loads from always-valid addresses + selects: behind `if (ptr)` hipcc sinks the load to its use, i.e. puts the
+    // cold miss of the residual back at the end of the kernel (measured: 3.5 k cycles between the reduction barrier and the stores)
+    const float bv = (G.bias ? G.bias : G.w)[rc];
+    const float rv = (G.res ? G.res : G.y)[eoff[i]];
+    ebias[i] = G.bias ? bv : 0.f;
+    eres[i] = G.res ? rv : 0.f;
   }
   __builtin_amdgcn_sched_barrier(0);
   CONV_DBG(1);
