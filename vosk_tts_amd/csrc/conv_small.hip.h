@@ -714,6 +714,10 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   constexpr bool FLIP = KT & 1;  // static tap counts: the odd ones alternate the slot parity per chunk
 #pragma unroll 1
   for (int ci = 0; ci < my_chunks; ci += 2) {
+    // (VALU issue on a SIMD is arbitrated by priority, then age: the SECOND wave of a SIMD gets its ~60 staging instructions through
+    // only when the first one's MFMA stream ends -- slab complete at 13.4 k cycles instead of 7.5 k.  Raising the staging priority
+    // with s_setprio fixes that and makes the kernel SLOWER: two interleaved dependency-paced MFMA chains run at 111 cycles per
+    // MFMA on the shared pipe, one after the other at 74-82.  Left as the hardware schedules it.)
     stage();
     if (ci + 1 < my_chunks) load_slab(ci + 1);
     if (ci == 0) CONV_DBG(2);
