@@ -1,11 +1,11 @@
 """Single conv launches through vits_op_conv1d with the timing build (phase stamps of block 0 + steady-state time per launch):
-   VITS_CONV_DBG=20 [VITS_KS_WAVES=..] [VITS_CONV_WP=..] python tools/convdbg.py [decoder|small]"""
+   VITS_CONV_DBG=20 [VITS_KS_WAVES=..] [VITS_CONV_WP=..] [CONVDBG_LIB=..] [CONVDBG_SLOPE=..] python tools/convdbg.py [decoder|small]"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 from vosk_tts_amd.capi import VitsLib, op_conv1d
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tl = os.path.join(root, "vosk_tts_amd", "csrc", "libvits_mi355_timing.so")
+tl = os.environ.get("CONVDBG_LIB", os.path.join(root, "vosk_tts_amd", "csrc", "libvits_mi355_timing.so"))
 lib = VitsLib(tl if os.path.exists(tl) and not os.environ.get("CONVDBG_PLAIN") else None)
 rng = np.random.default_rng(0)
 which = sys.argv[1] if len(sys.argv) > 1 else "decoder"

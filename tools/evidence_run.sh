@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 evidence run: full GPU test suite, default bench line, rocprofv3 kernel stats (c2-only and default), PMC passes (c2, c3).
+# evidence run of a round (set PROFILE_ROUND in bench.py accordingly): full GPU test suite, default bench line, rocprofv3 kernel stats (c2-only and default), PMC passes (c2, c3).
 # Outputs land in gpurun_out/final/ under the names profiles/ expects; copy them to profiles/ afterwards.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
