@@ -293,6 +293,9 @@ void vits_debug_attention_impl(int impl);
 void vits_debug_fast_path(int on);
 /* Test hook: waves per workgroup of the K-split conv kernel: 0 = size heuristic (default), 4 / 8 / 16 forced. */
 void vits_debug_ks_waves(int nw);
+/* Test hook: 1 (default) = the folded encoder LayerNorms take their channel statistics from the producing conv's epilogue,
+ * 0 = every consumer workgroup recomputes them. */
+void vits_debug_ln_stats(int on);
 /* Test hook: 1 (default) = WaveNet tail of the coupling layers in folded form (gate outputs of all layers kept, one conv =
  * post o sum of skip halves), 0 = per-layer res/skip accumulation + post as the reference executes it.  Same results to rounding. */
 void vits_debug_wn_fold(int on);

@@ -280,6 +280,45 @@ def test_wn_folded_and_unfolded_tail(hip_lib, hip_default, oracle_default):
         hip_lib.lib.vits_debug_wn_fold(1)
 
 
+def test_layernorm_statistics_from_the_producer(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny):
+    """Few-column regime: the encoders' LayerNorms are applied while their consumer conv stages its input, with the channel
+    statistics written by the PRODUCING conv's epilogue (per 16-row block: mean and centred second moment, merged in fixed order;
+    default) or recomputed by every consumer workgroup (vits_debug_ln_stats(0)).  Both against the oracle and each other: text
+    encoder (cond layer, final LayerNorm folded into proj), flow (one-layer pre-transformers), ragged lengths, T = 1..9 edge
+    fixtures, the 64-channel model (4 row blocks), and the bucketed fast path."""
+    rng = np.random.default_rng(77)
+    B, Ty = 2, 150
+    z_p = rng.standard_normal((B, 192, Ty)).astype(np.float32)
+    ylen = np.array([150, 61], np.int64)
+    sid = np.array([3, 9], np.int64)
+    want = oracle_default.flow(z_p, ylen, sid)
+    mask = (np.arange(Ty)[None, :] < ylen[:, None])[:, None, :]
+    ids = rng.integers(1, 62, size=(2, 50)).astype(np.int64)
+    lens = np.array([50, 23], np.int64)
+    x_ref, m_ref, l_ref = oracle_default.text_encoder(ids, lens, sid)
+    xm = (np.arange(50)[None, :] < lens[:, None])[:, None, :]
+    try:
+        got = {}
+        for on in (1, 0):
+            hip_lib.lib.vits_debug_ln_stats(on)
+            z = hip_default.flow(z_p, ylen, sid)
+            assert_close(f"flow, ln stats {on}", want * mask, z * mask, STAGE_TOL)
+            x, m_p, logs_p = hip_default.text_encoder(ids, lens, sid)
+            assert_close(f"text encoder x, ln stats {on}", x_ref * xm, x * xm, STAGE_TOL)
+            assert_close(f"text encoder m_p, ln stats {on}", m_ref * xm, m_p * xm, STAGE_TOL)
+            got[on] = (z * mask, x * xm)
+            _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
+            _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)
+            for T in (1, 3, 4, 5, 9):
+                g = golden(f"enc_T{T}")
+                xe, _, _ = hip_default.text_encoder(g["ids"], g["lengths"], g["sid"])
+                assert_close(f"enc T={T}, ln stats {on}", g["x"], xe, STAGE_TOL)
+        assert_close("flow: producer statistics vs consumer statistics", got[0][0], got[1][0], 2e-5)
+        assert_close("text encoder: producer statistics vs consumer statistics", got[0][1], got[1][1], 2e-5)
+    finally:
+        hip_lib.lib.vits_debug_ln_stats(1)
+
+
 def test_both_attention_kernels(hip_lib, hip_default, hip_tiny, oracle_default, oracle_tiny):
     """Three implementations of the same banded relative-position attention: the scalar-VALU kernel (1), the 32-query
     MFMA flash kernel (2, long sequences) and the 16-query MFMA kernel (3, short sequences; 0 = chosen by length).  All must

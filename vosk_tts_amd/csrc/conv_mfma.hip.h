@@ -119,6 +119,11 @@ struct ConvParams {
   const float* ln_g; const float* ln_b; const float* ln_base; const float* ln_vec;
   int ln_vec_stride, ln_vec_off;
   float* ln_out;
+  // PRO == 3: the channel statistics come from the PRODUCER of y (ln_stat_in: per (batch item, 16-row block of y, column) the
+  // block's mean and centred second moment, written by the producer conv's epilogue when its ln_stat_out is set); the consumer
+  // merges the ln_nmb partials in fixed order and normalises while staging -- no statistics pass, no extra barriers, and the
+  // ~C_out/16 workgroups that share a column tile no longer each redo the reduction.
+  const float* ln_stat_in; float* ln_stat_out; int ln_nmb;
   int row_len;        // LDS row = N_T + halo
   long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
   // Ragged batches: item b only needs columns up to rag[b] frames (its length + a halo wider than the

@@ -368,8 +368,33 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     constexpr int C16_SB = 16;
     const int chs = P.x_ch_sign * P.Tin_stride;           // element offset of one channel step (negative: Flip folded in)
     const int ch0 = P.x_ch_off * P.Tin_stride + tc;         // (x_ch_off + c*sign) >= 0 for every channel
+    // PRO == 3: LayerNorm of the staged tensor from the producer's per-block statistics; a thread's elements share ONE column
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    float stm[16], stq[16];
+    if (PRO == 3) {
+      const float* st = P.ln_stat_in + ((long long)b * P.ln_nmb * P.Tin + tc) * 2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ic = i < P.ln_nmb ? i : P.ln_nmb - 1;
+        stm[i] = st[(long long)ic * P.Tin * 2];
+        stq[i] = st[(long long)ic * P.Tin * 2 + 1];
+      }
+    }
     for (int cb = wave * rpi; cb < Cin; cb += step * C16_SB) {
       float v[C16_SB];
+      float lg[C16_SB], lb[C16_SB], lbase[C16_SB];
+      if (PRO == 3) {
+        const float* vec = P.ln_vec ? P.ln_vec + (long long)b * P.ln_vec_stride + P.ln_vec_off : nullptr;
+        const float* base = P.ln_base ? P.ln_base + (long long)b * P.x_bstride : nullptr;
+#pragma unroll
+        for (int k = 0; k < C16_SB; ++k) {
+          const int c = cb + k * step + rsub;
+          const int cc = c < Cin ? c : Cin - 1;
+          lg[k] = P.ln_g[cc];
+          lb[k] = P.ln_b[cc] + (vec ? vec[cc] : 0.f);
+          lbase[k] = base ? base[(long long)cc * P.Tin + tc] : 0.f;
+        }
+      }
       if (P.x_split == 0) {  // uniform base pointer + 32-bit lane offset: one address add per load
 #pragma unroll
         for (int k = 0; k < C16_SB; ++k) {
@@ -390,11 +415,40 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
       len_raw = __builtin_amdgcn_readfirstlane(len_raw);
       const int t_lim_ = (P.in_mask && len_raw < P.Tin) ? len_raw : P.Tin;
       const bool tok = jok && t >= 0 && t < t_lim_;
+      if (PRO == 3) {
+        if (cb == wave * rpi) {  // merge the blocks' (mean, M2) in fixed order: equal-sized blocks of 16 rows, the last one shorter
+          const int nmb = P.ln_nmb, last_n = Cin - 16 * (nmb - 1);
+          float ms = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ms += i < nmb ? stm[i] * (float)(i == nmb - 1 ? last_n : 16) : 0.f;
+          ln_mean = ms / (float)Cin;
+          float q = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float d = stm[i] - ln_mean;
+            q += i < nmb ? stq[i] + (float)(i == nmb - 1 ? last_n : 16) * d * d : 0.f;
+          }
+          ln_rstd = 1.0f / sqrtf(q / (float)Cin + 1e-5f);
+        }
+        // conv zero padding, the mask, and columns beyond the item's length of a tile-skipping producer (garbage statistics there)
+        const bool valid = tok && (!P.skip_len || t < len_raw);
+        const bool center = jok && t >= n0 && t < n0 + 16 && t < P.Tin && mt == 0 && P.ln_out;
+        float* out = P.ln_out ? P.ln_out + (long long)b * P.x_bstride : nullptr;
+#pragma unroll
+        for (int k = 0; k < C16_SB; ++k) {
+          const int c = cb + k * step + rsub;
+          float o = (v[k] - ln_mean) * ln_rstd * lg[k] + lb[k] + lbase[k];
+          o = valid ? o : 0.f;  // select: padding may hold NaN
+          if (jok && c < Cin) lds[c * ROWP + j] = o;
+          if (center && c < Cin) out[(long long)c * P.Tin + t] = o;
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < C16_SB; ++k) {
         const int c = cb + k * step + rsub;
         const float o = tok ? conv_act_in(v[k], scale, slope) : 0.f;  // select, not multiply: stale padding may hold NaN
         if (jok && c < Cin) lds[c * ROWP + j] = o;
+      }
       }
     }
   }
@@ -466,13 +520,16 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     if (col < P.Tout && c < P.H) G.y[(long long)b * P.y_bstride + (long long)c * P.Tout_stride + col] = tv * sv;
     return;
   }
-  if (tid >= 256) return;
-  const int row = tid >> 4, col = n0 + (tid & 15);
+  const bool want_stat = EPI == EPI_STORE && P.ln_stat_out != nullptr;  // kernel-uniform
+  if (tid >= 256 && !want_stat) return;
+  const bool act = tid < 256;
+  const int row = (tid >> 4) & 15, col = n0 + (tid & 15);
   float v = 0.f;
 #pragma unroll
   for (int w = 0; w < NW; ++w) v += red[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + (tid & 15)];
   const int r = m0 + row;
-  if (col >= P.Tout || r >= P.Cout) return;
+  const bool ok = act && col < P.Tout && r < P.Cout;
+  if (!ok && !want_stat) return;
   if (EPI == EPI_STORE) {
     v += ep0;
     v += ep1;
@@ -483,9 +540,36 @@ __global__ void __launch_bounds__(NW * 64) conv16_kernel(const ConvParams P) {
     v *= ep2;
     v += ep3;
     const long long o = (long long)b * P.y_bstride + (long long)r * P.Tout_stride + col;
-    G.y[o] = v;
-    if (G.y2) G.y2[o] = v;
+    if (ok) {
+      G.y[o] = v;
+      if (G.y2) G.y2[o] = v;
+    }
     CONV_DBG(5);
+    if (want_stat) {
+      // per-column mean and centred second moment over this block's rows (two passes, like F.layer_norm), for the LayerNorm
+      // the consumer applies while staging (PRO == 3): rows of a wave sit in lane bits 4..5, the 4 row-waves meet in LDS
+      float* st = lds + NW * 4 * 64;  // behind the reduction buffer
+      const int nrow = P.Cout - m0 < 16 ? P.Cout - m0 : 16;
+      float sv = ok ? v : 0.f;
+      sv += __shfl_xor(sv, 16, 64);
+      sv += __shfl_xor(sv, 32, 64);
+      if (act && lane < 16) st[wave * 16 + lane] = sv;
+      __syncthreads();
+      const int c15 = tid & 15;
+      const float mean = (st[c15] + st[16 + c15] + st[32 + c15] + st[48 + c15]) / (float)nrow;
+      const float d = ok ? v - mean : 0.f;
+      float q = d * d;
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      __syncthreads();
+      if (act && lane < 16) st[wave * 16 + lane] = q;
+      __syncthreads();
+      if (tid < 16 && col < P.Tout) {
+        float* dst = P.ln_stat_out + (((long long)b * P.ln_nmb + mt) * P.Tout + col) * 2;
+        dst[0] = mean;
+        dst[1] = st[c15] + st[16 + c15] + st[32 + c15] + st[48 + c15];
+      }
+    }
   } else if (EPI == EPI_RESSKIP) {
     // rows < H update x in place (modules.py:171); rows >= H (or every row of the last layer) feed the skip accumulator
     const bool to_skip = P.last || r >= P.H;

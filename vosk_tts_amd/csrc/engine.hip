@@ -60,6 +60,8 @@ static int g_poison = 0;
 static int g_tail_impl = 0;
 // 1 = folded WN tail (stacked gate outputs, one skip+post conv; default), 0 = per-layer res/skip epilogue + post
 static int g_wn_fold = 1;
+// 1 = LayerNorm statistics of the folded encoder LayerNorms from the producer conv's epilogue (default), 0 = redone by the consumer
+static int g_ln_stats = 1;
 
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
@@ -644,6 +646,7 @@ struct vits_session {
   int64_t* ylen64 = nullptr;
   float *x = nullptr, *qkv = nullptr, *att = nullptr, *y1 = nullptr, *ffh = nullptr, *stats = nullptr;
   float *xb = nullptr, *y1b = nullptr;  // second x / y pair of the LayerNorm-folded encoder schedule
+  float *lnst = nullptr;                // per (item, 16-row block, column) LayerNorm partial statistics (conv16 PRO == 3)
   float *condv = nullptr;
   float *dh = nullptr, *dy = nullptr, *dy2 = nullptr, *dc = nullptr, *dz = nullptr, *dpr = nullptr, *logw = nullptr, *dfh = nullptr;
   float *dq1 = nullptr, *dq2 = nullptr;  // second x / y pair of the per-layer DDSConv launches (ping-pong with dy / dy2)
@@ -705,6 +708,7 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->y1 = bump<float>(s, B * H * Tm);
   s->xb = bump<float>(s, B * H * Tm);
   s->y1b = bump<float>(s, B * H * Tm);
+  s->lnst = bump<float>(s, (size_t)B * 16 * Tm * 2);
   s->ffh = bump<float>(s, B * Fm * Tm);
   s->stats = bump<float>(s, B * 2 * I * Tx);
   s->dh = bump<float>(s, B * D * Tx); s->dy = bump<float>(s, B * D * Tx); s->dy2 = bump<float>(s, B * D * Tx);
@@ -958,8 +962,8 @@ static void launch_c16(vits_session* s, ConvParams& P, int epi, int nw) {
   P.ntiles_m = cdiv(epi == EPI_GATE ? 2 * P.H : P.Cout, 16);
   P.ntiles_n = cdiv(P.Tout, 16);
   P.row_len = c16_row_pitch(16 + (G.K - 1) * G.dil);
-  size_t lds = ((size_t)P.Cin * P.row_len + (P.ln_g ? (size_t)nw * 2 * 32 : 0)) * sizeof(float);
-  const size_t red = (size_t)nw * 4 * 64 * sizeof(float);
+  size_t lds = ((size_t)P.Cin * P.row_len + ((P.ln_g && !P.ln_stat_in) ? (size_t)nw * 2 * 32 : 0)) * sizeof(float);
+  const size_t red = ((size_t)nw * 4 * 64 + (P.ln_stat_out ? 64 : 0)) * sizeof(float);
   if (lds < red) lds = red;
   const dim3 grid(8 * cdiv(P.ntiles_m, 8) * P.ntiles_n * P.B);
   hipStream_t st = s->stream;
@@ -974,7 +978,15 @@ static void launch_c16(vits_session* s, ConvParams& P, int epi, int nw) {
       else launch_c16_inst<EPI_, 4, C16_MAXU>(st, P, grid, lds);                      \
     }                                                                                 \
   } while (0)
-  if (P.ln_g) {  // LayerNorm-on-load (EPI_STORE only)
+  if (P.ln_g && P.ln_stat_in) {  // LayerNorm-on-load from the producer's statistics (EPI_STORE only)
+    if (nw == 8) {
+      if (few) launch_c16_inst<EPI_STORE, 8, 8, 3>(st, P, grid, lds);
+      else launch_c16_inst<EPI_STORE, 8, C16_MAXU, 3>(st, P, grid, lds);
+    } else {
+      if (few) launch_c16_inst<EPI_STORE, 4, 8, 3>(st, P, grid, lds);
+      else launch_c16_inst<EPI_STORE, 4, C16_MAXU, 3>(st, P, grid, lds);
+    }
+  } else if (P.ln_g) {  // LayerNorm-on-load, statistics redone per workgroup (EPI_STORE only)
     if (nw == 8) {
       if (few) launch_c16_inst<EPI_STORE, 8, 8, 2>(st, P, grid, lds);
       else launch_c16_inst<EPI_STORE, 8, C16_MAXU, 2>(st, P, grid, lds);
@@ -1035,7 +1047,7 @@ static bool conv_wp_ok(const ConvParams& P, int epi, int halo, bool small) {
   static const int env_mode = getenv("VITS_CONV_WP") ? atoi(getenv("VITS_CONV_WP")) : 0;
   const int mode = g_wp_mode ? g_wp_mode : env_mode;
   if (mode == 1 || epi != EPI_STORE) return false;
-  if (P.x_ch_sign != 1 || P.x_ch_off || P.tile_start || P.ups_u || P.reflect || P.in_scale != 1.f || P.ln_g || P.dds_y2) return false;
+  if (P.x_ch_sign != 1 || P.x_ch_off || P.tile_start || P.ups_u || P.reflect || P.in_scale != 1.f || P.ln_g || P.dds_y2 || P.ln_stat_out) return false;
   if (P.Cin % CONV_CI_T || P.Tin < 4 || 32 + halo > WP_PITCH || P.in_slope < 0.f || P.in_slope > 1.f) return false;
   if (P.x_split && (P.n_groups != 1 || P.x_split % CONV_CI_T || !P.g[0].x2)) return false;
   for (int g = 0; g < P.n_groups; ++g)
@@ -1060,6 +1072,11 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
 static bool conv_takes_c16(const ConvParams& P, int epi) {
   static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
   if (!(g_force_tile == 3 || (g_force_tile == 0 && (long)P.B * P.Tout <= c16_cols))) return false;
+  // (launch_conv hands 200..1000-column convs with C_in >= 256 to the wave-pipelined kernel first, unless they carry a prologue or
+  // write LayerNorm statistics)
+  if (g_force_tile == 0 && (long)P.B * P.Tout > 192 && P.Cin >= 256 && !P.ln_g && !P.dds_y2 && !P.ln_stat_out &&
+      conv_wp_ok(P, epi, (P.g[0].K - 1) * P.g[0].dil, true))
+    return false;
   return c16_waves(P, epi) != 0;
 }
 
@@ -1260,7 +1277,7 @@ static void launch_attention(vits_session* s, const float* qkv, const EncLayerW&
 // attentions.py:52-56) into the staging of the next layer's fused q/k/v conv; each writes the normalised tensor once (the
 // residual path needs it).  The last norm_layers_2 is handed to the caller's consumer through `pend` when it has one
 // (TextEncoder.proj), otherwise it runs as the LayerNorm kernel (flow: + final_base, masked).
-struct PendingLN { const float* raw = nullptr; const float* g = nullptr; const float* b = nullptr; };
+struct PendingLN { const float* raw = nullptr; const float* g = nullptr; const float* b = nullptr; const float* stat = nullptr; int nmb = 0; };
 
 static bool enc_fold_ok(vits_session* s, const EncoderW& E, int B, int T) {
   static const bool no_fold = getenv("VITS_NO_LN_FOLD") != nullptr;  // A/B switch for tools/ and tests
@@ -1282,6 +1299,19 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
   const int H = E.H, F = E.F, K = E.K;
   const int n = (int)E.layers.size();
   const bool fold = enc_fold_ok(s, E, B, T);
+  // statistics of the folded LayerNorms come from the producing conv's epilogue (conv16 PRO == 3) instead of being redone by every
+  // workgroup of the consumer: test hook vits_debug_ln_stats
+  bool pstat = fold && g_ln_stats && s->lnst && H % 16 == 0 && H / 16 <= 16;
+  if (pstat) {  // the producers (conv_o, FFN conv_2) must run on the small-tile kernel too: only its epilogue writes the statistics
+    float dummy_stat = 0.f;
+    const EncLayerW& L0 = E.layers[0];
+    ConvParams Pp = conv_params(L0.o, s->att, s->y1, B, T, 1, 0);
+    Pp.ln_stat_out = &dummy_stat;
+    pstat = conv_takes_c16(Pp, EPI_STORE);
+    Pp = conv_params(L0.f2, s->ffh, s->y1, B, T, 1, (K - 1) / 2);
+    Pp.ln_stat_out = &dummy_stat; Pp.in_mask = 1; Pp.out_mask = 1; Pp.len = len;
+    pstat = pstat && conv_takes_c16(Pp, EPI_STORE);
+  }
   PendingLN prev;  // norm_layers_2 of the previous layer, not yet applied (fold only)
   for (int i = 0; i < n; ++i) {
     const EncLayerW& L = E.layers[i];
@@ -1292,6 +1322,7 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
     ConvParams P = conv_params(L.qkv, prev.raw ? prev.raw : x, s->qkv, B, T, 1, 0);
     if (prev.raw) {
       P.ln_g = prev.g; P.ln_b = prev.b; P.ln_out = x; P.len = len;
+      P.ln_stat_in = prev.stat; P.ln_nmb = prev.nmb;
       if (cond_here) { P.ln_vec = s->condv; P.ln_vec_stride = m->cond_rows; P.ln_vec_off = cond_off; }
     }
     mark_masked(s, P, len);
@@ -1299,6 +1330,7 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
     launch_attention(s, s->qkv, L, len, s->att, B, H, T);
     P = conv_params(L.o, s->att, s->y1, B, T, 1, 0);  // y1 = x + conv_o(att)
     P.g[0].res = x;
+    if (pstat) { P.ln_stat_out = s->lnst; P.ln_nmb = H / 16; }
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.o");
     const float* xf = x;  // input of the FFN (after norm_layers_1)
@@ -1307,16 +1339,19 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
     P = conv_params(L.f1, fold ? s->y1 : x, s->ffh, B, T, 1, (K - 1) / 2);
     P.in_mask = 1; P.len = len; P.relu = 1; P.out_mask = 1;
     if (fold) { P.ln_g = L.g1; P.ln_b = L.b1; P.ln_out = s->xb; xf = s->xb; }
+    if (pstat) { P.ln_stat_in = s->lnst; P.ln_nmb = H / 16; }
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.ffn1");
     float* y2 = fold ? s->y1b : s->y1;
     P = conv_params(L.f2, s->ffh, y2, B, T, 1, (K - 1) / 2);
     P.in_mask = 1; P.len = len; P.out_mask = 1; P.g[0].res = xf;  // y = x + ffn(x)
+    const bool lastl = i == n - 1;
+    const bool to_consumer = fold && (!lastl || pend);
+    if (pstat && to_consumer) { P.ln_stat_out = s->lnst; P.ln_nmb = H / 16; }
     mark_masked(s, P, len);
     launch_conv(s, P, EPI_STORE, "enc.ffn2");
-    const bool lastl = i == n - 1;
-    if (fold && !lastl) { prev.raw = y2; prev.g = L.g2; prev.b = L.b2; continue; }
-    if (fold && lastl && pend) { pend->raw = y2; pend->g = L.g2; pend->b = L.b2; return; }
+    if (fold && !lastl) { prev.raw = y2; prev.g = L.g2; prev.b = L.b2; prev.stat = pstat ? s->lnst : nullptr; prev.nmb = H / 16; continue; }
+    if (fold && lastl && pend) { pend->raw = y2; pend->g = L.g2; pend->b = L.b2; pend->stat = pstat ? s->lnst : nullptr; pend->nmb = H / 16; return; }
     launch_ln(s, y2, nullptr, lastl ? final_base : nullptr, (lastl && final_out) ? final_out : x, L.g2, L.b2, len, B, H,
               T, 0, lastl ? 1 : 0);
   }
@@ -1377,7 +1412,7 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   }
   ConvParams P = conv_params(m->enc_proj, pend.raw ? pend.raw : s->x, s->stats, B, Tx, 1, 0);
   P.out_mask = 1; P.len = s->len_x;
-  if (pend.raw) { P.ln_g = pend.g; P.ln_b = pend.b; P.ln_out = s->x; P.in_mask = 1; }  // x = encoder(...) * x_mask, also left in s->x
+  if (pend.raw) { P.ln_g = pend.g; P.ln_b = pend.b; P.ln_out = s->x; P.in_mask = 1; P.ln_stat_in = pend.stat; P.ln_nmb = pend.nmb; }  // x = encoder(...) * x_mask, also left in s->x
   mark_masked(s, P, s->len_x);
   launch_conv(s, P, EPI_STORE, "enc.proj");
 }
@@ -2580,6 +2615,7 @@ void vits_debug_attention_impl(int impl) { g_attn_impl = impl; }
 void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
+void vits_debug_ln_stats(int on) { g_ln_stats = on; }
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
 void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
