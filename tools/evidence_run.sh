@@ -7,6 +7,7 @@ if [ "$1" != "noprof_tests" ]; then
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $O/r2_gpu_tests.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2_gpu_tests.log
 tail -5 $O/r2_gpu_tests.log
 fi
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r2_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/r2_smoke.log
 timeout 600 python bench.py > $O/r2_default_bench.json.txt 2> $O/bench_default.err; echo "bench rc=$?"
 tail -c 600 $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
