@@ -491,6 +491,7 @@ static int load_model(vits_model* m) {
   load_encoder(m, m->enc_p, "enc_p.encoder", hp.n_layers, H, F, hp.kernel_size);
   m->enc_proj = conv_from(m, "enc_p.proj", 2 * I, H, 1, true);
   if (hp.bert_dim < 0 || hp.bert_dim % CONV_CI_T) return fail(VITS_ERR_UNSUPPORTED, "bert_dim %d must be a multiple of %d", hp.bert_dim, CONV_CI_T);
+  if (hp.conv_precision != 0 && hp.conv_precision != 1) return fail(VITS_ERR_UNSUPPORTED, "conv_precision %d (0 = fp32, 1 = split-bf16 decoder convs)", hp.conv_precision);
   if (hp.bert_dim > 0) m->bert_proj = conv_from(m, "enc_p.bert_proj", H, hp.bert_dim, 1, true);
   if (m->missing) return VITS_ERR_BLOB;
 
@@ -2219,8 +2220,25 @@ static int back_get(vits_session* F, int TyB, vits_session** out) {
   return VITS_OK;
 }
 
-static int capture_end(vits_session* s, hipGraphExec_t* out) {
+// A capture that does not reach capture_end (an early return between Begin and End) must not leave the stream in capture mode:
+// every later call on the session would fail.  The guard ends and discards it.
+struct CaptureGuard {
+  hipStream_t st; bool done = false;
+  explicit CaptureGuard(hipStream_t s) : st(s) {}
+  ~CaptureGuard() {
+    if (done) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      hipGraph_t g = nullptr;
+      hipStreamEndCapture(st, &g);
+      if (g) hipGraphDestroy(g);
+    }
+    (void)hipGetLastError();
+  }
+};
+static int capture_end(vits_session* s, hipGraphExec_t* out, CaptureGuard* guard = nullptr) {
   hipGraph_t g = nullptr;
+  if (guard) guard->done = true;
   HIP_TRY(hipStreamEndCapture(s->stream, &g));
   hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
@@ -2233,6 +2251,7 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
   if (!F->g1[gi]) {
     const int B = F->B, TxB = F->Tx;
     HIP_TRY(hipStreamBeginCapture(F->stream, hipStreamCaptureModeThreadLocal));
+    CaptureGuard cg(F->stream);
     hipMemcpyAsync(F->io_d, F->io_h, F->io_bytes, hipMemcpyHostToDevice, F->stream);
     F->ragged = true; F->solo = solo; F->tile_keys.clear();
     F->dv = reinterpret_cast<const SynthDev*>(F->io_d);
@@ -2248,7 +2267,7 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
     hipMemcpyAsync(F->h_ylen, F->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, F->stream);
     hipMemcpyAsync(F->h_ylen + B, F->d_err, sizeof(int), hipMemcpyDeviceToHost, F->stream);
     F->ragged = false; F->solo = false;
-    TRY(capture_end(F, &F->g1[gi]));
+    TRY(capture_end(F, &F->g1[gi], &cg));
   }
   HIP_TRY(hipGraphLaunch(F->g1[gi], F->stream));
   return VITS_OK;
@@ -2260,6 +2279,7 @@ static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm)
     const int B = F->B, TxB = F->Tx, TyB = Bk->Ty;
     const long long stride = (long long)TyB * F->m->hp.hop_length;
     HIP_TRY(hipStreamBeginCapture(F->stream, hipStreamCaptureModeThreadLocal));
+    CaptureGuard cg(F->stream);
     Bk->ragged = true; Bk->solo = solo; Bk->rag_b1 = true; Bk->tile_keys.clear();
     run_expand(Bk, nullptr, TyB, 0.f, 0, Bk->zA, B, TxB, TyB);
     float* z = run_flow(Bk, B, TyB);
@@ -2273,7 +2293,7 @@ static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm)
       hipMemcpyAsync(Bk->out_h, Bk->out_d, Bk->out_elems * sizeof(float), hipMemcpyDeviceToHost, F->stream);
     }
     Bk->ragged = false; Bk->solo = false;
-    TRY(capture_end(F, &Bk->g2[gi]));
+    TRY(capture_end(F, &Bk->g2[gi], &cg));
   }
   HIP_TRY(hipGraphLaunch(Bk->g2[gi], F->stream));
   return VITS_OK;
@@ -2453,8 +2473,9 @@ static int stream_launch(vits_stream* st, int lo) {
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     run_decoder(s, st->d_win, false, 1, st->W, st->d_aud, (long long)st->W * st->m->hp.hop_length, nullptr);
     HIP_TRY(hipStreamEndCapture(s->stream, &g));
-    HIP_TRY(hipGraphInstantiate(&st->graph, g, nullptr, nullptr, 0));
+    const hipError_t ie = hipGraphInstantiate(&st->graph, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
+    if (ie != hipSuccess) return fail(VITS_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
   }
   HIP_TRY(hipGraphLaunch(st->graph, s->stream));
   st->win_start = start;
@@ -2588,8 +2609,9 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
       HIP_TRY(hipStreamEndCapture(s->stream, &g));
       { size_t nn = 0; if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) s->graph_nodes = (int)nn; }
       hipGraphExec_t ge = nullptr;
-      HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
+      if (ie != hipSuccess) return fail(VITS_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
       it = s->graphs.emplace(key, ge).first;
     }
     HIP_TRY(hipGraphLaunch(it->second, s->stream));

@@ -752,12 +752,13 @@ static int stts_phase1(stts_model* m, SttsFront* F) {
     const size_t nmu = (size_t)hp.dp_out * F->TxB;
     s->arena_used = 0;
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    CaptureGuard cg(s->stream);
     hipMemcpyAsync(F->io_d, F->io_h, F->a_bytes, hipMemcpyHostToDevice, s->stream);
     stts_run_encoder(s, m, reinterpret_cast<const int64_t*>(F->io_d), reinterpret_cast<const int*>(F->io_d + F->o_len), nullptr, 1, F->TxB,
                      reinterpret_cast<const float*>(F->io_d + F->o_bert), F->d_x, F->d_mu, reinterpret_cast<const int64_t*>(F->io_d + F->o_sid));
     hipMemcpyAsync(F->mu_h, F->d_mu, sizeof(float) * nmu, hipMemcpyDeviceToHost, s->stream);
     hipMemcpyAsync(F->mu_h + nmu, s->d_err, sizeof(int), hipMemcpyDeviceToHost, s->stream);
-    TRY(capture_end(s, &F->g1));
+    TRY(capture_end(s, &F->g1, &cg));
   }
   HIP_TRY(hipGraphLaunch(F->g1, s->stream));
   return VITS_OK;
@@ -778,6 +779,7 @@ static int stts_phase2(stts_model* m, SttsFront* F, SttsBack* Bk, bool audio) {
     const SttsDev* dv = reinterpret_cast<const SttsDev*>(F->io_d + F->o_dev);
     s->arena_used = 0;
     HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    CaptureGuard cg(st);
     hipMemcpyAsync(F->io_d + F->a_bytes, F->io_h + F->a_bytes, F->io_bytes - F->a_bytes, hipMemcpyHostToDevice, st);
     hipLaunchKernelGGL(stts_expand_kernel, dim3(cdiv(TB, 64), CC, 1), dim3(64), 0, st, F->d_x, d_cum, F->TxB, Bk->d_mu2, CC, TB, d_pde, Bk->d_pau);
     if (hp.n_spks > 1) hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(G, 64), 1), dim3(64), 0, st, Bk->d_c, m->spk_emb, d_sid, G, hp.n_spks, s->d_err);
@@ -803,7 +805,7 @@ static int stts_phase2(stts_model* m, SttsFront* F, SttsBack* Bk, bool audio) {
       hipMemcpyAsync(Bk->out_h, Bk->d_audio, sizeof(float) * Bk->audio_elems, hipMemcpyDeviceToHost, st);
     }
     hipMemcpyAsync(Bk->out_h + Bk->audio_elems, Bk->d_mel, sizeof(float) * (size_t)NF * TB, hipMemcpyDeviceToHost, st);
-    TRY(capture_end(F->s, &Bk->g[gi]));
+    TRY(capture_end(F->s, &Bk->g[gi], &cg));
   }
   HIP_TRY(hipGraphLaunch(Bk->g[gi], st));
   return VITS_OK;

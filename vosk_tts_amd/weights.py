@@ -366,6 +366,8 @@ def validate_hparams(hp):
         if hp.subbands <= 0 or hp.istft_hop <= 0 or hp.istft_n_fft <= 0 or hp.istft_n_fft % hp.istft_hop:
             raise ValueError("iSTFT / PQMF parameters invalid")
         rate *= hp.istft_hop * hp.subbands
+    if hp.conv_precision not in (0, 1):
+        raise ValueError(f"conv_precision {hp.conv_precision}: 0 = fp32, 1 = split-bf16 decoder ResBlock convs")
     if rate != hp.hop_length:
         raise ValueError(f"decoder produces {rate} samples per frame but hop_length is {hp.hop_length}: upsample_rates / "
                          "gen_istft_hop_size / subbands / hop_length are inconsistent")
