@@ -19,12 +19,16 @@ struct Ctl {
   unsigned bar;          // round barrier counter (monotonic)
   unsigned errors;
   unsigned participants;
+  unsigned flags[64];    // MODE 4: one arrival word per worker
 };
 
 // MODE 0: workers = workgroups of XCD 0, agent-scope release/acquire fences (what __threadfence() gives), plain loads
 // MODE 1: workers = workgroups of XCD 0, stores drained (write-through L1) + agent-scope relaxed loads (L1 bypass, L2 hit): no L2 write-back / invalidate
 // MODE 2: workers = one workgroup per CU on all XCDs, agent-scope fences (the chip-wide variant)
-// MODE 3: MODE 1 with the barrier counter updated by workgroup-scope atomics (executed in the XCD's L2)
+// MODE 3: MODE 1 with the barrier counter updated by workgroup-scope atomics (hangs: not run)
+// MODE 4: MODE 1 with a flag barrier: no atomics, one arrival word per workgroup, polled with sc1 loads (P <= 64).  Same cost as the
+//         atomic counter: the price is the ~0.4 us per dependent agent-scope access, not the atomics.  (With sc0 = workgroup-scope
+//         loads / stores instead of sc1 the pollers read stale L1 lines forever: hangs.)
 template <int MODE>
 __global__ void __launch_bounds__(256) probe(Ctl* c, float* buf, int n_floats, int rounds, long long* cycles) {
   const int tid = threadIdx.x;
@@ -55,9 +59,25 @@ __global__ void __launch_bounds__(256) probe(Ctl* c, float* buf, int n_floats, i
     // produce this workgroup's slice
     for (int i = lo + tid; i < hi; i += 256) cur[i] = (float)(r * 7 + (i & 1023));
     // ---- barrier over the P workers
-    if (MODE == 1 || MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2 (the L1 is write-through)
+    if (MODE == 1 || MODE == 3 || MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2 (the L1 is write-through)
     else __threadfence();
     __syncthreads();
+    if (MODE == 4) {
+      // flag barrier without atomics: the XCD's L2 is the coherence point of its CUs.  Every workgroup publishes the round number in
+      // its own word (plain store, written through the L1), then wave 0 polls all P words with L1-bypassing loads (L2 hits).
+      if (tid == 0) {
+        unsigned val = (unsigned)(r + 1);
+        unsigned* fp = c->flags + rank;
+        asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" :: "v"(fp), "v"(val) : "memory");
+      }
+      if (tid < 64) {
+        const unsigned* fp = c->flags + (tid < (int)P ? tid : 0);
+        unsigned seen;
+        do {
+          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(fp) : "memory");
+        } while (__builtin_amdgcn_read_exec() != __builtin_amdgcn_ballot_w64(seen >= (unsigned)(r + 1)));
+      }
+    } else
     if (tid == 0) {
       const unsigned target = (unsigned)(r + 1) * P;
       if (MODE == 3) {  // workgroup-scope atomics execute in the XCD's own L2: coherent among the CUs of ONE XCD, no trip to the memory side
@@ -69,9 +89,9 @@ __global__ void __launch_bounds__(256) probe(Ctl* c, float* buf, int n_floats, i
       }
     }
     __syncthreads();
-    if (MODE != 1 && MODE != 3) __threadfence();
+    if (MODE != 1 && MODE != 3 && MODE != 4) __threadfence();
     // consume the whole tensor (MODE 1: sc1 loads = L1 bypass, L2 hit; 8 x dwordx4 in flight per thread)
-    if (MODE == 1 || MODE == 3) {
+    if (MODE == 1 || MODE == 3 || MODE == 4) {
       typedef float f4 __attribute__((ext_vector_type(4)));
       const int nv = n_floats >> 2;
       for (int i0 = tid; i0 < nv; i0 += 256 * 8) {
@@ -133,6 +153,7 @@ int main() {
     run<2>("  whole chip, agent-scope fences", n, rounds);
     run<0>("  one XCD, agent-scope fences", n, rounds);
     run<1>("  one XCD, stores drained + L1-bypassing loads (no L2 maintenance)", n, rounds);
+    run<4>("  one XCD, as above + flag barrier (plain stores, L1-bypassing polls)", n, rounds);
     // run<3>: the same with the barrier counter on workgroup-scope atomics (hoping for XCD-local L2 atomics) never sees the other
     // CUs' arrivals -- it hangs; not run
   }
