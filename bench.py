@@ -424,7 +424,7 @@ def main():
 
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are collected
         # by tools/pmc_passes.sh (separate rocprofv3 --pmc passes of THIS command, FETCH_SIZE/WRITE_SIZE calibrated with
-        # tools/pmc_calib as MI355X_MICROARCH.md prescribes) and committed as profiles/r1_pmc_<workload>.json.
+        # tools/pmc_calib as MI355X_MICROARCH.md prescribes) and committed as profiles/<PROFILE_ROUND>_pmc_<workload>.json.
         pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{wname}.json")
         if os.path.exists(pmc_path):
             try:
