@@ -122,7 +122,10 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
     from vosk_tts_amd.capi_stts import SttsModel
 
     lib = VitsLib()
-    vblob = W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234)
+    vhp = W.hifigan_v1_vocoder_hparams()
+    if getattr(args, "precision", "f32") == "bf16x3":
+        vhp.conv_precision = 1  # the vocoder's 256- / 128-channel ResBlock convs as split-bf16 at batch size (m3)
+    vblob = W.synthetic_blob(vhp, 1234)
     hp = S.default_hparams(62, 5)
     blob = S.synthetic_blob(hp, 1234)
     voc = lib.create(vblob, local_rank)
@@ -213,7 +216,7 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
         print(json.dumps({
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
+            "dtype": "f32" if getattr(args, "precision", "f32") == "f32" else "bf16x3", "data": "synthetic", "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
             "config": {"workload": f"{args.workload}: StableTTS/Matcha multistream graph (seeded synthetic weights) + bundled HiFi-GAN V1, "
                                    + (f"B=32 ragged {int(lengths.min())}..{int(lengths.max())} symbols" if batched else f"B=1, {Tx} symbols") + " x 5 streams, "
                                    f"zero BERT vectors, durations pinned 3/symbol -> T_y<={Ty}, {hp.n_timesteps} Euler steps with guidance {hp.guidance_scale:g}, "

@@ -120,6 +120,37 @@ def test_stts_medium_utterance_vs_oracle_and_long_form_properties(stts_pair):
     assert np.array_equal(m1, m3)
 
 
+def test_stts_batch_with_split_bf16_vocoder(hip_lib, oracle_lib):
+    """hparams.conv_precision = 1 on the vocoder-only model: the HiFi-GAN V1 ResBlock convs of the 256- / 128-channel stages run
+    as split-bf16 at batch size.  A batch of 8 utterances against the same batch on the fp32 vocoder (same acoustic model, same
+    seeds): fp32-class agreement."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.capi_stts import SttsModel
+
+    blob = S.synthetic_blob(S.default_hparams(40, 7), 1234)
+    vhp = W.hifigan_v1_vocoder_hparams()
+    v32 = hip_lib.create(W.synthetic_blob(vhp, 1234), 0)
+    vhp.conv_precision = 1
+    vbf = hip_lib.create(W.synthetic_blob(vhp, 1234), 0)
+    m32, mbf = SttsModel(hip_lib, blob, v32), SttsModel(hip_lib, blob, vbf)
+    rng = np.random.default_rng(5)
+    B, Tx = 8, 60
+    lengths = rng.integers(30, Tx + 1, size=B).astype(np.int64)
+    ids = rng.integers(1, 40, size=(B, 5, Tx)).astype(np.int64)
+    pde = np.full((B, Tx), 4.0, np.float32)
+    sid = rng.integers(0, 7, size=B).astype(np.int64)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+    try:
+        a32, l32 = m32.synthesize_batch(ids, lengths, sc, sid, None, pde, seed=9, n_timesteps=2)
+        abf, lbf = mbf.synthesize_batch(ids, lengths, sc, sid, None, pde, seed=9, n_timesteps=2)
+        assert np.array_equal(l32, lbf) and np.isfinite(abf).all()
+        assert not np.array_equal(a32, abf)  # the variant really ran
+        assert_close("batch audio: split-bf16 vocoder vs fp32 vocoder", a32, abf, 1e-4)
+    finally:
+        m32.close(); mbf.close()
+
+
 def test_stts_fast_path_equals_eager(hip_lib, stts_pair):
     """stts_synthesize replays two captured graphs per call (shape buckets: T_x to 8, frames to 32; scalars and inputs through
     a device block) -- against the eager path (vits_debug_fast_path(0)) on the same seeds: lengths inside and on bucket borders,
