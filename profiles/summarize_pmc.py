@@ -31,7 +31,7 @@ def label(name):
         if m[5] == "1":
             return f"{m[1]}<{EPI[m[2]]},dds>"
         return f"{m[1]}<{EPI[m[2]]},{'ln,' if m[5] == '2' else ''}{m[3]}>"
-    m = re.match(r"void (conv_wp_kernel)<(\d+)>", name)
+    m = re.match(r"void (conv_wp_kernel|conv_bf3_kernel)<(\d+)>", name)
     if m:
         return f"{m[1]}<{m[2]}>"
     m = re.match(r"(?:void )?(\w+)", name)

@@ -57,8 +57,10 @@ template <int V> struct bf3_int { static constexpr int value = V; };
 // weight-fragment slots are named statically (slot = tap parity; an odd tap count costs one 16-register move per CHUNK instead of
 // one per tap), one pointer per m-block advances by a constant, and the B reads use
 // immediate offsets.  The weight stream is read one step past its end (add_bf3_packing pads the array).
+// MI = 32-row blocks per wave: 2 -> 128 x 128 tiles, 1 -> 64 x 128 tiles (64-channel stages)
+template <int MI>
 static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b) {
-  constexpr int N_T = 128, M_T = 128;
+  constexpr int N_T = 128, M_T = 64 * MI;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -112,9 +114,9 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -123,10 +125,10 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   // weight stream: step s = chunk * K + tap; per step and m-block: [hi | lo] x 64 lanes x 16 B
   const int n_mblocks = P.M >> 5;
   const int nsteps = nchunks * K;
-  const bf16x8* wq[2];  // next step to fetch, per m-block
+  const bf16x8* wq[MI];  // next step to fetch, per m-block
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    int mb = (m0 >> 5) + wm * 2 + mi;
+  for (int mi = 0; mi < MI; ++mi) {
+    int mb = (m0 >> 5) + wm * MI + mi;
     if (mb >= n_mblocks) mb = 0;  // padded tile: compute on valid memory, never stored
     wq[mi] = reinterpret_cast<const bf16x8*>(G.wb) + (size_t)mb * nsteps * 128 + lane;
   }
@@ -136,9 +138,9 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   if (nchunks > 1) load_chunk(1, stg);
   __syncthreads();
 
-  bf16x8 a[2][2][2];  // [slot][mi][piece]
+  bf16x8 a[2][MI][2];  // [slot][mi][piece]
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     a[0][mi][0] = wq[mi][0];
     a[0][mi][1] = wq[mi][64];
     wq[mi] += 128;
@@ -147,7 +149,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   auto tap = [&](auto slot_, const char* lk0, const char* lk1) {
     constexpr int S = decltype(slot_)::value;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       a[S ^ 1][mi][0] = wq[mi][0];
       a[S ^ 1][mi][1] = wq[mi][64];
       wq[mi] += 128;
@@ -161,15 +163,15 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     __builtin_amdgcn_sched_barrier(0);  // loads of the next step and this tap's B reads in flight before the first MFMA
     // lo*hi + hi*lo + hi*hi, the four accumulators interleaved (no back-to-back dependent MFMAs)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][1], bh[ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][0], bl[ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][0], bh[ni], acc[mi][ni], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -192,7 +194,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     if (K & 1) {  // odd tap count: last tap from slot 0, then the next chunk's first tap (now in slot 1) moves to slot 0
       tap(bf3_int<0>{}, lk0, lk1);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) a[0][mi][pc] = a[1][mi][pc];
     }
@@ -207,7 +209,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   // ---- epilogue (shared with the fp32 kernels).  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const int lenb = P.out_mask ? P.len[b] : 0x7fffffff;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -215,15 +217,16 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][e0 + i];
-        conv_epilogue_frag<EPI_STORE, 4>(P, G, b, lenb, m0 + (wm * 2 + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
+        conv_epilogue_frag<EPI_STORE, 4>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
       }
 }
 
+template <int MI>
 __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   extern __shared__ float lds[];
   kernarg_warm<sizeof(ConvParams)>();
   int mt, grp, nt, b;
   if (!conv_decode_block(P, mt, grp, nt, b)) return;
   const ConvGroup& G = P.g[grp];
-  conv_bf3_body(P, G, lds, mt, nt, b);
+  conv_bf3_body<MI>(P, G, lds, mt, nt, b);
 }

@@ -420,7 +420,7 @@ static int load_decoder(vits_model* m) {
         R.dil[d] = hp.res_dilations[j][d];
         if ((R.K - 1) * R.dil[d] > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "resblock receptive field too wide");
         snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", i * hp.n_resk + j, d);
-        const bool bf3 = hp.conv_precision == 1 && C % 128 == 0;  // split-bf16 variant of the batch-size kernel (128-row tiles)
+        const bool bf3 = hp.conv_precision == 1 && C % 64 == 0;  // split-bf16 variant of the batch-size kernel (128- or 64-row tiles)
         R.c1[d] = conv_from(m, nm, C, C, R.K, true, false, bf3);
         snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", i * hp.n_resk + j, d);
         R.c2[d] = conv_from(m, nm, C, C, R.K, true, false, bf3);
@@ -1174,25 +1174,31 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   if ((P.ups_u && (P.ups_cout % 64)) || (!P.ups_u && P.M % 64 == 32)) {
     ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(s, P, halo); return;
   }
+  auto bf3_ok = [&]() {
+    bool ok = !g_no_bf3 && !P.ups_u && !P.reflect && !P.x_split && P.x_ch_sign == 1 && !P.x_ch_off && !P.ln_g;
+    for (int g = 0; g < P.n_groups; ++g) ok = ok && P.g[g].wb && !P.g[g].x2 && !P.g[g].x3;
+    return ok;
+  };
+  auto bf3_go = [&](int mi) {  // split-bf16 variant (hparams.conv_precision == 1): same staging pattern, 3 bf16 MFMAs per 16 channels x tap
+    ps.set_kernel(mi == 2 ? "conv_bf3_kernel<2>" : "conv_bf3_kernel<1>");
+    attach_tile_table(s, P, 128);
+    P.ntiles_m = cdiv(P.M, 64 * mi);
+    P.ntiles_n = cdiv(P.Tout, 128);
+    P.row_len = 128 + halo;
+    const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
+    const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
+    if (mi == 2) hipLaunchKernelGGL(conv_bf3_kernel<2>, grid, dim3(256), lds, s->stream, P);
+    else hipLaunchKernelGGL(conv_bf3_kernel<1>, grid, dim3(256), lds, s->stream, P);
+  };
   // 64-row outputs at batch size: 64 x 128 tiles (twice the columns per weight fragment of the 64 x 64 tile)
   if (!P.ups_u && P.M == 64 && (long)cdiv(P.Tout, 128) * P.B * P.n_groups >= 512) {
+    if (bf3_ok()) { bf3_go(1); return; }
     ps.set_kernel("conv_mfma_kernel<2,2,1,2,STORE>"); launch_cfg<2, 2, 1, 2, EPI_STORE>(s, P, halo); return;
   }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
   if (m_fits && big_blocks >= 512) {
-    bool bf3 = !g_no_bf3 && !P.ups_u && !P.reflect && !P.x_split && P.x_ch_sign == 1 && !P.x_ch_off && !P.ln_g;
-    for (int g = 0; g < P.n_groups; ++g) bf3 = bf3 && P.g[g].wb && !P.g[g].x2 && !P.g[g].x3;
-    if (bf3) {  // split-bf16 variant (hparams.conv_precision == 1): same tile, same staging pattern, 3 bf16 MFMAs per 16 channels x tap
-      ps.set_kernel("conv_bf3_kernel");
-      attach_tile_table(s, P, 128);
-      P.ntiles_m = cdiv(P.M, 128);
-      P.ntiles_n = cdiv(P.Tout, 128);
-      P.row_len = 128 + halo;
-      const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
-      hipLaunchKernelGGL(conv_bf3_kernel, dim3(P.ntiles_m * P.ntiles_n * P.B * P.n_groups), dim3(256), lds, s->stream, P);
-      return;
-    }
+    if (bf3_ok()) { bf3_go(2); return; }
     ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return;
   }
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
