@@ -473,7 +473,7 @@ def main():
         R4 = measure("c3", max(3, min(args.steps, 10)), 2, min(args.min_seconds, 0.5), model=model3)
         batch32_bf16x3 = {"value": round(R4["value"], 1), "unit": "samples/s", "ms_per_step": round(R4["ms_per_step"], 4), "dtype": "bf16x3",
                           "x_realtime": round(1.0 / R4["rtf"], 1), "batch": R4["B"], "T_x": R4["Tx"], "T_y": R4["Ty"],
-                          "workload": "c3 as batch32, decoder ResBlock convs split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), everything else fp32",
+                          "workload": "c3 as batch32, ResBlock, encoder / flow STORE and WaveNet gate convs split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), the rest fp32",
                           "timed_region_s": round(R4["timed_region_s"], 3),
                           "roofline": {k: R4["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us", "forward", "by_kernel_ms_per_forward") if k in R4["roofline"]}}
         model3.close()

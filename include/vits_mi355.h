@@ -96,10 +96,11 @@ typedef struct vits_hparams {
   int32_t bert_dim;          /* 0 = plain VITS2 (the in-repo TextEncoder).  > 0: BERT-conditioned flavour (vosk_tts/synth.py:88-99 feeds
                                 "bert" [B, bert_dim, T_x]): tensors enc_p.bert_proj.{weight [hidden, bert_dim, 1], bias} exist and the
                                 text encoder input is (emb(ids)*sqrt(hidden) + bert_proj(bert)) * mask -- see vits_synth_opts.bert */
-  int32_t conv_precision;    /* 0 = fp32 everywhere (default; every parity figure and the headline benchmark).  1 = "bf16x3": the
-                                decoder's ResBlock convs at batch size run on the bf16 matrix core with every operand split into two
-                                bf16 pieces (hi*hi + hi*lo + lo*hi, fp32 accumulation; csrc/conv_bf3.hip.h) -- BASELINE configs[2]'s
-                                reduced-precision variant in the form that keeps fp32-class accuracy (~4e-6 per conv) */
+  int32_t conv_precision;    /* 0 = fp32 everywhere (default; every parity figure and the headline benchmark).  1 = "bf16x3": at
+                                batch size the decoder's ResBlock convs, the encoders' / flow's plain convs and the WaveNet gate convs
+                                run on the bf16 matrix core with every operand split into two bf16 pieces (hi*hi + hi*lo + lo*hi,
+                                fp32 accumulation; csrc/conv_bf3.hip.h) -- BASELINE configs[2]'s reduced-precision variant in the
+                                form that keeps fp32-class accuracy (~4e-6 per conv) */
   int32_t reserved[6];
 } vits_hparams;
 

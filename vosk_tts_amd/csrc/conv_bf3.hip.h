@@ -57,8 +57,9 @@ template <int V> struct bf3_int { static constexpr int value = V; };
 // weight-fragment slots are named statically (slot = tap parity; an odd tap count costs one 16-register move per CHUNK instead of
 // one per tap), one pointer per m-block advances by a constant, and the B reads use
 // immediate offsets.  The weight stream is read one step past its end (add_bf3_packing pads the array).
-// MI = 32-row blocks per wave: 2 -> 128 x 128 tiles, 1 -> 64 x 128 tiles (64-channel stages)
-template <int MI>
+// MI = 32-row blocks per wave: 2 -> 128 x 128 tiles, 1 -> 64 x 128 tiles (64-channel stages).  EPI: EPI_STORE, or EPI_GATE with MI == 2
+// (a wave's two row blocks are the [tanh 32 | sigmoid 32] pre-activations of the same 32 channels, commons.py:100-107)
+template <int MI, int EPI>
 static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b) {
   constexpr int N_T = 128, M_T = 64 * MI;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
@@ -207,6 +208,19 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   }
 
   // ---- epilogue (shared with the fp32 kernels).  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  if (EPI == EPI_GATE) {
+    const int j = (m0 >> 6) + wm;  // channel block of 32
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e0 = 0; e0 < 16; e0 += 4) {
+        float at[4], as[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { at[i] = acc[0][ni][e0 + i]; as[i] = acc[MI - 1][ni][e0 + i]; }
+        conv_epilogue_gate<4>(P, G, b, j * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, at, as);
+      }
+    return;
+  }
   const int lenb = P.out_mask ? P.len[b] : 0x7fffffff;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -217,16 +231,16 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][e0 + i];
-        conv_epilogue_frag<EPI_STORE, 4>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
+        conv_epilogue_frag<EPI == EPI_GATE ? EPI_STORE : EPI, 4>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
       }
 }
 
-template <int MI>
+template <int MI, int EPI>
 __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   extern __shared__ float lds[];
   kernarg_warm<sizeof(ConvParams)>();
   int mt, grp, nt, b;
   if (!conv_decode_block(P, mt, grp, nt, b)) return;
   const ConvGroup& G = P.g[grp];
-  conv_bf3_body<MI>(P, G, lds, mt, nt, b);
+  conv_bf3_body<MI, EPI>(P, G, lds, mt, nt, b);
 }

@@ -290,18 +290,21 @@ static void load_encoder(vits_model* m, EncoderW& E, const char* pfx, int n_laye
     if (m->missing) return;
     std::vector<float> b3(3 * H);
     memcpy(b3.data(), bq, sizeof(float) * H); memcpy(b3.data() + H, bk, sizeof(float) * H); memcpy(b3.data() + 2 * H, bv, sizeof(float) * H);
-    L.qkv = make_conv(m, 3 * H, H, 1, b3.data(), [&](int r, int ci, int) {
+    auto qkv_src = [&](int r, int ci, int) {
       const float* w = r < H ? wq : (r < 2 * H ? wk : wv);
       return w[(size_t)(r % H) * H + ci];
-    });
+    };
+    L.qkv = make_conv(m, 3 * H, H, 1, b3.data(), qkv_src);
+    const bool bf3 = hp.conv_precision == 1 && H % 64 == 0 && F % 64 == 0;  // batch-size STORE convs of the encoders as split-bf16 too
+    if (bf3) add_bf3_packing(m, L.qkv, qkv_src);
     snprintf(nm, sizeof nm, "%s.attn_layers.%d.conv_o", pfx, i);
-    L.o = conv_from(m, nm, H, H, 1, true);
+    L.o = conv_from(m, nm, H, H, 1, true, true, bf3);
     L.ek = upload(m, tget(m, 3, 1, NW, dk, "%s.attn_layers.%d.emb_rel_k", pfx, i), (size_t)NW * dk);
     L.ev = upload(m, tget(m, 3, 1, NW, dk, "%s.attn_layers.%d.emb_rel_v", pfx, i), (size_t)NW * dk);
     snprintf(nm, sizeof nm, "%s.ffn_layers.%d.conv_1", pfx, i);
-    L.f1 = conv_from(m, nm, F, H, K, true);
+    L.f1 = conv_from(m, nm, F, H, K, true, true, bf3);
     snprintf(nm, sizeof nm, "%s.ffn_layers.%d.conv_2", pfx, i);
-    L.f2 = conv_from(m, nm, H, F, K, true);
+    L.f2 = conv_from(m, nm, H, F, K, true, true, bf3);
     L.g1 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_1.%d.gamma", pfx, i), H);
     L.b1 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_1.%d.beta", pfx, i), H);
     L.g2 = upload(m, tget(m, 1, H, -1, -1, "%s.norm_layers_2.%d.gamma", pfx, i), H);
@@ -549,15 +552,17 @@ static int load_model(vits_model* m) {
       const float* w = tget(m, 3, 2 * H, H, K5, "flow.flows.%d.enc.in_layers.%d.weight", 2 * f, i);
       const float* b = tget(m, 1, 2 * H, -1, -1, "flow.flows.%d.enc.in_layers.%d.bias", 2 * f, i);
       if (m->missing) break;
-      c.in_layers.push_back(make_conv2(m, 2 * H, H, K5, b, [&](int r, int ci, int kk) {
+      auto gate_src = [&](int r, int ci, int kk) {
         const int j = r / 64, q = r % 64;
         const int orig = q < 32 ? j * 32 + q : H + j * 32 + (q - 32);
         return w[((size_t)orig * H + ci) * K5 + kk];
-      }, true, [&](int r, int ci, int kk) {  // small-tile kernel: [8 tanh | 8 sigmoid] per 16 rows
+      };
+      c.in_layers.push_back(make_conv2(m, 2 * H, H, K5, b, gate_src, true, [&](int r, int ci, int kk) {  // small-tile kernel: [8 tanh | 8 sigmoid] per 16 rows
         const int j = r / 16, q = r % 16;
         const int orig = q < 8 ? j * 8 + q : H + j * 8 + (q - 8);
         return w[((size_t)orig * H + ci) * K5 + kk];
       }));
+      if (hp.conv_precision == 1 && (2 * H) % 128 == 0) add_bf3_packing(m, c.in_layers.back(), gate_src);
       snprintf(nm, sizeof nm, "flow.flows.%d.enc.res_skip_layers.%d", 2 * f, i);
       c.rs_layers.push_back(conv_from(m, nm, i < L - 1 ? 2 * H : H, H, 1, true));
     }
@@ -576,8 +581,11 @@ static int load_model(vits_model* m) {
         rb[i] = tget(m, 1, rows, -1, -1, "flow.flows.%d.enc.res_skip_layers.%d.bias", 2 * f, i);
       }
       if (!m->missing) {
-        for (int i = 0; i < L - 1; ++i)  // residual half: rows [0, H)
-          c.rsx.push_back(make_conv(m, H, H, 1, rb[i], [&](int r, int ci, int) { return rw[i][(size_t)r * H + ci]; }));
+        for (int i = 0; i < L - 1; ++i) {  // residual half: rows [0, H)
+          auto rs_src = [&](int r, int ci, int) { return rw[i][(size_t)r * H + ci]; };
+          c.rsx.push_back(make_conv(m, H, H, 1, rb[i], rs_src));
+          if (hp.conv_precision == 1 && H % 64 == 0) add_bf3_packing(m, c.rsx.back(), rs_src);
+        }
         const int half = I / 2;
         std::vector<double> Wf((size_t)half * L * H, 0.0), bf(half, 0.0);
         for (int o = 0; o < half; ++o) {
@@ -1146,7 +1154,16 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   if (epi == EPI_GATE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo, &ps); }
-    else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
+    else if (!g_no_bf3 && P.g[0].wb && P.n_groups == 1 && P.M % 128 == 0 && P.x_ch_sign == 1 && !P.x_ch_off && !P.g[0].x2 && !P.ln_g &&
+             (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B >= 256) {  // split-bf16 WaveNet gate conv (conv_precision == 1)
+      ps.set_kernel("conv_bf3_kernel<2,GATE>");
+      attach_tile_table(s, P, 128);
+      P.ntiles_m = cdiv(P.M, 128);
+      P.ntiles_n = cdiv(P.Tout, 128);
+      P.row_len = 128 + halo;
+      const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
+      hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(256), lds, s->stream, P);
+    } else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
     return;
   }
   if (epi == EPI_RESSKIP) {
@@ -1187,8 +1204,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     P.row_len = 128 + halo;
     const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
     const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
-    if (mi == 2) hipLaunchKernelGGL(conv_bf3_kernel<2>, grid, dim3(256), lds, s->stream, P);
-    else hipLaunchKernelGGL(conv_bf3_kernel<1>, grid, dim3(256), lds, s->stream, P);
+    if (mi == 2) hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
+    else hipLaunchKernelGGL((conv_bf3_kernel<1, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
   };
   // 64-row outputs at batch size: 64 x 128 tiles (twice the columns per weight fragment of the 64 x 64 tile)
   if (!P.ups_u && P.M == 64 && (long)cdiv(P.Tout, 128) * P.B * P.n_groups >= 512) {
@@ -1201,6 +1218,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     if (bf3_ok()) { bf3_go(2); return; }
     ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return;
   }
+  // 64-row multiples at batch size (encoder / flow STORE convs: 192, 576, 768 rows) of a conv_precision == 1 model
+  if (P.M % 64 == 0 && (long)cdiv(P.M, 64) * cdiv(P.Tout, 128) * P.B * P.n_groups >= 256 && bf3_ok()) { bf3_go(1); return; }
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
   launch_cfg<2, 2, 1, 1, EPI_STORE>(s, P, halo);
 }
