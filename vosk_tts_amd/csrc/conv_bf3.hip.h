@@ -70,6 +70,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   const int n0 = nt * N_T, m0 = mt * M_T;
   const int K = G.K, dil = G.dil;
   const int nchunks = P.Cin / CONV_CI_T;
+  const int tap_base = P.ups_u ? P.ups_shift[m0 / P.ups_cout] : 0;  // polyphase ConvTranspose1d rows: the tile's phase shifts its taps
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
   if (P.rag) {
@@ -183,7 +184,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     // than an HBM round trip under load -- with the fp32 kernel's one-chunk distance every chunk ended waiting for its successor
     if (c + 2 < nchunks) load_chunk(c + 2, stn);
     const int dstep = dil * (BF3_PITCH * 2);
-    const char* lk0 = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31) * (BF3_PITCH * 2) + 16 * h;
+    const char* lk0 = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31 + tap_base) * (BF3_PITCH * 2) + 16 * h;
     const char* lk1 = lk0 + piece_bytes;
 #pragma unroll 1
     for (int kk = 0; kk + 1 < K; kk += 2) {

@@ -345,7 +345,7 @@ static int load_decoder(vits_model* m) {
   const int I = hp.inter_channels;
   char nm[200];
   int C = hp.dec_initial_channel;
-  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true, false);
+  m->conv_pre = conv_from(m, "dec.conv_pre", C, I, 7, true, false, hp.conv_precision == 1 && C % 128 == 0);
   // Geometry checks before anything divides by a rate or sizes a buffer from hop_length: the decoder writes
   // T_y * prod(up_rates) [* istft_hop * subbands] samples per item while every output buffer is T_y * hop_length.
   {
@@ -409,11 +409,13 @@ static int load_decoder(vits_model* m) {
     U.halo = dmax_all - dmin_all;
     for (int r = 0; r < u; ++r) U.shift[r] = dmin[r] + U.pad_l;
     const int Cin = C;
-    U.w = make_conv(m, u * Co, Cin, U.taps, nullptr, [&](int row, int ci, int j) {
+    auto ups_src = [&](int row, int ci, int j) {
       const int r = row / Co, co = row % Co;
       const int k = r + p - u * (dmin[r] + j);
       return (k >= 0 && k < Ku) ? w[((size_t)ci * Co + co) * Ku + k] : 0.f;
-    }, false);
+    };
+    U.w = make_conv(m, u * Co, Cin, U.taps, nullptr, ups_src, false);
+    if (hp.conv_precision == 1 && Co % 128 == 0) add_bf3_packing(m, U.w, ups_src);  // (used when the input is a single tensor)
     U.w.bias = upload(m, b, Co);
     C = Co;
     for (int j = 0; j < hp.n_resk && !m->missing; ++j) {
@@ -1192,7 +1194,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     ps.set_kernel("conv_mfma_kernel<1,4,1,1,STORE>"); launch_cfg<1, 4, 1, 1, EPI_STORE>(s, P, halo); return;
   }
   auto bf3_ok = [&]() {
-    bool ok = !g_no_bf3 && !P.ups_u && !P.reflect && !P.x_split && P.x_ch_sign == 1 && !P.x_ch_off && !P.ln_g;
+    bool ok = !g_no_bf3 && !P.reflect && !P.x_split && P.x_ch_sign == 1 && !P.x_ch_off && !P.ln_g;
+    if (P.ups_u && (P.ups_cout % 128 || P.n_groups != 1)) ok = false;  // a 128-row tile must lie inside one polyphase phase
     for (int g = 0; g < P.n_groups; ++g) ok = ok && P.g[g].wb && !P.g[g].x2 && !P.g[g].x3;
     return ok;
   };
@@ -1686,7 +1689,7 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     // x = leaky_relu(x, 0.1); x = ups[i](x)  (models.py:1027-1028), polyphase
     memset(&P, 0, sizeof P);
     P.n_groups = 1;
-    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = U.w.w; P.g[0].bias = U.w.bias; P.g[0].y = y;
+    P.g[0].x = in1; P.g[0].x2 = in2; P.g[0].x3 = in3; P.g[0].w = U.w.w; P.g[0].wb = U.w.wb; P.g[0].bias = U.w.bias; P.g[0].y = y;
     P.g[0].K = U.taps; P.g[0].dil = 1; P.g[0].pad_l = U.pad_l; P.g[0].n_sg = U.w.n_sg;
     P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
     P.M = U.w.Mpad; P.Cout = U.w.M; P.Tout = T; P.Tout_stride = To; P.y_bstride = (long long)Co * To;
