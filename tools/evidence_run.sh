@@ -23,7 +23,9 @@ for w in c3 c4 c5 m2 m3; do
 done
 # the torch.distributed launch path (one rank here; the driver runs N = 1, 2, 4, 8): RCCL init, barrier, max-over-ranks reduction
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-host-api > $O/r2_c4_torchrun1_bench.json.txt 2> $O/bench_c4_torchrun.err; echo "bench c4 under torchrun rc=$?"
-timeout 300 python bench.py --workload c3 --precision bf16x3 --no-cpu-baseline --no-host-api > $O/r2_c3_bf16x3_bench.json.txt 2> $O/bench_c3b.err; echo "bench c3 bf16x3 rc=$?"
+for w in c3 c4 c5 m3; do
+  timeout 300 python bench.py --workload $w --precision bf16x3 --no-cpu-baseline --no-host-api > $O/r2_${w}_bf16x3_bench.json.txt 2> $O/bench_${w}b.err; echo "bench $w bf16x3 rc=$?"
+done
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/m2 -o trace -- python $R/bench.py --workload m2 --no-cpu-baseline --steps 30 > $O/r2_m2_bench_under_rocprof.json.txt 2> $O/prof_m2.err
 cp $(find $O/prof/m2 -name '*kernel_stats.csv' | head -1) $O/r2_m2_bench_rocprofv3_kernel_stats.csv
