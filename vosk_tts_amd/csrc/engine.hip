@@ -1104,8 +1104,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     macs += (double)(epi == EPI_GATE ? 2 * P.H : P.Cout) * P.Cin * P.g[g].K;
   }
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
-  hipStream_t st = s->stream;
 #ifdef CONV_TIMING
+  hipStream_t st = s->stream;
   // timing build only: VITS_DBG_LAUNCH=<i> attaches the phase-stamp buffer to the i-th conv launch of the process
   // and prints the stamps (cycles since kernel start, block 0) right after it
   static long dbg_counter = 0;

@@ -295,7 +295,7 @@ static void stts_est_setup(vits_session* s, const stts_model* m, SttsEst& E, con
 // one Decoder.forward (decoder.py:105-138) over the nb batch items; state x = rows [0,NF) of E.cat; result in E.dphi
 static void stts_est_step(vits_session* s, const stts_model* m, SttsEst& E, int step) {
   const stts_hparams& hp = m->hp;
-  const int H = hp.dec_hidden, F = hp.dec_filter, NF = hp.n_feats, NL = hp.dec_layers, K = hp.dec_kernel;
+  const int H = hp.dec_hidden, F = hp.dec_filter, NL = hp.dec_layers, K = hp.dec_kernel;
   const int nb = E.nb, T = E.T, n = E.n_steps;
   ConvParams P = conv_params(m->in_proj, E.cat, E.h, nb, T, 1, 0);
   stts_skip(s, P, E.len);
@@ -1212,7 +1212,7 @@ int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, in
   if (!m || !ids || !out || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
   const bert_hparams& hp = m->hp;
   if (T > hp.max_position) return fail(VITS_ERR_ARG, "%d tokens exceed max_position %d", T, hp.max_position);
-  const int H = hp.hidden, F = hp.intermediate, nh = hp.n_heads, dk = H / nh;
+  const int H = hp.hidden, F = hp.intermediate, nh = hp.n_heads;
   HIP_TRY(hipSetDevice(m->base.device));
   vits_session* s = nullptr;
   TRY(pool_acquire(&m->base, &s));
