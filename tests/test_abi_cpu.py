@@ -58,6 +58,31 @@ def test_hparams_struct_matches_header():
     assert ctypes.sizeof(BlobEntry) == 96 + 4 + 16 + 4 + 8 + 8
 
 
+def test_hparams_offsets_of_the_round_2_fields_match_the_header():
+    """bert_dim / conv_precision replaced reserved words: their offsets in the ctypes mirror must be where include/vits_mi355.h
+    puts them (a C compile of the header's struct), and pack_blob rejects a conv_precision the engine does not know."""
+    import os
+    import subprocess
+    import tempfile
+
+    from vosk_tts_amd import weights as W
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ('#include <stddef.h>\n#include <stdio.h>\n#include "vits_mi355.h"\nint main(void) { printf("%zu %zu %zu\\n", '
+           'offsetof(vits_hparams, bert_dim), offsetof(vits_hparams, conv_precision), sizeof(vits_hparams)); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "off.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "off")
+        subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", exe, c])
+        o_bert, o_prec, size = map(int, subprocess.check_output([exe]).split())
+    assert W.HParams.bert_dim.offset == o_bert and W.HParams.conv_precision.offset == o_prec and ctypes.sizeof(W.HParams) == size
+    hp = W.default_hparams()
+    hp.conv_precision = 2
+    with pytest.raises(ValueError, match="conv_precision"):
+        W.validate_hparams(hp)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from vosk_tts_amd.capi import VitsLib
 
