@@ -31,9 +31,12 @@ def label(name):
         if m[5] == "1":
             return f"{m[1]}<{EPI[m[2]]},dds>"
         return f"{m[1]}<{EPI[m[2]]},{'ln,' if m[5] == '2' else ''}{m[3]}>"
-    m = re.match(r"void (conv_wp_kernel|conv_bf3_kernel)<(\d+)>", name)
+    m = re.match(r"void (conv_wp_kernel)<(\d+)>", name)
     if m:
         return f"{m[1]}<{m[2]}>"
+    m = re.match(r"void (conv_bf3_kernel)<(\d+), (\d+)>", name)
+    if m:  # <MI, EPI>: 64*MI output rows per tile
+        return f"{m[1]}<{m[2]},{EPI[m[3]]}>"
     m = re.match(r"(?:void )?(\w+)", name)
     return m[1] if m else name
 
@@ -76,6 +79,8 @@ def main():
             o["hbm_bytes_per_launch"] = (f_read * o["FETCH_SIZE"] + f_write * o["WRITE_SIZE"]) * 1024.0
         if "SQ_INSTS_VALU_MFMA_MOPS_F32" in o:
             o["mfma_flops_per_launch"] = o["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
+        if o.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):  # split-bf16 kernels: 3 bf16 MFMAs per fp32-equivalent product
+            o["mfma_bf16_flops_per_launch"] = o["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0
         if "SQ_WAVE_CYCLES" in o and o["SQ_WAVE_CYCLES"] > 0:
             for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if n in o:

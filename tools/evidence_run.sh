@@ -3,6 +3,18 @@
 # Outputs land in gpurun_out/final/ under the names profiles/ expects; copy them to profiles/ afterwards.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
+bf16x3_profiles() {
+  # the split-bf16 second line (c3, conv_precision = 1): its own kernel stats and counter passes
+  cd /tmp && export TMPDIR=/tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c3b -o trace -- python $R/bench.py --workload c3 --precision bf16x3 --no-cpu-baseline --no-host-api > $O/r2_c3_bf16x3_bench_under_rocprof.json.txt 2> $O/prof_c3b.err
+  cp $(find $O/prof/c3b -name '*kernel_stats.csv' | head -1) $O/r2_c3_bf16x3_bench_rocprofv3_kernel_stats.csv
+  rm -rf $O/prof
+  cd $R
+  timeout 900 bash tools/pmc_passes.sh c3 "--precision bf16x3" _bf16x3 > $O/pmc_c3_bf16x3.log 2>&1
+  cp $R/gpurun_out/pmc_c3_bf16x3/pmc_c3_bf16x3.json $O/r2_pmc_c3_bf16x3.json
+  rm -rf $R/gpurun_out/pmc_c3_bf16x3
+}
+if [ "$1" == "bf16x3_only" ]; then bf16x3_profiles; ls -la $O; exit 0; fi
 if [ "$1" != "noprof_tests" ]; then
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $O/r2_gpu_tests.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2_gpu_tests.log
 tail -5 $O/r2_gpu_tests.log
@@ -36,5 +48,6 @@ for w in c2 c3; do
   cp $R/gpurun_out/pmc_$w/pmc_$w.json $O/r2_pmc_$w.json
   rm -rf $R/gpurun_out/pmc_$w
 done
+bf16x3_profiles
 ls -la $O
 head -c 1500 $O/r2_default_bench.json.txt

@@ -63,7 +63,7 @@ template <int MI, int EPI>
 static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b) {
   constexpr int N_T = 128, M_T = 64 * MI;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row / weight-block offsets stay scalar
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
   const int ROW = P.row_len;  // staged columns: 128 + the launch's largest halo
@@ -87,12 +87,16 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   const float in_scale = P.in_scale, in_slope = P.in_slope;
   const int t_base = n0 - G.pad_l;
   CONV_STAGE_COLS(JT)
+  unsigned tob[JT];  // byte offsets of the staging columns (buffer addressing: descriptor + scalar row offset + tob, conv_mfma.hip.h bt_ld)
+#pragma unroll
+  for (int j = 0; j < JT; ++j) tob[j] = (unsigned)toff[j] * 4u;
+  const __amdgpu_buffer_rsrc_t rx = bt_rsrc(xb);
   auto load_chunk = [&](int c, float (&dst)[4][JT]) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const long long ro = (long long)(c * CONV_CI_T + wave + 4 * rr) * P.Tin_stride;
+      const unsigned ro = (unsigned)((long long)(c * CONV_CI_T + wave + 4 * rr) * P.Tin_stride * 4);
 #pragma unroll
-      for (int j = 0; j < JT; ++j) dst[rr][j] = xb[ro + toff[j]];
+      for (int j = 0; j < JT; ++j) dst[rr][j] = bt_ld(rx, tob[j], ro);
     }
     // (nothing here may consume the loaded values: they ride through the tap loop and are split only in store_chunk)
   };
@@ -109,7 +113,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
         hi[rr] = (__bf16)v;
         lo[rr] = (__bf16)(v - (float)hi[rr]);
       }
-      if (col < ROW) {
+      if (j < JT - 1 || col < ROW) {  // 64 (JT - 1) <= N_T <= ROW: only the last column group needs the test
         *reinterpret_cast<bf16x4*>(dst + col * (BF3_PITCH * 2)) = hi;
         *reinterpret_cast<bf16x4*>(dst + piece_bytes + col * (BF3_PITCH * 2)) = lo;
       }
@@ -127,13 +131,15 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   // weight stream: step s = chunk * K + tap; per step and m-block: [hi | lo] x 64 lanes x 16 B
   const int n_mblocks = P.M >> 5;
   const int nsteps = nchunks * K;
-  const bf16x8* wq[MI];  // next step to fetch, per m-block
+  __amdgpu_buffer_rsrc_t wq[MI];  // descriptors of this wave's weight m-blocks: a fragment load is wq + step offset (scalar) + lane * 16
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     int mb = (m0 >> 5) + wm * MI + mi;
     if (mb >= n_mblocks) mb = 0;  // padded tile: compute on valid memory, never stored
-    wq[mi] = reinterpret_cast<const bf16x8*>(G.wb) + (size_t)mb * nsteps * 128 + lane;
+    wq[mi] = bt_rsrc(reinterpret_cast<const bf16x8*>(G.wb) + (size_t)mb * nsteps * 128);
   }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto wload = [&](__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, off, 0)); };
 
   load_chunk(0, stg);
   store_chunk(0);
@@ -143,19 +149,19 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   bf16x8 a[2][MI][2];  // [slot][mi][piece]
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    a[0][mi][0] = wq[mi][0];
-    a[0][mi][1] = wq[mi][64];
-    wq[mi] += 128;
+    a[0][mi][0] = wload(wq[mi], 0);
+    a[0][mi][1] = wload(wq[mi], 1024);
   }
+  unsigned ws = 2048;  // byte offset of the next step to fetch (2 KB per step and m-block; the packing is padded by one step for the last prefetch)
   // one tap: prefetch the next step into the other slot, read this tap's B fragments, 12 MFMAs
   auto tap = [&](auto slot_, const char* lk0, const char* lk1) {
     constexpr int S = decltype(slot_)::value;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      a[S ^ 1][mi][0] = wq[mi][0];
-      a[S ^ 1][mi][1] = wq[mi][64];
-      wq[mi] += 128;
+      a[S ^ 1][mi][0] = wload(wq[mi], ws);
+      a[S ^ 1][mi][1] = wload(wq[mi], ws + 1024);
     }
+    ws += 2048;
     bf16x8 bh[2], bl[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -180,21 +186,28 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   };
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
-    // activations are requested TWO chunks ahead: a chunk's taps take 1.2 k (3 taps) .. 4.2 k (11 taps) MFMA cycles per wave, less
-    // than an HBM round trip under load -- with the fp32 kernel's one-chunk distance every chunk ended waiting for its successor
-    if (c + 2 < nchunks) load_chunk(c + 2, stn);
     const int dstep = dil * (BF3_PITCH * 2);
     const char* lk0 = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31 + tap_base) * (BF3_PITCH * 2) + 16 * h;
     const char* lk1 = lk0 + piece_bytes;
+    // Tap 0 first, THEN the activation loads: vmcnt retires in order, so a wait for weight fragments requested behind the
+    // activation loads waits for those too (conv_mfma.hip.h, same rule).  They are requested TWO chunks ahead: a chunk's taps
+    // take 1.2 k (3 taps) .. 4.2 k (11 taps) MFMA cycles per wave, less than an HBM round trip under load.
+    tap(bf3_int<0>{}, lk0, lk1);
+    if (c + 2 < nchunks) load_chunk(c + 2, stn);
+    __builtin_amdgcn_sched_barrier(0);
+    lk0 += dstep;
+    lk1 += dstep;
+    int kk = 1;
 #pragma unroll 1
-    for (int kk = 0; kk + 1 < K; kk += 2) {
-      tap(bf3_int<0>{}, lk0, lk1);
-      tap(bf3_int<1>{}, lk0 + dstep, lk1 + dstep);
+    for (; kk + 1 < K; kk += 2) {
+      tap(bf3_int<1>{}, lk0, lk1);
+      tap(bf3_int<0>{}, lk0 + dstep, lk1 + dstep);
       lk0 += 2 * dstep;
       lk1 += 2 * dstep;
     }
-    if (K & 1) {  // odd tap count: last tap from slot 0, then the next chunk's first tap (now in slot 1) moves to slot 0
-      tap(bf3_int<0>{}, lk0, lk1);
+    if (kk < K) {
+      tap(bf3_int<1>{}, lk0, lk1);  // even tap count: the next chunk's first fragments are in slot 0 already
+    } else {                        // odd tap count: they are in slot 1
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

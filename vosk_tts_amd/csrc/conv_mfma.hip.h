@@ -25,6 +25,7 @@
 // fused_add_tanh_sigmoid_multiply (commons.py:100-107), the WN res/skip update
 // (modules.py:168-175) and the coupling-layer tail (models.py:390-392).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -395,16 +396,35 @@ __device__ __forceinline__ void conv_epilogue_gate(const ConvParams& P, const Co
     toff[j] = t < 0 ? 0 : (t >= P.Tin ? P.Tin - 1 : t);                                      \
   }
 
+// Buffer addressing for the big-tile kernel's streams: descriptor (4 SGPRs, wave-uniform base) + scalar byte offset (SGPR) +
+// per-lane byte offset (VGPR) -> buffer_load ... offen with NO 64-bit VALU address math per load (hipcc re-associates a
+// "uniform pointer + lane offset" global load into a per-lane 64-bit base + v_lshl_add_u64 per load).  Raw buffer, stride 0,
+// no range limit (every offset used is in bounds by construction; clamped indices for the prefetch overrun).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bt_rsrc(const void* p) {
+  // the base IS wave-uniform (block / wave indices only); say so, or the descriptor lands in VGPRs and every load gets a waterfall loop
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float bt_ld(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, uni_off, 0));
+}
+__device__ __forceinline__ f32x4 bt_ld4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni_off, 0));
+}
+
 template <int WM, int WN, int MI, int NI, int EPI>
 __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {  // 3 workgroups per CU
   static_assert(WM * WN == 4, "256-thread workgroups");
   constexpr int M_T = WM * MI * 32;
   constexpr int N_T = WN * NI * 32;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
+  static_assert(64 * (JT - 1) <= N_T, "staging column groups");
   extern __shared__ float lds[];
   kernarg_warm<sizeof(ConvParams)>();
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row / weight-block address math stays scalar
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l31 = lane & 31;
 
@@ -437,32 +457,34 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   const int t_base = n0 - G.pad_l;
 
   CONV_STAGE_COLS(JT)
+  unsigned tob[JT];  // byte offsets of the staging columns: row pointers are wave-uniform, so a load is base (SGPR pair) + tob (VGPR)
+#pragma unroll
+  for (int j = 0; j < JT; ++j) tob[j] = (unsigned)toff[j] * 4u;
+  const __amdgpu_buffer_rsrc_t rx = bt_rsrc(xb), rx2 = bt_rsrc(xb2 ? xb2 : xb), rx3 = bt_rsrc(xb3 ? xb3 : xb);
   auto load_chunk = [&](int c) {
-    long long roff[4];
+    unsigned roff[4];  // byte offset of the chunk's rows inside the item (wave-uniform; < 2^31 by the arena's size limits)
     // channel-concatenated second input (x_split): chunks at or beyond the split read g.x2 at channel ci - x_split
     const bool second = P.x_split && c * CONV_CI_T >= P.x_split;  // block-uniform
     const int cb = second ? c * CONV_CI_T - P.x_split : c * CONV_CI_T;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) roff[rr] = (long long)(P.x_ch_off + (cb + wave + 4 * rr) * P.x_ch_sign) * P.Tin_stride;
+    for (int rr = 0; rr < 4; ++rr) roff[rr] = (unsigned)((long long)(P.x_ch_off + (cb + wave + 4 * rr) * P.x_ch_sign) * P.Tin_stride * 4);
     if (P.x_split) {
-      const float* src = second ? xb2 : xb;
+      const __amdgpu_buffer_rsrc_t rs = second ? rx2 : rx;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) stg[rr][j] = src[roff[rr] + toff[j]];
+        for (int j = 0; j < JT; ++j) stg[rr][j] = bt_ld(rs, tob[j], roff[rr]);
     } else if (xb2) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-          const long long o = roff[rr] + toff[j];
-          stg[rr][j] = xb[o] + xb2[o] + (xb3 ? xb3[o] : 0.f);
-        }
+        for (int j = 0; j < JT; ++j)
+          stg[rr][j] = bt_ld(rx, tob[j], roff[rr]) + bt_ld(rx2, tob[j], roff[rr]) + (xb3 ? bt_ld(rx3, tob[j], roff[rr]) : 0.f);
     } else {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) stg[rr][j] = xb[roff[rr] + toff[j]];
+        for (int j = 0; j < JT; ++j) stg[rr][j] = bt_ld(rx, tob[j], roff[rr]);
     }
     // NOTE: nothing here may CONSUME the loaded values — the raw registers ride through the whole tap
     // loop and are activated only in store_chunk, otherwise every chunk starts with a memory-latency stall
@@ -475,7 +497,7 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
       for (int j = 0; j < JT; ++j) {
         const int col = lane + 64 * j;
         const float v = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;
-        if (col < ROW) dst[(wave + 4 * rr) * ROW + col] = v;
+        if (j < JT - 1 || col < ROW) dst[(wave + 4 * rr) * ROW + col] = v;  // 64 (JT - 1) <= N_T <= ROW: only the last group needs the test
       }
     }
   };
@@ -490,13 +512,14 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   const int n_mblocks = P.M >> 5;
-  const f32x4* wp[MI];
+  __amdgpu_buffer_rsrc_t wp[MI];  // wave-uniform descriptors of this wave's weight m-blocks: a fragment load is wp + step-group offset (scalar) + lane * 16
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     int mb = (m0 >> 5) + wm * MI + mi;
     if (mb >= n_mblocks) mb = 0;  // padded tile: compute on valid memory, never stored
-    wp[mi] = reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64 + lane;
+    wp[mi] = bt_rsrc(reinterpret_cast<const f32x4*>(G.w) + (size_t)mb * G.n_sg * 64);
   }
+  const unsigned lane16 = (unsigned)lane * 16u;
   const int n_sg = G.n_sg;
 
   CONV_DBG_DO(long long dbg_t0 = 0; long long dbg_tap = 0; long long dbg_sync = 0; long long dbg_x = 0; if (P.dbg) dbg_t0 = __builtin_readcyclecounter();)
@@ -505,50 +528,74 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   __syncthreads();
   CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;)
 
-  f32x4 a_cur[MI][2], a_nxt[MI][2];
+  // Weight fragments live in two STATIC slots: a tap computes on one and requests the next tap's fragments into the other,
+  // taps run in pairs (slot 0 -> 1 -> 0), so nothing is copied between taps; an odd tap count leaves the next chunk's first
+  // fragments in slot 1 and they are moved once per chunk.  (One slot pair + a rotation per tap cost 8 v_mov_b64 per 32 MFMAs.)
+  f32x4 a[2][MI][2];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    a_cur[mi][0] = wp[mi][0];
-    a_cur[mi][1] = wp[mi][64];
+    a[0][mi][0] = bt_ld4(wp[mi], lane16, 0);
+    a[0][mi][1] = bt_ld4(wp[mi], lane16, 1024);
   }
   int sg = 2;  // next step-group to fetch
 
-  for (int c = 0; c < nchunks; ++c) {
-    CONV_DBG_DO(if (P.dbg) dbg_x = __builtin_readcyclecounter();)
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    const float* lb = lds + (c & 1) * (CONV_CI_T * ROW) + h * ROW + wn * (NI * 32) + l31 + tap_base;
-#pragma unroll 1
-    for (int kk = 0; kk < K; ++kk) {
-      {
-        // unconditional (clamped) prefetch: a fixed number of loads per tap lets hipcc emit a counted
-        // s_waitcnt vmcnt(N) instead of draining the prefetch it has just issued
-        const int sgc = sg < n_sg ? sg : n_sg - 2;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          a_nxt[mi][0] = wp[mi][(size_t)sgc * 64];
-          a_nxt[mi][1] = wp[mi][(size_t)(sgc + 1) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of this tap's MFMAs
-      }
-      sg += 2;
-      const float* lk = lb + kk * dil;
-      float bv[8][NI];
-#pragma unroll
-      for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[p][ni] = lk[2 * p * ROW + ni * 32];
-      __builtin_amdgcn_sched_barrier(0);  // all B-fragment reads of the tap in flight before its first MFMA
-#pragma unroll
-      for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mi][p >> 2][p & 3], bv[p][ni], acc[mi][ni], 0, 0, 0);
+  // one tap on slot CUR; the next tap's fragments are requested into the other slot first
+  auto tap = [&](auto CUR, const float* lb, int kk) {
+    constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+    {
+      // unconditional (clamped) prefetch: a fixed number of loads per tap lets hipcc emit a counted
+      // s_waitcnt vmcnt(N) instead of draining the prefetch it has just issued
+      const int sgc = sg < n_sg ? sg : n_sg - 2;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        a_cur[mi][0] = a_nxt[mi][0];
-        a_cur[mi][1] = a_nxt[mi][1];
+        a[nxt][mi][0] = bt_ld4(wp[mi], lane16, (unsigned)sgc * 1024u);
+        a[nxt][mi][1] = bt_ld4(wp[mi], lane16, (unsigned)sgc * 1024u + 1024u);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of this tap's MFMAs
+    }
+    sg += 2;
+    const float* lk = lb + kk * dil;
+    float bv[8][NI];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bv[p][ni] = lk[2 * p * ROW + ni * 32];
+    __builtin_amdgcn_sched_barrier(0);  // all B-fragment reads of the tap in flight before its first MFMA
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi][p >> 2][p & 3], bv[p][ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using slot0 = std::integral_constant<int, 0>;
+  using slot1 = std::integral_constant<int, 1>;
+
+  for (int c = 0; c < nchunks; ++c) {
+    CONV_DBG_DO(if (P.dbg) dbg_x = __builtin_readcyclecounter();)
+    const float* lb = lds + (c & 1) * (CONV_CI_T * ROW) + h * ROW + wn * (NI * 32) + l31 + tap_base;
+    // Tap 0 first, THEN the next chunk's activation loads: vmcnt retires in order, so a wait for weight fragments that were
+    // requested behind the activation loads also waits for those.  Issued ahead of tap 0, the 12 loads' full latency sat in
+    // front of the chunk's first MFMA; issued here the next wait that covers them is the one before tap 1 (>= 2048 MFMA cycles
+    // later; for a 1-tap conv the fragment move below, counted exactly).
+    tap(slot0{}, lb, 0);
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    int kk = 1;
+#pragma unroll 1
+    for (; kk + 1 < K; kk += 2) {
+      tap(slot1{}, lb, kk);
+      tap(slot0{}, lb, kk + 1);
+    }
+    if (kk < K) {
+      tap(slot1{}, lb, kk);  // even tap count: the next chunk's first fragments are in slot 0 already
+    } else {                 // odd tap count (block-uniform): they are in slot 1
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        a[0][mi][0] = a[1][mi][0];
+        a[0][mi][1] = a[1][mi][1];
       }
     }
     CONV_DBG_DO(if (P.dbg) { const long long t_ = __builtin_readcyclecounter(); dbg_tap += t_ - dbg_x; dbg_x = t_; })

@@ -762,6 +762,19 @@ static void drop_graphs(vits_session* s) {
 // arena when needed.  Captured graphs hold raw workspace pointers, so a re-plan drops them.
 static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
   if (s->arena && B == s->B && Tx == s->Tx && Ty == s->Ty) return VITS_OK;
+  {
+    // the batch-size conv kernels address one item's [C, T] tensor with 32-bit byte offsets (buffer loads, conv_mfma.hip.h bt_ld):
+    // every per-item tensor must stay below 2 GiB.  The widest are the decoder stages, C_i x T_y x prod(rates[0..i]).
+    const vits_hparams& hp = s->m->hp;
+    long long worst = (long long)(hp.filter_channels > hp.dec_initial_channel ? hp.filter_channels : hp.dec_initial_channel) * (Ty > Tx ? Ty : Tx);
+    long long rate = 1;
+    for (int i = 0; i < hp.n_ups && i < VITS_MAX_UPS; ++i) {
+      rate *= hp.up_rates[i];
+      const long long e = (long long)(hp.dec_initial_channel >> (i + 1)) * Ty * rate;
+      if (e > worst) worst = e;
+    }
+    if (worst * 4 >= (1LL << 31)) return fail(VITS_ERR_ARG, "T_y = %d frames: a per-item decoder tensor would exceed 2 GiB", Ty);
+  }
   drop_graphs(s);
   char* keep = s->arena;
   s->arena = nullptr;

@@ -859,7 +859,7 @@ static int stts_synth_fast(stts_model* m, const int64_t* ids, int32_t Tx, const 
   int* h_cum = reinterpret_cast<int*>(F->io_h + F->o_cum);
   int ylen = 0;
   for (int j = 0; j < TxB; ++j) { if (j < Tx) ylen += dur[j]; h_cum[j] = ylen; }  // only the utterance's own tokens count
-  if (ylen > (1 << 22)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  if (ylen > (1 << 18)) return fail(VITS_ERR_ARG, "T_y unreasonably large");  // (also keeps every per-item [C <= 2048, T] tensor below the 2 GiB the conv kernels' 32-bit offsets address)
   const int T4 = (ylen + 3) / 4 * 4;  // fix_len_compatibility (utils/model.py:14-20): where the exact-size run's tensors end
   const int TB = (T4 + 31) / 32 * 32;
   SttsDev* hv = reinterpret_cast<SttsDev*>(F->io_h + F->o_dev);
@@ -927,7 +927,7 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
   std::vector<int32_t> dur(Tx);
   int64_t ylen = 0;
   stts_durations_host(hp, mu_dp.data(), 1, Tx, length_scale, pde, dur.data(), &ylen);
-  if (ylen > (1 << 22)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  if (ylen > (1 << 18)) return fail(VITS_ERR_ARG, "T_y unreasonably large");  // (also keeps every per-item [C <= 2048, T] tensor below the 2 GiB the conv kernels' 32-bit offsets address)
   const int T = (int)((ylen + 3) / 4 * 4);  // fix_len_compatibility (utils/model.py:14-20)
   std::vector<int> cum(Tx);
   for (int j = 0, a = 0; j < Tx; ++j) { a += dur[j]; cum[j] = a; }
