@@ -430,6 +430,10 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
 
   int mt, grp, nt, b;
   if (!conv_decode_block(P, mt, grp, nt, b)) return;
+  // block-uniform by construction, but the ragged tile map is read with vector loads: tell the compiler, so that row / column /
+  // item offsets stay in SGPRs (buffer addressing needs wave-uniform scalar offsets, else every access gets a waterfall loop)
+  mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);
+  nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
   const ConvGroup& G = P.g[grp];
 
   const int ROW = P.row_len;
@@ -523,10 +527,6 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   const int n_sg = G.n_sg;
 
   CONV_DBG_DO(long long dbg_t0 = 0; long long dbg_tap = 0; long long dbg_sync = 0; long long dbg_x = 0; if (P.dbg) dbg_t0 = __builtin_readcyclecounter();)
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;)
 
   // Weight fragments live in two STATIC slots: a tap computes on one and requests the next tap's fragments into the other,
   // taps run in pairs (slot 0 -> 1 -> 0), so nothing is copied between taps; an odd tap count leaves the next chunk's first
@@ -538,6 +538,11 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
     a[0][mi][1] = bt_ld4(wp[mi], lane16, 1024);
   }
   int sg = 2;  // next step-group to fetch
+  // (the first fragments are requested BEFORE the first activation chunk: one memory round trip in the tile's prologue, not two)
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;)
 
   // one tap on slot CUR; the next tap's fragments are requested into the other slot first
   auto tap = [&](auto CUR, const float* lb, int kk) {
@@ -625,6 +630,64 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
         for (int i = 0; i < 4; ++i) { at[i] = acc[0][ni][e0 + i]; as[i] = acc[MI - 1][ni][e0 + i]; }
         conv_epilogue_gate<4>(P, G, b, j * 32 + 4 * h, e0, n0 + wn * (NI * 32) + ni * 32 + l31, at, as);
       }
+    return;
+  }
+  if (EPI == EPI_STORE && !P.ups_u && !P.bias_b && !P.scale_b && P.relu == 0 && !G.y2 && (P.Cout & 7) == 0) {  // block-uniform
+    // Plain epilogue (bias, mask, residual) -- every ResBlock / encoder / flow STORE conv -- one 32x32 fragment at a time: ALL of
+    // a fragment's operands (4 x dwordx4 bias, 16 residual values) are requested at once and the NEXT fragment's before this
+    // one's stores, on buffer addressing (descriptor + scalar row offset + one lane offset).  The general path below walks the
+    // 64 values four at a time with two dependent round trips (bias, residual) and a branch per element.
+    constexpr int NF = MI * NI;
+    const __amdgpu_buffer_rsrc_t ry = bt_rsrc(G.y + (long long)b * P.y_bstride);
+    const __amdgpu_buffer_rsrc_t rr = bt_rsrc((G.res ? G.res : G.y) + (long long)b * P.y_bstride);
+    const __amdgpu_buffer_rsrc_t rb = bt_rsrc(G.bias ? G.bias : G.w);
+    const bool has_b = G.bias != nullptr, has_r = G.res != nullptr;
+    f32x4 bq[2][4];
+    float rv[2][16];
+    auto frag_rows = [&](int f) { return m0 + (wm * MI + f / NI) * 32; };               // wave-uniform first row of fragment f (lane rows: + 4 h)
+    auto frag_col = [&](int f) { return n0 + wn * (NI * 32) + (f % NI) * 32 + l31; };
+    auto frag_voff = [&](int f) {
+      const int col = frag_col(f);
+      return (unsigned)((4 * h) * P.Tout_stride + (col < P.Tout ? col : P.Tout - 1)) * 4u;
+    };
+    auto request = [&](int f, int slot) {
+      const int R = frag_rows(f);
+      const unsigned vo = frag_voff(f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int rq = R + 8 * q;  // rows rq + 4 h + (0..3); C_out is a multiple of 8, so the quad is valid for both half-waves or for neither
+        if (rq > P.Cout - 8) rq = P.Cout - 8;
+        bq[slot][q] = bt_ld4(rb, (unsigned)(4 * h) * 4u, (unsigned)rq * 4u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rv[slot][4 * q + i] = bt_ld(rr, vo, (unsigned)(rq + i) * (unsigned)P.Tout_stride * 4u);
+      }
+    };
+    request(0, 0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (f + 1 < NF) request(f + 1, (f + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int R = frag_rows(f), col = frag_col(f);
+      const unsigned vo = frag_voff(f);
+      const bool masked = P.out_mask && col >= lenb;
+      float x[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float t = acc[f / NI][f % NI][e] + (has_b ? bq[f & 1][e >> 2][e & 3] : 0.f);
+        if (masked) t = 0.f;
+        x[e] = t + (has_r ? rv[f & 1][e] : 0.f);
+      }
+      if (col < P.Tout) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (R + 8 * q < P.Cout) {  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[4 * q + i]), ry, vo, (unsigned)(R + 8 * q + i) * (unsigned)P.Tout_stride * 4u, 0);
+          }
+      }
+    }
+    CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 4] = __builtin_readcyclecounter() - dbg_t0;)
     return;
   }
 #pragma unroll
