@@ -2734,6 +2734,7 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
   if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || K <= 0 || dil <= 0) return fail(VITS_ERR_ARG, "bad argument");
   if (Cin % CONV_CI_T) return fail(VITS_ERR_UNSUPPORTED, "C_in must be a multiple of %d", CONV_CI_T);
   if ((K - 1) * dil > CONV_MAX_HALO) return fail(VITS_ERR_UNSUPPORTED, "(K-1)*dil > %d", CONV_MAX_HALO);
+  if ((long long)(Cin > Cout ? Cin : Cout) * T * 4 >= (1LL << 31)) return fail(VITS_ERR_ARG, "one item's tensor must stay below 2 GiB (32-bit offsets inside an item)");
   HIP_TRY(hipSetDevice(device));
   vits_model tmp;
   tmp.device = device;
