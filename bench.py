@@ -232,6 +232,59 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
         dist.destroy_process_group()
 
 
+
+def vits_cpu_baseline(blob, hp, ids, lengths, dur, workload, cpu_seconds):
+    """TEST-INFRASTRUCTURE leg of the default run: the CPU oracle (plain C restatement of the reference arithmetic) timed on this
+    box's host cores on a bounded sample of the same workload.  Needs no GPU (tests/test_host_api.py runs it on a toy model)."""
+    import ctypes
+
+    from vosk_tts_amd.capi import VitsLib
+
+    so = os.path.join(ROOT, "oracle", "libvits_oracle.so")
+    if not os.path.exists(so):
+        return None
+    ref_lib = VitsLib(so, "vitsref_")
+    ref = ref_lib.create(blob)
+    ref_lib.lib.vitsref_num_threads.restype = ctypes.c_int
+    all_threads = int(ref_lib.lib.vitsref_num_threads())
+    scales = np.array([0.8, 1.0, 0.8], np.float32)
+    nb = min(ids.shape[0], 2)  # bounded sample: at most 2 utterances of the batch per call
+    sub = (ids[:nb], lengths[:nb], dur[:nb])
+    sub_samples = int(sub[2].sum()) * hp.hop_length
+
+    def forward():
+        c0 = time.perf_counter()
+        ref.synthesize(sub[0], sub[1], scales, np.full(nb, 2), forced_durations=sub[2], seed=7)
+        return time.perf_counter() - c0
+
+    # thread count: a single utterance has limited parallel grain (256 output rows x a few hundred columns per conv), so all
+    # hardware threads of a 128-thread host are slower than a fraction of them -- two forwards per candidate, keep the fastest
+    scan = {}
+    set_threads = getattr(ref_lib.lib, "vitsref_set_num_threads", None)
+    if set_threads is not None:
+        set_threads.restype = None
+        for nt in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4), max(1, all_threads // 8), min(all_threads, 8)}, reverse=True):
+            set_threads(ctypes.c_int(nt))
+            scan[nt] = round(min(forward(), forward()), 4)  # (the first call after a change of team size pays the thread start-up)
+            if scan[nt] > 8.0:
+                break
+        cores = min(scan, key=scan.get)
+        set_threads(ctypes.c_int(cores))
+    else:
+        cores = all_threads
+    n, t_cpu = 0, 0.0
+    while t_cpu < cpu_seconds and n < 50:
+        t_cpu += forward()
+        n += 1
+    return {"value": round(sub_samples * n / t_cpu, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forward(s) of {nb} utterance(s) of workload {workload} "
+                      f"({sub_samples} samples each) through oracle/libvits_oracle.so (OpenMP, {cores} threads), {t_cpu:.1f} s",
+            "x_realtime": round(sub_samples * n / t_cpu / SAMPLE_RATE, 2),
+            "threads_available": all_threads, "seconds_per_forward_by_threads": {str(k): v for k, v in scan.items()},
+            "note": "the port is a plain-C checker, not a tuned CPU implementation: the reference's own PyTorch CPU path "
+                    "is the faster CPU data point (reference_pytorch_cpu); neither ratio is a statement about kernel quality",
+            "reference_pytorch_cpu": REFERENCE_PYTORCH_CPU}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -546,32 +599,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # TEST-INFRASTRUCTURE leg: the CPU oracle (plain C restatement of the reference arithmetic)
-        # timed on this box's host cores on a bounded sample of the same workload.
-        so = os.path.join(ROOT, "oracle", "libvits_oracle.so")
-        if os.path.exists(so):
-            import ctypes
-
-            ref_lib = VitsLib(so, "vitsref_")
-            ref = ref_lib.create(blob)
-            ref_lib.lib.vitsref_num_threads.restype = ctypes.c_int
-            cores = int(ref_lib.lib.vitsref_num_threads())
-            nb = min(B, 2)  # bounded sample: at most 2 utterances of the batch per call
-            sub = (ids[:nb], lengths[:nb], dur[:nb])
-            sub_samples = int(sub[2].sum()) * hp.hop_length
-            n, t_cpu = 0, 0.0
-            while t_cpu < args.cpu_seconds and n < 50:
-                c0 = time.perf_counter()
-                ref.synthesize(sub[0], sub[1], scales, np.full(nb, 2), forced_durations=sub[2], seed=7)
-                t_cpu += time.perf_counter() - c0
-                n += 1
-            cpu_baseline = {"value": round(sub_samples * n / t_cpu, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-                            "sample": f"{n} forward(s) of {nb} utterance(s) of workload {args.workload} "
-                                      f"({sub_samples} samples each) through oracle/libvits_oracle.so (OpenMP), {t_cpu:.1f} s",
-                            "x_realtime": round(sub_samples * n / t_cpu / SAMPLE_RATE, 2),
-                            "note": "the port is a plain-C checker, not a tuned CPU implementation: the reference's own PyTorch CPU path "
-                                    "is the faster CPU data point (reference_pytorch_cpu); neither ratio is a statement about kernel quality",
-                            "reference_pytorch_cpu": REFERENCE_PYTORCH_CPU}
+        cpu_baseline = vits_cpu_baseline(blob, hp, ids, lengths, dur, args.workload, args.cpu_seconds)
 
     if rank == 0:
         line = {

@@ -1011,6 +1011,15 @@ int API(num_threads)(void) {
   return 1;
 #endif
 }
+/* bench.py's cpu_baseline leg picks the thread count that serves one utterance best (B = 1 has limited parallel grain:
+ * all 128 hardware threads of the GPU box's host are slower than 16) */
+void API(set_num_threads)(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 /* constants for pinning against the reference buffers */
 const float* API(debug_istft_basis)(const vits_model* m) { return m->istft_basis; }
 const float* API(debug_pqmf_filter)(const vits_model* m) { return m->pqmf_syn; }

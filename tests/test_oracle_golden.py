@@ -174,3 +174,26 @@ def test_error_paths(oracle_lib, oracle_default, default_blob):
         oracle_lib.create(default_blob[:4096])
     with pytest.raises(VitsError):
         oracle_lib.create(b"NOTABLOB" + default_blob[8:])
+
+
+def test_bench_cpu_baseline_leg_runs_without_a_gpu(tiny_blob):
+    """bench.py's cpu_baseline leg (the oracle timed on the host, thread count picked by a short scan) is plain host code: run it
+    here on the tiny model so that a slip in it cannot take the driver's default bench line down."""
+    import importlib.util
+    import os
+
+    from vosk_tts_amd import weights as W
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hp = W.tiny_hparams()
+    ids, lengths, dur = bench.make_workload("c1", np.random.default_rng(1234))
+    ids = np.minimum(ids, hp.n_vocab - 1)
+    out = bench.vits_cpu_baseline(tiny_blob, hp, ids, lengths, dur, "c1", 0.2)
+    assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1 and out["cores"] <= out["threads_available"]
+    assert str(out["cores"]) in out["seconds_per_forward_by_threads"]
+    import json
+
+    json.dumps(out)  # the bench prints it as part of its one JSON line
