@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -57,6 +58,42 @@ def test_plan_shards_balances_and_covers():
     assert load.max() / load.min() < 1.05
     # within a shard requests are length-sorted (tight padding)
     assert all(list(lengths[s]) == sorted(lengths[s], reverse=True) for s in shards)
+
+
+def test_sharding_helpers_properties():
+    """plan_shards / pad_batch / scatter_results for arbitrary request lists: the shards partition the requests, respect the
+    per-shard cap, are length-sorted; padding keeps every token; results come back in request order."""
+    from hypothesis import given, settings, strategies as st
+
+    from vosk_tts_amd.batching import pad_batch, plan_shards, scatter_results
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(1, 300), min_size=0, max_size=70), st.integers(1, 9), st.data())
+    def run(lengths, n_shards, data):
+        cap = data.draw(st.one_of(st.none(), st.integers(-(-max(len(lengths), 1) // n_shards), 80)))
+        shards = plan_shards(lengths, n_shards, max_batch=cap)
+        assert len(shards) == n_shards
+        assert sorted(i for s in shards for i in s) == list(range(len(lengths)))
+        assert cap is None or all(len(s) <= cap for s in shards)
+        assert all([lengths[i] for i in s] == sorted((lengths[i] for i in s), reverse=True) for s in shards)
+        # no shard is left empty while another holds two requests more than it needs to
+        sizes = [len(s) for s in shards]
+        assert len(lengths) < n_shards or min(sizes) >= 1
+        reqs = [list(range(1, n + 1)) for n in lengths]
+        outs = []
+        for s in shards:
+            ids, lens = pad_batch(reqs, s)
+            assert ids.shape == (len(s), max([lengths[i] for i in s], default=0)) and list(lens) == [lengths[i] for i in s]
+            for r, i in enumerate(s):
+                assert list(ids[r, :lens[r]]) == reqs[i] and not ids[r, lens[r]:].any()
+            outs.append([int(ids[r, :lens[r]].sum()) for r in range(len(s))])
+        assert scatter_results(len(lengths), shards, outs) == [n * (n + 1) // 2 for n in lengths]
+
+    run()
+    with pytest.raises(ValueError):
+        plan_shards([5, 6, 7], 1, max_batch=2)
+    with pytest.raises(ValueError):
+        scatter_results(3, [[0, 1]], [["a", "b"]])
 
 
 def test_two_process_replicas_match_single_process(tmp_path, oracle_lib, tiny_blob):
