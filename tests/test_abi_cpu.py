@@ -83,6 +83,34 @@ def test_hparams_offsets_of_the_round_2_fields_match_the_header():
         W.validate_hparams(hp)
 
 
+def test_every_ctypes_mirror_has_the_layout_of_its_header_struct(tmp_path):
+    """Size and every field offset of each ctypes.Structure the host side passes across the C ABI, against a C compile of
+    include/*.h: a field added on one side only (or reordered) shows up here, not as garbage on the device."""
+    import os
+    import subprocess
+
+    from vosk_tts_amd import capi, capi_stts, weights, weights_bert, weights_stts
+
+    pairs = [(weights.HParams, "vits_hparams"), (weights.BlobEntry, "vits_blob_entry"), (capi.SynthOpts, "vits_synth_opts"),
+             (weights_stts.SttsHParams, "stts_hparams"), (capi_stts.SttsOpts, "stts_synth_opts"), (weights_bert.BertHParams, "bert_hparams")]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "vits_mi355.h"', '#include "stts_mi355.h"', 'int main(void) {']
+    for cls, cname in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    c_layout = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cls, cname in pairs:
+        assert ctypes.sizeof(cls) == int(c_layout[cname]), cname
+        for fname, *_ in cls._fields_:
+            assert getattr(cls, fname).offset == int(c_layout[f"{cname}.{fname}"]), f"{cname}.{fname}"
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from vosk_tts_amd.capi import VitsLib
 
