@@ -111,6 +111,63 @@ def test_every_ctypes_mirror_has_the_layout_of_its_header_struct(tmp_path):
             assert getattr(cls, fname).offset == int(c_layout[f"{cname}.{fname}"]), f"{cname}.{fname}"
 
 
+def _header_prototypes():
+    """name -> list of argument kinds ('p' pointer, 'f' floating point, 'i' integer) of every function include/*.h declares"""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    protos = {}
+    for h in ("vits_mi355.h", "stts_mi355.h"):
+        text = open(os.path.join(root, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        for m in re.finditer(r"\b(?:int|void|double|const\s+char\s*\*)\s*((?:vits|stts|bert)_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+            args = [a.strip() for a in m.group(2).split(",")]
+            if args == ["void"] or args == [""]:
+                args = []
+            protos[m.group(1)] = ["p" if "*" in a else ("f" if re.match(r"(const\s+)?(float|double)\b", a) else "i") for a in args]
+    return protos
+
+
+def _ctypes_kind(t):
+    if t in (ctypes.c_float, ctypes.c_double):
+        return "f"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or issubclass(t, ctypes._Pointer):
+        return "p"
+    return "i"
+
+
+def test_ctypes_bindings_agree_with_the_header_prototypes(hip_lib, oracle_lib):
+    """Argument count and kind (pointer / integer / floating point) of every binding the Python host side declares, against the
+    prototypes in include/*.h (a missing or swapped argument is undefined behaviour that no parity test is guaranteed to catch).
+    The stts_* / stts_bert_* bindings are declared when a model object is built: built here on the oracle library, which exports the
+    same prototypes under its own prefix."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.capi_stts import BertEncoder, SttsModel
+
+    protos = _header_prototypes()
+    assert len(protos) >= 40 and "vits_synthesize" in protos and "stts_synthesize" in protos
+    voc = oracle_lib.create(W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234))
+    keep = [SttsModel(oracle_lib, S.synthetic_blob(S.default_hparams(40, 7), 1234), voc),
+            BertEncoder(oracle_lib, BW.synthetic_blob(BW.small_hparams(120, 64, 2), 1234))]
+    checked = set()
+    for lib, rename in ((hip_lib, lambda n: n), (oracle_lib, lambda n: n.replace("vits_", "vitsref_", 1).replace("stts_", "sttsref_", 1))):
+        for name, kinds in protos.items():
+            try:
+                fn = getattr(lib.lib, rename(name))
+            except AttributeError:
+                continue
+            if fn.argtypes is None:
+                continue
+            got = [_ctypes_kind(t) for t in fn.argtypes]
+            assert got == kinds, f"{rename(name)}: ctypes {got} vs header {kinds}"
+            checked.add(name)
+    del keep
+    assert len(checked) >= 30 and {"stts_synthesize", "stts_synthesize_batch", "stts_bert_encode", "vits_synthesize_pcm16"} <= checked, sorted(checked)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from vosk_tts_amd.capi import VitsLib
 
