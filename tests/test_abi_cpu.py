@@ -168,6 +168,37 @@ def test_ctypes_bindings_agree_with_the_header_prototypes(hip_lib, oracle_lib):
     assert len(checked) >= 30 and {"stts_synthesize", "stts_synthesize_batch", "stts_bert_encode", "vits_synthesize_pcm16"} <= checked, sorted(checked)
 
 
+def test_integration_md_ctypes_stub_is_current(tmp_path, tiny_blob):
+    """The reduced binding INTEGRATION.md shows a maintainer is executed as written (library path and blob file made absolute): its
+    struct and argument lists must equal the ones vosk_tts_amd/capi.py uses, and on a box without a GPU it must stop at vits_create
+    with the library's own error, not crash."""
+    import os
+    import re
+
+    from vosk_tts_amd import capi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "lib.vits_synthesize.argtypes" in b)
+    blob_path = tmp_path / "model.vitsw"
+    blob_path.write_bytes(tiny_blob)
+    stub = stub.replace('"vosk_tts_amd/csrc/libvits_mi355.so"', repr(os.path.join(root, "vosk_tts_amd", "csrc", "libvits_mi355.so")))
+    stub = stub.replace('"model.vitsw"', repr(str(blob_path)))
+    head, tail = stub.split("blob = open(", 1)
+    ns = {}
+    exec(head, ns)  # imports, struct, argtypes
+    assert [(n, t) for n, t in ns["SynthOpts"]._fields_] == [(n, t) for n, t in capi.SynthOpts._fields_]
+    ref = capi.VitsLib()
+    assert list(ns["lib"].vits_synthesize.argtypes[:7]) == list(ref.lib.vits_synthesize.argtypes[:7]) and len(ns["lib"].vits_synthesize.argtypes) == len(ref.lib.vits_synthesize.argtypes)
+    assert list(ns["lib"].vits_create.argtypes) == list(ref.lib.vits_create.argtypes)
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(AssertionError, match="(?i)gpu|device|hip"):
+            exec("blob = open(" + tail, ns)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from vosk_tts_amd.capi import VitsLib
 
