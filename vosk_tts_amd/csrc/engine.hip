@@ -766,7 +766,10 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     // the batch-size conv kernels address one item's [C, T] tensor with 32-bit byte offsets (buffer loads, conv_mfma.hip.h bt_ld):
     // every per-item tensor must stay below 2 GiB.  The widest are the decoder stages, C_i x T_y x prod(rates[0..i]).
     const vits_hparams& hp = s->m->hp;
-    long long worst = (long long)(hp.filter_channels > hp.dec_initial_channel ? hp.filter_channels : hp.dec_initial_channel) * (Ty > Tx ? Ty : Tx);
+    int widest = hp.filter_channels;
+    for (int c : {hp.dec_initial_channel, 2 * hp.hidden_channels, 2 * hp.inter_channels, hp.dp_filter_channels, hp.bert_dim})
+      if (c > widest) widest = c;
+    long long worst = (long long)widest * (Ty > Tx ? Ty : Tx);
     long long rate = 1;
     for (int i = 0; i < hp.n_ups && i < VITS_MAX_UPS; ++i) {
       rate *= hp.up_rates[i];
