@@ -616,8 +616,9 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
-  // 4 accumulator elements at a time: a 16-wide epilogue needs >100 live registers (64-bit offsets, rows,
-  // residuals) and would set the whole kernel's allocation, i.e. its occupancy
+  // general forms: 4 accumulator elements at a time -- 16-wide with 64-bit per-element offsets needs >100 live registers (offsets,
+  // rows, residuals) and would set the whole kernel's allocation, i.e. its occupancy.  (The plain STORE form below is 16-wide on
+  // buffer addressing: one lane offset + scalar row offsets.)
   if (EPI == EPI_GATE) {
     // packed m-blocks alternate [tanh 32 rows | sigmoid 32 rows] of the same 32 channels
     const int j = (m0 >> 6) + wm;  // channel block of 32
