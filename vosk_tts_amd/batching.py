@@ -94,7 +94,11 @@ class MultiDeviceSynth:
             if not hasattr(m.onnx, "run_pcm16"):
                 raise NotImplementedError("MultiDeviceSynth drives VITS voices (batched C ABI); multistream voices batch through "
                                           "SttsModel.synthesize_batch")
+            if getattr(m.onnx, "hp", None) is not None and m.onnx.hp.bert_dim > 0:
+                raise NotImplementedError("MultiDeviceSynth front-ends with g2p_noembed and feeds no `bert` tensor: BERT-conditioned "
+                                          "VITS voices (hparams.bert_dim > 0) go through Synth.synth_audio per request")
         self.synths = [Synth(m) for m in self.models]
+        self._replica_locks = [threading.Lock() for _ in self.models]  # one batch at a time per replica (shared pool threads)
         self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="vits-dev")
         self._seed = 0
         self._lock = threading.Lock()
@@ -114,8 +118,9 @@ class MultiDeviceSynth:
             feed = {"input": ids, "input_lengths": lens, "scales": scales, "sid": np.array([sids[i] for i in part], np.int64),
                     "bert": None, "phone_duration_extra": None, "vits.solo": True,
                     "vits.item_seeds": np.array([seeds[i] for i in part], np.uint64)}
-            pcm = sess.run_pcm16(feed, scale)
-            out.extend(pcm[j, :int(sess.last_lengths[j])].copy() for j in range(len(part)))
+            with self._replica_locks[r]:  # concurrent synth_batch() calls do not interleave on one replica
+                pcm, lengths = sess.run_pcm16(feed, scale, return_lengths=True)  # lengths of THIS call (not the shared attribute)
+            out.extend(pcm[j, :int(lengths[j])].copy() for j in range(len(part)))
         return out
 
     def synth_batch(self, texts, speaker_ids=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None, seeds=None):

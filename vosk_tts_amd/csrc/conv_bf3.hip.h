@@ -236,6 +236,10 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     return;
   }
   const int lenb = P.out_mask ? P.len[b] : 0x7fffffff;
+  if (EPI == EPI_STORE && conv_epilogue_store_fast_ok(P, G)) {  // block-uniform: the fragment-wide epilogue of the fp32 kernel
+    conv_epilogue_store_fragments<MI, 2>(P, G, b, lenb, m0 + wm * MI * 32, n0 + wn * 64, h, l31, acc);
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -255,6 +259,8 @@ __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   kernarg_warm<sizeof(ConvParams)>();
   int mt, grp, nt, b;
   if (!conv_decode_block(P, mt, grp, nt, b)) return;
+  mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);  // block-uniform (see conv_mfma_kernel)
+  nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
   const ConvGroup& G = P.g[grp];
   conv_bf3_body<MI, EPI>(P, G, lds, mt, nt, b);
 }

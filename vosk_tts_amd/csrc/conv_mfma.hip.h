@@ -414,6 +414,69 @@ __device__ __forceinline__ f32x4 bt_ld4(__amdgpu_buffer_rsrc_t r, unsigned lane_
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni_off, 0));
 }
 
+// ---- fragment-wide plain epilogue (bias, mask, residual) of the 128x128 / 64x128 kernels --------------------------------------
+// Every ResBlock / encoder / flow STORE conv.  One 32x32 fragment at a time: ALL of a fragment's operands (4 x dwordx4 bias, 16
+// residual values) are requested at once and the NEXT fragment's before this one's stores, on buffer addressing (descriptor +
+// scalar row offset + one lane offset).  conv_epilogue_frag walks the 64 values of a wave four at a time with two dependent round
+// trips (bias, residual) and a branch per element.  mw / nw: first row / column of the wave's fragments (wave-uniform).
+__device__ __forceinline__ bool conv_epilogue_store_fast_ok(const ConvParams& P, const ConvGroup& G) {
+  return !P.ups_u && !P.bias_b && !P.scale_b && P.relu == 0 && !G.y2 && (P.Cout & 7) == 0;
+}
+template <int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_store_fragments(const ConvParams& P, const ConvGroup& G, int b, int lenb, int mw, int nw, int h,
+                                                              int l31, f32x16 (&acc)[MI][NI]) {
+  constexpr int NF = MI * NI;
+  const __amdgpu_buffer_rsrc_t ry = bt_rsrc(G.y + (long long)b * P.y_bstride);
+  const __amdgpu_buffer_rsrc_t rr = bt_rsrc((G.res ? G.res : G.y) + (long long)b * P.y_bstride);
+  const __amdgpu_buffer_rsrc_t rb = bt_rsrc(G.bias ? G.bias : G.w);
+  const bool has_b = G.bias != nullptr, has_r = G.res != nullptr;
+  f32x4 bq[2][4];
+  float rv[2][16];
+  auto frag_rows = [&](int f) { return mw + (f / NI) * 32; };  // wave-uniform first row of fragment f (lane rows: + 4 h)
+  auto frag_col = [&](int f) { return nw + (f % NI) * 32 + l31; };
+  auto frag_voff = [&](int f) {
+    const int col = frag_col(f);
+    return (unsigned)((4 * h) * P.Tout_stride + (col < P.Tout ? col : P.Tout - 1)) * 4u;
+  };
+  auto request = [&](int f, int slot) {
+    const int R = frag_rows(f);
+    const unsigned vo = frag_voff(f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int rq = R + 8 * q;  // rows rq + 4 h + (0..3); C_out is a multiple of 8, so the quad is valid for both half-waves or for neither
+      if (rq > P.Cout - 8) rq = P.Cout - 8;
+      bq[slot][q] = bt_ld4(rb, (unsigned)(4 * h) * 4u, (unsigned)rq * 4u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rv[slot][4 * q + i] = bt_ld(rr, vo, (unsigned)(rq + i) * (unsigned)P.Tout_stride * 4u);
+    }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (f + 1 < NF) request(f + 1, (f + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int R = frag_rows(f), col = frag_col(f);
+    const unsigned vo = frag_voff(f);
+    const bool masked = P.out_mask && col >= lenb;
+    float x[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float t = acc[f / NI][f % NI][e] + (has_b ? bq[f & 1][e >> 2][e & 3] : 0.f);
+      if (masked) t = 0.f;
+      x[e] = t + (has_r ? rv[f & 1][e] : 0.f);
+    }
+    if (col < P.Tout) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (R + 8 * q < P.Cout) {  // wave-uniform
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[4 * q + i]), ry, vo, (unsigned)(R + 8 * q + i) * (unsigned)P.Tout_stride * 4u, 0);
+        }
+    }
+  }
+}
+
 template <int WM, int WN, int MI, int NI, int EPI>
 __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {  // 3 workgroups per CU
   static_assert(WM * WN == 4, "256-thread workgroups");
@@ -633,61 +696,8 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
       }
     return;
   }
-  if (EPI == EPI_STORE && !P.ups_u && !P.bias_b && !P.scale_b && P.relu == 0 && !G.y2 && (P.Cout & 7) == 0) {  // block-uniform
-    // Plain epilogue (bias, mask, residual) -- every ResBlock / encoder / flow STORE conv -- one 32x32 fragment at a time: ALL of
-    // a fragment's operands (4 x dwordx4 bias, 16 residual values) are requested at once and the NEXT fragment's before this
-    // one's stores, on buffer addressing (descriptor + scalar row offset + one lane offset).  The general path below walks the
-    // 64 values four at a time with two dependent round trips (bias, residual) and a branch per element.
-    constexpr int NF = MI * NI;
-    const __amdgpu_buffer_rsrc_t ry = bt_rsrc(G.y + (long long)b * P.y_bstride);
-    const __amdgpu_buffer_rsrc_t rr = bt_rsrc((G.res ? G.res : G.y) + (long long)b * P.y_bstride);
-    const __amdgpu_buffer_rsrc_t rb = bt_rsrc(G.bias ? G.bias : G.w);
-    const bool has_b = G.bias != nullptr, has_r = G.res != nullptr;
-    f32x4 bq[2][4];
-    float rv[2][16];
-    auto frag_rows = [&](int f) { return m0 + (wm * MI + f / NI) * 32; };               // wave-uniform first row of fragment f (lane rows: + 4 h)
-    auto frag_col = [&](int f) { return n0 + wn * (NI * 32) + (f % NI) * 32 + l31; };
-    auto frag_voff = [&](int f) {
-      const int col = frag_col(f);
-      return (unsigned)((4 * h) * P.Tout_stride + (col < P.Tout ? col : P.Tout - 1)) * 4u;
-    };
-    auto request = [&](int f, int slot) {
-      const int R = frag_rows(f);
-      const unsigned vo = frag_voff(f);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int rq = R + 8 * q;  // rows rq + 4 h + (0..3); C_out is a multiple of 8, so the quad is valid for both half-waves or for neither
-        if (rq > P.Cout - 8) rq = P.Cout - 8;
-        bq[slot][q] = bt_ld4(rb, (unsigned)(4 * h) * 4u, (unsigned)rq * 4u);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rv[slot][4 * q + i] = bt_ld(rr, vo, (unsigned)(rq + i) * (unsigned)P.Tout_stride * 4u);
-      }
-    };
-    request(0, 0);
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      if (f + 1 < NF) request(f + 1, (f + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const int R = frag_rows(f), col = frag_col(f);
-      const unsigned vo = frag_voff(f);
-      const bool masked = P.out_mask && col >= lenb;
-      float x[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float t = acc[f / NI][f % NI][e] + (has_b ? bq[f & 1][e >> 2][e & 3] : 0.f);
-        if (masked) t = 0.f;
-        x[e] = t + (has_r ? rv[f & 1][e] : 0.f);
-      }
-      if (col < P.Tout) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (R + 8 * q < P.Cout) {  // wave-uniform
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[4 * q + i]), ry, vo, (unsigned)(R + 8 * q + i) * (unsigned)P.Tout_stride * 4u, 0);
-          }
-      }
-    }
+  if (EPI == EPI_STORE && conv_epilogue_store_fast_ok(P, G)) {  // block-uniform
+    conv_epilogue_store_fragments<MI, NI>(P, G, b, lenb, m0 + wm * MI * 32, n0 + wn * (NI * 32), h, l31, acc);
     CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 4] = __builtin_readcyclecounter() - dbg_t0;)
     return;
   }

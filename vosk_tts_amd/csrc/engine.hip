@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -905,6 +906,14 @@ static void launch_cfg(vits_session* s, ConvParams& P, int halo) {
 }
 
 // waves per workgroup of the K-split kernel: 0 = heuristic (ks_pick_waves), else forced (tests / tools: VITS_KS_WAVES)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: in-process multi-device replicas
+// (MultiDeviceSynth) need it once per device, not once per process.  Returns true the first time per (flag word, device).
+static bool big_lds_needed(std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  return !(done.fetch_or(bit) & bit);
+}
 static int g_ks_waves = 0;
 static int ks_pick_waves(const ConvParams& P, long nblk) {
   static const int env_nw = getenv("VITS_KS_WAVES") ? atoi(getenv("VITS_KS_WAVES")) : 0;
@@ -926,8 +935,8 @@ static void launch_ks_inst(hipStream_t st, const ConvParams& P, dim3 grid) {
   constexpr size_t lds = (size_t)NW * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
   auto kern = conv_mfma_ks_kernel<MI, NI, EPI, NIN, NW>;
   if (lds > 64 * 1024) {
-    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)once;
+    static std::atomic<unsigned long long> done{0};  // once per (kernel instantiation, DEVICE): the attribute is per device
+    if (big_lds_needed(done)) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, P);
 }
@@ -962,8 +971,8 @@ template <int EPI, int NW, int MAXU, int PRO = 0>
 static void launch_c16_inst(hipStream_t st, const ConvParams& P, dim3 grid, size_t lds) {
   auto kern = conv16_kernel<EPI, NW, MAXU, PRO>;
   if (lds > 64 * 1024) {
-    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)once;
+    static std::atomic<unsigned long long> done{0};  // once per (kernel instantiation, DEVICE)
+    if (big_lds_needed(done)) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, P);
 }

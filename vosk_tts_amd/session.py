@@ -92,10 +92,11 @@ class VitsSession:
         self.last_lengths = lengths
         return [audio[:, None, None, :]]
 
-    def run_pcm16(self, input_feed, scale=1.0):
+    def run_pcm16(self, input_feed, scale=1.0, return_lengths=False):
         """run() followed by `audio.squeeze() * scale` and Synth.audio_float_to_int16 (vosk_tts/synth.py:127-130), with the
         conversion done on the device (vits_synthesize_pcm16): returns int16 [B, S] -- bit-identical to converting run()'s
-        float output with numpy, half the bytes over PCIe."""
+        float output with numpy, half the bytes over PCIe.  return_lengths: also return the per-item sample counts
+        (concurrent callers must take them from the call, not from the shared `last_lengths` attribute)."""
         feed, ids, sid, seed = self._validated(None, input_feed)
         pcm, lengths = self._model.synthesize_pcm16(
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
@@ -103,7 +104,7 @@ class VitsSession:
             forced_durations=feed.get("vits.forced_durations"), seed=int(seed), solo=bool(feed.get("vits.solo", False)),
             item_seeds=feed.get("vits.item_seeds"), bert=feed.get("bert"))
         self.last_lengths = lengths
-        return pcm
+        return (pcm, lengths) if return_lengths else pcm
 
     def run_stream(self, output_names, input_feed, chunk_frames=64):
         """Streaming form of run() for ONE utterance (extension; the reference's transport is already
