@@ -745,6 +745,33 @@ def test_duration_predictor_both_dds_paths(hip_default, oracle_default, B, T):
     assert_close("logw", want * m, got * m, STAGE_TOL)
 
 
+@pytest.mark.parametrize("T", [1, 3, 15, 16, 17, 33, 50, 64, 100, 128])
+def test_persistent_duration_predictor(hip_lib, hip_default, oracle_default, T):
+    """The single-utterance duration predictor as ONE persistent kernel (csrc/persist.hip.h: steps exchange 8-byte {value, epoch}
+    cells, no launches and no barriers in between) against the launch-per-layer path (vits_debug_persist(0)) and the oracle;
+    ragged length inside the bucket, several calls in a row (the epoch advances, stale cells of the previous forward must not be
+    taken for this one's), and a speaker change between calls (dp.cond rides on the first step's epilogue)."""
+    rng = np.random.default_rng(1000 + T)
+    for it, L in enumerate(sorted({T, max(1, T - 5), max(1, (T + 1) // 2)}, reverse=True)):
+        x = rng.standard_normal((1, 192, T)).astype(np.float32)
+        lens = np.array([L], np.int64)
+        x *= (np.arange(T)[None, None, :] < L)
+        sid = np.array([it + 1], np.int64)
+        noise = rng.standard_normal((1, 2, T)).astype(np.float32)
+        want = oracle_default.duration(x, lens, sid, noise, 0.8)
+        hip_lib.lib.vits_debug_persist(1)
+        got = hip_default.duration(x, lens, sid, noise, 0.8)
+        got2 = hip_default.duration(x, lens, sid, noise, 0.8)
+        hip_lib.lib.vits_debug_persist(0)
+        base = hip_default.duration(x, lens, sid, noise, 0.8)
+        hip_lib.lib.vits_debug_persist(1)
+        m = np.arange(T)[None, :] < L
+        assert np.array_equal(got, got2), "two forwards on the same inputs differ (stale cells taken for fresh ones?)"
+        assert_close("logw persistent vs oracle", want * m, got * m, STAGE_TOL)
+        assert_close("logw persistent vs launch path", base * m, got * m, STAGE_TOL)
+        assert np.all(got[~m] == 0)
+
+
 def test_stabletts_hifigan_v1_vocoder(hip_lib, oracle_lib):
     """Vocoder-only blob (n_vocab = 0): StableTTS' bundled HiFi-GAN V1 on the decoder kernels -- golden from the
     reference module, a longer mel against the oracle, and the acoustic entry points refuse such a model."""

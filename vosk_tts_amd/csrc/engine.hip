@@ -27,6 +27,7 @@
 #include "conv_small.hip.h"
 #include "conv_bf3.hip.h"
 #include "kernels_misc.hip.h"
+#include "persist.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512];
@@ -63,6 +64,8 @@ static int g_tail_impl = 0;
 static int g_wn_fold = 1;
 // 1 = LayerNorm statistics of the folded encoder LayerNorms from the producer conv's epilogue (default), 0 = redone by the consumer
 static int g_ln_stats = 1;
+// single-utterance duration predictor as one persistent kernel (persist.hip.h): 1 = when eligible (default), 0 = launch path
+static int g_persist = getenv("VITS_NO_PERSIST") ? 0 : 1;  // (environment switch: A/B runs of bench.py and tools/)
 
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
@@ -146,6 +149,7 @@ struct vits_model {
   std::vector<ResBlockW> rb;
   float *istft_basis = nullptr, *pqmf = nullptr;
   bool use_g = false;
+  int n_cu = 0;       // compute units of the device = workgroups of a persistent kernel (persist.hip.h)
   int rag_halo = 32;  // frames decoded beyond an item's end in ragged batches / streaming windows: >= the decoder's receptive field
 
   std::mutex pool_mu;
@@ -664,6 +668,15 @@ struct vits_session {
   float *dq1 = nullptr, *dq2 = nullptr;  // second x / y pair of the per-layer DDSConv launches (ping-pong with dy / dy2)
   float *zA = nullptr, *zB = nullptr, *fh = nullptr, *fx = nullptr, *facts = nullptr, *fskip = nullptr;
   std::vector<float*> dec_bufs;
+  // persistent duration-predictor kernel (persist.hip.h): LL-cell exchange buffers (inside the arena, zeroed at every re-plan),
+  // the step program (host copy + device copy, rebuilt at every re-plan) and the epoch / completion block (never re-planned)
+  ll_t* ps_ll = nullptr;
+  size_t ps_ll_cells = 0;
+  SdpProgram ps_prog_h;
+  SdpProgram* ps_prog_d = nullptr;
+  PersistCtl* ps_ctl = nullptr;
+  bool ps_ok = false;
+  double ps_flops = 0;
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
   // session, so a steady stream of vits_synthesize calls does no hipMalloc / hipFree (both synchronise the device)
   char* stage = nullptr;
@@ -700,6 +713,31 @@ static T* bump(vits_session* s, size_t n) {
   return s->arena ? reinterpret_cast<T*>(s->arena + off) : nullptr;
 }
 
+// ---- persistent duration predictor (persist.hip.h): eligibility and the size of its exchange buffers
+static bool persist_sdp_eligible(const vits_model* m, int B, int Tx) {
+  const vits_hparams& hp = m->hp;
+  if (!m->acoustic || B != 1 || Tx < 1 || Tx > 128 || m->n_cu < 16) return false;
+  const int D = hp.dp_filter_channels, H = hp.hidden_channels;
+  if (D % 32 || D > PS_MAXC || H % 16 || H > PS_MAXC || hp.dp_kernel_size != 3) return false;
+  const int nl = (int)m->dp_dds.pw.size();
+  if (nl < 1 || nl > 3 || hp.dp_n_flows < 2 || hp.dp_num_bins > 16 || 3 * hp.dp_num_bins - 1 > 32) return false;
+  if (1 + (nl + 1) * hp.dp_n_flows > PS_MAX_STEPS) return false;
+  if (!m->dp_pre.w16 || !m->dp_proj.w16) return false;
+  for (const ConvW& c : m->dp_dds.pw) if (!c.w16) return false;
+  for (int k = 1; k < hp.dp_n_flows; ++k) {
+    if ((int)m->cf[k].dds.pw.size() != nl || !m->cf[k].proj.w16) return false;
+    for (const ConvW& c : m->cf[k].dds.pw) if (!c.w16) return false;
+  }
+  return true;
+}
+static size_t persist_sdp_cells(const vits_model* m, int B, int Tx) {
+  if (!persist_sdp_eligible(m, B, Tx)) return 0;
+  const vits_hparams& hp = m->hp;
+  const size_t Tp = (size_t)cdiv(Tx, 16) * 16, D = hp.dp_filter_channels, nl = m->dp_dds.pw.size(), nf = hp.dp_n_flows;
+  // x0 (dp.pre), per DDSConv layer its finished input and its 1x1 output, dc (dp.proj), z after init and after every flow
+  return Tp * (D * (2 + 2 * nl * nf) + 2 * (nf + 1));
+}
+
 // lays out every activation buffer for the given capacity; with arena == nullptr only measures
 static void plan(vits_session* s, int B, int Tx, int Ty) {
   const vits_hparams& hp = s->m->hp;
@@ -727,6 +765,8 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->dc = bump<float>(s, B * D * Tx); s->dfh = bump<float>(s, B * D * Tx);
   s->dq1 = bump<float>(s, B * D * Tx); s->dq2 = bump<float>(s, B * D * Tx);
   s->dz = bump<float>(s, (size_t)B * 2 * Tx); s->dpr = bump<float>(s, (size_t)B * 32 * Tx); s->logw = bump<float>(s, (size_t)B * Tx);
+  s->ps_ll_cells = persist_sdp_cells(s->m, B, Tx);
+  s->ps_ll = bump<ll_t>(s, s->ps_ll_cells);
   s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
   s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
   s->facts = bump<float>(s, B * H * Ty * (size_t)(hp.flow_wn_layers > 0 ? hp.flow_wn_layers : 1));  // gate outputs of all WN layers, stacked
@@ -757,6 +797,89 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
 static void drop_graphs(vits_session* s) {
   for (auto& kv : s->graphs) hipGraphExecDestroy(kv.second);
   s->graphs.clear();
+}
+
+// Builds the step program of the persistent duration predictor for the session's current layout (persist.hip.h): called at every
+// re-plan, outside any capture.  The exchange cells are zeroed (epoch 0 = "never written": whatever the arena held before must not
+// look like a cell of a later forward); the epoch block survives re-plans, so epochs only ever grow.
+static int persist_plan(vits_session* s) {
+  s->ps_ok = false;
+  vits_model* m = s->m;
+  if (!s->ps_ll_cells || !s->ps_ll) return VITS_OK;
+  const vits_hparams& hp = m->hp;
+  if (!s->ps_ctl) {
+    HIP_TRY(hipMalloc((void**)&s->ps_ctl, sizeof(PersistCtl)));
+    HIP_TRY(hipMemsetAsync(s->ps_ctl, 0, sizeof(PersistCtl), s->stream));
+    HIP_TRY(hipMalloc((void**)&s->ps_prog_d, sizeof(SdpProgram)));
+  }
+  HIP_TRY(hipMemsetAsync(s->ps_ll, 0, s->ps_ll_cells * sizeof(ll_t), s->stream));
+  const int Tx = s->Tx, Tp = cdiv(Tx, 16) * 16, ntn = Tp / 16, D = hp.dp_filter_channels;
+  const int nl = (int)m->dp_dds.pw.size(), K = hp.dp_kernel_size;
+  SdpProgram& P = s->ps_prog_h;
+  memset(&P, 0, sizeof P);
+  P.T = Tx; P.Tp = Tp; P.ntn = ntn;
+  P.nb = hp.dp_num_bins; P.bound = hp.dp_tail_bound; P.inv_sqrt_d = 1.0f / sqrtf((float)D);
+  P.len = s->len_x; P.ea_m = m->ea_m; P.ea_logs = m->ea_logs; P.logw = s->logw; P.err = s->d_err;
+  ll_t* cur = s->ps_ll;
+  auto take = [&](int rows) { ll_t* p = cur; cur += (size_t)rows * Tp; return p; };
+  double flops = 0;
+  auto add = [&](SdpStep st, const ConvW& W) -> SdpStep& {
+    st.Cin = W.Cin; st.Cout = W.M; st.n_mb = cdiv(W.M, 16); st.w16 = W.w16; st.bias = W.bias;
+    if (st.kind == PS_CFPROJ) { st.mbg = st.n_mb; st.G = 1; }
+    else { st.mbg = cdiv(st.n_mb * ntn, m->n_cu); st.G = cdiv(st.n_mb, st.mbg); }
+    flops += 2.0 * Tx * ((double)W.M * W.Cin + (st.kind == PS_DDS ? (double)D * K : 0.0));
+    P.steps[P.n_steps] = st;
+    return P.steps[P.n_steps++];
+  };
+  SdpStep st;
+  // dp.pre (+ cond(g)) -> x0 ; z = noise * noise_scale_w          (models.py:58-60,96)
+  memset(&st, 0, sizeof st);
+  st.kind = PS_PRE;
+  st.cond = m->use_g ? s->condv + m->cond_dp_off : nullptr;
+  st.yout = take(D); st.zout = take(2);
+  const ll_t* x = add(st, m->dp_pre).yout;
+  const ll_t* z = P.steps[0].zout;
+  // one DDSConv stack + the 1x1 conv that consumes it (modules.py:96-108)
+  auto stack = [&](const DDSW& W, const ConvW& proj, int proj_kind, const ll_t* xin, const ll_t* zc, int z_row, const float* pw, const float* pb) -> SdpStep& {
+    const ll_t* y2 = nullptr;
+    int dil = 1;
+    for (int i = 0; i < nl; ++i) {
+      memset(&st, 0, sizeof st);
+      st.kind = PS_DDS; st.dil = dil;
+      st.xin = xin; st.y2 = y2;
+      if (i > 0) { st.g2 = W.g2[i - 1]; st.b2 = W.b2[i - 1]; }
+      else if (zc) { st.z = zc; st.z_row = z_row; st.pw = pw; st.pb = pb; }
+      st.sw = W.sw[i]; st.sb = W.sb[i]; st.g1 = W.g1[i]; st.b1 = W.b1[i];
+      st.yout = take(D); st.xout = take(D);
+      SdpStep& a = add(st, W.pw[i]);
+      xin = a.xout; y2 = a.yout;
+      dil *= K;
+    }
+    memset(&st, 0, sizeof st);
+    st.kind = proj_kind;
+    st.xin = xin; st.y2 = y2; st.g2 = W.g2[nl - 1]; st.b2 = W.b2[nl - 1];
+    return add(st, proj);
+  };
+  {
+    SdpStep& pj = stack(m->dp_dds, m->dp_proj, PS_PROJ, x, nullptr, 0, nullptr, nullptr);
+    pj.yout = take(D);
+  }
+  const ll_t* dc = P.steps[P.n_steps - 1].yout;
+  int swap = 0;
+  for (int k = hp.dp_n_flows - 1; k >= 1; --k) {
+    swap ^= 1;  // Flip (modules.py:270-277) is a row relabel on the 2-channel z
+    const ConvFlowW& c = m->cf[k];
+    SdpStep& pj = stack(c.dds, c.proj, PS_CFPROJ, dc, z, swap, c.pre_w, c.pre_b);
+    pj.z = z; pj.z_row = swap;
+    if (k > 1) { pj.zout = take(2); z = pj.zout; }
+    else { pj.last = 1; pj.ea_row = swap ^ 1; }
+  }
+  if ((size_t)(cur - s->ps_ll) > s->ps_ll_cells) return fail(VITS_ERR_DEVICE, "persistent duration predictor: exchange buffers overflow the plan");
+  s->ps_flops = flops;
+  HIP_TRY(hipMemcpyAsync(s->ps_prog_d, &P, sizeof P, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));  // P lives in pageable memory of the session: the copy must not outlive this call's view of it
+  s->ps_ok = true;
+  return VITS_OK;
 }
 
 // (re)lays the workspace out for exactly (B,Tx,Ty) so every [B,C,T] tensor is dense; grows the
@@ -798,7 +921,7 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);
     hipStreamSynchronize(s->stream);
   }
-  return VITS_OK;
+  return persist_plan(s);
 }
 
 static int session_new(vits_model* m, vits_session** out) {
@@ -833,6 +956,8 @@ static void session_free(vits_session* s) {
   if (s->out_h) hipHostFree(s->out_h);
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
+  if (s->ps_ctl) hipFree(s->ps_ctl);
+  if (s->ps_prog_d) hipFree(s->ps_prog_d);
   if (s->stage) hipFree(s->stage);
   if (s->d_err) hipFree(s->d_err);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -1423,6 +1548,10 @@ static int check_err(vits_session* s) {
     if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
     if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
     if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
+    if (e & PS_ERR_TIMEOUT) {
+      g_persist = 0;  // the launch path stays available: do not try again in this process
+      return fail(VITS_ERR_DEVICE, "persistent duration-predictor kernel: exchange timed out (workgroups not co-resident?); disabled for this process");
+    }
   }
   return VITS_OK;
 }
@@ -1574,6 +1703,16 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int D = hp.dp_filter_channels;
+  if (g_persist && s->ps_ok && B == 1 && Tx == s->Tx) {  // one persistent kernel instead of ~21 launches (persist.hip.h)
+    ProfScope ps(s, "dp.persist", s->ps_flops, "sdp_persist_kernel");
+    SdpCall c;
+    c.ctl = s->ps_ctl; c.x = x; c.noise = d_noise; c.nsw = nsw; c.seed = seed; c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds;
+    static std::atomic<unsigned long long> done{0};
+    if (big_lds_needed(done)) hipFuncSetAttribute((const void*)sdp_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS_BYTES);
+    hipLaunchKernelGGL(sdp_persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), PS_LDS_BYTES, s->stream, s->ps_prog_d, c);
+    s->ea_pending = false;
+    return;
+  }
   ConvParams P = conv_params(m->dp_pre, x, s->dh, B, Tx, 1, 0);
   if (m->use_g) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dp_off; }
   mark_masked(s, P, s->len_x);
@@ -1892,6 +2031,10 @@ int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
   vits_model* m = new vits_model();
   memcpy(&m->hp, p + 12, sizeof(vits_hparams));
   m->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) m->n_cu = cus > 256 ? 256 : cus;
+  }
   if (m->hp.abi_version != VITS_ABI_VERSION) { delete m; return fail(VITS_ERR_BLOB, "abi version mismatch"); }
   m->blob = p; m->blob_bytes = bytes;
   memcpy(&m->n_entries, p + 12 + hb, 4);
@@ -2691,6 +2834,7 @@ void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
 void vits_debug_ln_stats(int on) { g_ln_stats = on; }
+void vits_debug_persist(int on) { g_persist = on; }
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
 void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }

@@ -728,25 +728,17 @@ __global__ void convflow_pre_kernel(const float* z, int x0_row, const float* pw,
 
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 
-// Inverse rational-quadratic spline with linear tails, one element per thread
-// (transforms.py:55-177, inverse branch 152-167; searchsorted :47-52), then cat(x0,x1)*mask
-// (modules.py:386).  pr: [B, 3*nb-1 (padded rows ignored), T] = proj(h)*mask.
-__global__ void spline_inverse_kernel(float* z, int x0_row, const float* pr, int pr_rows, const int* len, int T, int nb,
-                                      float bound, float inv_sqrt_d) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (t >= T) return;
-  const int x1_row = 1 - x0_row;
-  float* p0 = &z[((long long)b * 2 + x0_row) * T + t];
-  float* p1 = &z[((long long)b * 2 + x1_row) * T + t];
-  if (t >= len[b]) { *p0 = 0.f; *p1 = 0.f; return; }
-  const float y = *p1;
-  if (!(y >= -bound && y <= bound)) return;  // identity outside the interval (transforms.py:65-77)
-  const float* pp = pr + (long long)b * pr_rows * T + t;
+// Inverse rational-quadratic spline with linear tails for ONE element (transforms.py:55-177, inverse branch 152-167;
+// searchsorted :47-52).  pp(i) = row i of proj(h)*mask at this element's column (3*nb - 1 rows).  Shared by the launch path
+// (spline_inverse_kernel) and the persistent duration-predictor kernel (persist.hip.h) so both run the same arithmetic.
+template <typename PP>
+__device__ __forceinline__ float spline_inverse_elem(float y, PP pp, int nb, float bound, float inv_sqrt_d) {
+  if (!(y >= -bound && y <= bound)) return y;  // identity outside the interval (transforms.py:65-77)
   const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
   constexpr int NB = 16;
   float w[NB], cw[NB + 1], hh[NB], ch[NB + 1];
   float mx = -3.0e38f;
-  for (int i = 0; i < nb; ++i) { w[i] = pp[(long long)i * T] * inv_sqrt_d; mx = fmaxf(mx, w[i]); }
+  for (int i = 0; i < nb; ++i) { w[i] = pp(i) * inv_sqrt_d; mx = fmaxf(mx, w[i]); }
   float sum = 0.f;
   for (int i = 0; i < nb; ++i) { w[i] = expf(w[i] - mx); sum += w[i]; }
   float acc = 0.f;
@@ -757,7 +749,7 @@ __global__ void spline_inverse_kernel(float* z, int x0_row, const float* pr, int
   }
   cw[nb] = bound;
   mx = -3.0e38f;
-  for (int i = 0; i < nb; ++i) { hh[i] = pp[(long long)(nb + i) * T] * inv_sqrt_d; mx = fmaxf(mx, hh[i]); }
+  for (int i = 0; i < nb; ++i) { hh[i] = pp(nb + i) * inv_sqrt_d; mx = fmaxf(mx, hh[i]); }
   sum = 0.f;
   for (int i = 0; i < nb; ++i) { hh[i] = expf(hh[i] - mx); sum += hh[i]; }
   acc = 0.f;
@@ -777,8 +769,8 @@ __global__ void spline_inverse_kernel(float* z, int x0_row, const float* pr, int
   for (int i = 0; i < nb; ++i)
     if (i == bin) { in_cw = cw[i]; in_w = cw[i + 1] - cw[i]; in_ch = ch[i]; in_h = ch[i + 1] - ch[i]; }
   const float cst = logf(expf(1.f - min_d) - 1.f);
-  const float ud0 = (bin == 0) ? cst : pp[(long long)(2 * nb + bin - 1) * T];
-  const float ud1 = (bin == nb - 1) ? cst : pp[(long long)(2 * nb + bin) * T];
+  const float ud0 = (bin == 0) ? cst : pp(2 * nb + bin - 1);
+  const float ud1 = (bin == nb - 1) ? cst : pp(2 * nb + bin);
   const float d0 = min_d + softplus_f(ud0), d1 = min_d + softplus_f(ud1);
   const float delta = in_h / in_w;
   const float t1 = (y - in_ch) * (d0 + d1 - 2.f * delta);
@@ -787,7 +779,22 @@ __global__ void spline_inverse_kernel(float* z, int x0_row, const float* pr, int
   const float c = -delta * (y - in_ch);
   const float disc = bq * bq - 4.f * a * c;
   const float root = (2.f * c) / (-bq - sqrtf(disc));
-  *p1 = root * in_w + in_cw;
+  return root * in_w + in_cw;
+}
+
+// one element per thread, then cat(x0,x1)*mask (modules.py:386).  pr: [B, 3*nb-1 (padded rows ignored), T] = proj(h)*mask.
+__global__ void spline_inverse_kernel(float* z, int x0_row, const float* pr, int pr_rows, const int* len, int T, int nb,
+                                      float bound, float inv_sqrt_d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const int x1_row = 1 - x0_row;
+  float* p0 = &z[((long long)b * 2 + x0_row) * T + t];
+  float* p1 = &z[((long long)b * 2 + x1_row) * T + t];
+  if (t >= len[b]) { *p0 = 0.f; *p1 = 0.f; return; }
+  const float y = *p1;
+  if (!(y >= -bound && y <= bound)) return;
+  const float* pp = pr + (long long)b * pr_rows * T + t;
+  *p1 = spline_inverse_elem(y, [&](int i) { return pp[(long long)i * T]; }, nb, bound, inv_sqrt_d);
 }
 
 // ElementwiseAffine reverse + logw = z0 (modules.py:293-295, models.py:99-100)
