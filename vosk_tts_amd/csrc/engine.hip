@@ -149,6 +149,7 @@ struct vits_model {
   std::vector<ResBlockW> rb;
   float *istft_basis = nullptr, *pqmf = nullptr;
   bool use_g = false;
+  float* zeros = nullptr;  // 4096 zeros: the "unused" parameter pointers of persistent-kernel steps (persist.hip.h)
   int n_cu = 0;       // compute units of the device = workgroups of a persistent kernel (persist.hip.h)
   int rag_halo = 32;  // frames decoded beyond an item's end in ragged batches / streaming windows: >= the decoder's receptive field
 
@@ -721,7 +722,7 @@ static bool persist_sdp_eligible(const vits_model* m, int B, int Tx) {
   if (D % 32 || D > PS_MAXC || H % 16 || H > PS_MAXC || hp.dp_kernel_size != 3) return false;
   const int nl = (int)m->dp_dds.pw.size();
   if (nl < 1 || nl > 3 || hp.dp_n_flows < 2 || hp.dp_num_bins > 16 || 3 * hp.dp_num_bins - 1 > 32) return false;
-  if (1 + (nl + 1) * hp.dp_n_flows > PS_MAX_STEPS) return false;
+  if (1 + 2 * (nl + 1) * hp.dp_n_flows > PS_MAX_STEPS) return false;
   if (!m->dp_pre.w16 || !m->dp_proj.w16) return false;
   for (const ConvW& c : m->dp_dds.pw) if (!c.w16) return false;
   for (int k = 1; k < hp.dp_n_flows; ++k) {
@@ -734,8 +735,9 @@ static size_t persist_sdp_cells(const vits_model* m, int B, int Tx) {
   if (!persist_sdp_eligible(m, B, Tx)) return 0;
   const vits_hparams& hp = m->hp;
   const size_t Tp = (size_t)cdiv(Tx, 16) * 16, D = hp.dp_filter_channels, nl = m->dp_dds.pw.size(), nf = hp.dp_n_flows;
-  // x0 (dp.pre), per DDSConv layer its finished input and its 1x1 output, dc (dp.proj), z after init and after every flow
-  return Tp * (D * (2 + 2 * nl * nf) + 2 * (nf + 1));
+  // x0 (dp.pre); per DDSConv stack: per layer the finished input, the 1x1 operand and the 1x1 output, the last finish, and the
+  // proj output (dc; the ConvFlow projections stay in LDS); z after init and after every flow
+  return Tp * (D * (1 + nf * (3 * nl + 2)) + 2 * (nf + 1));
 }
 
 // lays out every activation buffer for the given capacity; with arena == nullptr only measures
@@ -823,45 +825,56 @@ static int persist_plan(vits_session* s) {
   ll_t* cur = s->ps_ll;
   auto take = [&](int rows) { ll_t* p = cur; cur += (size_t)rows * Tp; return p; };
   double flops = 0;
-  auto add = [&](SdpStep st, const ConvW& W) -> SdpStep& {
-    st.Cin = W.Cin; st.Cout = W.M; st.n_mb = cdiv(W.M, 16); st.w16 = W.w16; st.bias = W.bias;
-    if (st.kind == PS_CFPROJ) { st.mbg = st.n_mb; st.G = 1; }
+  SdpStep st;
+  auto blank = [&](int kind) {  // every parameter pointer valid (zeros when unused): the kernel prefetches them unconditionally
+    memset(&st, 0, sizeof st);
+    st.kind = kind;
+    st.Cin = 16; st.Cout = 16; st.n_mb = 1; st.G = 1; st.mbg = 1; st.D = PS_MAXC;
+    st.w16 = st.bias = st.cond = st.g2 = st.b2 = st.sw = st.sb = st.g1 = st.b1 = st.pw = st.pb = m->zeros;
+  };
+  auto add_mm = [&](const ConvW& W) -> SdpStep& {  // st carries kind / epi / operands
+    st.Cin = W.Cin; st.Cout = W.M; st.n_mb = cdiv(W.M, 16); st.w16 = W.w16; st.bias = W.bias; st.ypitch = cdiv(W.M, 16) * 16;
+    if (st.epi == PS_EPI_SPLINE) { st.mbg = st.n_mb; st.G = 1; }
     else { st.mbg = cdiv(st.n_mb * ntn, m->n_cu); st.G = cdiv(st.n_mb, st.mbg); }
-    flops += 2.0 * Tx * ((double)W.M * W.Cin + (st.kind == PS_DDS ? (double)D * K : 0.0));
+    flops += 2.0 * Tx * (double)W.M * W.Cin;
     P.steps[P.n_steps] = st;
     return P.steps[P.n_steps++];
   };
-  SdpStep st;
   // dp.pre (+ cond(g)) -> x0 ; z = noise * noise_scale_w          (models.py:58-60,96)
-  memset(&st, 0, sizeof st);
-  st.kind = PS_PRE;
-  st.cond = m->use_g ? s->condv + m->cond_dp_off : nullptr;
+  blank(PS_PRE);
+  if (m->use_g) st.cond = s->condv + m->cond_dp_off;
   st.yout = take(D); st.zout = take(2);
-  const ll_t* x = add(st, m->dp_pre).yout;
+  const ll_t* x = add_mm(m->dp_pre).yout;
   const ll_t* z = P.steps[0].zout;
-  // one DDSConv stack + the 1x1 conv that consumes it (modules.py:96-108)
-  auto stack = [&](const DDSW& W, const ConvW& proj, int proj_kind, const ll_t* xin, const ll_t* zc, int z_row, const float* pw, const float* pb) -> SdpStep& {
+  // one DDSConv stack + the 1x1 conv that consumes it (modules.py:96-108): per layer a column step (finish the previous layer,
+  // depthwise conv, LN1, GELU) and a matrix step (the layer's 1x1 conv); then the last finish and the projection
+  auto stack = [&](const DDSW& W, const ConvW& proj, int proj_epi, const ll_t* xin, const ll_t* zc, int z_row, const float* pw, const float* pb) -> SdpStep& {
     const ll_t* y2 = nullptr;
     int dil = 1;
-    for (int i = 0; i < nl; ++i) {
-      memset(&st, 0, sizeof st);
-      st.kind = PS_DDS; st.dil = dil;
+    for (int i = 0; i <= nl; ++i) {
+      const bool fin = i == nl;
+      blank(PS_COL);
+      st.D = D; st.dw = fin ? 0 : 1; st.dil = fin ? 0 : dil;
       st.xin = xin; st.y2 = y2;
-      if (i > 0) { st.g2 = W.g2[i - 1]; st.b2 = W.b2[i - 1]; }
-      else if (zc) { st.z = zc; st.z_row = z_row; st.pw = pw; st.pb = pb; }
-      st.sw = W.sw[i]; st.sb = W.sb[i]; st.g1 = W.g1[i]; st.b1 = W.b1[i];
-      st.yout = take(D); st.xout = take(D);
-      SdpStep& a = add(st, W.pw[i]);
-      xin = a.xout; y2 = a.yout;
+      if (i > 0) { st.fin = 1; st.g2 = W.g2[i - 1]; st.b2 = W.b2[i - 1]; }
+      else if (zc) { st.fin = 2; st.z = zc; st.z_row = z_row; st.g2 = pw; st.b2 = pb; }  // (pw / pb ride in the g2 / b2 slots)
+      if (!fin) { st.sw = W.sw[i]; st.sb = W.sb[i]; st.g1 = W.g1[i]; st.b1 = W.b1[i]; st.bout = take(D); }
+      st.xout = take(D);
+      flops += 2.0 * Tx * (double)D * (fin ? 0 : K);
+      P.steps[P.n_steps] = st;
+      const SdpStep& col = P.steps[P.n_steps++];
+      xin = col.xout;
+      blank(PS_MM);
+      st.bin = fin ? col.xout : col.bout;
+      if (fin) { st.epi = proj_epi; return add_mm(proj); }
+      st.epi = PS_EPI_RAW; st.yout = take(D);
+      y2 = add_mm(W.pw[i]).yout;
       dil *= K;
     }
-    memset(&st, 0, sizeof st);
-    st.kind = proj_kind;
-    st.xin = xin; st.y2 = y2; st.g2 = W.g2[nl - 1]; st.b2 = W.b2[nl - 1];
-    return add(st, proj);
+    return P.steps[P.n_steps - 1];  // not reached
   };
   {
-    SdpStep& pj = stack(m->dp_dds, m->dp_proj, PS_PROJ, x, nullptr, 0, nullptr, nullptr);
+    SdpStep& pj = stack(m->dp_dds, m->dp_proj, PS_EPI_MASK, x, nullptr, 0, nullptr, nullptr);
     pj.yout = take(D);
   }
   const ll_t* dc = P.steps[P.n_steps - 1].yout;
@@ -869,7 +882,7 @@ static int persist_plan(vits_session* s) {
   for (int k = hp.dp_n_flows - 1; k >= 1; --k) {
     swap ^= 1;  // Flip (modules.py:270-277) is a row relabel on the 2-channel z
     const ConvFlowW& c = m->cf[k];
-    SdpStep& pj = stack(c.dds, c.proj, PS_CFPROJ, dc, z, swap, c.pre_w, c.pre_b);
+    SdpStep& pj = stack(c.dds, c.proj, PS_EPI_SPLINE, dc, z, swap, c.pre_w, c.pre_b);
     pj.z = z; pj.z_row = swap;
     if (k > 1) { pj.zout = take(2); z = pj.zout; }
     else { pj.last = 1; pj.ea_row = swap ^ 1; }
@@ -1707,10 +1720,30 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
     ProfScope ps(s, "dp.persist", s->ps_flops, "sdp_persist_kernel");
     SdpCall c;
     c.ctl = s->ps_ctl; c.x = x; c.noise = d_noise; c.nsw = nsw; c.seed = seed; c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds;
-    static std::atomic<unsigned long long> done{0};
-    if (big_lds_needed(done)) hipFuncSetAttribute((const void*)sdp_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS_BYTES);
-    hipLaunchKernelGGL(sdp_persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), PS_LDS_BYTES, s->stream, s->ps_prog_d, c);
+    c.trace = nullptr;
+    static const char* trace_path = getenv("VITS_PS_TRACE");  // tools/ps_trace.py: per-worker, per-step cycle stamps of an EAGER forward
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (trace_path) hipStreamIsCapturing(s->stream, &cap);
+    const size_t trace_n = (size_t)m->n_cu * PS_MAX_STEPS * 4;
+    if (trace_path && cap == hipStreamCaptureStatusNone) {
+      hipMalloc((void**)&c.trace, trace_n * sizeof(long long));
+      hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), s->stream);
+    }
+    hipLaunchKernelGGL(sdp_persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), 0, s->stream, s->ps_prog_d, c);
     s->ea_pending = false;
+    if (c.trace) {
+      std::vector<long long> h(trace_n);
+      hipMemcpyAsync(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost, s->stream);
+      hipStreamSynchronize(s->stream);
+      hipFree(c.trace);
+      if (FILE* f = fopen(trace_path, "wb")) {
+        const int hdr[4] = {m->n_cu, PS_MAX_STEPS, s->ps_prog_h.n_steps, Tx};
+        fwrite(hdr, sizeof hdr, 1, f);
+        for (int i = 0; i < s->ps_prog_h.n_steps; ++i) fwrite(&s->ps_prog_h.steps[i].kind, sizeof(int), 1, f);
+        fwrite(h.data(), sizeof(long long), trace_n, f);
+        fclose(f);
+      }
+    }
     return;
   }
   ConvParams P = conv_params(m->dp_pre, x, s->dh, B, Tx, 1, 0);
@@ -2045,6 +2078,11 @@ int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
     if (off > bytes || ne > (bytes - off) / 4) { delete m; return fail(VITS_ERR_BLOB, "truncated data"); }
   }
   int rc = load_model(m);
+  if (rc == VITS_OK) {
+    std::vector<float> z(4096, 0.f);
+    m->zeros = upload(m, z.data(), z.size());
+    if (!m->zeros) rc = VITS_ERR_NOMEM;
+  }
   m->blob = nullptr; m->entries = nullptr;
   if (rc != VITS_OK) { for (void* a : m->allocs) hipFree(a); delete m; return rc; }
   hipDeviceSynchronize();
