@@ -297,9 +297,10 @@ void vits_debug_ks_waves(int nw);
 /* Test hook: 1 (default) = the folded encoder LayerNorms take their channel statistics from the producing conv's epilogue,
  * 0 = every consumer workgroup recomputes them. */
 void vits_debug_ln_stats(int on);
-/* 1 (default): the duration predictor of a single utterance (B = 1, T_x <= 128) runs as ONE persistent kernel with in-band
- * ("LL cell") exchange between its steps (csrc/persist.hip.h); 0: the launch-per-layer path (the A/B reference, and the batch path). */
-void vits_debug_persist(int on);
+/* Bit mask of the single-utterance stages (B = 1, T <= 256) that run as ONE persistent kernel each, with in-band ("LL cell")
+ * exchange between their steps (csrc/persist.hip.h): 1 duration predictor, 2 text encoder, 4 flow.  Default 7; 0: the launch-per-layer
+ * path everywhere (the A/B reference, and the batch path). */
+void vits_debug_persist(int mask);
 /* Test hook: 1 (default) = WaveNet tail of the coupling layers in folded form (gate outputs of all layers kept, one conv =
  * post o sum of skip halves), 0 = per-layer res/skip accumulation + post as the reference executes it.  Same results to rounding. */
 void vits_debug_wn_fold(int on);

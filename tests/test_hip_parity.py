@@ -759,17 +759,65 @@ def test_persistent_duration_predictor(hip_lib, hip_default, oracle_default, T):
         sid = np.array([it + 1], np.int64)
         noise = rng.standard_normal((1, 2, T)).astype(np.float32)
         want = oracle_default.duration(x, lens, sid, noise, 0.8)
-        hip_lib.lib.vits_debug_persist(1)
+        hip_lib.lib.vits_debug_persist(7)
         got = hip_default.duration(x, lens, sid, noise, 0.8)
         got2 = hip_default.duration(x, lens, sid, noise, 0.8)
         hip_lib.lib.vits_debug_persist(0)
         base = hip_default.duration(x, lens, sid, noise, 0.8)
-        hip_lib.lib.vits_debug_persist(1)
+        hip_lib.lib.vits_debug_persist(7)
         m = np.arange(T)[None, :] < L
         assert np.array_equal(got, got2), "two forwards on the same inputs differ (stale cells taken for fresh ones?)"
         assert_close("logw persistent vs oracle", want * m, got * m, STAGE_TOL)
         assert_close("logw persistent vs launch path", base * m, got * m, STAGE_TOL)
         assert np.all(got[~m] == 0)
+
+
+@pytest.mark.parametrize("T", [1, 5, 16, 17, 50, 64, 100, 130, 200])
+def test_persistent_text_encoder(hip_lib, hip_default, oracle_default, T):
+    """TextEncoder (models.py:317-326; attentions.py:48-65) of a single utterance as ONE persistent step program (embedding, per layer
+    q|k|v, 16 x 16 attention blocks + merge, conv_o + residual, LayerNorm, FFN in K-slices, LayerNorm, then proj) against the
+    launch path (vits_debug_persist(0)) and the oracle: ragged length inside the bucket, repeated forwards, speaker change."""
+    rng = np.random.default_rng(2000 + T)
+    for it, L in enumerate(sorted({T, max(1, T - 7), max(1, (T + 1) // 2)}, reverse=True)):
+        ids = rng.integers(1, 62, size=(1, T)).astype(np.int64)
+        lens = np.array([L], np.int64)
+        sid = np.array([it + 3], np.int64)
+        want = oracle_default.text_encoder(ids, lens, sid)
+        hip_lib.lib.vits_debug_persist(7)
+        got = hip_default.text_encoder(ids, lens, sid)
+        got2 = hip_default.text_encoder(ids, lens, sid)
+        hip_lib.lib.vits_debug_persist(0)
+        base = hip_default.text_encoder(ids, lens, sid)
+        hip_lib.lib.vits_debug_persist(7)
+        m = (np.arange(T)[None, None, :] < L)
+        for name, w, g, g2, b in zip(("x", "m_p", "logs_p"), want, got, got2, base):
+            assert np.array_equal(g, g2), f"{name}: two forwards on the same inputs differ"
+            assert_close(f"{name} persistent vs oracle", w * m, g * m, STAGE_TOL)
+            assert_close(f"{name} persistent vs launch path", b * m, g * m, STAGE_TOL)
+            assert np.all((g * ~m) == 0), f"{name}: padding columns must be zero"
+
+
+@pytest.mark.parametrize("T", [1, 16, 33, 150, 160, 250])
+def test_persistent_flow(hip_lib, hip_default, oracle_default, T):
+    """ResidualCouplingTransformersBlock reverse (models.py:750-757, 374-393) of a single utterance as ONE persistent step program
+    (per coupling layer: pre with the Flip folded into the read, the pre-transformer layer, WaveNet gates / residual updates,
+    the folded skip + post projection in K-slices, the coupling tail) against the launch path and the oracle."""
+    rng = np.random.default_rng(3000 + T)
+    for it, L in enumerate(sorted({T, max(1, T - 9), max(1, (T + 1) // 2)}, reverse=True)):
+        z_p = rng.standard_normal((1, 192, T)).astype(np.float32)
+        lens = np.array([L], np.int64)
+        sid = np.array([it + 5], np.int64)
+        want = oracle_default.flow(z_p, lens, sid)
+        hip_lib.lib.vits_debug_persist(7)
+        got = hip_default.flow(z_p, lens, sid)
+        got2 = hip_default.flow(z_p, lens, sid)
+        hip_lib.lib.vits_debug_persist(0)
+        base = hip_default.flow(z_p, lens, sid)
+        hip_lib.lib.vits_debug_persist(7)
+        m = (np.arange(T)[None, None, :] < L)
+        assert np.array_equal(got, got2), "two forwards on the same inputs differ"
+        assert_close("z persistent vs oracle", want * m, got * m, STAGE_TOL)
+        assert_close("z persistent vs launch path", base * m, got * m, STAGE_TOL)
 
 
 def test_stabletts_hifigan_v1_vocoder(hip_lib, oracle_lib):

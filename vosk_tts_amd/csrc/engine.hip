@@ -65,7 +65,7 @@ static int g_wn_fold = 1;
 // 1 = LayerNorm statistics of the folded encoder LayerNorms from the producer conv's epilogue (default), 0 = redone by the consumer
 static int g_ln_stats = 1;
 // single-utterance duration predictor as one persistent kernel (persist.hip.h): 1 = when eligible (default), 0 = launch path
-static int g_persist = getenv("VITS_NO_PERSIST") ? 0 : 1;  // (environment switch: A/B runs of bench.py and tools/)
+static int g_persist = getenv("VITS_NO_PERSIST") ? 0 : (getenv("VITS_PERSIST") ? atoi(getenv("VITS_PERSIST")) : 7);  // mask: 1 duration predictor, 2 text encoder, 4 flow (environment switches: A/B runs of bench.py and tools/)
 
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
@@ -85,6 +85,7 @@ struct EncoderW {
 };
 struct DDSW {
   std::vector<float*> sw, sb, g1, b1, g2, b2;
+  std::vector<float*> swk[3];  // the depthwise taps as three per-channel vectors (persistent column steps: thread = channel)
   std::vector<float*> wt;  // 1x1 weights transposed [ci][co] for the fused layer kernel
   std::vector<ConvW> pw;
 };
@@ -322,6 +323,14 @@ static void load_dds(vits_model* m, DDSW& D, const char* pfx, int C, int K, int 
   char nm[200];
   for (int i = 0; i < n && !m->missing; ++i) {
     D.sw.push_back(upload(m, tget(m, 3, C, 1, K, "%s.convs_sep.%d.weight", pfx, i), (size_t)C * K));
+    if (K == 3 && !m->missing) {
+      const float* w = tget(m, 3, C, 1, K, "%s.convs_sep.%d.weight", pfx, i);
+      for (int k = 0; k < 3; ++k) {
+        std::vector<float> t(C);
+        for (int c = 0; c < C; ++c) t[c] = w[(size_t)c * 3 + k];
+        D.swk[k].push_back(upload(m, t.data(), t.size()));
+      }
+    }
     D.sb.push_back(upload(m, tget(m, 1, C, -1, -1, "%s.convs_sep.%d.bias", pfx, i), C));
     snprintf(nm, sizeof nm, "%s.convs_1x1.%d", pfx, i);
     D.pw.push_back(conv_from(m, nm, C, C, 1, true));
@@ -669,15 +678,19 @@ struct vits_session {
   float *dq1 = nullptr, *dq2 = nullptr;  // second x / y pair of the per-layer DDSConv launches (ping-pong with dy / dy2)
   float *zA = nullptr, *zB = nullptr, *fh = nullptr, *fx = nullptr, *facts = nullptr, *fskip = nullptr;
   std::vector<float*> dec_bufs;
-  // persistent duration-predictor kernel (persist.hip.h): LL-cell exchange buffers (inside the arena, zeroed at every re-plan),
-  // the step program (host copy + device copy, rebuilt at every re-plan) and the epoch / completion block (never re-planned)
-  ll_t* ps_ll = nullptr;
-  size_t ps_ll_cells = 0;
-  SdpProgram ps_prog_h;
-  SdpProgram* ps_prog_d = nullptr;
+  // persistent step programs of a single utterance (persist.hip.h / persist_plan.hip.h): text encoder and duration predictor
+  // (laid out for T_x) and flow (T_y).  LL-cell exchange buffers live inside the arena and are zeroed at every re-plan; the
+  // programs are rebuilt at every re-plan; the epoch / completion block survives re-plans (epochs only ever grow).
+  struct PersistProg {
+    PProgram h;            // host copy
+    PProgram* d = nullptr; // device copy
+    ll_t* ll = nullptr;    // exchange cells
+    size_t cells = 0;
+    bool ok = false;
+    double flops = 0;
+  };
+  PersistProg ps_enc, ps_sdp, ps_flow;
   PersistCtl* ps_ctl = nullptr;
-  bool ps_ok = false;
-  double ps_flops = 0;
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
   // session, so a steady stream of vits_synthesize calls does no hipMalloc / hipFree (both synchronise the device)
   char* stage = nullptr;
@@ -714,31 +727,7 @@ static T* bump(vits_session* s, size_t n) {
   return s->arena ? reinterpret_cast<T*>(s->arena + off) : nullptr;
 }
 
-// ---- persistent duration predictor (persist.hip.h): eligibility and the size of its exchange buffers
-static bool persist_sdp_eligible(const vits_model* m, int B, int Tx) {
-  const vits_hparams& hp = m->hp;
-  if (!m->acoustic || B != 1 || Tx < 1 || Tx > 128 || m->n_cu < 16) return false;
-  const int D = hp.dp_filter_channels, H = hp.hidden_channels;
-  if (D % 32 || D > PS_MAXC || H % 16 || H > PS_MAXC || hp.dp_kernel_size != 3) return false;
-  const int nl = (int)m->dp_dds.pw.size();
-  if (nl < 1 || nl > 3 || hp.dp_n_flows < 2 || hp.dp_num_bins > 16 || 3 * hp.dp_num_bins - 1 > 32) return false;
-  if (1 + 2 * (nl + 1) * hp.dp_n_flows > PS_MAX_STEPS) return false;
-  if (!m->dp_pre.w16 || !m->dp_proj.w16) return false;
-  for (const ConvW& c : m->dp_dds.pw) if (!c.w16) return false;
-  for (int k = 1; k < hp.dp_n_flows; ++k) {
-    if ((int)m->cf[k].dds.pw.size() != nl || !m->cf[k].proj.w16) return false;
-    for (const ConvW& c : m->cf[k].dds.pw) if (!c.w16) return false;
-  }
-  return true;
-}
-static size_t persist_sdp_cells(const vits_model* m, int B, int Tx) {
-  if (!persist_sdp_eligible(m, B, Tx)) return 0;
-  const vits_hparams& hp = m->hp;
-  const size_t Tp = (size_t)cdiv(Tx, 16) * 16, D = hp.dp_filter_channels, nl = m->dp_dds.pw.size(), nf = hp.dp_n_flows;
-  // x0 (dp.pre); per DDSConv stack: per layer the finished input, the 1x1 operand and the 1x1 output, the last finish, and the
-  // proj output (dc; the ConvFlow projections stay in LDS); z after init and after every flow
-  return Tp * (D * (1 + nf * (3 * nl + 2)) + 2 * (nf + 1));
-}
+#include "persist_plan.hip.h"
 
 // lays out every activation buffer for the given capacity; with arena == nullptr only measures
 static void plan(vits_session* s, int B, int Tx, int Ty) {
@@ -767,8 +756,12 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->dc = bump<float>(s, B * D * Tx); s->dfh = bump<float>(s, B * D * Tx);
   s->dq1 = bump<float>(s, B * D * Tx); s->dq2 = bump<float>(s, B * D * Tx);
   s->dz = bump<float>(s, (size_t)B * 2 * Tx); s->dpr = bump<float>(s, (size_t)B * 32 * Tx); s->logw = bump<float>(s, (size_t)B * Tx);
-  s->ps_ll_cells = persist_sdp_cells(s->m, B, Tx);
-  s->ps_ll = bump<ll_t>(s, s->ps_ll_cells);
+  s->ps_enc.cells = persist_enc_cells(s->m, B, Tx);
+  s->ps_enc.ll = bump<ll_t>(s, s->ps_enc.cells);
+  s->ps_sdp.cells = persist_sdp_cells(s->m, B, Tx);
+  s->ps_sdp.ll = bump<ll_t>(s, s->ps_sdp.cells);
+  s->ps_flow.cells = persist_flow_cells(s->m, B, Ty);
+  s->ps_flow.ll = bump<ll_t>(s, s->ps_flow.cells);
   s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
   s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
   s->facts = bump<float>(s, B * H * Ty * (size_t)(hp.flow_wn_layers > 0 ? hp.flow_wn_layers : 1));  // gate outputs of all WN layers, stacked
@@ -799,100 +792,6 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
 static void drop_graphs(vits_session* s) {
   for (auto& kv : s->graphs) hipGraphExecDestroy(kv.second);
   s->graphs.clear();
-}
-
-// Builds the step program of the persistent duration predictor for the session's current layout (persist.hip.h): called at every
-// re-plan, outside any capture.  The exchange cells are zeroed (epoch 0 = "never written": whatever the arena held before must not
-// look like a cell of a later forward); the epoch block survives re-plans, so epochs only ever grow.
-static int persist_plan(vits_session* s) {
-  s->ps_ok = false;
-  vits_model* m = s->m;
-  if (!s->ps_ll_cells || !s->ps_ll) return VITS_OK;
-  const vits_hparams& hp = m->hp;
-  if (!s->ps_ctl) {
-    HIP_TRY(hipMalloc((void**)&s->ps_ctl, sizeof(PersistCtl)));
-    HIP_TRY(hipMemsetAsync(s->ps_ctl, 0, sizeof(PersistCtl), s->stream));
-    HIP_TRY(hipMalloc((void**)&s->ps_prog_d, sizeof(SdpProgram)));
-  }
-  HIP_TRY(hipMemsetAsync(s->ps_ll, 0, s->ps_ll_cells * sizeof(ll_t), s->stream));
-  const int Tx = s->Tx, Tp = cdiv(Tx, 16) * 16, ntn = Tp / 16, D = hp.dp_filter_channels;
-  const int nl = (int)m->dp_dds.pw.size(), K = hp.dp_kernel_size;
-  SdpProgram& P = s->ps_prog_h;
-  memset(&P, 0, sizeof P);
-  P.T = Tx; P.Tp = Tp; P.ntn = ntn;
-  P.nb = hp.dp_num_bins; P.bound = hp.dp_tail_bound; P.inv_sqrt_d = 1.0f / sqrtf((float)D);
-  P.len = s->len_x; P.ea_m = m->ea_m; P.ea_logs = m->ea_logs; P.logw = s->logw; P.err = s->d_err;
-  ll_t* cur = s->ps_ll;
-  auto take = [&](int rows) { ll_t* p = cur; cur += (size_t)rows * Tp; return p; };
-  double flops = 0;
-  SdpStep st;
-  auto blank = [&](int kind) {  // every parameter pointer valid (zeros when unused): the kernel prefetches them unconditionally
-    memset(&st, 0, sizeof st);
-    st.kind = kind;
-    st.Cin = 16; st.Cout = 16; st.n_mb = 1; st.G = 1; st.mbg = 1; st.D = PS_MAXC;
-    st.w16 = st.bias = st.cond = st.g2 = st.b2 = st.sw = st.sb = st.g1 = st.b1 = st.pw = st.pb = m->zeros;
-  };
-  auto add_mm = [&](const ConvW& W) -> SdpStep& {  // st carries kind / epi / operands
-    st.Cin = W.Cin; st.Cout = W.M; st.n_mb = cdiv(W.M, 16); st.w16 = W.w16; st.bias = W.bias; st.ypitch = cdiv(W.M, 16) * 16;
-    if (st.epi == PS_EPI_SPLINE) { st.mbg = st.n_mb; st.G = 1; }
-    else { st.mbg = cdiv(st.n_mb * ntn, m->n_cu); st.G = cdiv(st.n_mb, st.mbg); }
-    flops += 2.0 * Tx * (double)W.M * W.Cin;
-    P.steps[P.n_steps] = st;
-    return P.steps[P.n_steps++];
-  };
-  // dp.pre (+ cond(g)) -> x0 ; z = noise * noise_scale_w          (models.py:58-60,96)
-  blank(PS_PRE);
-  if (m->use_g) st.cond = s->condv + m->cond_dp_off;
-  st.yout = take(D); st.zout = take(2);
-  const ll_t* x = add_mm(m->dp_pre).yout;
-  const ll_t* z = P.steps[0].zout;
-  // one DDSConv stack + the 1x1 conv that consumes it (modules.py:96-108): per layer a column step (finish the previous layer,
-  // depthwise conv, LN1, GELU) and a matrix step (the layer's 1x1 conv); then the last finish and the projection
-  auto stack = [&](const DDSW& W, const ConvW& proj, int proj_epi, const ll_t* xin, const ll_t* zc, int z_row, const float* pw, const float* pb) -> SdpStep& {
-    const ll_t* y2 = nullptr;
-    int dil = 1;
-    for (int i = 0; i <= nl; ++i) {
-      const bool fin = i == nl;
-      blank(PS_COL);
-      st.D = D; st.dw = fin ? 0 : 1; st.dil = fin ? 0 : dil;
-      st.xin = xin; st.y2 = y2;
-      if (i > 0) { st.fin = 1; st.g2 = W.g2[i - 1]; st.b2 = W.b2[i - 1]; }
-      else if (zc) { st.fin = 2; st.z = zc; st.z_row = z_row; st.g2 = pw; st.b2 = pb; }  // (pw / pb ride in the g2 / b2 slots)
-      if (!fin) { st.sw = W.sw[i]; st.sb = W.sb[i]; st.g1 = W.g1[i]; st.b1 = W.b1[i]; st.bout = take(D); }
-      st.xout = take(D);
-      flops += 2.0 * Tx * (double)D * (fin ? 0 : K);
-      P.steps[P.n_steps] = st;
-      const SdpStep& col = P.steps[P.n_steps++];
-      xin = col.xout;
-      blank(PS_MM);
-      st.bin = fin ? col.xout : col.bout;
-      if (fin) { st.epi = proj_epi; return add_mm(proj); }
-      st.epi = PS_EPI_RAW; st.yout = take(D);
-      y2 = add_mm(W.pw[i]).yout;
-      dil *= K;
-    }
-    return P.steps[P.n_steps - 1];  // not reached
-  };
-  {
-    SdpStep& pj = stack(m->dp_dds, m->dp_proj, PS_EPI_MASK, x, nullptr, 0, nullptr, nullptr);
-    pj.yout = take(D);
-  }
-  const ll_t* dc = P.steps[P.n_steps - 1].yout;
-  int swap = 0;
-  for (int k = hp.dp_n_flows - 1; k >= 1; --k) {
-    swap ^= 1;  // Flip (modules.py:270-277) is a row relabel on the 2-channel z
-    const ConvFlowW& c = m->cf[k];
-    SdpStep& pj = stack(c.dds, c.proj, PS_EPI_SPLINE, dc, z, swap, c.pre_w, c.pre_b);
-    pj.z = z; pj.z_row = swap;
-    if (k > 1) { pj.zout = take(2); z = pj.zout; }
-    else { pj.last = 1; pj.ea_row = swap ^ 1; }
-  }
-  if ((size_t)(cur - s->ps_ll) > s->ps_ll_cells) return fail(VITS_ERR_DEVICE, "persistent duration predictor: exchange buffers overflow the plan");
-  s->ps_flops = flops;
-  HIP_TRY(hipMemcpyAsync(s->ps_prog_d, &P, sizeof P, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));  // P lives in pageable memory of the session: the copy must not outlive this call's view of it
-  s->ps_ok = true;
-  return VITS_OK;
 }
 
 // (re)lays the workspace out for exactly (B,Tx,Ty) so every [B,C,T] tensor is dense; grows the
@@ -970,7 +869,7 @@ static void session_free(vits_session* s) {
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
   if (s->ps_ctl) hipFree(s->ps_ctl);
-  if (s->ps_prog_d) hipFree(s->ps_prog_d);
+  for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow}) if (pp->d) hipFree(pp->d);
   if (s->stage) hipFree(s->stage);
   if (s->d_err) hipFree(s->d_err);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -1010,6 +909,46 @@ struct ProfScope {
   ~ProfScope() { if (on) hipEventRecord(s->prof.back().e1, s->stream); }
 };
 
+
+// ---- one persistent step program (persist.hip.h) as ONE launch of P = #CUs workgroups
+static bool big_lds_needed(std::atomic<unsigned long long>& done);
+static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const char* name, const float* d_noise = nullptr, float nsw = 0.f,
+                           uint64_t seed = 0, const int64_t* d_ids = nullptr) {
+  vits_model* m = s->m;
+  ProfScope ps(s, name, pp.flops, "persist_kernel");
+  PCall c;
+  c.ctl = s->ps_ctl; c.ids = reinterpret_cast<const long long*>(d_ids); c.noise = d_noise; c.nsw = nsw; c.seed = seed;
+  c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds; c.trace = nullptr;
+  static const char* trace_path = getenv("VITS_PS_TRACE");  // tools/ps_trace.py: per-worker, per-step cycle stamps of an EAGER forward
+  static const char* trace_name = getenv("VITS_PS_TRACE_PROG");  // which program ("dp.persist" by default)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool want_trace = trace_path && !strcmp(name, trace_name ? trace_name : "dp.persist");
+  if (want_trace) hipStreamIsCapturing(s->stream, &cap);
+  const size_t trace_n = (size_t)m->n_cu * PS_MAX_STEPS * 4;
+  if (want_trace && cap == hipStreamCaptureStatusNone) {
+    hipMalloc((void**)&c.trace, trace_n * sizeof(long long));
+    hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), s->stream);
+  }
+  const size_t lds = ps_lds_bytes(pp.h.n_steps);
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> done{0};
+    if (big_lds_needed(done)) hipFuncSetAttribute((const void*)persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps_lds_bytes(PS_MAX_STEPS));
+  }
+  hipLaunchKernelGGL(persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), lds, s->stream, pp.d, c);
+  if (c.trace) {
+    std::vector<long long> h(trace_n);
+    hipMemcpyAsync(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost, s->stream);
+    hipStreamSynchronize(s->stream);
+    hipFree(c.trace);
+    if (FILE* f = fopen(trace_path, "wb")) {
+      const int hdr[4] = {m->n_cu, PS_MAX_STEPS, pp.h.n_steps, pp.h.T};
+      fwrite(hdr, sizeof hdr, 1, f);
+      for (int i = 0; i < pp.h.n_steps; ++i) fwrite(&pp.h.steps[i].kind, sizeof(int), 1, f);
+      fwrite(h.data(), sizeof(long long), trace_n, f);
+      fclose(f);
+    }
+  }
+}
 
 // compact tile map for a ragged launch (see conv_decode_block); nullptr when no table slot is left
 static const int* tile_table(vits_session* s, const int* len, int mul, int add, int cap, int tile) {
@@ -1563,7 +1502,7 @@ static int check_err(vits_session* s) {
     if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
     if (e & PS_ERR_TIMEOUT) {
       g_persist = 0;  // the launch path stays available: do not try again in this process
-      return fail(VITS_ERR_DEVICE, "persistent duration-predictor kernel: exchange timed out (workgroups not co-resident?); disabled for this process");
+      return fail(VITS_ERR_DEVICE, "persistent kernel: exchange timed out (workgroups not co-resident?); disabled for this process");
     }
   }
   return VITS_OK;
@@ -1587,6 +1526,10 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels;
+  if ((g_persist & PERSIST_ENC) && s->ps_enc.ok && B == 1 && Tx == s->Tx && !d_bert) {  // one persistent kernel instead of ~35 launches
+    persist_launch(s, s->ps_enc, "enc.persist", nullptr, 0.f, 0, d_ids);
+    return;
+  }
   hipLaunchKernelGGL(embed_kernel, dim3(cdiv(Tx, 64), 8, B), dim3(64), 0, s->stream, d_ids, s->len_x, m->emb, s->x, H, Tx,
                      hp.n_vocab, sqrtf((float)H), s->d_err);
   if (d_bert && m->bert_proj.w) {  // x = (emb * sqrt(H) + bert_proj(bert)) * mask   (BERT-conditioned flavour, synth.py:88-99)
@@ -1716,34 +1659,11 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int D = hp.dp_filter_channels;
-  if (g_persist && s->ps_ok && B == 1 && Tx == s->Tx) {  // one persistent kernel instead of ~21 launches (persist.hip.h)
-    ProfScope ps(s, "dp.persist", s->ps_flops, "sdp_persist_kernel");
-    SdpCall c;
-    c.ctl = s->ps_ctl; c.x = x; c.noise = d_noise; c.nsw = nsw; c.seed = seed; c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds;
-    c.trace = nullptr;
-    static const char* trace_path = getenv("VITS_PS_TRACE");  // tools/ps_trace.py: per-worker, per-step cycle stamps of an EAGER forward
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (trace_path) hipStreamIsCapturing(s->stream, &cap);
-    const size_t trace_n = (size_t)m->n_cu * PS_MAX_STEPS * 4;
-    if (trace_path && cap == hipStreamCaptureStatusNone) {
-      hipMalloc((void**)&c.trace, trace_n * sizeof(long long));
-      hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), s->stream);
-    }
-    hipLaunchKernelGGL(sdp_persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), 0, s->stream, s->ps_prog_d, c);
+  if ((g_persist & PERSIST_SDP) && s->ps_sdp.ok && B == 1 && Tx == s->Tx) {  // one persistent kernel instead of ~21 launches (persist.hip.h)
+    // the program reads the text-encoder output from the session's own buffer (stage-level callers bring theirs)
+    if (x != s->x) hipMemcpyAsync(s->x, x, sizeof(float) * (size_t)hp.hidden_channels * Tx, hipMemcpyDeviceToDevice, s->stream);
+    persist_launch(s, s->ps_sdp, "dp.persist", d_noise, nsw, seed);
     s->ea_pending = false;
-    if (c.trace) {
-      std::vector<long long> h(trace_n);
-      hipMemcpyAsync(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost, s->stream);
-      hipStreamSynchronize(s->stream);
-      hipFree(c.trace);
-      if (FILE* f = fopen(trace_path, "wb")) {
-        const int hdr[4] = {m->n_cu, PS_MAX_STEPS, s->ps_prog_h.n_steps, Tx};
-        fwrite(hdr, sizeof hdr, 1, f);
-        for (int i = 0; i < s->ps_prog_h.n_steps; ++i) fwrite(&s->ps_prog_h.steps[i].kind, sizeof(int), 1, f);
-        fwrite(h.data(), sizeof(long long), trace_n, f);
-        fclose(f);
-      }
-    }
     return;
   }
   ConvParams P = conv_params(m->dp_pre, x, s->dh, B, Tx, 1, 0);
@@ -1793,6 +1713,10 @@ static float* run_flow(vits_session* s, int B, int Ty) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels, I = hp.inter_channels, half = I / 2, L = hp.flow_wn_layers, K5 = hp.flow_kernel_size;
+  if ((g_persist & PERSIST_FLOW) && s->ps_flow.ok && B == 1 && Ty == s->Ty) {  // one persistent kernel instead of ~75 launches
+    persist_launch(s, s->ps_flow, "flow.persist");
+    return s->zB;
+  }
   float* u = s->zA;
   float* v = s->zB;
   for (int f = hp.flow_n_flows - 1; f >= 0; --f) {

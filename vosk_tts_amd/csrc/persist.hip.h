@@ -1,33 +1,38 @@
-// persist.hip.h — the single-utterance stochastic duration predictor as ONE persistent kernel (round 3).
+// persist.hip.h — the latency-bound three quarters of a single utterance as PERSISTENT step programs (round 3).
 //
-// What it replaces: StochasticDurationPredictor.forward(reverse=True) (training/vits2/models.py:56-63,93-101; DDSConv
-// modules.py:96-108, ConvFlow modules.py:363-390, spline transforms.py:55-177) at B = 1 is a chain of ~21 dependent launches on a
-// [256 x T_x] tensor (16 x 11.96 us DDSConv layers + pre + init + 3 splines = 0.27 ms of the 1.33 ms forward for 0.4 % of its FLOPs).
-// Every launch pays the dispatch, a cold L2 and its own chain of dependent cold misses.
+// What it replaces: at B = 1 the text encoder, the stochastic duration predictor and the flow are ~120 dependent launches on
+// [192..768 x 50..160] tensors that carry 21 % of the forward's FLOPs and take 0.9 of its 1.33 ms: every launch pays the dispatch, a
+// cold L2 and its own chain of dependent cold misses, 5.5-13 us each.
 //
-// How: the whole predictor is a step program run by ONE kernel of P workgroups (one per CU) that never leave the machine.  Between
-// steps there is NO barrier and NO flag: every exchanged tensor is an array of 8-byte "LL cells" {float value, u32 epoch}
-// written with one agent-scope 8-byte store and polled by the consumers with agent-scope (L1-bypassing, sc1) 8-byte loads until the
-// epoch matches this forward -- the data is its own arrival signal (tools/llprobe.hip: 0.32 us one-way inside an XCD, 0.73 us across
-// XCDs, coherent chip-wide with sc1 stores).  A worker that is idle in a step simply moves on; a consumer waits only for the cells
-// it reads.  Epochs make stale data harmless: every forward uses epoch = (last completed forward) + 1, cells are never reset, every
-// step of a forward writes its OWN buffers (no reuse inside a forward, so there is no write-after-read hazard either), and a cell
-// whose epoch does not match is simply not there yet.  Every poll loop is bounded (PS_SPIN_LIMIT): a lost worker turns into an
-// error word, never into a hung GPU.
+// How: a stage is a STEP PROGRAM run by ONE kernel of P workgroups (one per CU) that never leave the machine.  Between steps there
+// is NO barrier and NO flag: every exchanged tensor is an array of 8-byte "LL cells" {float value, u32 epoch} written with one
+// agent-scope 8-byte store and polled by the consumers with agent-scope (L1-bypassing, sc1) 8-byte loads until the epoch matches
+// this forward -- the data is its own arrival signal (tools/llprobe.hip: 0.32 us one-way inside an XCD, 0.73 us across XCDs,
+// coherent chip-wide with sc1 stores).  A worker that is idle in a step simply moves on; a consumer waits only for the cells it
+// reads.  Epochs make stale data harmless: every forward uses epoch = (last completed forward) + 1, cells are never reset, every step
+// of a forward writes its OWN buffers (no reuse inside a forward, so there is no write-after-read hazard either), and a cell whose
+// epoch does not match is simply not there yet.  Every poll loop is bounded (PS_SPIN_LIMIT): a lost worker turns into an error
+// word, never into a hung GPU.
 //
-// Decomposition (v2; v1 ran a whole DDSConv layer per step like conv16_kernel's PRO == 1 and was bound by what that costs per
-// workgroup: every one of the 16 workgroups of a column tile pulled the full 256-channel x 34-column window of two tensors through
-// L1-bypassing loads -- 131-262 KB per step at the ~30 GB/s one CU sustains on such loads -- and redid its LayerNorms and 8 k erf
-// evaluations: 12 us per step, measured 208 us for the predictor).  A layer is now TWO kinds of steps over column-major cells
-// [T][C] (a column's channels are contiguous: 2 KB):
-//   * column step (PS_COL), one worker per COLUMN t: finish the previous layer for the three columns the depthwise taps touch
-//     (x + gelu(LN2(y2)) at t - d, t, t + d: 6 column vectors = 12 KB gathered), depthwise conv, LN1, GELU -> the layer's 1x1
-//     input column and the finished residual column.  Thread = channel; a LayerNorm is a DPP wave reduction + one LDS exchange.
-//     Every element of the layer is computed once on the chip (3x for the finish), not once per row block.
-//   * matrix step (PS_MM), one worker per (16-column tile, 16-row block): gather the [C_in x 16] operand (32 KB, 4 KB per wave
-//     load instruction batch), 16x16x4 fp32 MFMAs with the 8 waves splitting the contraction, weights prefetched into registers
-//     during the PREVIOUS step, bias / mask epilogue, cells out.  ConvFlow.proj workers own all 29 rows of their columns and run
-//     the spline inverse in their epilogue; the last one folds the final ElementwiseAffine and writes logw.
+// What bounds a step is how many bytes ONE workgroup must pull through L1-bypassing loads (~30 GB/s per CU) and how often an
+// element is recomputed, so the programs are built from two kinds of steps over COLUMN-MAJOR cells [T][C] (a column's channels are
+// contiguous):
+//   * column steps, one worker per COLUMN t, thread = channel: LayerNorm (+ K-slice partial sums, bias, residual, speaker vector),
+//     the DDSConv elementwise chain (finish the previous layer at t - d, t, t + d, depthwise conv, LN, GELU), embedding lookup,
+//     attention merge, coupling tail.  A LayerNorm is a DPP wave reduction + one LDS exchange; every element is computed once.
+//   * matrix steps, one worker per (16-column tile, group of 16-row blocks, K-slice): gather the [C_in x (16 + taps - 1)] operand
+//     window (<= 40 KB), 16x16x4 fp32 MFMAs with the 8 waves splitting the contraction at tap-unit granularity, weights prefetched
+//     into registers during the PREVIOUS step, epilogue (bias / per-item bias / ReLU / mask / residual, WaveNet gate, spline
+//     inverse), cells out.  Contractions over 768 channels are split into 4 K-slices whose partial sums the consuming LayerNorm /
+//     coupling column step adds up -- no worker ever gathers more than 192 x 20 cells.
+//   * attention = 16 x 16 (query tile, key tile) block steps (each gathers three 16 x d_k tiles, partial softmax with the banded
+//     relative-position terms of attentions.py:165-260) + a merge column step -- instead of one worker per query tile pulling all
+//     keys and values (245 KB at T = 160).
+// (v1 of the duration predictor ran a whole DDSConv layer per step like conv16_kernel's PRO == 1: every one of the 16 workgroups of
+// a column tile pulled the full 256-channel x 34-column window of two tensors and redid its LayerNorms and 8 k erf evaluations:
+// 12 us per step, 208 us for the predictor; the column / matrix split brought it to 109 us against 265 us of launches.)
+// Reference ops: attentions.py:48-65,133-260,292-317 (Encoder / MultiHeadAttention / FFN), models.py:56-63,93-101 (duration
+// predictor), modules.py:96-108,148-176,363-390 (DDSConv, WN, ConvFlow), models.py:374-393 (coupling layer).
 #pragma once
 #include "conv_small.hip.h"
 #include "kernels_misc.hip.h"
@@ -36,10 +41,12 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 
 #define PS_THREADS 512
 #define PS_WAVES 8
-#define PS_MAX_STEPS 40
-#define PS_MAXC 256      // channels of an exchanged tensor / contraction length
-#define PS_MAXU 2        // tap units (16 channels) per wave: PS_MAXC / 16 / PS_WAVES
-#define PS_TP 17         // LDS pitch of the MFMA operand tile [C_in][16] (odd: the transposing writes are conflict-free)
+#define PS_MAX_STEPS 96
+#define PS_MAXC 256      // channels of a column step / contraction channels of one K-slice
+#define PS_MAXU 8        // tap units (16 channels x 1 tap) per wave
+#define PS_TP 21         // LDS pitch of the MFMA operand window [C_in][16 + taps - 1] (odd: the transposing writes are conflict-free)
+#define PS_MAXROW 20     // 16 + taps - 1, taps <= 5
+#define PS_DKP 128       // attention: head-dimension slots per row of threads (d_k <= 128)
 #define PS_SPIN_LIMIT (1 << 18)
 #define PS_ERR_TIMEOUT 8  // bit in the session error word
 
@@ -50,55 +57,88 @@ struct PersistCtl {
   unsigned timeouts;  // diagnostics
 };
 
-enum { PS_PRE = 0, PS_COL = 1, PS_MM = 2 };
-enum { PS_EPI_RAW = 0, PS_EPI_MASK = 1, PS_EPI_SPLINE = 2 };
+enum { PK_MM = 0, PK_DDS = 1, PK_LN = 2, PK_EMB = 3, PK_ATT = 4, PK_MERGE = 5, PK_COUPLE = 6 };
+enum { PS_EPI_STORE = 0, PS_EPI_SPLINE = 1, PS_EPI_GATE = 2 };
 
-struct SdpStep {
+// One step.  EVERY pointer that the prefetch touches (w16, bias, cond, par[]) is valid in EVERY step -- unused ones point at a block
+// of zeros -- so that the one-step-ahead prefetch is straight-line code: a load behind a branch makes hipcc wait for it at the join,
+// i.e. puts a cold round trip in the middle of a step (measured 4-5 k cycles per matrix step).
+struct PStep {
   int kind;
-  // ---- PS_PRE / PS_MM: y[Cout x 16-column tile] = W[Cout x Cin] * B + bias
-  int Cin, Cout, n_mb;     // contraction channels, rows stored, 16-row blocks of the packed matrix
-  int G, mbg;              // workers per column tile, 16-row blocks per worker
-  int epi;                 // PS_EPI_*
-  int ypitch;              // channel pitch of yout
-  const float* w16;        // [n_mb][Cin/16][64][4] 16x16x4 A-fragment order (pack_conv_weights16)
-  const float* bias;
-  const float* cond;       // PS_PRE: per-item bias rows (cond(g), models.py:60) or null
-  const ll_t* bin;         // PS_MM: operand cells [Tp][Cin]
-  ll_t* yout;              // [Tp][ypitch]
-  // PS_EPI_SPLINE (ConvFlow.proj + spline inverse) and flow layer 0 of PS_COL
+  // ---- PK_MM: y[Cout x 16-column tile] (+)= W[Cout x ks*Cin*K] * window(B)
+  int Cin;                 // contraction channels of ONE K-slice (multiple of 16, <= PS_MAXC)
+  int cin_pitch;           // channel pitch of the operand cells
+  int c_off, c_sign;       // operand channel of slice-local channel c: c_off + c_sign * (slice * Cin + c)   (Flip folded into the read)
+  int Cout, n_mb;          // rows stored, 16-row blocks of the packed matrix
+  int G, mbg, ks;          // row-block groups per column tile, 16-row blocks per worker, K-slices
+  int K, pad;              // taps, left padding: operand column of (output t, tap kk) = t + kk - pad
+  int epi, relu;           // PS_EPI_*; 1 = ReLU on acc + bias
+  int in_mask, out_mask;   // operand columns >= len read as 0 ; output columns >= len written as 0
+  int ypitch, y_off;       // output channel pitch, first output channel
+  int gate_H;              // PS_EPI_GATE: hidden channels (packed rows = [8 tanh | 8 sigmoid] per 16-row block)
+  int plain_T;             // row length of bin_plain / yplain / oplain / u_plain
+  int zinit;               // also draw z = noise * noise_scale_w into zout (duration predictor, first step)
+  int blen;                // valid entries of bias / cond
+  const float* w16;        // [n_mb][ks][Cin/16*K][64][4] 16x16x4 A-fragment order (pack_conv_weights16: slices are consecutive units)
+  const float* bias;       // [Cout] (zeros for K-sliced steps: the consumer adds it once)
+  const float* cond;       // per-item bias rows (cond(g)) or zeros
+  const ll_t* bin;         // operand cells [Tp][cin_pitch] ...
+  const float* bin_plain;  // ... or plain floats [channels][plain_T] written by an earlier kernel (null: cells)
+  const ll_t* res;         // residual cells [Tp][rpitch] added after the mask (null: none)
+  int rpitch;
+  ll_t* yout;              // cells [ks][Tp][ypitch] (null: no cell output)
+  float* yplain;           // plain floats [Cout][plain_T] for later kernels (null: none)
+  // PS_EPI_SPLINE (ConvFlow.proj + spline inverse) and flow layer 0 of PK_DDS
   const ll_t* z;           // z cells [2][Tp]
-  ll_t* zout;              // PS_PRE: z = noise * noise_scale_w; PS_EPI_SPLINE: transformed z (null for the last flow)
+  ll_t* zout;              // zinit / PS_EPI_SPLINE: z cells out (null for the last flow)
   int z_row;               // row of z that conditions (x0); the spline acts on 1 - z_row
   int last, ea_row;        // last flow: write logw = ElementwiseAffine^-1(z[ea_row]) (modules.py:293-295)
-  // ---- PS_COL: column t of   x_in = (xin + gelu(LN(y2; g2, b2))) * mask      [y2 == null: xin * mask; pw != null: pw * z + pb + xin]
-  //                            b    = gelu(LN(depthwise3(x_in; sw, sb, dil); g1, b1))          (dw != 0)
-  // (every parameter pointer of EVERY step is valid -- unused ones point at a block of zeros -- so that the one-step-ahead
-  //  prefetch is straight-line code: a load behind a branch makes hipcc wait for it at the join, i.e. puts a cold round trip
-  //  in the middle of a step; measured 4-5 k cycles per matrix step)
-  int D, dil, dw;
-  int fin;                 // 0: x_in = xin; 1: xin + gelu(LN(y2)); 2: pw * z + pb + xin
-  const ll_t* xin; const ll_t* y2;   // [Tp][D]
-  const float* g2; const float* b2;
-  const float* sw; const float* sb; const float* g1; const float* b1;
-  const float* pw; const float* pb;  // flow layer 0: ConvFlow.pre (Conv1d(1, D, 1)), modules.py:365
-  ll_t* xout;              // x_in column [Tp][D] (next layer's residual stream; the proj layers' MFMA operand)
-  ll_t* bout;              // b column [Tp][D] (dw != 0)
+  // ---- column steps: C channels (threads), per-channel parameter vectors par[k] (prefetched: value k of thread tid is
+  //      par[k][min((tid & pmask) + padd[k], plen - 1)])
+  int C, pmask, plen;
+  int padd[8];
+  const float* par[8];
+  // PK_DDS: x_in = (xin + gelu(LN(y2; par0, par1))) * mask   [fin 0: xin * mask; fin 2: par0 * z + par1 + xin]
+  //         b    = gelu(LN(depthwise3(x_in; par3..5, par2, dil); par6, par7))          (dw != 0)
+  int dil, dw, fin;
+  const ll_t* xin; const ll_t* y2;   // [Tp][C]
+  ll_t* xout;              // x_in column
+  ll_t* bout;              // b column (dw != 0)
+  // PK_LN: v = par2 (bias) + sum_{k < np} part[k][t][c] + res[t][c] ; out = (LN(v; par0, par1) + par3 (per-item vector) + base[t][c]) * mask
+  //        (ln == 0: out = (v + base) * mask: the plain sum of K-slices)
+  int np, ln;
+  const ll_t* part; long long part_stride;   // cells [np][Tp][C]
+  const ll_t* base;        // residual base added AFTER the norm (flow: h + pre_transformer(h)) or null
+  // PK_EMB: out = emb[ids[t]][c] * scale * mask (+ par3)        (models.py:318-322)
+  const float* emb; float scale; int n_vocab;   // (the ids come with the call: PCall::ids)
+  // PK_ATT: block (head, query tile, key tile) of softmax(q k^T / sqrt(dk) + rel_k) (v + rel_v): partial (O, m, l) cells
+  //         (par0/1 = E_k[tid], E_k[tid + 512]; par2/3 = E_v likewise)
+  // PK_MERGE: column t: out[h*dk + d] = sum_b e^(m_b - M) O_b / sum_b e^(m_b - M) l_b
+  int nh, dk, W;           // heads, head dimension, relative-position window (0: no relative terms)
+  const ll_t* qkv;         // cells [Tp][3*nh*dk]: q | k | v
+  ll_t* ap;                // partial cells [key tile][Tp][nh][dk + 2]
+  // PK_COUPLE: new z (Flip folded): out[r] = u[2H-1-r] (r < H) ; out[H + r] = (u[H-1-r] - (par2[r] + sum_k part[k][t][r])) * mask
+  const ll_t* u; const float* u_plain;  // previous z: cells [Tp][2H] or plain floats [2H][plain_T]
+  int H;
+  // common outputs of column steps
+  ll_t* out;               // cells [Tp][C] (null: none)
+  float* oplain;           // plain floats [C][plain_T] (null: none)
 };
 
-struct SdpProgram {
+struct PProgram {
   int n_steps, T, Tp, ntn;
   int nb; float bound, inv_sqrt_d;      // spline
   const int* len;
   const float* ea_m; const float* ea_logs;
-  float* logw;                          // [T] plain floats (the kernel's result)
+  float* logw;                          // duration predictor result [T] (plain floats)
   int* err;
-  SdpStep steps[PS_MAX_STEPS];
+  PStep steps[PS_MAX_STEPS];
 };
 
-struct SdpCall {                        // per-call values (by value: a captured graph re-reads `dv`, not these, when dv != null)
+struct PCall {                          // per-call values (by value: a captured graph re-reads `dv`, not these, when dv != null)
   PersistCtl* ctl;
-  const float* x;                       // text-encoder output [H][T], plain floats
-  const float* noise;                   // [2][T] injected noise or null (Philox)
+  const long long* ids;                 // text encoder: token ids [T] (the feed's int64 tensor)
+  const float* noise;                   // duration predictor: [2][T] injected noise or null (Philox)
   float nsw;
   unsigned long long seed;
   int solo;
@@ -117,7 +157,11 @@ __device__ __forceinline__ void ll_store(PS_G ll_t* p, float v, unsigned e) {
 __device__ __forceinline__ ll_t ll_load(const PS_G ll_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_dwordx2 ... sc1
 }
+__device__ __forceinline__ ll_t ll_load_off(const PS_G ll_t* base, unsigned byte_off) {
+  return ll_load((const PS_G ll_t*)((const PS_G char*)base + byte_off));
+}
 __device__ __forceinline__ float ll_val(ll_t q) { return __uint_as_float((unsigned)q); }
+__device__ __forceinline__ unsigned ll_bad(ll_t q, unsigned epoch) { return (unsigned)(q >> 32) ^ epoch; }
 __device__ __forceinline__ int ps_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <typename T>
 __device__ __forceinline__ PS_G T* ps_unip(T* p) {
@@ -133,7 +177,6 @@ __device__ __forceinline__ PS_G T* ps_unip(T* p) {
 #define PS_GELU(v) c16_gelu(v)
 #endif
 
-#define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
 struct PsCtx {
   unsigned epoch;
   int aborted;        // this wave gave up (or saw ctl->abort): polls return at once
@@ -158,26 +201,36 @@ __device__ __forceinline__ bool ps_again(PsCtx& cx, bool pending) {
   }
   return true;
 }
+#define PS_PENDING(bad) (__builtin_amdgcn_ballot_w64((bad) != 0) != 0)
 
-// sum over the 64 lanes of a wave, returned in every lane (DPP row operations + two row broadcasts: no LDS, ~10 instructions).
-// Lanes disabled by ROW_MASK contribute old = 0.
+// sum / max over lanes (DPP row operations + two row broadcasts: no LDS, ~10 instructions).  Lanes disabled by ROW_MASK contribute 0.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float ps_dpp_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float ps_wave_sum(float v) {
-#ifdef PS_SHFL_REDUCE
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-#else
+template <int CTRL>
+__device__ __forceinline__ float ps_dpp_max(float v) {  // row-local controls only: every lane has a source
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false)));
+}
+__device__ __forceinline__ float ps_row_sum(float v) {  // sum over each 16-lane row, in every lane of the row
   v = ps_dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v = ps_dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
   v = ps_dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = ps_dpp_add<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+  v = ps_dpp_add<0x140, 0xF>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float ps_row_max(float v) {
+  v = ps_dpp_max<0xB1>(v);
+  v = ps_dpp_max<0x4E>(v);
+  v = ps_dpp_max<0x141>(v);
+  v = ps_dpp_max<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float ps_wave_sum(float v) {  // sum over the 64 lanes, in every lane
+  v = ps_row_sum(v);
   v = ps_dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
   v = ps_dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-#endif
 }
 // sums of two values over the 256 threads of each HALF of the workgroup (waves 0-3 / 4-7): one barrier; `red` is a private
 // 16-float scratch of this call site (no second barrier: the next call site uses another one)
@@ -191,57 +244,94 @@ __device__ __forceinline__ void ps_half_sum2(float& a, float& b, float* red, int
   b = (red[8 + w0] + red[8 + w0 + 1]) + (red[8 + w0 + 2] + red[8 + w0 + 3]);
 }
 
-// this wave's weight fragments of 16-row block mb: tap units u = wave + PS_WAVES * i (K = 1: unit = 16-channel chunk)
-__device__ __forceinline__ void ps_load_weights(const PS_G float* w16, int mb, int n_u, int wave, int lane, f32x4 (&a)[PS_MAXU]) {
-  const PS_G f32x4* wp = (const PS_G f32x4*)w16 + (size_t)mb * n_u * 64 + lane;
+// ---- what a worker requests one step ahead (registers; straight-line, see PStep)
+struct PsPre {
+  f32x4 a[PS_MAXU];   // weight fragments of the first 16-row block: tap units u = wave + PS_WAVES * i
+  float par[8];       // per-channel parameters of a column step / table values of an attention step
+  float eb0, eb1, ec0, ec1;  // epilogue operands of thread tid < 256 (bias, per-item bias; second pair: the sigmoid row of a gate)
+};
+// matrix-step item: item = (slice * G + g) * ntn + j
+struct PsItem { int j, g, slice; };
+__device__ __forceinline__ PsItem ps_item(const PStep& st, int item, int ntn) {
+  const int G = ps_uni(st.G);
+  PsItem it;
+  it.j = item % ntn;
+  const int q = item / ntn;
+  it.g = q % G;
+  it.slice = q / G;
+  return it;
+}
+__device__ __forceinline__ void ps_load_weights(const PStep& st, int mb, int slice, int wave, int lane, f32x4 (&a)[PS_MAXU]) {
+  const int n_u = (ps_uni(st.Cin) >> 4) * ps_uni(st.K), ks = ps_uni(st.ks);
+  const PS_G f32x4* wp = (const PS_G f32x4*)ps_unip(st.w16) + ((size_t)mb * ks + slice) * n_u * 64 + lane;
 #pragma unroll
   for (int i = 0; i < PS_MAXU; ++i) {
     const int u = wave + PS_WAVES * i;
     a[i] = wp[(size_t)(u < n_u ? u : n_u - 1) * 64];
   }
 }
-
-// what a worker requests one step ahead (registers): the per-channel parameters of a column step (thread = channel c = tid & 255),
-// or the weights + epilogue operand of a matrix step
-struct PsPar { float v[8]; };  // g2 | pw, b2 | pb, sb, sw0, sw1, sw2, g1, b1
-__device__ __forceinline__ void ps_load_par(const SdpStep& st, int tid, PsPar& p) {
-  const int D = ps_uni(st.D);
-  int c = tid & 255;
-  c = c < D ? c : D - 1;
-  const PS_G float* sw = ps_unip(st.sw);
-  p.v[0] = ps_unip(st.g2)[c]; p.v[1] = ps_unip(st.b2)[c];
-  p.v[2] = ps_unip(st.sb)[c]; p.v[3] = sw[c * 3]; p.v[4] = sw[c * 3 + 1]; p.v[5] = sw[c * 3 + 2];
-  p.v[6] = ps_unip(st.g1)[c]; p.v[7] = ps_unip(st.b1)[c];
+__device__ __forceinline__ void ps_load_bias(const PStep& st, int mb, int tid, float& eb0, float& eb1, float& ec0, float& ec1) {
+  const int blen = ps_uni(st.blen), gate = ps_uni(st.epi) == PS_EPI_GATE, gH = ps_uni(st.gate_H);
+  int i0 = gate ? mb * 8 + (tid & 7) : mb * 16 + (tid & 15);
+  int i1 = gate ? gH + i0 : i0;
+  i0 = i0 < blen ? i0 : blen - 1;
+  i1 = i1 < blen ? i1 : blen - 1;
+  const PS_G float* b = ps_unip(st.bias);
+  const PS_G float* c = ps_unip(st.cond);
+  eb0 = b[i0]; eb1 = b[i1]; ec0 = c[i0]; ec1 = c[i1];
 }
-// epilogue operands of thread tid < 256 (row tid & 15 of 16-row block mb): bias and the per-item conditioning row (dp.pre; zeros elsewhere)
-__device__ __forceinline__ void ps_load_bias(const SdpStep& st, int mb, int tid, float& eb, float& ec) {
-  const int Cout = ps_uni(st.Cout);
-  const int r = mb * 16 + (tid & 15), rc = r < Cout ? r : Cout - 1;
-  eb = ps_unip(st.bias)[rc];
-  ec = ps_unip(st.cond)[rc];
+__device__ __forceinline__ void ps_prefetch(const PStep& st, int rank, int ntn, int tid, int wave, int lane, PsPre& r) {
+  const int plen = ps_uni(st.plen), pm = ps_uni(st.pmask);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int i = (tid & pm) + ps_uni(st.padd[k]);
+    i = i < 0 ? 0 : (i < plen ? i : plen - 1);
+    r.par[k] = ps_unip(st.par[k])[i];
+  }
+  const PsItem it = ps_item(st, rank, ntn);
+  const int n_mb = ps_uni(st.n_mb), ks = ps_uni(st.ks);
+  int mb0 = it.g * ps_uni(st.mbg);
+  mb0 = mb0 < n_mb ? mb0 : n_mb - 1;
+  const int sl = it.slice < ks ? it.slice : ks - 1;
+  ps_load_bias(st, mb0, tid, r.eb0, r.eb1, r.ec0, r.ec1);
+  ps_load_weights(st, mb0, sl, wave, lane, r.a);
 }
 
-__global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgram* __restrict__ prog, const SdpCall call) {
-  __shared__ SdpProgram sp;
+#define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+
+// LDS of the kernel (floats).  Matrix steps: operand window + partial tiles + spline scratch; attention blocks: Q / K / V tiles and
+// the two relative-position tables alias the operand window, scores / probabilities alias the partial tiles.
+#define PS_LDS_TILE (3 * 16 * (PS_DKP + 1) + 2 * 9 * PS_DKP)   // >= PS_MAXC * PS_TP
+#define PS_LDS_MRED (PS_WAVES * 256)
+#define PS_LDS_FLOATS (PS_LDS_TILE + PS_LDS_MRED + 32 * 16 + 3 * PS_MAXC + 4 * 16)
+static_assert(PS_LDS_TILE >= PS_MAXC * PS_TP, "operand window does not fit");
+
+__global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __restrict__ prog, const PCall call) {
+  extern __shared__ int ps_dyn[];          // the program (up to its last step), then the float buffers
   __shared__ unsigned s_epoch;
-  __shared__ float tile[PS_MAXC * PS_TP];   // MFMA operand [C_in][16] (pitch 17)
-  __shared__ float mred[PS_WAVES * 256];    // partial tiles of the 8 waves
-  __shared__ float hb[32 * 16];             // ConvFlow.proj output of the tile (spline parameters)
-  __shared__ float xs[3 * PS_MAXC];         // column step: x_in at t - d, t, t + d
-  __shared__ float red[4 * 16];             // block reductions (one 16-float scratch per call site)
+  __shared__ int s_nsteps;
   const int tid0 = threadIdx.x;
   const int wave = ps_uni(tid0 >> 6);
   const int rank = blockIdx.x, P = gridDim.x;
-  {
-    const int* src = reinterpret_cast<const int*>(prog);
-    int* dst = reinterpret_cast<int*>(&sp);
-    for (int i = tid0; i < (int)(sizeof(SdpProgram) / 4); i += PS_THREADS) dst[i] = src[i];
-    if (tid0 == 0) {
-      unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      s_epoch = e ? e : 1u;  // 0 marks "never written"
-    }
+  if (tid0 == 0) {
+    s_nsteps = prog->n_steps;
+    unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    s_epoch = e ? e : 1u;  // 0 marks "never written"
   }
   __syncthreads();
+  const int prog_words = (int)((sizeof(PProgram) - (size_t)(PS_MAX_STEPS - s_nsteps) * sizeof(PStep)) / 4);
+  {
+    const int* src = reinterpret_cast<const int*>(prog);
+    for (int i = tid0; i < prog_words; i += PS_THREADS) ps_dyn[i] = src[i];
+  }
+  __syncthreads();
+  const PProgram& sp = *reinterpret_cast<const PProgram*>(ps_dyn);
+  float* fl = reinterpret_cast<float*>(ps_dyn + ((prog_words + 3) & ~3));
+  float* tile = fl;                         // MFMA operand window [C_in][16 + taps - 1] (pitch 21)
+  float* mred = tile + PS_LDS_TILE;         // partial tiles of the 8 waves
+  float* hb = mred + PS_LDS_MRED;           // ConvFlow.proj output of the tile (spline parameters)
+  float* xs = hb + 32 * 16;                 // column steps: x_in at t - d, t, t + d
+  float* red = xs + 3 * PS_MAXC;            // block reductions (one 16-float scratch per call site)
   PsCtx cx;
   cx.epoch = s_epoch; cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl;
   const unsigned epoch = cx.epoch;
@@ -253,24 +343,15 @@ __global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgra
     len_raw = ps_unip(sp.len)[zero];  // vector load (stays off the scalar counter), first used in step 0
   }
   const float ea_m = ps_unip(sp.ea_m)[0], ea_is = expf(-ps_unip(sp.ea_logs)[0]);  // requested now, used by the very last epilogue
-  f32x4 a[PS_MAXU];
-  PsPar pp;
-  float eb = 0.f, ec = 0.f;
+  PsPre pre;
   bool prefetched = false;
-  const int wj = rank % ntn, wg = rank / ntn;  // matrix steps: this worker's column tile and row-block group
 
-  // is this worker busy in step `st`?  column steps: column `rank` (and rank + P, ...); matrix steps: item `rank`
-  auto busy = [&](const SdpStep& st) -> bool {
-    return ps_uni(st.kind) == PS_COL ? rank < Tp : rank < ntn * ps_uni(st.G);
-  };
-  // everything a step needs from read-only memory, requested one step ahead (straight-line: see SdpStep)
-  auto prefetch = [&](const SdpStep& st, int tid, int lane) {
-    ps_load_par(st, tid, pp);
-    const int n_mb = ps_uni(st.n_mb);
-    int mb0 = wg * ps_uni(st.mbg);
-    mb0 = mb0 < n_mb ? mb0 : n_mb - 1;
-    ps_load_bias(st, mb0, tid, eb, ec);
-    ps_load_weights(ps_unip(st.w16), mb0, ps_uni(st.Cin) >> 4, wave, lane, a);
+  // work items of a step: column steps: columns; matrix steps: (column tile, row-block group, K-slice); attention: blocks
+  auto n_items = [&](const PStep& st) -> int {
+    const int kind = ps_uni(st.kind);
+    if (kind == PK_MM) return ntn * ps_uni(st.G) * ps_uni(st.ks);
+    if (kind == PK_ATT) return ps_uni(st.nh) * ntn * ntn;
+    return Tp;
   };
 
   for (int s = 0; s < n_steps; ++s) {
@@ -279,28 +360,31 @@ __global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgra
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const SdpStep& st = sp.steps[s];
+    const PStep& st = sp.steps[s];
+    const PStep& nx = sp.steps[s + 1 < n_steps ? s + 1 : s];
     const int kind = ps_uni(st.kind);
-    if (!busy(st)) { prefetched = false; continue; }  // idle in this step: nothing to wait for
+    const int items = n_items(st);
+    if (rank >= items) { prefetched = false; continue; }  // idle in this step: nothing to wait for
     PS_STAMP(0);
-    if (!prefetched) prefetch(st, tid, lane);
+    if (!prefetched) ps_prefetch(st, rank, ntn, tid, wave, lane, pre);
     prefetched = false;
     __syncthreads();  // the previous step's readers of the LDS buffers are done
     const int L = len_raw < T ? len_raw : T;
 
-    if (kind == PS_COL) {
-      // ================================================================== column step
-      const int D = ps_uni(st.D), dw = ps_uni(st.dw), d = ps_uni(st.dil);
+    if (kind == PK_DDS) {
+      // ================================================================== DDSConv column step
+      const int D = ps_uni(st.C), dw = ps_uni(st.dw), d = ps_uni(st.dil), fin = ps_uni(st.fin);
       const float invD = 1.0f / (float)D;
       const PS_G ll_t* xin = ps_unip(st.xin);
-      const int fin = ps_uni(st.fin);
       const PS_G ll_t* y2 = fin == 1 ? ps_unip(st.y2) : nullptr;
       const PS_G ll_t* zc = fin == 2 ? ps_unip(st.z) + (long long)ps_uni(st.z_row) * Tp : nullptr;
       PS_G ll_t* xout = ps_unip(st.xout);
       PS_G ll_t* bout = ps_unip(st.bout);
-      const PsPar par = pp;  // this step's parameters; pp is re-requested for the next step below
+      float par[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) par[k] = pre.par[k];
       // the next step's operands fly under this step (in-order vmcnt: they are older than every poll of the next step)
-      prefetch(sp.steps[s + 1 < n_steps ? s + 1 : s], tid, lane);
+      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
       prefetched = true;
       const int c = tid & 255, h = tid >> 8;
       const bool cok = c < D;
@@ -325,24 +409,24 @@ __global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgra
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(oz0), "+v"(oz1));  // (addresses stay inside the loop body: no hoisted 64-bit pairs)
             ll_t qx0 = 0, qy0 = 0, qz0 = 0, qx1 = 0, qy1 = 0, qz1 = 0;
             if (n0) {
-              qx0 = ll_load((const PS_G ll_t*)((const PS_G char*)xin + o0));
-              if (y2) qy0 = ll_load((const PS_G ll_t*)((const PS_G char*)y2 + o0));
-              if (zc) qz0 = ll_load((const PS_G ll_t*)((const PS_G char*)zc + oz0));
+              qx0 = ll_load_off(xin, o0);
+              if (y2) qy0 = ll_load_off(y2, o0);
+              if (zc) qz0 = ll_load_off(zc, oz0);
             }
             if (n1) {
-              qx1 = ll_load((const PS_G ll_t*)((const PS_G char*)xin + o1));
-              if (y2) qy1 = ll_load((const PS_G ll_t*)((const PS_G char*)y2 + o1));
-              if (zc) qz1 = ll_load((const PS_G ll_t*)((const PS_G char*)zc + oz1));
+              qx1 = ll_load_off(xin, o1);
+              if (y2) qy1 = ll_load_off(y2, o1);
+              if (zc) qz1 = ll_load_off(zc, oz1);
             }
             unsigned bad = 0;
-            if (n0) bad |= ((unsigned)(qx0 >> 32) ^ epoch) | (y2 ? (unsigned)(qy0 >> 32) ^ epoch : 0u) | (zc ? (unsigned)(qz0 >> 32) ^ epoch : 0u);
-            if (n1) bad |= ((unsigned)(qx1 >> 32) ^ epoch) | (y2 ? (unsigned)(qy1 >> 32) ^ epoch : 0u) | (zc ? (unsigned)(qz1 >> 32) ^ epoch : 0u);
+            if (n0) bad |= ll_bad(qx0, epoch) | (y2 ? ll_bad(qy0, epoch) : 0u) | (zc ? ll_bad(qz0, epoch) : 0u);
+            if (n1) bad |= ll_bad(qx1, epoch) | (y2 ? ll_bad(qy1, epoch) : 0u) | (zc ? ll_bad(qz1, epoch) : 0u);
             x0 = ll_val(qx0); y0 = ll_val(qy0); z0 = ll_val(qz0); x1 = ll_val(qx1); y1 = ll_val(qy1); z1 = ll_val(qz1);
-            pending = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+            pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
         }
         PS_STAMP(1);
-        if (zc) { x0 = par.v[0] * z0 + par.v[1] + x0; x1 = par.v[0] * z1 + par.v[1] + x1; }  // ConvFlow.pre(x0) + g  (modules.py:365-366)
+        if (zc) { x0 = par[0] * z0 + par[1] + x0; x1 = par[0] * z1 + par[1] + x1; }  // ConvFlow.pre(x0) + g  (modules.py:365-366)
         if (y2) {  // x + gelu(LN2(y2)), two-pass statistics like F.layer_norm; both slots of a half in the same reductions
           float m0 = n0 ? y0 : 0.f, m1 = n1 ? y1 : 0.f;
           ps_half_sum2(m0, m1, red, wave, lane);
@@ -350,8 +434,8 @@ __global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgra
           const float e0 = y0 - m0, e1 = y1 - m1;
           float q0 = n0 ? e0 * e0 : 0.f, q1 = n1 ? e1 * e1 : 0.f;
           ps_half_sum2(q0, q1, red + 16, wave, lane);
-          x0 += PS_GELU(e0 * (1.0f / sqrtf(q0 * invD + 1e-5f)) * par.v[0] + par.v[1]);
-          x1 += PS_GELU(e1 * (1.0f / sqrtf(q1 * invD + 1e-5f)) * par.v[0] + par.v[1]);
+          x0 += PS_GELU(e0 * (1.0f / sqrtf(q0 * invD + 1e-5f)) * par[0] + par[1]);
+          x1 += PS_GELU(e1 * (1.0f / sqrtf(q1 * invD + 1e-5f)) * par[0] + par[1]);
         }
         // x = (x + y) * mask: columns outside [0, L) are zero (never polled)
         const float xi0 = (n0 && t0 < L) ? x0 : 0.f, xi1 = n1 ? x1 : 0.f;
@@ -364,225 +448,591 @@ __global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgra
           // depthwise conv (modules.py:100), LN1, GELU: the 256 threads of half 1 (one erf so far; half 0 had two and runs
           // along for the barriers)
           float v = 0.f;
-          if (cok) v = par.v[2] + par.v[3] * xs[c] + par.v[4] * xs[PS_MAXC + c] + par.v[5] * xs[2 * PS_MAXC + c];
+          if (cok) v = par[2] + par[3] * xs[c] + par[4] * xs[PS_MAXC + c] + par[5] * xs[2 * PS_MAXC + c];
           float m = (cok && h) ? v : 0.f, dummy = 0.f;
           ps_half_sum2(m, dummy, red + 32, wave, lane);
           m *= invD;
           const float e = v - m;
           float q = (cok && h) ? e * e : 0.f;
           ps_half_sum2(q, dummy, red + 48, wave, lane);
-          if (cok && h) ll_store(bout + (long long)t * D + c, PS_GELU(e * (1.0f / sqrtf(q * invD + 1e-5f)) * par.v[6] + par.v[7]), epoch);
+          if (cok && h) ll_store(bout + (long long)t * D + c, PS_GELU(e * (1.0f / sqrtf(q * invD + 1e-5f)) * par[6] + par[7]), epoch);
         }
       }
       PS_STAMP(3);
       continue;
     }
 
-    // ==================================================================== matrix step (PS_PRE / PS_MM)
-    const int Cin = ps_uni(st.Cin), Cout = ps_uni(st.Cout), n_mb = ps_uni(st.n_mb), mbg = ps_uni(st.mbg), epi = ps_uni(st.epi);
-    const int j = wj, g = wg;
-    const int n0 = j * 16, n_u = Cin >> 4, mb0 = g * mbg;
-    // ---- operand tile [Cin][16] -> LDS (transposed: cells are column-major)
-    if (kind == PS_PRE) {
-      // x = text-encoder output [H][T] (already masked), plain floats written by the previous kernel
-      const float* xg = call.x;
-      const int col = tid & 15, r0 = tid >> 4;
-      const int t = n0 + col, tc = t < T ? t : T - 1;
-      float xv[PS_MAXC / 32];
+    if (kind == PK_MERGE) {
+      // ================================================================== attention merge, column t:
+      // out = sum_b w_b O_b / sum_b w_b l_b, w_b = e^(m_b - max m) over the key tiles b; thread = (d = tid & 127, head = tid >> 7)
+      const int C = ps_uni(st.C), nh = ps_uni(st.nh), dk = ps_uni(st.dk), dk2 = dk + 2;
+      PS_G ll_t* out = ps_unip(st.out);
+      const PS_G ll_t* ap = ps_unip(st.ap);
+      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      prefetched = true;
+      const int d = tid & (PS_DKP - 1), hd = tid >> 7;
+      const bool ok = d < dk && hd < nh;
+      const int nkt = (L + 15) >> 4;
+      const long long kstr = (long long)Tp * nh * dk2;
+      for (int t = rank; t < Tp; t += P) {
+        float r = 0.f;
+        if (t < L) {
+          float M = -3.0e38f, num = 0.f, den = 0.f;
+          for (int k0 = 0; k0 < nkt; k0 += 4) {
+            float ov[4], mv[4], lv[4];
+            unsigned ob = (unsigned)((t * nh + (hd < nh ? hd : 0)) * dk2) * 8u, od = (unsigned)(d < dk ? d : 0) * 8u;
+            bool pending;
+            do {
+              asm volatile("" : "+v"(ob), "+v"(od));
+              ll_t qo[4] = {0, 0, 0, 0}, qm[4] = {0, 0, 0, 0}, ql[4] = {0, 0, 0, 0};
+              if (ok) {
 #pragma unroll
-      for (int i = 0; i < PS_MAXC / 32; ++i) {
-        const int c = r0 + 32 * i;
-        xv[i] = xg[(long long)(c < Cin ? c : Cin - 1) * T + tc];
-      }
-#pragma unroll
-      for (int i = 0; i < PS_MAXC / 32; ++i) {
-        const int c = r0 + 32 * i;
-        if (c < Cin) tile[c * PS_TP + col] = t < T ? xv[i] : 0.f;
-      }
-    } else {
-      // thread = (channel c = tid & 255, column pair): cells (column 2 k + (tid >> 8), channel c), k < 8 -- no index arithmetic
-      // beyond one multiply per cell; a wave-load covers 64 consecutive channels of one column (512 contiguous bytes)
-      const PS_G ll_t* bin = ps_unip(st.bin) + (long long)n0 * Cin;  // the tile's 16 columns are one contiguous 16 * Cin block
-      const int c = tid & 255, jh = tid >> 8;
-      const bool cok = c < Cin;
-      const int cc = cok ? c : Cin - 1;
-      constexpr int NG = 8;
-      unsigned off[NG];
-#pragma unroll
-      for (int k = 0; k < NG; ++k) off[k] = (unsigned)((2 * k + jh) * Cin + cc) * 8u;
-      float v[NG];
-      bool pending;
-      do {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) asm volatile("" : "+v"(off[k]));
-        ll_t q[NG];
-#pragma unroll
-        for (int k = 0; k < NG; ++k) q[k] = ll_load((const PS_G ll_t*)((const PS_G char*)bin + off[k]));
-        unsigned bad = 0;
-#pragma unroll
-        for (int k = 0; k < NG; ++k) { bad |= (unsigned)(q[k] >> 32) ^ epoch; v[k] = ll_val(q[k]); }
-        pending = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
-      } while (ps_again(cx, pending));
-      PS_STAMP(1);
-      if (cok) {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) tile[c * PS_TP + 2 * k + jh] = v[k];
-      }
-    }
-    __syncthreads();
-
-    PS_STAMP(2);
-    // ---- MFMA tiles of this worker's 16-row blocks + epilogues
-    const float* bl = tile + (lane >> 4) * PS_TP + (lane & 15);
-    for (int mi = 0; mi < mbg; ++mi) {
-      const int mb = mb0 + mi;
-      if (mb >= n_mb) break;
-      if (mi > 0) {
-        __syncthreads();  // mred of the previous block has been read
-        ps_load_bias(st, mb, tid, eb, ec);
-        ps_load_weights(ps_unip(st.w16), mb, n_u, wave, lane, a);
-      }
-      const float ebias = eb, econd = ec;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < PS_MAXU; ++i) {
-        const int u = wave + PS_WAVES * i;
-        if (u < n_u) {  // wave-uniform
-          const float* bp = bl + u * (16 * PS_TP);
-          const float b0 = bp[0], b1 = bp[4 * PS_TP], b2 = bp[8 * PS_TP], b3 = bp[12 * PS_TP];
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0], b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1], b1, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][2], b2, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][3], b3, acc1, 0, 0, 0);
-        }
-      }
-      // the weight registers are free: request the NEXT step's operands now, so that they fly under this step's reduction,
-      // epilogue and the exchange
-      if (mi == mbg - 1 || mb == n_mb - 1) { prefetch(sp.steps[s + 1 < n_steps ? s + 1 : s], tid, lane); prefetched = true; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mred[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
-      __syncthreads();
-      if (tid < 256) {
-        const int row = tid & 15, col = tid >> 4;  // rows fastest: a column's 16 cells are one 128-byte segment
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < PS_WAVES; ++w) v += mred[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + col];
-        const int r = mb * 16 + row;
-        const int t = n0 + col;
-        if (r < Cout) {
-          v += ebias + econd;
-          if (epi == PS_EPI_MASK && t >= L) v = 0.f;  // proj(x) * x_mask (models.py:63)
-          if (epi == PS_EPI_SPLINE) hb[r * 16 + col] = v;
-          else ll_store(ps_unip(st.yout) + (long long)t * ps_uni(st.ypitch) + r, v, epoch);
-        }
-      }
-    }
-    if (kind == PS_PRE && g == 0 && tid < 32) {
-      // z = randn * noise_scale_w (models.py:96): injected noise or the Philox stream of dp_init_z_kernel
-      const int c = tid >> 4, t = n0 + (tid & 15);
-      float nsw = call.nsw;
-      unsigned long long seed = call.seed;
-      if (call.dv) { nsw = call.dv->scales[2]; seed = call.dv->seed; }
-      float e = 0.f;
-      if (t < T) e = call.noise ? call.noise[(long long)c * T + t]
-                                : (call.solo ? philox_normal(call.item_seeds ? call.item_seeds[0] : seed, 1, (uint32_t)c, (uint32_t)t)
-                                             : philox_normal(seed, 1, (uint32_t)c, (uint32_t)t));
-      ll_store(ps_unip(st.zout) + (long long)c * Tp + t, e * nsw, epoch);
-    }
-    if (epi == PS_EPI_SPLINE) {
-      // Inverse rational-quadratic spline of the tile's 16 columns (transforms.py:55-177), the arithmetic of spline_inverse_elem
-      // (kernels_misc.hip.h) spread over the workgroup: one thread per column ran ~23 k cycles (20 expf and 20 divisions in a
-      // dependent chain); here the exponentials are one per thread, the two short serial scans (sum, cumulative widths / heights:
-      // same order as the serial form) run on 32 threads, and 16 threads finish (bin search, quadratic).
-      __syncthreads();  // h complete
-      const int nb = ps_uni(sp.nb);
-      const float bound = sp.bound, isd = sp.inv_sqrt_d;
-      float* se = mred;            // [32][16] exp(w - max): slots 0..nb-1 widths, 16..16+nb-1 heights
-      float* sc = mred + 32 * 16;  // [2][17][16] cumulative widths / heights (knots)
-      {
-        const int col = tid & 15, slot = tid >> 4, which = slot >> 4, i = slot & 15;
-        if (i < nb) {
-          const float* src = hb + (which * nb) * 16 + col;
-          float mx = -3.0e38f;
-          for (int k = 0; k < nb; ++k) mx = fmaxf(mx, src[k * 16] * isd);
-          se[slot * 16 + col] = expf(src[i * 16] * isd - mx);
-        }
-      }
-      __syncthreads();
-      if (tid < 32) {
-        const int col = tid & 15, which = tid >> 4;
-        const float* e = se + which * 256 + col;
-        float* cdst = sc + which * 17 * 16 + col;
-        const float mn = 1e-3f;  // min_bin_width == min_bin_height
-        float sum = 0.f;
-        for (int k = 0; k < nb; ++k) sum += e[k * 16];
-        float acc = 0.f;
-        cdst[0] = -bound;
-        for (int k = 0; k < nb; ++k) {
-          acc += mn + (1.f - mn * nb) * (e[k * 16] / sum);
-          cdst[(k + 1) * 16] = 2.f * bound * acc - bound;
-        }
-        cdst[nb * 16] = bound;
-      }
-      __syncthreads();
-      if (wave == 0) {  // one column per lane (lanes >= 16 ride along in the wave-uniform poll)
-        const int col = lane & 15, t = n0 + col;
-        const int x0r = ps_uni(st.z_row), x1r = 1 - x0r;
-        const PS_G ll_t* zin = ps_unip(st.z);
-        const bool need = lane < 16 && t < L;
-        unsigned o0 = (unsigned)(x0r * Tp + t) * 8u, o1 = (unsigned)(x1r * Tp + t) * 8u;
-        float z0 = 0.f, z1 = 0.f;
-        bool pending;
-        do {
-          asm volatile("" : "+v"(o0), "+v"(o1));
-          ll_t q0 = 0, q1 = 0;
-          if (need) {
-            q0 = ll_load((const PS_G ll_t*)((const PS_G char*)zin + o0));
-            q1 = ll_load((const PS_G ll_t*)((const PS_G char*)zin + o1));
-          }
-          const unsigned bad = need ? (((unsigned)(q0 >> 32) ^ epoch) | ((unsigned)(q1 >> 32) ^ epoch)) : 0u;
-          z0 = ll_val(q0); z1 = ll_val(q1);
-          pending = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
-        } while (ps_again(cx, pending));
-        if (lane < 16) {
-          float v0 = 0.f, v1 = 0.f;
-          if (t < L) {
-            v0 = z0;
-            v1 = z1;
-            const float y = z1;
-            if (y >= -bound && y <= bound) {  // identity outside the interval (transforms.py:65-77)
-              const float* cw = sc + col;
-              const float* ch = sc + 17 * 16 + col;
-              int bin = -1;
-              for (int k = 0; k <= nb; ++k) {
-                const float loc = ch[k * 16] + (k == nb ? 1e-6f : 0.f);
-                if (y >= loc) bin++;
+                for (int k = 0; k < 4; ++k)
+                  if (k0 + k < nkt) {
+                    const PS_G ll_t* b = ap + (k0 + k) * kstr;
+                    qo[k] = ll_load_off(b, ob + od);
+                    qm[k] = ll_load_off(b, ob + (unsigned)dk * 8u);
+                    ql[k] = ll_load_off(b, ob + (unsigned)(dk + 1) * 8u);
+                  }
               }
-              bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
-              const float in_cw = cw[bin * 16], in_w = cw[(bin + 1) * 16] - in_cw;
-              const float in_ch = ch[bin * 16], in_h = ch[(bin + 1) * 16] - in_ch;
-              const float min_d = 1e-3f;
-              const float cst = logf(expf(1.f - min_d) - 1.f);
-              const float ud0 = (bin == 0) ? cst : hb[(2 * nb + bin - 1) * 16 + col];
-              const float ud1 = (bin == nb - 1) ? cst : hb[(2 * nb + bin) * 16 + col];
-              const float d0 = min_d + softplus_f(ud0), d1 = min_d + softplus_f(ud1);
-              const float delta = in_h / in_w;
-              const float t1 = (y - in_ch) * (d0 + d1 - 2.f * delta);
-              const float qa = t1 + in_h * (delta - d0);
-              const float qb = in_h * d0 - t1;
-              const float qc = -delta * (y - in_ch);
-              const float disc = qb * qb - 4.f * qa * qc;
-              const float root = (2.f * qc) / (-qb - sqrtf(disc));
-              v1 = root * in_w + in_cw;
+              unsigned bad = 0;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (ok && k0 + k < nkt) bad |= ll_bad(qo[k], epoch) | ll_bad(qm[k], epoch) | ll_bad(ql[k], epoch);
+                ov[k] = ll_val(qo[k]); mv[k] = ll_val(qm[k]); lv[k] = ll_val(ql[k]);
+              }
+              pending = PS_PENDING(bad);
+            } while (ps_again(cx, pending));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k0 + k < nkt) {
+                const float Mn = fmaxf(M, mv[k]);
+                const float a0 = __expf(M - Mn), a1 = __expf(mv[k] - Mn);
+                num = num * a0 + ov[k] * a1;
+                den = den * a0 + lv[k] * a1;
+                M = Mn;
+              }
+          }
+          r = den > 0.f ? num / den : 0.f;
+        }
+        PS_STAMP(1);
+        if (ok) ll_store(out + (long long)t * C + hd * dk + d, r, epoch);
+      }
+      PS_STAMP(3);
+      continue;
+    }
+
+    if (kind == PK_LN || kind == PK_EMB || kind == PK_COUPLE) {
+      // ================================================================== LayerNorm / embedding / coupling tail, column t
+      const int C = ps_uni(st.C), pT = ps_uni(st.plain_T);
+      PS_G ll_t* out = ps_unip(st.out);
+      PS_G float* oplain = ps_unip(st.oplain);
+      float par[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) par[k] = pre.par[k];
+      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      prefetched = true;
+      const int c = tid & 255, h = tid >> 8;
+      const bool cok = c < C && h == 0;  // one column per worker: the channel threads of half 0
+      for (int t = rank; t < Tp; t += P) {
+        if (t != rank) __syncthreads();
+        float o = 0.f;
+        if (t < L) {  // (worker-uniform) padding columns: zeros, nothing to wait for
+          if (kind == PK_EMB) {
+            // x = emb[id] * sqrt(H) (+ the speaker vector when the first layer is the conditioned one)   (models.py:318-322)
+            long long id = call.ids[t];
+            if (id < 0 || id >= ps_uni(st.n_vocab)) { if (tid == 0) atomicOr((int*)sp.err, 1); id = 0; }
+            if (cok) o = ps_unip(st.emb)[id * C + c] * st.scale + par[3];
+          } else if (kind == PK_LN) {
+            const int np = ps_uni(st.np);
+            const PS_G ll_t* part = ps_unip(st.part);
+            const PS_G ll_t* res = ps_unip(st.res);
+            const PS_G ll_t* base = ps_unip(st.base);
+            const long long pstr = st.part_stride;
+            float v = par[2], bs = 0.f;
+            {
+              unsigned o0 = (unsigned)(t * C + c) * 8u;
+              bool pending;
+              do {
+                asm volatile("" : "+v"(o0));
+                ll_t q[4] = {0, 0, 0, 0}, qr = 0, qb = 0;
+                if (cok) {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k)
+                    if (k < np) q[k] = ll_load_off(part + k * pstr, o0);
+                  if (res) qr = ll_load_off(res, o0);
+                  if (base) qb = ll_load_off(base, o0);
+                }
+                unsigned bad = 0;
+                v = par[2];
+                if (cok) {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k)
+                    if (k < np) { bad |= ll_bad(q[k], epoch); v += ll_val(q[k]); }
+                  if (res) { bad |= ll_bad(qr, epoch); v += ll_val(qr); }
+                  if (base) bad |= ll_bad(qb, epoch);
+                }
+                bs = ll_val(qb);
+                pending = PS_PENDING(bad);
+              } while (ps_again(cx, pending));
+            }
+            PS_STAMP(1);
+            if (ps_uni(st.ln)) {
+              const float invC = 1.0f / (float)C;
+              float m = cok ? v : 0.f, dummy = 0.f;
+              ps_half_sum2(m, dummy, red, wave, lane);
+              m *= invC;
+              const float e = v - m;
+              float q = cok ? e * e : 0.f;
+              ps_half_sum2(q, dummy, red + 16, wave, lane);
+              o = e * (1.0f / sqrtf(q * invC + 1e-5f)) * par[0] + par[1] + par[3] + bs;
+            } else {
+              o = v + bs;
+            }
+          } else {
+            // new z = cat(x0, (x1 - m) * mask) with the following Flip folded in (models.py:390-392, modules.py:270-277)
+            const int H = ps_uni(st.H), np = ps_uni(st.np);
+            const PS_G ll_t* part = ps_unip(st.part);
+            const PS_G ll_t* u = ps_unip(st.u);
+            const PS_G float* up = ps_unip(st.u_plain);
+            const long long pstr = st.part_stride;
+            const int r = c < H ? c : c - H;               // c < H: copy of x0 ; else row r of the transformed half
+            const int src = c < H ? 2 * H - 1 - c : H - 1 - r;
+            float uv = 0.f, mv = 0.f;
+            if (up) { if (cok) uv = up[(long long)src * pT + t]; }
+            {
+              unsigned ou = (unsigned)(t * 2 * H + src) * 8u, om = (unsigned)(t * H + r) * 8u;
+              const bool needm = cok && c >= H;
+              bool pending;
+              do {
+                asm volatile("" : "+v"(ou), "+v"(om));
+                ll_t qu = 0, q[4] = {0, 0, 0, 0};
+                if (cok && !up) qu = ll_load_off(u, ou);
+                if (needm) {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k)
+                    if (k < np) q[k] = ll_load_off(part + k * pstr, om);
+                }
+                unsigned bad = 0;
+                if (cok && !up) { bad |= ll_bad(qu, epoch); uv = ll_val(qu); }
+                mv = par[2];
+                if (needm) {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k)
+                    if (k < np) { bad |= ll_bad(q[k], epoch); mv += ll_val(q[k]); }
+                }
+                pending = PS_PENDING(bad);
+              } while (ps_again(cx, pending));
+            }
+            PS_STAMP(1);
+            o = c < H ? uv : uv - mv;
+          }
+        }
+        if (cok) {
+          if (out) ll_store(out + (long long)t * C + c, o, epoch);
+          if (oplain && t < pT) oplain[(long long)c * pT + t] = o;
+        }
+      }
+      PS_STAMP(3);
+      continue;
+    }
+
+    if (kind == PK_ATT) {
+      // ================================================================== attention block (head, query tile, key tile)
+      // s_ij = q~_i . k_j (+ q~_i . E_k[j - i + W] inside the band) ; p_ij = exp(s_ij - m_i) ; O_i = sum_j p_ij (v_j + E_v[j - i + W])
+      // (attentions.py:165-260 in the exact banded form of relpos_attention_kernel); partial (O, m, l) per block, merged by PK_MERGE
+      const int nh = ps_uni(st.nh), dk = ps_uni(st.dk), W = ps_uni(st.W), dk2 = dk + 2, H3 = 3 * nh * dk;
+      const PS_G ll_t* qkv = ps_unip(st.qkv);
+      PS_G ll_t* ap = ps_unip(st.ap);
+      float* Qs = tile;                  // [16][dk + 1]
+      float* Ks = Qs + 16 * (PS_DKP + 1);
+      float* Vs = Ks + 16 * (PS_DKP + 1);
+      float* Ek = Vs + 16 * (PS_DKP + 1);  // [2W + 1][dk]
+      float* Ev = Ek + 9 * PS_DKP;
+      float* Ss = mred;                  // [2][16][17] partial dot products of the two d-halves, then [16][17] probabilities
+      const int dkp = dk + 1;
+      const float tb0 = pre.par[0], tb1 = pre.par[1], tb2 = pre.par[2], tb3 = pre.par[3];  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]
+      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      prefetched = true;
+      const float scale = 1.0f / sqrtf((float)dk);
+      for (int item = rank; item < items; item += P) {
+        if (item != rank) __syncthreads();
+        const int kt = item % ntn, qt = (item / ntn) % ntn, hd = item / (ntn * ntn);
+        const int i0 = qt * 16, j0 = kt * 16;
+        if (i0 >= L || j0 >= L) continue;  // nothing to compute: the merge step never looks at these blocks
+        if (W > 0) {
+          const int tab = (2 * W + 1) * dk;
+          if (tid < tab) { Ek[tid] = tb0; Ev[tid] = tb2; }
+          if (tid + 512 < tab) { Ek[tid + 512] = tb1; Ev[tid + 512] = tb3; }
+        }
+        // ---- gather q (16 x dk), k, v tiles: thread = (d = tid & 127, rows (tid >> 7) + 4 k)
+        {
+          const int d = tid & (PS_DKP - 1), r0 = tid >> 7;
+          const bool dok = d < dk;
+          unsigned oq[4], okv[4];
+          bool nq[4], nk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 4 * k;
+            nq[k] = dok && i0 + r < L;
+            nk[k] = dok && j0 + r < L;
+            const int tq = i0 + r < Tp ? i0 + r : Tp - 1, tk = j0 + r < Tp ? j0 + r : Tp - 1;
+            oq[k] = (unsigned)(tq * H3 + hd * dk + (dok ? d : 0)) * 8u;
+            okv[k] = (unsigned)(tk * H3 + nh * dk + hd * dk + (dok ? d : 0)) * 8u;
+          }
+          float vq[4], vk[4], vv[4];
+          bool pending;
+          do {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(oq[k]), "+v"(okv[k]));
+            ll_t qq[4] = {0, 0, 0, 0}, qk[4] = {0, 0, 0, 0}, qv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (nq[k]) qq[k] = ll_load_off(qkv, oq[k]);
+              if (nk[k]) { qk[k] = ll_load_off(qkv, okv[k]); qv[k] = ll_load_off(qkv, okv[k] + (unsigned)(nh * dk) * 8u); }
+            }
+            unsigned bad = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (nq[k]) bad |= ll_bad(qq[k], epoch);
+              if (nk[k]) bad |= ll_bad(qk[k], epoch) | ll_bad(qv[k], epoch);
+              vq[k] = ll_val(qq[k]); vk[k] = ll_val(qk[k]); vv[k] = ll_val(qv[k]);
+            }
+            pending = PS_PENDING(bad);
+          } while (ps_again(cx, pending));
+          PS_STAMP(1);
+          if (dok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int r = r0 + 4 * k;
+              Qs[r * dkp + d] = nq[k] ? vq[k] * scale : 0.f;
+              Ks[r * dkp + d] = nk[k] ? vk[k] : 0.f;
+              Vs[r * dkp + d] = nk[k] ? vv[k] : 0.f;
             }
           }
-          if (st.zout) {
-            ll_store(ps_unip(st.zout) + (long long)x0r * Tp + t, v0, epoch);
-            ll_store(ps_unip(st.zout) + (long long)x1r * Tp + t, v1, epoch);
+        }
+        __syncthreads();
+        // ---- scores: thread = (pair (i, j) = tid & 255, d-half = tid >> 8)
+        {
+          const int i = (tid >> 4) & 15, j = tid & 15, dh = tid >> 8;
+          const int d0 = dh * (dk >> 1), d1 = dh ? dk : (dk >> 1);
+          const float* qp = Qs + i * dkp;
+          const float* kp = Ks + j * dkp;
+          float a = 0.f;
+          for (int dd = d0; dd < d1; ++dd) a += qp[dd] * kp[dd];
+          const int rel = (j0 + j) - (i0 + i);
+          if (W > 0 && rel >= -W && rel <= W) {
+            const float* ep = Ek + (rel + W) * dk;
+            for (int dd = d0; dd < d1; ++dd) a += qp[dd] * ep[dd];
           }
-          if (ps_uni(st.last) && t < T) {
-            const float zz = ps_uni(st.ea_row) == x0r ? v0 : v1;
-            ps_unip(sp.logw)[t] = t < L ? (zz - ea_m) * ea_is : 0.f;
+          Ss[(dh * 16 + i) * 17 + j] = a;
+        }
+        __syncthreads();
+        float m_i = 0.f, l_i = 0.f;
+        if (tid < 256) {  // lanes of a 16-lane row = the 16 keys of query i
+          const int i = tid >> 4, j = tid & 15;
+          float sc = Ss[i * 17 + j] + Ss[(16 + i) * 17 + j];
+          const bool kok = j0 + j < L;
+          sc = kok ? sc : -3.0e38f;
+          m_i = ps_row_max(sc);
+          const float p = kok ? __expf(sc - m_i) : 0.f;
+          l_i = ps_row_sum(p);
+          Ss[(32 + i) * 17 + j] = p;
+        }
+        __syncthreads();
+        // ---- O = P V (+ the relative-value band): thread = (d = tid & 127, rows (tid >> 7) + 4 k)
+        {
+          const int d = tid & (PS_DKP - 1), r0 = tid >> 7;
+          if (d < dk) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int i = r0 + 4 * k;
+              if (i0 + i < L) {
+                const float* pp = Ss + (32 + i) * 17;
+                float o = 0.f;
+                for (int j = 0; j < 16; ++j) o += pp[j] * Vs[j * dkp + d];
+                if (W > 0) {
+                  for (int j = 0; j < 16; ++j) {
+                    const int rel = (j0 + j) - (i0 + i);
+                    if (rel >= -W && rel <= W) o += pp[j] * Ev[(rel + W) * dk + d];
+                  }
+                }
+                ll_store(ap + (((long long)kt * Tp + i0 + i) * nh + hd) * dk2 + d, o, epoch);
+              }
+            }
+          }
+        }
+        if (tid < 256 && (tid & 15) == 0) {
+          const int i = tid >> 4;
+          if (i0 + i < L) {
+            PS_G ll_t* dst = ap + (((long long)kt * Tp + i0 + i) * nh + hd) * dk2 + dk;
+            ll_store(dst, m_i, epoch);
+            ll_store(dst + 1, l_i, epoch);
+          }
+        }
+      }
+      PS_STAMP(3);
+      continue;
+    }
+
+    // ==================================================================== matrix step
+    const int Cin = ps_uni(st.Cin), Cout = ps_uni(st.Cout), n_mb = ps_uni(st.n_mb), mbg = ps_uni(st.mbg), epi = ps_uni(st.epi);
+    const int K = ps_uni(st.K), ROW = 16 + K - 1, pad = ps_uni(st.pad), pT = ps_uni(st.plain_T);
+    const int n_u = (Cin >> 4) * K;
+    for (int item = rank; item < items; item += P) {
+      const PsItem it = ps_item(st, item, ntn);
+      const int n0 = it.j * 16, mb0 = it.g * mbg;
+      if (item != rank) {
+        __syncthreads();
+        ps_load_bias(st, mb0, tid, pre.eb0, pre.eb1, pre.ec0, pre.ec1);
+        ps_load_weights(st, mb0, it.slice, wave, lane, pre.a);
+      }
+      // ---- operand window [Cin][ROW] -> LDS (transposed: cells are column-major); thread = (channel c = tid & 255, columns 2 k + (tid >> 8))
+      {
+        const int c = tid & 255, jh = tid >> 8;
+        const bool cok = c < Cin;
+        const int ch = ps_uni(st.c_off) + ps_uni(st.c_sign) * (it.slice * Cin + (cok ? c : 0));
+        const int lim = ps_uni(st.in_mask) ? L : Tp;
+        constexpr int NG = PS_MAXROW / 2;
+        float v[NG];
+        bool need[NG];
+        const PS_G float* bp = ps_unip(st.bin_plain);
+        if (bp) {
+          // plain floats [channels][plain_T] written by an earlier kernel
+#pragma unroll
+          for (int k = 0; k < NG; ++k) {
+            const int jj = 2 * k + jh, t = n0 - pad + jj;
+            need[k] = cok && jj < ROW && t >= 0 && t < (lim < pT ? lim : pT);
+            v[k] = bp[(long long)ch * pT + (need[k] ? t : 0)];
+          }
+        } else {
+          const PS_G ll_t* bin = ps_unip(st.bin);
+          const int cp = ps_uni(st.cin_pitch);
+          unsigned off[NG];
+#pragma unroll
+          for (int k = 0; k < NG; ++k) {
+            const int jj = 2 * k + jh, t = n0 - pad + jj;
+            need[k] = cok && jj < ROW && t >= 0 && t < lim;
+            off[k] = (unsigned)((need[k] ? t : 0) * cp + ch) * 8u;
+          }
+          bool pending;
+          do {
+#pragma unroll
+            for (int k = 0; k < NG; ++k) asm volatile("" : "+v"(off[k]));
+            ll_t q[NG];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) { q[k] = 0; if (need[k]) q[k] = ll_load_off(bin, off[k]); }
+            unsigned bad = 0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) { if (need[k]) bad |= ll_bad(q[k], epoch); v[k] = ll_val(q[k]); }
+            pending = PS_PENDING(bad);
+          } while (ps_again(cx, pending));
+        }
+        PS_STAMP(1);
+        if (cok) {
+#pragma unroll
+          for (int k = 0; k < NG; ++k) {
+            const int jj = 2 * k + jh;
+            if (jj < ROW) tile[c * PS_TP + jj] = need[k] ? v[k] : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+      PS_STAMP(2);
+
+      // ---- MFMA tiles of this item's 16-row blocks + epilogues
+      const float* bl = tile + (lane >> 4) * PS_TP + (lane & 15);
+      for (int mi = 0; mi < mbg; ++mi) {
+        const int mb = mb0 + mi;
+        if (mb >= n_mb) break;
+        if (mi > 0) {
+          __syncthreads();  // mred of the previous block has been read
+          ps_load_bias(st, mb, tid, pre.eb0, pre.eb1, pre.ec0, pre.ec1);
+          ps_load_weights(st, mb, it.slice, wave, lane, pre.a);
+        }
+        const float eb0 = pre.eb0, eb1 = pre.eb1, ec0 = pre.ec0, ec1 = pre.ec1;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        {
+          int uc = wave / K, uk = wave - uc * K;
+          const int step_c = PS_WAVES / K, step_k = PS_WAVES - step_c * K;
+#pragma unroll
+          for (int i = 0; i < PS_MAXU; ++i) {
+            const int u = wave + PS_WAVES * i;
+            if (u < n_u) {  // wave-uniform
+              const float* bp = bl + uc * (16 * PS_TP) + uk;
+              const float b0 = bp[0], b1 = bp[4 * PS_TP], b2 = bp[8 * PS_TP], b3 = bp[12 * PS_TP];
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][0], b0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][1], b1, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][2], b2, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][3], b3, acc1, 0, 0, 0);
+            }
+            uk += step_k;
+            uc += step_c + (uk >= K ? 1 : 0);
+            uk -= uk >= K ? K : 0;
+          }
+        }
+        // the weight registers are free: request the NEXT step's operands now, so that they fly under this step's reduction,
+        // epilogue and the exchange
+        if ((mi == mbg - 1 || mb == n_mb - 1) && item + P >= items) { ps_prefetch(nx, rank, ntn, tid, wave, lane, pre); prefetched = true; }
+        // residual cells of this block (data of an older step: normally one round trip)
+        float rv = 0.f;
+        const PS_G ll_t* res = ps_unip(st.res);
+        if (res && tid < 256) {
+          unsigned ro = (unsigned)((n0 + (tid >> 4)) * ps_uni(st.rpitch) + mb * 16 + (tid & 15)) * 8u;
+          const bool rok = mb * 16 + (tid & 15) < Cout;
+          bool pending;
+          do {
+            asm volatile("" : "+v"(ro));
+            ll_t q = 0;
+            if (rok) q = ll_load_off(res, ro);
+            rv = ll_val(q);
+            pending = PS_PENDING(rok ? ll_bad(q, epoch) : 0u);
+          } while (ps_again(cx, pending));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mred[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (epi == PS_EPI_GATE) {
+          // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8 * mb .. 8 * mb + 7 (commons.py:100-107)
+          if (tid < 128) {
+            const int ch = tid & 7, col = tid >> 3;
+            float at = 0.f, as = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_WAVES; ++w) {
+              at += mred[(w * 4 + (ch & 3)) * 64 + (ch >> 2) * 16 + col];
+              as += mred[(w * 4 + (ch & 3)) * 64 + ((ch >> 2) + 2) * 16 + col];
+            }
+            const int c = mb * 8 + ch, t = n0 + col;
+            const float tv = tanhf(at + eb0 + ec0);
+            const float sv = 1.0f / (1.0f + __expf(-(as + eb1 + ec1)));
+            if (c < ps_uni(st.gate_H)) ll_store(ps_unip(st.yout) + (long long)t * ps_uni(st.ypitch) + ps_uni(st.y_off) + c, tv * sv, epoch);
+          }
+        } else if (tid < 256) {
+          const int row = tid & 15, col = tid >> 4;  // rows fastest: a column's 16 cells are one 128-byte segment
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < PS_WAVES; ++w) v += mred[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + col];
+          const int r = mb * 16 + row;
+          const int t = n0 + col;
+          if (r < Cout) {
+            v += eb0 + ec0;
+            if (ps_uni(st.relu)) v = v > 0.f ? v : 0.f;
+            if (ps_uni(st.out_mask) && t >= L) v = 0.f;
+            v += rv;
+            if (epi == PS_EPI_SPLINE) hb[r * 16 + col] = v;
+            else {
+              PS_G ll_t* yo = ps_unip(st.yout);
+              PS_G float* yp = ps_unip(st.yplain);
+              if (yo) ll_store(yo + ((long long)it.slice * Tp + t) * ps_uni(st.ypitch) + ps_uni(st.y_off) + r, v, epoch);
+              if (yp && t < pT) yp[(long long)r * pT + t] = v;
+            }
+          }
+        }
+      }
+      if (ps_uni(st.zinit) && it.g == 0 && it.slice == 0 && tid < 32) {
+        // z = randn * noise_scale_w (models.py:96): injected noise or the Philox stream of dp_init_z_kernel
+        const int c = tid >> 4, t = n0 + (tid & 15);
+        float nsw = call.nsw;
+        unsigned long long seed = call.seed;
+        if (call.dv) { nsw = call.dv->scales[2]; seed = call.dv->seed; }
+        float e = 0.f;
+        if (t < T) e = call.noise ? call.noise[(long long)c * T + t]
+                                  : (call.solo ? philox_normal(call.item_seeds ? call.item_seeds[0] : seed, 1, (uint32_t)c, (uint32_t)t)
+                                               : philox_normal(seed, 1, (uint32_t)c, (uint32_t)t));
+        ll_store(ps_unip(st.zout) + (long long)c * Tp + t, e * nsw, epoch);
+      }
+      if (epi == PS_EPI_SPLINE) {
+        // Inverse rational-quadratic spline of the tile's 16 columns (transforms.py:55-177), the arithmetic of spline_inverse_elem
+        // (kernels_misc.hip.h) spread over the workgroup: one thread per column ran ~23 k cycles (20 expf and 20 divisions in a
+        // dependent chain); here the exponentials are one per thread, the two short serial scans (sum, cumulative widths / heights:
+        // same order as the serial form) run on 32 threads, and 16 threads finish (bin search, quadratic).
+        __syncthreads();  // h complete
+        const int nb = ps_uni(sp.nb);
+        const float bound = sp.bound, isd = sp.inv_sqrt_d;
+        float* se = mred;            // [32][16] exp(w - max): slots 0..nb-1 widths, 16..16+nb-1 heights
+        float* sc = mred + 32 * 16;  // [2][17][16] cumulative widths / heights (knots)
+        {
+          const int col = tid & 15, slot = tid >> 4, which = slot >> 4, i = slot & 15;
+          if (i < nb) {
+            const float* src = hb + (which * nb) * 16 + col;
+            float mx = -3.0e38f;
+            for (int k = 0; k < nb; ++k) mx = fmaxf(mx, src[k * 16] * isd);
+            se[slot * 16 + col] = expf(src[i * 16] * isd - mx);
+          }
+        }
+        __syncthreads();
+        if (tid < 32) {
+          const int col = tid & 15, which = tid >> 4;
+          const float* e = se + which * 256 + col;
+          float* cdst = sc + which * 17 * 16 + col;
+          const float mn = 1e-3f;  // min_bin_width == min_bin_height
+          float sum = 0.f;
+          for (int k = 0; k < nb; ++k) sum += e[k * 16];
+          float acc = 0.f;
+          cdst[0] = -bound;
+          for (int k = 0; k < nb; ++k) {
+            acc += mn + (1.f - mn * nb) * (e[k * 16] / sum);
+            cdst[(k + 1) * 16] = 2.f * bound * acc - bound;
+          }
+          cdst[nb * 16] = bound;
+        }
+        __syncthreads();
+        if (wave == 0) {  // one column per lane (lanes >= 16 ride along in the wave-uniform poll)
+          const int col = lane & 15, t = n0 + col;
+          const int x0r = ps_uni(st.z_row), x1r = 1 - x0r;
+          const PS_G ll_t* zin = ps_unip(st.z);
+          const bool need = lane < 16 && t < L;
+          unsigned o0 = (unsigned)(x0r * Tp + t) * 8u, o1 = (unsigned)(x1r * Tp + t) * 8u;
+          float z0 = 0.f, z1 = 0.f;
+          bool pending;
+          do {
+            asm volatile("" : "+v"(o0), "+v"(o1));
+            ll_t q0 = 0, q1 = 0;
+            if (need) { q0 = ll_load_off(zin, o0); q1 = ll_load_off(zin, o1); }
+            const unsigned bad = need ? (ll_bad(q0, epoch) | ll_bad(q1, epoch)) : 0u;
+            z0 = ll_val(q0); z1 = ll_val(q1);
+            pending = PS_PENDING(bad);
+          } while (ps_again(cx, pending));
+          if (lane < 16) {
+            float v0 = 0.f, v1 = 0.f;
+            if (t < L) {
+              v0 = z0;
+              v1 = z1;
+              const float y = z1;
+              if (y >= -bound && y <= bound) {  // identity outside the interval (transforms.py:65-77)
+                const float* cw = sc + col;
+                const float* ch = sc + 17 * 16 + col;
+                int bin = -1;
+                for (int k = 0; k <= nb; ++k) {
+                  const float loc = ch[k * 16] + (k == nb ? 1e-6f : 0.f);
+                  if (y >= loc) bin++;
+                }
+                bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+                const float in_cw = cw[bin * 16], in_w = cw[(bin + 1) * 16] - in_cw;
+                const float in_ch = ch[bin * 16], in_h = ch[(bin + 1) * 16] - in_ch;
+                const float min_d = 1e-3f;
+                const float cst = logf(expf(1.f - min_d) - 1.f);
+                const float ud0 = (bin == 0) ? cst : hb[(2 * nb + bin - 1) * 16 + col];
+                const float ud1 = (bin == nb - 1) ? cst : hb[(2 * nb + bin) * 16 + col];
+                const float d0 = min_d + softplus_f(ud0), d1 = min_d + softplus_f(ud1);
+                const float delta = in_h / in_w;
+                const float t1 = (y - in_ch) * (d0 + d1 - 2.f * delta);
+                const float qa = t1 + in_h * (delta - d0);
+                const float qb = in_h * d0 - t1;
+                const float qc = -delta * (y - in_ch);
+                const float disc = qb * qb - 4.f * qa * qc;
+                const float root = (2.f * qc) / (-qb - sqrtf(disc));
+                v1 = root * in_w + in_cw;
+              }
+            }
+            if (st.zout) {
+              ll_store(ps_unip(st.zout) + (long long)x0r * Tp + t, v0, epoch);
+              ll_store(ps_unip(st.zout) + (long long)x1r * Tp + t, v1, epoch);
+            }
+            if (ps_uni(st.last) && t < T) {
+              const float zz = ps_uni(st.ea_row) == x0r ? v0 : v1;
+              ps_unip(sp.logw)[t] = t < L ? (zz - ea_m) * ea_is : 0.f;
+            }
           }
         }
       }
@@ -600,4 +1050,10 @@ __global__ void __launch_bounds__(PS_THREADS) sdp_persist_kernel(const SdpProgra
       __hip_atomic_store(&call.ctl->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// dynamic LDS of a launch: the program up to its last step, then the float buffers
+static inline size_t ps_lds_bytes(int n_steps) {
+  const size_t prog = sizeof(PProgram) - (size_t)(PS_MAX_STEPS - n_steps) * sizeof(PStep);
+  return ((prog / 4 + 3) & ~(size_t)3) * 4 + (size_t)PS_LDS_FLOATS * sizeof(float);
 }
