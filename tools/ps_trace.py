@@ -1,33 +1,48 @@
-"""Timeline of the persistent duration-predictor kernel (csrc/persist.hip.h): per step, over the busy workers, when the step was
-entered, when its input cells had arrived, when it ended (cycles of the shader clock relative to the kernel's first stamp).
-    VITS_PS_TRACE=/tmp/ps.bin python tools/ps_trace.py [T]      (eager stage call; the trace file is rewritten by every forward)"""
+"""Timeline of a persistent step program (csrc/persist.hip.h): per step, over the busy workers, how long they waited for their
+input cells and how long they worked (cycles of the shader clock; stamps of different XCDs are not synchronised, so only
+per-worker differences and the stamps of ONE worker are meaningful).
+    python tools/ps_trace.py dp|enc|flow [T]      (eager stage call; the trace file is rewritten by every forward)"""
 import os, sys, struct
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+prog = sys.argv[1] if len(sys.argv) > 1 else "dp"
+T = int(sys.argv[2]) if len(sys.argv) > 2 else (150 if prog == "flow" else 50)
 path = os.environ.setdefault("VITS_PS_TRACE", "/tmp/ps.bin")
+os.environ["VITS_PS_TRACE_PROG"] = prog + ".persist"
 import torch  # noqa
 from vosk_tts_amd import weights as W
 from vosk_tts_amd.capi import VitsLib
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 lib = VitsLib()
 m = lib.create(W.synthetic_blob(W.default_hparams(), 1234), 0)
 rng = np.random.default_rng(0)
-x = rng.standard_normal((1, 192, T)).astype(np.float32)
 for _ in range(3):
-    m.duration(x, np.array([T], np.int64), np.array([2], np.int64), rng.standard_normal((1, 2, T)).astype(np.float32), 0.8)
+    if prog == "dp":
+        m.duration(rng.standard_normal((1, 192, T)).astype(np.float32), np.array([T], np.int64), np.array([2], np.int64), rng.standard_normal((1, 2, T)).astype(np.float32), 0.8)
+    elif prog == "enc":
+        m.text_encoder(rng.integers(1, 62, size=(1, T)).astype(np.int64), np.array([T], np.int64), np.array([2], np.int64))
+    else:
+        m.flow(rng.standard_normal((1, 192, T)).astype(np.float32), np.array([T], np.int64), np.array([2], np.int64))
 raw = open(path, "rb").read()
 P, MS, n, Tx = struct.unpack("4i", raw[:16])
 kinds = struct.unpack(f"{n}i", raw[16:16 + 4 * n])
-st = np.frombuffer(raw[16 + 4 * n:], dtype=np.int64).reshape(P, MS, 4)[:, :n]
-t0 = st[st > 0].min()
-names = {0: "PRE", 1: "COL", 2: "MM "}
-print(f"T={Tx} workers={P} steps={n}; cycles relative to the first stamp (2.4 GHz: 2400 cycles = 1 us)")
-prev_end = 0
+st = np.frombuffer(raw[16 + 4 * n:], dtype=np.int64).reshape(P, MS, 8)[:, :n]
+names = {0: "MM", 1: "DDS", 2: "LN", 3: "EMB", 4: "ATT", 5: "MERGE", 6: "COUPLE"}
+print(f"{prog}: T={Tx} workers={P} steps={n}; 2400 cycles = 1 us")
+# the timeline of ONE worker that is busy in most steps: rank 0
+r0 = st[0]
+t0 = r0[r0 > 0].min()
+prev = 0
+tot_wait = tot_work = 0
 for s in range(n):
     busy = st[:, s, 0] > 0
     a = st[busy, s]
-    ent, got, end = a[:, 0] - t0, a[:, 1] - t0, a[:, 3] - t0
-    print(f"step {s:2d} {names[kinds[s]]} workers {busy.sum():3d}  enter {ent.min():7d}..{ent.max():7d}  data {got.min():7d}..{got.max():7d}  end {end.min():7d}..{end.max():7d}"
-          f"   wait {np.median(got - ent):6.0f}  work {np.median(end - got):6.0f}   step span {end.max() - prev_end:6d}")
-    prev_end = end.max()
-print(f"total {prev_end} cycles = {prev_end / 2400:.1f} us")
+    got = np.where(a[:, 1] > 0, a[:, 1], a[:, 0])
+    wait = np.median(got - a[:, 0]); work = np.median(a[:, 3] - got)
+    e0 = r0[s, 3] - t0 if r0[s, 3] > 0 else -1
+    print(f"step {s:2d} {names[kinds[s]]:6s} workers {busy.sum():3d}  wait {wait:6.0f} (max {np.max(got - a[:, 0]):6d})  work {work:6.0f} (max {np.max(a[:, 3] - got):6d})   rank0 end {e0:8d} (+{e0 - prev if e0 >= 0 else 0:6d})")
+    if e0 >= 0: prev = e0
+    if kinds[s] == 0 and r0[s, 0] > 0:  # matrix step phases of rank 0: descriptor -> poll done -> tile in LDS -> MFMAs -> prefetch issued -> partials reduced -> end
+        q = r0[s]
+        print("          rank0 phases: poll %6d  tile %5d  mfma %5d  prefetch %5d  reduce %5d  epilogue %5d" % (q[1] - q[0], q[2] - q[1], q[4] - q[2], q[5] - q[4], q[6] - q[5], q[3] - q[6]))
+    tot_wait += wait; tot_work += work
+print(f"sum of medians: wait {tot_wait:.0f} work {tot_work:.0f} cycles = {(tot_wait + tot_work) / 2400:.1f} us; rank 0 timeline {prev / 2400:.1f} us")

@@ -924,7 +924,7 @@ static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool want_trace = trace_path && !strcmp(name, trace_name ? trace_name : "dp.persist");
   if (want_trace) hipStreamIsCapturing(s->stream, &cap);
-  const size_t trace_n = (size_t)m->n_cu * PS_MAX_STEPS * 4;
+  const size_t trace_n = (size_t)m->n_cu * PS_MAX_STEPS * 8;
   if (want_trace && cap == hipStreamCaptureStatusNone) {
     hipMalloc((void**)&c.trace, trace_n * sizeof(long long));
     hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), s->stream);

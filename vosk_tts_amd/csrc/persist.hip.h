@@ -63,7 +63,7 @@ enum { PS_EPI_STORE = 0, PS_EPI_SPLINE = 1, PS_EPI_GATE = 2 };
 // One step.  EVERY pointer that the prefetch touches (w16, bias, cond, par[]) is valid in EVERY step -- unused ones point at a block
 // of zeros -- so that the one-step-ahead prefetch is straight-line code: a load behind a branch makes hipcc wait for it at the join,
 // i.e. puts a cold round trip in the middle of a step (measured 4-5 k cycles per matrix step).
-struct PStep {
+struct alignas(16) PStep {
   int kind;
   // ---- PK_MM: y[Cout x 16-column tile] (+)= W[Cout x ks*Cin*K] * window(B)
   int Cin;                 // contraction channels of ONE K-slice (multiple of 16, <= PS_MAXC)
@@ -144,7 +144,7 @@ struct PCall {                          // per-call values (by value: a captured
   int solo;
   const SynthDev* dv;
   const unsigned long long* item_seeds;
-  long long* trace;                     // tools only (VITS_PS_TRACE): [P][PS_MAX_STEPS][4] cycle stamps, null in production
+  long long* trace;                     // tools only (VITS_PS_TRACE): [P][PS_MAX_STEPS][8] cycle stamps, null in production
 };
 
 // Pointers of the step program come out of LDS as generic ("flat") per-lane values: make them what they are -- wave-uniform
@@ -297,7 +297,25 @@ __device__ __forceinline__ void ps_prefetch(const PStep& st, int rank, int ntn, 
   ps_load_weights(st, mb0, sl, wave, lane, r.a);
 }
 
-#define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+// A step descriptor from the LDS copy of the program into SCALAR registers, in one batch: read field by field at its point of use every
+// ps_uni(st.x) was an LDS round trip + s_waitcnt of its own -- ~60 per matrix step, measured +8 k cycles per step.  (The compiler
+// spills what does not fit the SGPR file into VGPR lanes: v_readlane, a few cycles.)
+__device__ __forceinline__ void ps_load_step(PStep& dst, const PStep* src) {
+  constexpr int NW = (int)(sizeof(PStep) / 4);
+  static_assert(sizeof(PStep) % 16 == 0, "PStep is read as dwordx4");
+  const int4* s4 = reinterpret_cast<const int4*>(src);
+  int tmp[NW];
+#pragma unroll
+  for (int i = 0; i < NW / 4; ++i) {
+    const int4 v = s4[i];
+    tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) tmp[i] = __builtin_amdgcn_readfirstlane(tmp[i]);
+  __builtin_memcpy(&dst, tmp, sizeof(PStep));
+}
+
+#define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 // LDS of the kernel (floats).  Matrix steps: operand window + partial tiles + spline scratch; attention blocks: Q / K / V tiles and
 // the two relative-position tables alias the operand window, scores / probabilities alias the partial tiles.
@@ -307,7 +325,7 @@ __device__ __forceinline__ void ps_prefetch(const PStep& st, int rank, int ntn, 
 static_assert(PS_LDS_TILE >= PS_MAXC * PS_TP, "operand window does not fit");
 
 __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __restrict__ prog, const PCall call) {
-  extern __shared__ int ps_dyn[];          // the program (up to its last step), then the float buffers
+  extern __shared__ __attribute__((aligned(16))) int ps_dyn[];  // the program (up to its last step), then the float buffers
   __shared__ unsigned s_epoch;
   __shared__ int s_nsteps;
   const int tid0 = threadIdx.x;
@@ -360,12 +378,14 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const PStep& st = sp.steps[s];
-    const PStep& nx = sp.steps[s + 1 < n_steps ? s + 1 : s];
+    PStep st, nx;
+    ps_load_step(st, &sp.steps[s]);
+    ps_load_step(nx, &sp.steps[s + 1 < n_steps ? s + 1 : s]);
+    const long long t_desc = call.trace ? __builtin_readcyclecounter() : 0;
     const int kind = ps_uni(st.kind);
     const int items = n_items(st);
     if (rank >= items) { prefetched = false; continue; }  // idle in this step: nothing to wait for
-    PS_STAMP(0);
+    if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + 0] = t_desc;
     if (!prefetched) ps_prefetch(st, rank, ntn, tid, wave, lane, pre);
     prefetched = false;
     __syncthreads();  // the previous step's readers of the LDS buffers are done
@@ -871,6 +891,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             uk -= uk >= K ? K : 0;
           }
         }
+        PS_STAMP(4);
         // the weight registers are free: request the NEXT step's operands now, so that they fly under this step's reduction,
         // epilogue and the exchange
         if ((mi == mbg - 1 || mb == n_mb - 1) && item + P >= items) { ps_prefetch(nx, rank, ntn, tid, wave, lane, pre); prefetched = true; }
@@ -889,9 +910,11 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             pending = PS_PENDING(rok ? ll_bad(q, epoch) : 0u);
           } while (ps_again(cx, pending));
         }
+        PS_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 4; ++r) mred[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
         __syncthreads();
+        PS_STAMP(6);
         if (epi == PS_EPI_GATE) {
           // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8 * mb .. 8 * mb + 7 (commons.py:100-107)
           if (tid < 128) {
