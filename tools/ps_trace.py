@@ -26,7 +26,7 @@ raw = open(path, "rb").read()
 P, MS, n, Tx = struct.unpack("4i", raw[:16])
 kinds = struct.unpack(f"{n}i", raw[16:16 + 4 * n])
 st = np.frombuffer(raw[16 + 4 * n:], dtype=np.int64).reshape(P, MS, 8)[:, :n]
-names = {0: "MM", 1: "DDS", 2: "LN", 3: "EMB", 4: "ATT", 5: "MERGE", 6: "COUPLE"}
+names = {0: "IDLE", 1: "MM", 2: "DDS", 3: "LN", 4: "EMB", 5: "ATT", 6: "MERGE", 7: "COUPLE"}
 print(f"{prog}: T={Tx} workers={P} steps={n}; 2400 cycles = 1 us")
 # the timeline of ONE worker that is busy in most steps: rank 0
 r0 = st[0]
@@ -41,8 +41,5 @@ for s in range(n):
     e0 = r0[s, 3] - t0 if r0[s, 3] > 0 else -1
     print(f"step {s:2d} {names[kinds[s]]:6s} workers {busy.sum():3d}  wait {wait:6.0f} (max {np.max(got - a[:, 0]):6d})  work {work:6.0f} (max {np.max(a[:, 3] - got):6d})   rank0 end {e0:8d} (+{e0 - prev if e0 >= 0 else 0:6d})")
     if e0 >= 0: prev = e0
-    if kinds[s] == 0 and r0[s, 0] > 0:  # matrix step phases of rank 0: descriptor -> poll done -> tile in LDS -> MFMAs -> prefetch issued -> partials reduced -> end
-        q = r0[s]
-        print("          rank0 phases: poll %6d  tile %5d  mfma %5d  prefetch %5d  reduce %5d  epilogue %5d" % (q[1] - q[0], q[2] - q[1], q[4] - q[2], q[5] - q[4], q[6] - q[5], q[3] - q[6]))
     tot_wait += wait; tot_work += work
 print(f"sum of medians: wait {tot_wait:.0f} work {tot_work:.0f} cycles = {(tot_wait + tot_work) / 2400:.1f} us; rank 0 timeline {prev / 2400:.1f} us")

@@ -151,6 +151,8 @@ struct vits_model {
   float *istft_basis = nullptr, *pqmf = nullptr;
   bool use_g = false;
   float* zeros = nullptr;  // 4096 zeros: the "unused" parameter pointers of persistent-kernel steps (persist.hip.h)
+  std::mutex pack_mu;      // packed per-thread parameter vectors of persistent steps, keyed by their sources (persist_plan.hip.h)
+  std::map<std::vector<long long>, const float*> packs;
   int n_cu = 0;       // compute units of the device = workgroups of a persistent kernel (persist.hip.h)
   int rag_halo = 32;  // frames decoded beyond an item's end in ragged batches / streaming windows: >= the decoder's receptive field
 
@@ -682,8 +684,12 @@ struct vits_session {
   // (laid out for T_x) and flow (T_y).  LL-cell exchange buffers live inside the arena and are zeroed at every re-plan; the
   // programs are rebuilt at every re-plan; the epoch / completion block survives re-plans (epochs only ever grow).
   struct PersistProg {
-    PProgram h;            // host copy
+    PProgram h;            // host copy of the header
     PProgram* d = nullptr; // device copy
+    std::vector<PRec> recs_h;  // per (step, worker) records: host copy (pageable source of the upload)
+    PRec* recs_d = nullptr;
+    size_t recs_bytes = 0;
+    std::vector<int> kinds;    // kind of every step (tools)
     ll_t* ll = nullptr;    // exchange cells
     size_t cells = 0;
     bool ok = false;
@@ -869,7 +875,7 @@ static void session_free(vits_session* s) {
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
   if (s->ps_ctl) hipFree(s->ps_ctl);
-  for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow}) if (pp->d) hipFree(pp->d);
+  for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow}) { if (pp->d) hipFree(pp->d); if (pp->recs_d) hipFree(pp->recs_d); }
   if (s->stage) hipFree(s->stage);
   if (s->d_err) hipFree(s->d_err);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -929,12 +935,7 @@ static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const
     hipMalloc((void**)&c.trace, trace_n * sizeof(long long));
     hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), s->stream);
   }
-  const size_t lds = ps_lds_bytes(pp.h.n_steps);
-  if (lds > 64 * 1024) {
-    static std::atomic<unsigned long long> done{0};
-    if (big_lds_needed(done)) hipFuncSetAttribute((const void*)persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps_lds_bytes(PS_MAX_STEPS));
-  }
-  hipLaunchKernelGGL(persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), lds, s->stream, pp.d, c);
+  hipLaunchKernelGGL(persist_kernel, dim3(m->n_cu), dim3(PS_THREADS), 0, s->stream, pp.d, c);
   if (c.trace) {
     std::vector<long long> h(trace_n);
     hipMemcpyAsync(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost, s->stream);
@@ -943,7 +944,7 @@ static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const
     if (FILE* f = fopen(trace_path, "wb")) {
       const int hdr[4] = {m->n_cu, PS_MAX_STEPS, pp.h.n_steps, pp.h.T};
       fwrite(hdr, sizeof hdr, 1, f);
-      for (int i = 0; i < pp.h.n_steps; ++i) fwrite(&pp.h.steps[i].kind, sizeof(int), 1, f);
+      for (int i = 0; i < pp.h.n_steps; ++i) fwrite(&pp.kinds[i], sizeof(int), 1, f);
       fwrite(h.data(), sizeof(long long), trace_n, f);
       fclose(f);
     }

@@ -14,23 +14,27 @@
 // epoch does not match is simply not there yet.  Every poll loop is bounded (PS_SPIN_LIMIT): a lost worker turns into an error
 // word, never into a hung GPU.
 //
-// What bounds a step is how many bytes ONE workgroup must pull through L1-bypassing loads (~30 GB/s per CU) and how often an
-// element is recomputed, so the programs are built from two kinds of steps over COLUMN-MAJOR cells [T][C] (a column's channels are
-// contiguous):
-//   * column steps, one worker per COLUMN t, thread = channel: LayerNorm (+ K-slice partial sums, bias, residual, speaker vector),
-//     the DDSConv elementwise chain (finish the previous layer at t - d, t, t + d, depthwise conv, LN, GELU), embedding lookup,
-//     attention merge, coupling tail.  A LayerNorm is a DPP wave reduction + one LDS exchange; every element is computed once.
+// What bounds a step (measured, tools/ps_trace.py): (1) how many bytes ONE workgroup must pull through L1-bypassing loads (~30 GB/s
+// per CU), (2) how often an element is recomputed, (3) the INSTRUCTIONS every wave issues for bookkeeping (a wave issues at most one
+// instruction per 4 cycles: a generic interpreter that decoded its step descriptors on the device ran 15.6 k cycles per matrix step
+// against 6.1 k for hand-specialised code).  So:
+//   * the HOST resolves everything: per (step, worker) one 128-byte RECORD holds the final pointers of that worker's work item
+//     (operand window, weight fragments of its row blocks, epilogue operands, output tile) and a few packed integers; the kernel
+//     keeps the record in 4 VGPRs of lanes 0..7 and reads fields with v_readlane -- no divisions, no clamping, no descriptor
+//     decode on the device; records and read-only operands are requested two / one steps ahead in straight-line code;
+//   * column steps, one worker per COLUMN t of the column-major cells [T][C], thread = channel: LayerNorm (+ K-slice partial
+//     sums, bias, residual, speaker vector), the DDSConv elementwise chain (finish the previous layer at t - d, t, t + d,
+//     depthwise conv, LN, GELU), embedding lookup, attention merge, coupling tail.  A LayerNorm is a DPP wave reduction + one LDS
+//     exchange; every element is computed once;
 //   * matrix steps, one worker per (16-column tile, group of 16-row blocks, K-slice): gather the [C_in x (16 + taps - 1)] operand
-//     window (<= 40 KB), 16x16x4 fp32 MFMAs with the 8 waves splitting the contraction at tap-unit granularity, weights prefetched
-//     into registers during the PREVIOUS step, epilogue (bias / per-item bias / ReLU / mask / residual, WaveNet gate, spline
-//     inverse), cells out.  Contractions over 768 channels are split into 4 K-slices whose partial sums the consuming LayerNorm /
-//     coupling column step adds up -- no worker ever gathers more than 192 x 20 cells.
+//     window (<= 40 KB), 16x16x4 fp32 MFMAs with the 8 waves splitting the contraction at tap-unit granularity, epilogue (bias /
+//     per-item bias / ReLU / mask / residual, WaveNet gate, spline inverse), cells out.  Contractions over 768 channels are split
+//     into K-slices whose partial sums the consuming LayerNorm / coupling column step adds up;
 //   * attention = 16 x 16 (query tile, key tile) block steps (each gathers three 16 x d_k tiles, partial softmax with the banded
-//     relative-position terms of attentions.py:165-260) + a merge column step -- instead of one worker per query tile pulling all
-//     keys and values (245 KB at T = 160).
+//     relative-position terms of attentions.py:165-260) + a merge column step.
 // (v1 of the duration predictor ran a whole DDSConv layer per step like conv16_kernel's PRO == 1: every one of the 16 workgroups of
 // a column tile pulled the full 256-channel x 34-column window of two tensors and redid its LayerNorms and 8 k erf evaluations:
-// 12 us per step, 208 us for the predictor; the column / matrix split brought it to 109 us against 265 us of launches.)
+// 12 us per step, 208 us for the predictor against 265 us of launches.)
 // Reference ops: attentions.py:48-65,133-260,292-317 (Encoder / MultiHeadAttention / FFN), models.py:56-63,93-101 (duration
 // predictor), modules.py:96-108,148-176,363-390 (DDSConv, WN, ConvFlow), models.py:374-393 (coupling layer).
 #pragma once
@@ -41,7 +45,7 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 
 #define PS_THREADS 512
 #define PS_WAVES 8
-#define PS_MAX_STEPS 96
+#define PS_MAX_STEPS 128
 #define PS_MAXC 256      // channels of a column step / contraction channels of one K-slice
 #define PS_MAXU 8        // tap units (16 channels x 1 tap) per wave
 #define PS_TP 21         // LDS pitch of the MFMA operand window [C_in][16 + taps - 1] (odd: the transposing writes are conflict-free)
@@ -57,82 +61,47 @@ struct PersistCtl {
   unsigned timeouts;  // diagnostics
 };
 
-enum { PK_MM = 0, PK_DDS = 1, PK_LN = 2, PK_EMB = 3, PK_ATT = 4, PK_MERGE = 5, PK_COUPLE = 6 };
-enum { PS_EPI_STORE = 0, PS_EPI_SPLINE = 1, PS_EPI_GATE = 2 };
-
-// One step.  EVERY pointer that the prefetch touches (w16, bias, cond, par[]) is valid in EVERY step -- unused ones point at a block
-// of zeros -- so that the one-step-ahead prefetch is straight-line code: a load behind a branch makes hipcc wait for it at the join,
-// i.e. puts a cold round trip in the middle of a step (measured 4-5 k cycles per matrix step).
-struct alignas(16) PStep {
-  int kind;
-  // ---- PK_MM: y[Cout x 16-column tile] (+)= W[Cout x ks*Cin*K] * window(B)
-  int Cin;                 // contraction channels of ONE K-slice (multiple of 16, <= PS_MAXC)
-  int cin_pitch;           // channel pitch of the operand cells
-  int c_off, c_sign;       // operand channel of slice-local channel c: c_off + c_sign * (slice * Cin + c)   (Flip folded into the read)
-  int Cout, n_mb;          // rows stored, 16-row blocks of the packed matrix
-  int G, mbg, ks;          // row-block groups per column tile, 16-row blocks per worker, K-slices
-  int K, pad;              // taps, left padding: operand column of (output t, tap kk) = t + kk - pad
-  int epi, relu;           // PS_EPI_*; 1 = ReLU on acc + bias
-  int in_mask, out_mask;   // operand columns >= len read as 0 ; output columns >= len written as 0
-  int ypitch, y_off;       // output channel pitch, first output channel
-  int gate_H;              // PS_EPI_GATE: hidden channels (packed rows = [8 tanh | 8 sigmoid] per 16-row block)
-  int plain_T;             // row length of bin_plain / yplain / oplain / u_plain
-  int zinit;               // also draw z = noise * noise_scale_w into zout (duration predictor, first step)
-  int blen;                // valid entries of bias / cond
-  const float* w16;        // [n_mb][ks][Cin/16*K][64][4] 16x16x4 A-fragment order (pack_conv_weights16: slices are consecutive units)
-  const float* bias;       // [Cout] (zeros for K-sliced steps: the consumer adds it once)
-  const float* cond;       // per-item bias rows (cond(g)) or zeros
-  const ll_t* bin;         // operand cells [Tp][cin_pitch] ...
-  const float* bin_plain;  // ... or plain floats [channels][plain_T] written by an earlier kernel (null: cells)
-  const ll_t* res;         // residual cells [Tp][rpitch] added after the mask (null: none)
-  int rpitch;
-  ll_t* yout;              // cells [ks][Tp][ypitch] (null: no cell output)
-  float* yplain;           // plain floats [Cout][plain_T] for later kernels (null: none)
-  // PS_EPI_SPLINE (ConvFlow.proj + spline inverse) and flow layer 0 of PK_DDS
-  const ll_t* z;           // z cells [2][Tp]
-  ll_t* zout;              // zinit / PS_EPI_SPLINE: z cells out (null for the last flow)
-  int z_row;               // row of z that conditions (x0); the spline acts on 1 - z_row
-  int last, ea_row;        // last flow: write logw = ElementwiseAffine^-1(z[ea_row]) (modules.py:293-295)
-  // ---- column steps: C channels (threads), per-channel parameter vectors par[k] (prefetched: value k of thread tid is
-  //      par[k][min((tid & pmask) + padd[k], plen - 1)])
-  int C, pmask, plen;
-  int padd[8];
-  const float* par[8];
-  // PK_DDS: x_in = (xin + gelu(LN(y2; par0, par1))) * mask   [fin 0: xin * mask; fin 2: par0 * z + par1 + xin]
-  //         b    = gelu(LN(depthwise3(x_in; par3..5, par2, dil); par6, par7))          (dw != 0)
-  int dil, dw, fin;
-  const ll_t* xin; const ll_t* y2;   // [Tp][C]
-  ll_t* xout;              // x_in column
-  ll_t* bout;              // b column (dw != 0)
-  // PK_LN: v = par2 (bias) + sum_{k < np} part[k][t][c] + res[t][c] ; out = (LN(v; par0, par1) + par3 (per-item vector) + base[t][c]) * mask
-  //        (ln == 0: out = (v + base) * mask: the plain sum of K-slices)
-  int np, ln;
-  const ll_t* part; long long part_stride;   // cells [np][Tp][C]
-  const ll_t* base;        // residual base added AFTER the norm (flow: h + pre_transformer(h)) or null
-  // PK_EMB: out = emb[ids[t]][c] * scale * mask (+ par3)        (models.py:318-322)
-  const float* emb; float scale; int n_vocab;   // (the ids come with the call: PCall::ids)
-  // PK_ATT: block (head, query tile, key tile) of softmax(q k^T / sqrt(dk) + rel_k) (v + rel_v): partial (O, m, l) cells
-  //         (par0/1 = E_k[tid], E_k[tid + 512]; par2/3 = E_v likewise)
-  // PK_MERGE: column t: out[h*dk + d] = sum_b e^(m_b - M) O_b / sum_b e^(m_b - M) l_b
-  int nh, dk, W;           // heads, head dimension, relative-position window (0: no relative terms)
-  const ll_t* qkv;         // cells [Tp][3*nh*dk]: q | k | v
-  ll_t* ap;                // partial cells [key tile][Tp][nh][dk + 2]
-  // PK_COUPLE: new z (Flip folded): out[r] = u[2H-1-r] (r < H) ; out[H + r] = (u[H-1-r] - (par2[r] + sum_k part[k][t][r])) * mask
-  const ll_t* u; const float* u_plain;  // previous z: cells [Tp][2H] or plain floats [2H][plain_T]
-  int H;
-  // common outputs of column steps
-  ll_t* out;               // cells [Tp][C] (null: none)
-  float* oplain;           // plain floats [C][plain_T] (null: none)
+enum { PK_IDLE = 0, PK_MM = 1, PK_DDS = 2, PK_LN = 3, PK_EMB = 4, PK_ATT = 5, PK_MERGE = 6, PK_COUPLE = 7 };
+// flags (record dword 0, bits 8..)
+enum {
+  PF_RELU = 1 << 8, PF_INMASK = 1 << 9, PF_OUTMASK = 1 << 10, PF_GATE = 1 << 11, PF_SPLINE = 1 << 12, PF_ZINIT = 1 << 13, PF_LAST = 1 << 14,
+  PF_PLAIN_IN = 1 << 15,   // PK_MM: operand = plain floats [channels][pT]; PK_COUPLE: previous z = plain floats
+  PF_DW = 1 << 16, PF_FIN_LN = 1 << 17, PF_FIN_PRE = 1 << 18,  // PK_DDS
+  PF_LN = 1 << 19,         // PK_LN: normalise (else: plain sum)
 };
 
+// One work item of one worker in one step, resolved on the host (persist_plan.hip.h): 32 dwords.
+//   dword 0      kind | flags
+//   dwords 1..3  a1..a3 (kind-specific integers)
+//   dwords 4..23 p0..p9 (pointers; p6 = weight fragments, p7 = bias, p8 = per-item bias / vector, p9 = packed per-thread parameters:
+//                these four are valid in EVERY record -- zeros when unused -- so that the prefetch is straight-line code)
+//   dwords 24..31 b0..b7 (kind-specific integers)
+// PK_MM    a1 = Cs | K << 16 ; a2 = cell pitch of the operand * channel direction (signed; plain operands: +-1); a3 = t0 (first window column)
+//          p0 operand (cells: (column 0, LOWEST channel of the slice); plain: the row of the slice's first channel),
+//          p1 yout tile (cell (n0, first row)), p2 yplain (first row, column n0), p3 res tile, p4 z, p5 zout
+//          b0 = n_u | nblk << 16; b1 = floats between consecutive row blocks of the weights; b2 = ypitch; b3 = rows left (Cout - first row);
+//          b4 = pT; b5 = rpitch; b6 = n0 | z_row << 16 | ea_row << 20; b7 = gate_H
+// PK_DDS   a1 = C | dil << 16; a2 = t; p0 xin, p1 y2, p2 z row, p3 xout, p4 bout
+// PK_LN    a1 = C; a2 = t; a3 = np; p0 part, p1 res, p2 base, p3 out, p4 oplain; b0/b1 = part stride (cells, 64 bit); b4 = pT
+// PK_EMB   a1 = C; a2 = t; p0 emb, p3 out, p4 oplain; b0 = scale (float bits); b1 = n_vocab; b4 = pT
+// PK_ATT   a1 = dk | nh << 8 | W << 16; a2 = i0 | j0 << 16; a3 = head | key tile << 8; p0 qkv, p1 ap
+// PK_MERGE a1 = C; a2 = t; a3 = dk | nh << 8; p0 ap, p3 out; b0 = cells per key tile
+// PK_COUPLE a1 = C (= 2H); a2 = t; a3 = np | H << 16; p0 part, p1 u cells, p2 u plain, p3 out, p4 oplain; b0/b1 = part stride; b4 = pT
+struct alignas(16) PRec {
+  int kf, a1, a2, a3;
+  unsigned long long p[10];
+  int b[8];
+};
+static_assert(sizeof(PRec) == 128, "PRec is 32 dwords");
+
 struct PProgram {
-  int n_steps, T, Tp, ntn;
+  int n_steps, T, Tp, P;
   int nb; float bound, inv_sqrt_d;      // spline
   const int* len;
   const float* ea_m; const float* ea_logs;
   float* logw;                          // duration predictor result [T] (plain floats)
   int* err;
-  PStep steps[PS_MAX_STEPS];
+  const PRec* recs;                     // [n_steps][P]
 };
 
 struct PCall {                          // per-call values (by value: a captured graph re-reads `dv`, not these, when dv != null)
@@ -147,8 +116,6 @@ struct PCall {                          // per-call values (by value: a captured
   long long* trace;                     // tools only (VITS_PS_TRACE): [P][PS_MAX_STEPS][8] cycle stamps, null in production
 };
 
-// Pointers of the step program come out of LDS as generic ("flat") per-lane values: make them what they are -- wave-uniform
-// GLOBAL pointers -- so that loads become global_load instead of flat_load on per-lane 64-bit addresses.
 #define PS_G __attribute__((address_space(1)))
 __device__ __forceinline__ ll_t ll_pack(float v, unsigned e) { return ((ll_t)e << 32) | (ll_t)__float_as_uint(v); }
 __device__ __forceinline__ void ll_store(PS_G ll_t* p, float v, unsigned e) {
@@ -162,13 +129,12 @@ __device__ __forceinline__ ll_t ll_load_off(const PS_G ll_t* base, unsigned byte
 }
 __device__ __forceinline__ float ll_val(ll_t q) { return __uint_as_float((unsigned)q); }
 __device__ __forceinline__ unsigned ll_bad(ll_t q, unsigned epoch) { return (unsigned)(q >> 32) ^ epoch; }
-__device__ __forceinline__ int ps_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <typename T>
-__device__ __forceinline__ PS_G T* ps_unip(T* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (PS_G T*)(((unsigned long long)hi << 32) | lo);
-}
+
+// a record lives in 4 VGPRs (dwordx4 of lanes 0..7); fields are read with v_readlane (wave-uniform results in SGPRs)
+typedef int ps_i4 __attribute__((ext_vector_type(4)));
+#define PR_I(rv, i) __builtin_amdgcn_readlane((rv)[(i) & 3], (i) >> 2)
+#define PR_P(T, rv, k) ((PS_G T*)(((unsigned long long)(unsigned)PR_I(rv, 5 + 2 * (k)) << 32) | (unsigned long long)(unsigned)PR_I(rv, 4 + 2 * (k))))
+#define PR_B(rv, k) PR_I(rv, 24 + (k))
 
 // time-only experiment switches for tools/ab_build.sh (results are garbage): -DPS_EXP_NOGELU, -DPS_EXP_NOPOLL
 #ifdef PS_EXP_NOGELU
@@ -244,75 +210,43 @@ __device__ __forceinline__ void ps_half_sum2(float& a, float& b, float* red, int
   b = (red[8 + w0] + red[8 + w0 + 1]) + (red[8 + w0 + 2] + red[8 + w0 + 3]);
 }
 
-// ---- what a worker requests one step ahead (registers; straight-line, see PStep)
+// ---- what a worker requests one step ahead (registers; straight-line: a load behind a branch makes hipcc wait for it at the join,
+//      i.e. puts a cold round trip in the middle of a step)
 struct PsPre {
   f32x4 a[PS_MAXU];   // weight fragments of the first 16-row block: tap units u = wave + PS_WAVES * i
-  float par[8];       // per-channel parameters of a column step / table values of an attention step
-  float eb0, eb1, ec0, ec1;  // epilogue operands of thread tid < 256 (bias, per-item bias; second pair: the sigmoid row of a gate)
+  f32x4 pk0, pk1;     // packed per-thread parameters: 8 floats of row (tid & 255) -- attention: row tid of the table pack
+  float eb0, eb1, ec0, ec1;  // epilogue operands of thread tid < 256 (bias, per-item bias / vector; second pair: the sigmoid row of a gate)
 };
-// matrix-step item: item = (slice * G + g) * ntn + j
-struct PsItem { int j, g, slice; };
-__device__ __forceinline__ PsItem ps_item(const PStep& st, int item, int ntn) {
-  const int G = ps_uni(st.G);
-  PsItem it;
-  it.j = item % ntn;
-  const int q = item / ntn;
-  it.g = q % G;
-  it.slice = q / G;
-  return it;
-}
-__device__ __forceinline__ void ps_load_weights(const PStep& st, int mb, int slice, int wave, int lane, f32x4 (&a)[PS_MAXU]) {
-  const int n_u = (ps_uni(st.Cin) >> 4) * ps_uni(st.K), ks = ps_uni(st.ks);
-  const PS_G f32x4* wp = (const PS_G f32x4*)ps_unip(st.w16) + ((size_t)mb * ks + slice) * n_u * 64 + lane;
+__device__ __forceinline__ void ps_load_weights(const PS_G float* w, int n_u, int wave, int lane, f32x4 (&a)[PS_MAXU]) {
+  const PS_G f32x4* wp = (const PS_G f32x4*)w + lane;
 #pragma unroll
   for (int i = 0; i < PS_MAXU; ++i) {
     const int u = wave + PS_WAVES * i;
     a[i] = wp[(size_t)(u < n_u ? u : n_u - 1) * 64];
   }
 }
-__device__ __forceinline__ void ps_load_bias(const PStep& st, int mb, int tid, float& eb0, float& eb1, float& ec0, float& ec1) {
-  const int blen = ps_uni(st.blen), gate = ps_uni(st.epi) == PS_EPI_GATE, gH = ps_uni(st.gate_H);
-  int i0 = gate ? mb * 8 + (tid & 7) : mb * 16 + (tid & 15);
-  int i1 = gate ? gH + i0 : i0;
-  i0 = i0 < blen ? i0 : blen - 1;
-  i1 = i1 < blen ? i1 : blen - 1;
-  const PS_G float* b = ps_unip(st.bias);
-  const PS_G float* c = ps_unip(st.cond);
-  eb0 = b[i0]; eb1 = b[i1]; ec0 = c[i0]; ec1 = c[i1];
-}
-__device__ __forceinline__ void ps_prefetch(const PStep& st, int rank, int ntn, int tid, int wave, int lane, PsPre& r) {
-  const int plen = ps_uni(st.plen), pm = ps_uni(st.pmask);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int i = (tid & pm) + ps_uni(st.padd[k]);
-    i = i < 0 ? 0 : (i < plen ? i : plen - 1);
-    r.par[k] = ps_unip(st.par[k])[i];
+// epilogue operand indices of thread tid relative to the record's bias / vector pointers
+__device__ __forceinline__ void ps_epi_idx(int kf, int rows_left, int gate_H, int tid, int blk, int& i0, int& i1) {
+  if (kf & PF_GATE) { i0 = blk * 8 + (tid & 7); i1 = gate_H + i0; }   // [8 tanh | 8 sigmoid] rows of channels 8 * mb + ch
+  else {
+    i0 = blk * 16 + (tid & 15);
+    i0 = i0 < rows_left ? i0 : rows_left - 1;
+    i1 = i0;
   }
-  const PsItem it = ps_item(st, rank, ntn);
-  const int n_mb = ps_uni(st.n_mb), ks = ps_uni(st.ks);
-  int mb0 = it.g * ps_uni(st.mbg);
-  mb0 = mb0 < n_mb ? mb0 : n_mb - 1;
-  const int sl = it.slice < ks ? it.slice : ks - 1;
-  ps_load_bias(st, mb0, tid, r.eb0, r.eb1, r.ec0, r.ec1);
-  ps_load_weights(st, mb0, sl, wave, lane, r.a);
 }
-
-// A step descriptor from the LDS copy of the program into SCALAR registers, in one batch: read field by field at its point of use every
-// ps_uni(st.x) was an LDS round trip + s_waitcnt of its own -- ~60 per matrix step, measured +8 k cycles per step.  (The compiler
-// spills what does not fit the SGPR file into VGPR lanes: v_readlane, a few cycles.)
-__device__ __forceinline__ void ps_load_step(PStep& dst, const PStep* src) {
-  constexpr int NW = (int)(sizeof(PStep) / 4);
-  static_assert(sizeof(PStep) % 16 == 0, "PStep is read as dwordx4");
-  const int4* s4 = reinterpret_cast<const int4*>(src);
-  int tmp[NW];
-#pragma unroll
-  for (int i = 0; i < NW / 4; ++i) {
-    const int4 v = s4[i];
-    tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w;
-  }
-#pragma unroll
-  for (int i = 0; i < NW; ++i) tmp[i] = __builtin_amdgcn_readfirstlane(tmp[i]);
-  __builtin_memcpy(&dst, tmp, sizeof(PStep));
+__device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, int lane, PsPre& pre) {
+  const int kf = PR_I(r, 0), kind = kf & 0xff;
+  const PS_G f32x4* pk = PR_P(const f32x4, r, 9);
+  const int row = tid & (kind == PK_ATT ? 511 : 255);
+  pre.pk0 = pk[row * 2];
+  pre.pk1 = pk[row * 2 + 1];
+  int i0, i1;
+  if (kind == PK_MM) ps_epi_idx(kf, PR_B(r, 3), PR_B(r, 7), tid, 0, i0, i1);
+  else { const int C = PR_I(r, 1) & 0xffff; i0 = tid & 255; i0 = i0 < C ? i0 : C - 1; i0 = i0 < 0 ? 0 : i0; i1 = i0; }
+  const PS_G float* b = PR_P(const float, r, 7);
+  const PS_G float* c = PR_P(const float, r, 8);
+  pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
+  ps_load_weights(PR_P(const float, r, 6), kind == PK_MM ? (PR_B(r, 0) & 0xffff) : 1, wave, lane, pre.a);
 }
 
 #define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -321,56 +255,41 @@ __device__ __forceinline__ void ps_load_step(PStep& dst, const PStep* src) {
 // the two relative-position tables alias the operand window, scores / probabilities alias the partial tiles.
 #define PS_LDS_TILE (3 * 16 * (PS_DKP + 1) + 2 * 9 * PS_DKP)   // >= PS_MAXC * PS_TP
 #define PS_LDS_MRED (PS_WAVES * 256)
-#define PS_LDS_FLOATS (PS_LDS_TILE + PS_LDS_MRED + 32 * 16 + 3 * PS_MAXC + 4 * 16)
 static_assert(PS_LDS_TILE >= PS_MAXC * PS_TP, "operand window does not fit");
 
 __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __restrict__ prog, const PCall call) {
-  extern __shared__ __attribute__((aligned(16))) int ps_dyn[];  // the program (up to its last step), then the float buffers
-  __shared__ unsigned s_epoch;
-  __shared__ int s_nsteps;
+  __shared__ float tile[PS_LDS_TILE];      // MFMA operand window [C_in][16 + taps - 1] (pitch 21) / attention tiles
+  __shared__ float mred[PS_LDS_MRED];      // partial tiles of the 8 waves / attention scores
+  __shared__ float hb[32 * 16];            // ConvFlow.proj output of the tile (spline parameters)
+  __shared__ float xs[3 * PS_MAXC];        // column steps: x_in at t - d, t, t + d
+  __shared__ float red[4 * 16];            // block reductions (one 16-float scratch per call site)
   const int tid0 = threadIdx.x;
-  const int wave = ps_uni(tid0 >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int rank = blockIdx.x, P = gridDim.x;
-  if (tid0 == 0) {
-    s_nsteps = prog->n_steps;
-    unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    s_epoch = e ? e : 1u;  // 0 marks "never written"
-  }
-  __syncthreads();
-  const int prog_words = (int)((sizeof(PProgram) - (size_t)(PS_MAX_STEPS - s_nsteps) * sizeof(PStep)) / 4);
-  {
-    const int* src = reinterpret_cast<const int*>(prog);
-    for (int i = tid0; i < prog_words; i += PS_THREADS) ps_dyn[i] = src[i];
-  }
-  __syncthreads();
-  const PProgram& sp = *reinterpret_cast<const PProgram*>(ps_dyn);
-  float* fl = reinterpret_cast<float*>(ps_dyn + ((prog_words + 3) & ~3));
-  float* tile = fl;                         // MFMA operand window [C_in][16 + taps - 1] (pitch 21)
-  float* mred = tile + PS_LDS_TILE;         // partial tiles of the 8 waves
-  float* hb = mred + PS_LDS_MRED;           // ConvFlow.proj output of the tile (spline parameters)
-  float* xs = hb + 32 * 16;                 // column steps: x_in at t - d, t, t + d
-  float* red = xs + 3 * PS_MAXC;            // block reductions (one 16-float scratch per call site)
+  const int n_steps = prog->n_steps, T = prog->T, Tp = prog->Tp;
+  const PS_G PRec* recs = (const PS_G PRec*)prog->recs;
+  // record of step s for this worker: lanes 0..7 read its eight dwordx4 (the other lanes read along: same lines)
+  auto load_rec = [&](int s) -> ps_i4 {
+    const PS_G ps_i4* p = (const PS_G ps_i4*)(recs + ((size_t)(s < n_steps ? s : n_steps - 1) * P + rank));
+    return p[tid0 & 7];
+  };
+  ps_i4 rvA = load_rec(0), rvB = load_rec(1);
   PsCtx cx;
-  cx.epoch = s_epoch; cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl;
+  {
+    unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    cx.epoch = __builtin_amdgcn_readfirstlane(e ? e : 1u);  // 0 marks "never written"
+  }
+  cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl;
   const unsigned epoch = cx.epoch;
-  const int n_steps = ps_uni(sp.n_steps), T = ps_uni(sp.T), Tp = ps_uni(sp.Tp), ntn = ps_uni(sp.ntn);
   int len_raw;
   {
     int zero = 0;
     asm volatile("" : "+v"(zero));
-    len_raw = ps_unip(sp.len)[zero];  // vector load (stays off the scalar counter), first used in step 0
+    len_raw = ((const PS_G int*)prog->len)[zero];  // vector load (stays off the scalar counter), first used in step 0
   }
-  const float ea_m = ps_unip(sp.ea_m)[0], ea_is = expf(-ps_unip(sp.ea_logs)[0]);  // requested now, used by the very last epilogue
+  const float ea_m = ((const PS_G float*)prog->ea_m)[0], ea_is = expf(-((const PS_G float*)prog->ea_logs)[0]);  // used by the very last epilogue
   PsPre pre;
   bool prefetched = false;
-
-  // work items of a step: column steps: columns; matrix steps: (column tile, row-block group, K-slice); attention: blocks
-  auto n_items = [&](const PStep& st) -> int {
-    const int kind = ps_uni(st.kind);
-    if (kind == PK_MM) return ntn * ps_uni(st.G) * ps_uni(st.ks);
-    if (kind == PK_ATT) return ps_uni(st.nh) * ntn * ntn;
-    return Tp;
-  };
 
   for (int s = 0; s < n_steps; ++s) {
     // (opaque per step: every per-thread index below derives from this copy, so that the compiler does not hoist the address
@@ -378,43 +297,44 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    PStep st, nx;
-    ps_load_step(st, &sp.steps[s]);
-    ps_load_step(nx, &sp.steps[s + 1 < n_steps ? s + 1 : s]);
-    const long long t_desc = call.trace ? __builtin_readcyclecounter() : 0;
-    const int kind = ps_uni(st.kind);
-    const int items = n_items(st);
-    if (rank >= items) { prefetched = false; continue; }  // idle in this step: nothing to wait for
-    if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + 0] = t_desc;
-    if (!prefetched) ps_prefetch(st, rank, ntn, tid, wave, lane, pre);
+    const ps_i4 rv = rvA, r1 = rvB;
+    rvA = rvB;
+    const int kf = PR_I(rv, 0), kind = kf & 0xff;
+    if (kind == PK_IDLE) {  // nothing to do and nothing to wait for in this step
+      rvB = load_rec(s + 2);
+      prefetched = false;
+      continue;
+    }
+    PS_STAMP(0);
+    if (!prefetched) ps_prefetch(rv, tid, wave, lane, pre);
     prefetched = false;
     __syncthreads();  // the previous step's readers of the LDS buffers are done
     const int L = len_raw < T ? len_raw : T;
 
     if (kind == PK_DDS) {
       // ================================================================== DDSConv column step
-      const int D = ps_uni(st.C), dw = ps_uni(st.dw), d = ps_uni(st.dil), fin = ps_uni(st.fin);
+      const int D = PR_I(rv, 1) & 0xffff, d = PR_I(rv, 1) >> 16, t = PR_I(rv, 2);
+      const bool dw = (kf & PF_DW) != 0;
       const float invD = 1.0f / (float)D;
-      const PS_G ll_t* xin = ps_unip(st.xin);
-      const PS_G ll_t* y2 = fin == 1 ? ps_unip(st.y2) : nullptr;
-      const PS_G ll_t* zc = fin == 2 ? ps_unip(st.z) + (long long)ps_uni(st.z_row) * Tp : nullptr;
-      PS_G ll_t* xout = ps_unip(st.xout);
-      PS_G ll_t* bout = ps_unip(st.bout);
-      float par[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) par[k] = pre.par[k];
+      const PS_G ll_t* xin = PR_P(const ll_t, rv, 0);
+      const PS_G ll_t* y2 = (kf & PF_FIN_LN) ? PR_P(const ll_t, rv, 1) : nullptr;
+      const PS_G ll_t* zc = (kf & PF_FIN_PRE) ? PR_P(const ll_t, rv, 2) : nullptr;
+      PS_G ll_t* xout = PR_P(ll_t, rv, 3);
+      PS_G ll_t* bout = PR_P(ll_t, rv, 4);
+      const float par[8] = {pre.pk0[0], pre.pk0[1], pre.pk0[2], pre.pk0[3], pre.pk1[0], pre.pk1[1], pre.pk1[2], pre.pk1[3]};
       // the next step's operands fly under this step (in-order vmcnt: they are older than every poll of the next step)
-      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      ps_prefetch(r1, tid, wave, lane, pre);
+      rvB = load_rec(s + 2);
       prefetched = true;
       const int c = tid & 255, h = tid >> 8;
       const bool cok = c < D;
-      for (int t = rank; t < Tp; t += P) {
-        if (t != rank) __syncthreads();
+      {
         if (t >= L) {  // padding column (worker-uniform): zeros, nothing to wait for
           if (h == 1 && cok) {
             ll_store(xout + (long long)t * D + c, 0.f, epoch);
-            if (bout) ll_store(bout + (long long)t * D + c, 0.f, epoch);
+            if (dw) ll_store(bout + (long long)t * D + c, 0.f, epoch);
           }
+          PS_STAMP(3);
           continue;
         }
         // slots of this thread: half 1 -> column t; half 0 -> columns t - d and t + d (depthwise steps only)
@@ -485,16 +405,17 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     if (kind == PK_MERGE) {
       // ================================================================== attention merge, column t:
       // out = sum_b w_b O_b / sum_b w_b l_b, w_b = e^(m_b - max m) over the key tiles b; thread = (d = tid & 127, head = tid >> 7)
-      const int C = ps_uni(st.C), nh = ps_uni(st.nh), dk = ps_uni(st.dk), dk2 = dk + 2;
-      PS_G ll_t* out = ps_unip(st.out);
-      const PS_G ll_t* ap = ps_unip(st.ap);
-      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      const int C = PR_I(rv, 1), t = PR_I(rv, 2), dk = PR_I(rv, 3) & 0xff, nh = PR_I(rv, 3) >> 8, dk2 = dk + 2;
+      const PS_G ll_t* ap = PR_P(const ll_t, rv, 0);
+      PS_G ll_t* out = PR_P(ll_t, rv, 3);
+      ps_prefetch(r1, tid, wave, lane, pre);
+      rvB = load_rec(s + 2);
       prefetched = true;
       const int d = tid & (PS_DKP - 1), hd = tid >> 7;
       const bool ok = d < dk && hd < nh;
       const int nkt = (L + 15) >> 4;
-      const long long kstr = (long long)Tp * nh * dk2;
-      for (int t = rank; t < Tp; t += P) {
+      const long long kstr = PR_B(rv, 0);
+      {
         float r = 0.f;
         if (t < L) {
           float M = -3.0e38f, num = 0.f, den = 0.f;
@@ -544,31 +465,29 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
 
     if (kind == PK_LN || kind == PK_EMB || kind == PK_COUPLE) {
       // ================================================================== LayerNorm / embedding / coupling tail, column t
-      const int C = ps_uni(st.C), pT = ps_uni(st.plain_T);
-      PS_G ll_t* out = ps_unip(st.out);
-      PS_G float* oplain = ps_unip(st.oplain);
-      float par[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) par[k] = pre.par[k];
-      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      const int C = PR_I(rv, 1) & 0xffff, t = PR_I(rv, 2), pT = PR_B(rv, 4);
+      PS_G ll_t* out = PR_P(ll_t, rv, 3);
+      PS_G float* oplain = PR_P(float, rv, 4);
+      const float par[4] = {pre.pk0[0], pre.pk0[1], pre.pk0[2], pre.ec0};  // g, b, bias, per-item vector
+      ps_prefetch(r1, tid, wave, lane, pre);
+      rvB = load_rec(s + 2);
       prefetched = true;
       const int c = tid & 255, h = tid >> 8;
       const bool cok = c < C && h == 0;  // one column per worker: the channel threads of half 0
-      for (int t = rank; t < Tp; t += P) {
-        if (t != rank) __syncthreads();
+      {
         float o = 0.f;
         if (t < L) {  // (worker-uniform) padding columns: zeros, nothing to wait for
           if (kind == PK_EMB) {
             // x = emb[id] * sqrt(H) (+ the speaker vector when the first layer is the conditioned one)   (models.py:318-322)
             long long id = call.ids[t];
-            if (id < 0 || id >= ps_uni(st.n_vocab)) { if (tid == 0) atomicOr((int*)sp.err, 1); id = 0; }
-            if (cok) o = ps_unip(st.emb)[id * C + c] * st.scale + par[3];
+            if (id < 0 || id >= PR_B(rv, 1)) { if (tid == 0) atomicOr((int*)prog->err, 1); id = 0; }
+            if (cok) o = PR_P(const float, rv, 0)[id * C + c] * __int_as_float(PR_B(rv, 0)) + par[3];
           } else if (kind == PK_LN) {
-            const int np = ps_uni(st.np);
-            const PS_G ll_t* part = ps_unip(st.part);
-            const PS_G ll_t* res = ps_unip(st.res);
-            const PS_G ll_t* base = ps_unip(st.base);
-            const long long pstr = st.part_stride;
+            const int np = PR_I(rv, 3);
+            const PS_G ll_t* part = PR_P(const ll_t, rv, 0);
+            const PS_G ll_t* res = PR_P(const ll_t, rv, 1);
+            const PS_G ll_t* base = PR_P(const ll_t, rv, 2);
+            const long long pstr = ((long long)(unsigned)PR_B(rv, 1) << 32) | (unsigned)PR_B(rv, 0);
             float v = par[2], bs = 0.f;
             {
               unsigned o0 = (unsigned)(t * C + c) * 8u;
@@ -597,7 +516,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
               } while (ps_again(cx, pending));
             }
             PS_STAMP(1);
-            if (ps_uni(st.ln)) {
+            if (kf & PF_LN) {
               const float invC = 1.0f / (float)C;
               float m = cok ? v : 0.f, dummy = 0.f;
               ps_half_sum2(m, dummy, red, wave, lane);
@@ -611,11 +530,11 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             }
           } else {
             // new z = cat(x0, (x1 - m) * mask) with the following Flip folded in (models.py:390-392, modules.py:270-277)
-            const int H = ps_uni(st.H), np = ps_uni(st.np);
-            const PS_G ll_t* part = ps_unip(st.part);
-            const PS_G ll_t* u = ps_unip(st.u);
-            const PS_G float* up = ps_unip(st.u_plain);
-            const long long pstr = st.part_stride;
+            const int np = PR_I(rv, 3) & 0xffff, H = PR_I(rv, 3) >> 16;
+            const PS_G ll_t* part = PR_P(const ll_t, rv, 0);
+            const PS_G ll_t* u = PR_P(const ll_t, rv, 1);
+            const PS_G float* up = (kf & PF_PLAIN_IN) ? PR_P(const float, rv, 2) : nullptr;
+            const long long pstr = ((long long)(unsigned)PR_B(rv, 1) << 32) | (unsigned)PR_B(rv, 0);
             const int r = c < H ? c : c - H;               // c < H: copy of x0 ; else row r of the transformed half
             const int src = c < H ? 2 * H - 1 - c : H - 1 - r;
             float uv = 0.f, mv = 0.f;
@@ -661,9 +580,10 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       // ================================================================== attention block (head, query tile, key tile)
       // s_ij = q~_i . k_j (+ q~_i . E_k[j - i + W] inside the band) ; p_ij = exp(s_ij - m_i) ; O_i = sum_j p_ij (v_j + E_v[j - i + W])
       // (attentions.py:165-260 in the exact banded form of relpos_attention_kernel); partial (O, m, l) per block, merged by PK_MERGE
-      const int nh = ps_uni(st.nh), dk = ps_uni(st.dk), W = ps_uni(st.W), dk2 = dk + 2, H3 = 3 * nh * dk;
-      const PS_G ll_t* qkv = ps_unip(st.qkv);
-      PS_G ll_t* ap = ps_unip(st.ap);
+      const int dk = PR_I(rv, 1) & 0xff, nh = (PR_I(rv, 1) >> 8) & 0xff, W = PR_I(rv, 1) >> 16, dk2 = dk + 2, H3 = 3 * nh * dk;
+      const int i0 = PR_I(rv, 2) & 0xffff, j0 = PR_I(rv, 2) >> 16, hd = PR_I(rv, 3) & 0xff, kt = PR_I(rv, 3) >> 8;
+      const PS_G ll_t* qkv = PR_P(const ll_t, rv, 0);
+      PS_G ll_t* ap = PR_P(ll_t, rv, 1);
       float* Qs = tile;                  // [16][dk + 1]
       float* Ks = Qs + 16 * (PS_DKP + 1);
       float* Vs = Ks + 16 * (PS_DKP + 1);
@@ -671,15 +591,13 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       float* Ev = Ek + 9 * PS_DKP;
       float* Ss = mred;                  // [2][16][17] partial dot products of the two d-halves, then [16][17] probabilities
       const int dkp = dk + 1;
-      const float tb0 = pre.par[0], tb1 = pre.par[1], tb2 = pre.par[2], tb3 = pre.par[3];  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]
-      ps_prefetch(nx, rank, ntn, tid, wave, lane, pre);
+      const float tb0 = pre.pk0[0], tb1 = pre.pk0[1], tb2 = pre.pk0[2], tb3 = pre.pk0[3];  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]
+      ps_prefetch(r1, tid, wave, lane, pre);
+      rvB = load_rec(s + 2);
       prefetched = true;
       const float scale = 1.0f / sqrtf((float)dk);
-      for (int item = rank; item < items; item += P) {
-        if (item != rank) __syncthreads();
-        const int kt = item % ntn, qt = (item / ntn) % ntn, hd = item / (ntn * ntn);
-        const int i0 = qt * 16, j0 = kt * 16;
-        if (i0 >= L || j0 >= L) continue;  // nothing to compute: the merge step never looks at these blocks
+      {
+        if (i0 >= L || j0 >= L) { PS_STAMP(3); continue; }  // nothing to compute: the merge step never looks at these blocks
         if (W > 0) {
           const int tab = (2 * W + 1) * dk;
           if (tid < tab) { Ek[tid] = tb0; Ev[tid] = tb2; }
@@ -796,44 +714,39 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     }
 
     // ==================================================================== matrix step
-    const int Cin = ps_uni(st.Cin), Cout = ps_uni(st.Cout), n_mb = ps_uni(st.n_mb), mbg = ps_uni(st.mbg), epi = ps_uni(st.epi);
-    const int K = ps_uni(st.K), ROW = 16 + K - 1, pad = ps_uni(st.pad), pT = ps_uni(st.plain_T);
-    const int n_u = (Cin >> 4) * K;
-    for (int item = rank; item < items; item += P) {
-      const PsItem it = ps_item(st, item, ntn);
-      const int n0 = it.j * 16, mb0 = it.g * mbg;
-      if (item != rank) {
-        __syncthreads();
-        ps_load_bias(st, mb0, tid, pre.eb0, pre.eb1, pre.ec0, pre.ec1);
-        ps_load_weights(st, mb0, it.slice, wave, lane, pre.a);
-      }
+    {
+      const int Cin = PR_I(rv, 1) & 0xffff, K = (PR_I(rv, 1) >> 16) & 0xf, ROW = 16 + K - 1;
+      const int cps = PR_I(rv, 2), t0w = PR_I(rv, 3);
+      const int n_u = PR_B(rv, 0) & 0xffff, nblk = PR_B(rv, 0) >> 16, wstride = PR_B(rv, 1), ypitch = PR_B(rv, 2), rows_left = PR_B(rv, 3);
+      const int pT = PR_B(rv, 4), n0 = PR_B(rv, 6) & 0xffff, gate_H = PR_B(rv, 7);
       // ---- operand window [Cin][ROW] -> LDS (transposed: cells are column-major); thread = (channel c = tid & 255, columns 2 k + (tid >> 8))
       {
         const int c = tid & 255, jh = tid >> 8;
         const bool cok = c < Cin;
-        const int ch = ps_uni(st.c_off) + ps_uni(st.c_sign) * (it.slice * Cin + (cok ? c : 0));
-        const int lim = ps_uni(st.in_mask) ? L : Tp;
+        const int lim = (kf & PF_INMASK) ? L : Tp;
         constexpr int NG = PS_MAXROW / 2;
         float v[NG];
         bool need[NG];
-        const PS_G float* bp = ps_unip(st.bin_plain);
-        if (bp) {
-          // plain floats [channels][plain_T] written by an earlier kernel
+        if (kf & PF_PLAIN_IN) {
+          // plain floats [channels][pT] written by an earlier kernel; cps = +-1 (channel direction)
+          const PS_G float* bp = PR_P(const float, rv, 0);
+          const int limp = lim < pT ? lim : pT;
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
-            const int jj = 2 * k + jh, t = n0 - pad + jj;
-            need[k] = cok && jj < ROW && t >= 0 && t < (lim < pT ? lim : pT);
-            v[k] = bp[(long long)ch * pT + (need[k] ? t : 0)];
+            const int jj = 2 * k + jh, t = t0w + jj;
+            need[k] = cok && jj < ROW && t >= 0 && t < limp;
+            v[k] = bp[(long long)(cok ? c : 0) * cps * pT + (need[k] ? t : 0)];
           }
         } else {
-          const PS_G ll_t* bin = ps_unip(st.bin);
-          const int cp = ps_uni(st.cin_pitch);
+          const PS_G ll_t* bin = PR_P(const ll_t, rv, 0);
+          const int acp = cps < 0 ? -cps : cps;
+          const int cc = cok ? (cps < 0 ? Cin - 1 - c : c) : 0;  // (negative direction: the record's base points at the slice's LOWEST channel)
           unsigned off[NG];
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
-            const int jj = 2 * k + jh, t = n0 - pad + jj;
+            const int jj = 2 * k + jh, t = t0w + jj;
             need[k] = cok && jj < ROW && t >= 0 && t < lim;
-            off[k] = (unsigned)((need[k] ? t : 0) * cp + ch) * 8u;
+            off[k] = (unsigned)((need[k] ? t : 0) * acp + cc) * 8u;
           }
           bool pending;
           do {
@@ -862,19 +775,24 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
 
       // ---- MFMA tiles of this item's 16-row blocks + epilogues
       const float* bl = tile + (lane >> 4) * PS_TP + (lane & 15);
-      for (int mi = 0; mi < mbg; ++mi) {
-        const int mb = mb0 + mi;
-        if (mb >= n_mb) break;
+      const PS_G float* wbase = PR_P(const float, rv, 6);
+      for (int mi = 0; mi < nblk; ++mi) {
         if (mi > 0) {
           __syncthreads();  // mred of the previous block has been read
-          ps_load_bias(st, mb, tid, pre.eb0, pre.eb1, pre.ec0, pre.ec1);
-          ps_load_weights(st, mb, it.slice, wave, lane, pre.a);
+          int i0, i1;
+          ps_epi_idx(kf, rows_left, gate_H, tid, mi, i0, i1);
+          const PS_G float* b = PR_P(const float, rv, 7);
+          const PS_G float* c = PR_P(const float, rv, 8);
+          pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
+          ps_load_weights(wbase + (size_t)mi * wstride, n_u, wave, lane, pre.a);
         }
         const float eb0 = pre.eb0, eb1 = pre.eb1, ec0 = pre.ec0, ec1 = pre.ec1;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         {
-          int uc = wave / K, uk = wave - uc * K;
-          const int step_c = PS_WAVES / K, step_k = PS_WAVES - step_c * K;
+          // unit u = chunk * K + tap for u = wave + 8 i: (chunk, tap) advance by (8 / K, 8 % K); K in {1, 3, 5} without a division
+          const int kmul = K == 1 ? 64 : (K == 3 ? 22 : (K == 5 ? 13 : 0));
+          int uc = kmul ? (wave * kmul) >> 6 : wave / K, uk = wave - uc * K;
+          const int step_c = kmul ? (PS_WAVES * kmul) >> 6 : PS_WAVES / K, step_k = PS_WAVES - step_c * K;
 #pragma unroll
           for (int i = 0; i < PS_MAXU; ++i) {
             const int u = wave + PS_WAVES * i;
@@ -891,31 +809,28 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             uk -= uk >= K ? K : 0;
           }
         }
-        PS_STAMP(4);
         // the weight registers are free: request the NEXT step's operands now, so that they fly under this step's reduction,
         // epilogue and the exchange
-        if ((mi == mbg - 1 || mb == n_mb - 1) && item + P >= items) { ps_prefetch(nx, rank, ntn, tid, wave, lane, pre); prefetched = true; }
+        if (mi == nblk - 1) { ps_prefetch(r1, tid, wave, lane, pre); rvB = load_rec(s + 2); prefetched = true; }
         // residual cells of this block (data of an older step: normally one round trip)
-        float rv = 0.f;
-        const PS_G ll_t* res = ps_unip(st.res);
+        float rsd = 0.f;
+        const PS_G ll_t* res = PR_P(const ll_t, rv, 3);
         if (res && tid < 256) {
-          unsigned ro = (unsigned)((n0 + (tid >> 4)) * ps_uni(st.rpitch) + mb * 16 + (tid & 15)) * 8u;
-          const bool rok = mb * 16 + (tid & 15) < Cout;
+          unsigned ro = (unsigned)((tid >> 4) * PR_B(rv, 5) + mi * 16 + (tid & 15)) * 8u;
+          const bool rok = mi * 16 + (tid & 15) < rows_left;
           bool pending;
           do {
             asm volatile("" : "+v"(ro));
             ll_t q = 0;
             if (rok) q = ll_load_off(res, ro);
-            rv = ll_val(q);
+            rsd = ll_val(q);
             pending = PS_PENDING(rok ? ll_bad(q, epoch) : 0u);
           } while (ps_again(cx, pending));
         }
-        PS_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 4; ++r) mred[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
         __syncthreads();
-        PS_STAMP(6);
-        if (epi == PS_EPI_GATE) {
+        if (kf & PF_GATE) {
           // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8 * mb .. 8 * mb + 7 (commons.py:100-107)
           if (tid < 128) {
             const int ch = tid & 7, col = tid >> 3;
@@ -925,34 +840,33 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
               at += mred[(w * 4 + (ch & 3)) * 64 + (ch >> 2) * 16 + col];
               as += mred[(w * 4 + (ch & 3)) * 64 + ((ch >> 2) + 2) * 16 + col];
             }
-            const int c = mb * 8 + ch, t = n0 + col;
             const float tv = tanhf(at + eb0 + ec0);
             const float sv = 1.0f / (1.0f + __expf(-(as + eb1 + ec1)));
-            if (c < ps_uni(st.gate_H)) ll_store(ps_unip(st.yout) + (long long)t * ps_uni(st.ypitch) + ps_uni(st.y_off) + c, tv * sv, epoch);
+            ll_store(PR_P(ll_t, rv, 1) + (long long)col * ypitch + mi * 8 + ch, tv * sv, epoch);  // (p1 points at channel 8 * first block)
           }
         } else if (tid < 256) {
           const int row = tid & 15, col = tid >> 4;  // rows fastest: a column's 16 cells are one 128-byte segment
           float v = 0.f;
 #pragma unroll
           for (int w = 0; w < PS_WAVES; ++w) v += mred[(w * 4 + (row & 3)) * 64 + (row >> 2) * 16 + col];
-          const int r = mb * 16 + row;
+          const int rl = mi * 16 + row;
           const int t = n0 + col;
-          if (r < Cout) {
+          if (rl < rows_left) {
             v += eb0 + ec0;
-            if (ps_uni(st.relu)) v = v > 0.f ? v : 0.f;
-            if (ps_uni(st.out_mask) && t >= L) v = 0.f;
-            v += rv;
-            if (epi == PS_EPI_SPLINE) hb[r * 16 + col] = v;
+            if (kf & PF_RELU) v = v > 0.f ? v : 0.f;
+            if ((kf & PF_OUTMASK) && t >= L) v = 0.f;
+            v += rsd;
+            if (kf & PF_SPLINE) hb[rl * 16 + col] = v;
             else {
-              PS_G ll_t* yo = ps_unip(st.yout);
-              PS_G float* yp = ps_unip(st.yplain);
-              if (yo) ll_store(yo + ((long long)it.slice * Tp + t) * ps_uni(st.ypitch) + ps_uni(st.y_off) + r, v, epoch);
-              if (yp && t < pT) yp[(long long)r * pT + t] = v;
+              PS_G ll_t* yo = PR_P(ll_t, rv, 1);
+              PS_G float* yp = PR_P(float, rv, 2);
+              if (yo) ll_store(yo + (long long)col * ypitch + rl, v, epoch);
+              if (yp && t < pT) yp[(long long)rl * pT + col] = v;
             }
           }
         }
       }
-      if (ps_uni(st.zinit) && it.g == 0 && it.slice == 0 && tid < 32) {
+      if ((kf & PF_ZINIT) && tid < 32) {
         // z = randn * noise_scale_w (models.py:96): injected noise or the Philox stream of dp_init_z_kernel
         const int c = tid >> 4, t = n0 + (tid & 15);
         float nsw = call.nsw;
@@ -962,16 +876,16 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         if (t < T) e = call.noise ? call.noise[(long long)c * T + t]
                                   : (call.solo ? philox_normal(call.item_seeds ? call.item_seeds[0] : seed, 1, (uint32_t)c, (uint32_t)t)
                                                : philox_normal(seed, 1, (uint32_t)c, (uint32_t)t));
-        ll_store(ps_unip(st.zout) + (long long)c * Tp + t, e * nsw, epoch);
+        ll_store(PR_P(ll_t, rv, 5) + (long long)c * Tp + t, e * nsw, epoch);
       }
-      if (epi == PS_EPI_SPLINE) {
+      if (kf & PF_SPLINE) {
         // Inverse rational-quadratic spline of the tile's 16 columns (transforms.py:55-177), the arithmetic of spline_inverse_elem
         // (kernels_misc.hip.h) spread over the workgroup: one thread per column ran ~23 k cycles (20 expf and 20 divisions in a
         // dependent chain); here the exponentials are one per thread, the two short serial scans (sum, cumulative widths / heights:
         // same order as the serial form) run on 32 threads, and 16 threads finish (bin search, quadratic).
         __syncthreads();  // h complete
-        const int nb = ps_uni(sp.nb);
-        const float bound = sp.bound, isd = sp.inv_sqrt_d;
+        const int nb = prog->nb;
+        const float bound = prog->bound, isd = prog->inv_sqrt_d;
         float* se = mred;            // [32][16] exp(w - max): slots 0..nb-1 widths, 16..16+nb-1 heights
         float* sc = mred + 32 * 16;  // [2][17][16] cumulative widths / heights (knots)
         {
@@ -1002,8 +916,9 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         __syncthreads();
         if (wave == 0) {  // one column per lane (lanes >= 16 ride along in the wave-uniform poll)
           const int col = lane & 15, t = n0 + col;
-          const int x0r = ps_uni(st.z_row), x1r = 1 - x0r;
-          const PS_G ll_t* zin = ps_unip(st.z);
+          const int x0r = (PR_B(rv, 6) >> 16) & 1, x1r = 1 - x0r, ea_row = (PR_B(rv, 6) >> 20) & 1;
+          const PS_G ll_t* zin = PR_P(const ll_t, rv, 4);
+          PS_G ll_t* zout = PR_P(ll_t, rv, 5);
           const bool need = lane < 16 && t < L;
           unsigned o0 = (unsigned)(x0r * Tp + t) * 8u, o1 = (unsigned)(x1r * Tp + t) * 8u;
           float z0 = 0.f, z1 = 0.f;
@@ -1048,13 +963,13 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                 v1 = root * in_w + in_cw;
               }
             }
-            if (st.zout) {
-              ll_store(ps_unip(st.zout) + (long long)x0r * Tp + t, v0, epoch);
-              ll_store(ps_unip(st.zout) + (long long)x1r * Tp + t, v1, epoch);
+            if (zout) {
+              ll_store(zout + (long long)x0r * Tp + t, v0, epoch);
+              ll_store(zout + (long long)x1r * Tp + t, v1, epoch);
             }
-            if (ps_uni(st.last) && t < T) {
-              const float zz = ps_uni(st.ea_row) == x0r ? v0 : v1;
-              ps_unip(sp.logw)[t] = t < L ? (zz - ea_m) * ea_is : 0.f;
+            if ((kf & PF_LAST) && t < T) {
+              const float zz = ea_row == x0r ? v0 : v1;
+              ((PS_G float*)prog->logw)[t] = t < L ? (zz - ea_m) * ea_is : 0.f;
             }
           }
         }
@@ -1065,7 +980,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   // ---- the last worker to finish publishes the epoch (every worker read it before doing anything else)
   __syncthreads();
   if (tid0 == 0) {
-    if (cx.aborted || __hip_atomic_load(&call.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr((int*)sp.err, PS_ERR_TIMEOUT);
+    if (cx.aborted || __hip_atomic_load(&call.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr((int*)prog->err, PS_ERR_TIMEOUT);
     const unsigned old = atomicAdd(&call.ctl->done, 1u);
     if (old == gridDim.x - 1) {
       __hip_atomic_store(&call.ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1075,8 +990,12 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   }
 }
 
-// dynamic LDS of a launch: the program up to its last step, then the float buffers
-static inline size_t ps_lds_bytes(int n_steps) {
-  const size_t prog = sizeof(PProgram) - (size_t)(PS_MAX_STEPS - n_steps) * sizeof(PStep);
-  return ((prog / 4 + 3) & ~(size_t)3) * 4 + (size_t)PS_LDS_FLOATS * sizeof(float);
+// ---- packed per-thread parameters of a step (built once per model: persist_plan.hip.h): dst[row][k] = src[k][row + add[k]] or 0
+struct PsPackArgs { const float* src[8]; int add[8]; int len[8]; };
+__global__ void ps_pack_kernel(float* dst, PsPackArgs a, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 8) return;
+  const int row = i >> 3, k = i & 7;
+  const int idx = row + a.add[k];
+  dst[i] = (a.src[k] && idx >= 0 && idx < a.len[k]) ? a.src[k][idx] : 0.f;
 }

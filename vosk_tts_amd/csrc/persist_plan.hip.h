@@ -100,10 +100,92 @@ static size_t persist_flow_cells(const vits_model* m, int B, int Ty) {
   return per * hp.flow_n_flows;
 }
 
+// ------------------------------------------------------------------------------------------------ host-side step descriptors
+// What a builder says about one step; persist_resolve() turns it into one 128-byte record per worker (persist.hip.h).
+enum { PS_EPI_STORE = 0, PS_EPI_SPLINE = 1, PS_EPI_GATE = 2 };
+struct PStep {
+  int kind;
+  // ---- PK_MM: y[Cout x 16-column tile] (+)= W[Cout x ks*Cin*K] * window(B)
+  int Cin;                 // contraction channels of ONE K-slice (multiple of 16, <= PS_MAXC)
+  int cin_pitch;           // channel pitch of the operand cells
+  int c_off, c_sign;       // operand channel of slice-local channel c: c_off + c_sign * (slice * Cin + c)   (Flip folded into the read)
+  int Cout, n_mb;          // rows stored, 16-row blocks of the packed matrix
+  int G, mbg, ks;          // row-block groups per column tile, 16-row blocks per worker, K-slices
+  int K, pad;              // taps, left padding: operand column of (output t, tap kk) = t + kk - pad
+  int epi, relu;           // PS_EPI_*; 1 = ReLU on acc + bias
+  int in_mask, out_mask;   // operand columns >= len read as 0 ; output columns >= len written as 0
+  int ypitch, y_off;       // output channel pitch, first output channel
+  int gate_H;              // PS_EPI_GATE: hidden channels (packed rows = [8 tanh | 8 sigmoid] per 16-row block)
+  int plain_T;             // row length of bin_plain / yplain / oplain / u_plain
+  int zinit;               // also draw z = noise * noise_scale_w into zout (duration predictor, first step)
+  int blen;                // valid entries of bias / cond
+  const float* w16;        // [n_mb][ks][Cin/16*K][64][4] 16x16x4 A-fragment order (pack_conv_weights16: slices are consecutive units)
+  const float* bias;       // [Cout] (zeros for K-sliced steps: the consumer adds it once)
+  const float* cond;       // per-item bias rows (cond(g)) or zeros
+  const ll_t* bin;         // operand cells [Tp][cin_pitch] ...
+  const float* bin_plain;  // ... or plain floats [channels][plain_T] written by an earlier kernel (null: cells)
+  const ll_t* res;         // residual cells [Tp][rpitch] added after the mask (null: none)
+  int rpitch;
+  ll_t* yout;              // cells [ks][Tp][ypitch] (null: no cell output)
+  float* yplain;           // plain floats [Cout][plain_T] for later kernels (null: none)
+  const ll_t* z;           // z cells [2][Tp]  (PS_EPI_SPLINE; flow layer 0 of PK_DDS)
+  ll_t* zout;              // zinit / PS_EPI_SPLINE: z cells out (null for the last flow)
+  int z_row;               // row of z that conditions (x0); the spline acts on 1 - z_row
+  int last, ea_row;        // last flow: write logw = ElementwiseAffine^-1(z[ea_row]) (modules.py:293-295)
+  // ---- column steps: C channels (threads); par[k]: per-channel parameter vectors, packed 8 per thread (value k of thread row is
+  //      par[k][row + padd[k]], 0 outside [0, plen))
+  int C, plen;
+  int padd[8];
+  const float* par[8];
+  const float* vec;        // per-item vector (speaker embedding), runtime data: not packed
+  // PK_DDS: x_in = (xin + gelu(LN(y2; par0, par1))) * mask   [fin 0: xin * mask; fin 2: par0 * z + par1 + xin]
+  //         b    = gelu(LN(depthwise3(x_in; par3..5, par2, dil); par6, par7))          (dw != 0)
+  int dil, dw, fin;
+  const ll_t* xin; const ll_t* y2;   // [Tp][C]
+  ll_t* xout;              // x_in column
+  ll_t* bout;              // b column (dw != 0)
+  // PK_LN: v = par2 (bias) + sum_{k < np} part[k][t][c] + res[t][c] ; out = (LN(v; par0, par1) + vec + base[t][c]) * mask
+  int np, ln;
+  const ll_t* part; long long part_stride;   // cells [np][Tp][C]
+  const ll_t* base;        // residual base added AFTER the norm (flow: h + pre_transformer(h)) or null
+  // PK_EMB: out = emb[ids[t]][c] * scale * mask (+ vec)        (models.py:318-322)
+  const float* emb; float scale; int n_vocab;
+  // PK_ATT / PK_MERGE
+  int nh, dk, W;           // heads, head dimension, relative-position window (0: no relative terms)
+  const ll_t* qkv;         // cells [Tp][3*nh*dk]: q | k | v
+  ll_t* ap;                // partial cells [key tile][Tp][nh][dk + 2]
+  const float* ek; const float* ev;
+  // PK_COUPLE: new z (Flip folded): out[r] = u[2H-1-r] (r < H) ; out[H + r] = (u[H-1-r] - (par2[r] + sum_k part[k][t][r])) * mask
+  const ll_t* u; const float* u_plain;  // previous z: cells [Tp][2H] or plain floats [2H][plain_T]
+  int H;
+  // common outputs of column steps
+  ll_t* out;               // cells [Tp][C] (null: none)
+  float* oplain;           // plain floats [C][plain_T] (null: none)
+};
+
+// packed per-thread parameters (dst[row][k] = src[k][row + add[k]]), built once per distinct source tuple and kept with the model
+static const float* persist_pack(vits_session* s, const float* const (&src)[8], const int (&add)[8], int len, int rows) {
+  vits_model* m = s->m;
+  std::vector<long long> key;
+  for (int k = 0; k < 8; ++k) { key.push_back((long long)(uintptr_t)src[k]); key.push_back(add[k]); }
+  key.push_back(len); key.push_back(rows);
+  std::lock_guard<std::mutex> g(m->pack_mu);
+  auto it = m->packs.find(key);
+  if (it != m->packs.end()) return it->second;
+  float* dst = nullptr;
+  if (hipMalloc((void**)&dst, sizeof(float) * 8 * (size_t)rows) != hipSuccess) return nullptr;
+  m->allocs.push_back(dst);
+  PsPackArgs a;
+  for (int k = 0; k < 8; ++k) { a.src[k] = src[k] == m->zeros ? nullptr : src[k]; a.add[k] = add[k]; a.len[k] = len; }
+  hipLaunchKernelGGL(ps_pack_kernel, dim3(cdiv(rows * 8, 256)), dim3(256), 0, s->stream, dst, a, rows);
+  m->packs[key] = dst;
+  return dst;
+}
+
 // ------------------------------------------------------------------------------------------------ program builders
 struct PBuild {
   vits_model* m;
-  PProgram* P;
+  std::vector<PStep>* steps;  // (reserved to PS_MAX_STEPS: references returned by push() stay valid)
   ll_t* cur;
   ll_t* end;
   int T, Tp, ntn;
@@ -121,15 +203,15 @@ struct PBuild {
     memset(&st, 0, sizeof st);
     st.kind = kind;
     st.Cin = 16; st.cin_pitch = 16; st.c_sign = 1; st.Cout = 16; st.n_mb = 1; st.G = 1; st.mbg = 1; st.ks = 1; st.K = 1; st.blen = 16;
-    st.C = 16; st.pmask = 255; st.plen = 256; st.plain_T = T; st.np = 0; st.nh = 1; st.dk = 16;
+    st.C = 16; st.plen = 256; st.plain_T = T; st.np = 0; st.nh = 1; st.dk = 16;
     st.w16 = st.bias = st.cond = m->zeros;
     for (int k = 0; k < 8; ++k) st.par[k] = m->zeros;
     return st;
   }
   PStep& push(const PStep& st) {
-    if (P->n_steps >= PS_MAX_STEPS) { overflow = true; return P->steps[PS_MAX_STEPS - 1]; }
-    P->steps[P->n_steps] = st;
-    return P->steps[P->n_steps++];
+    if ((int)steps->size() >= PS_MAX_STEPS) { overflow = true; return steps->back(); }
+    steps->push_back(st);
+    return steps->back();
   }
   // matrix step skeleton for conv W over cells `bin` (channel pitch cin_pitch, first channel c_off, direction c_sign)
   PStep mm(const ConvW& W, const ll_t* bin, int cin_pitch, int c_off = 0, int c_sign = 1) {
@@ -142,14 +224,20 @@ struct PBuild {
     st.bias = (st.ks == 1 && W.bias) ? W.bias : m->zeros;
     st.bin = bin;
     st.ypitch = cdiv(W.M, 16) * 16;
-    st.mbg = cdiv(st.n_mb * ntn * st.ks, m->n_cu);
-    st.G = cdiv(st.n_mb, st.mbg);
+    set_groups(st);
     flops += 2.0 * T * (double)W.M * W.Cin * W.K;
     return st;
   }
-  void col_par(PStep& st, int C, const float* p0, const float* p1, const float* p2, const float* p3) {
-    st.C = C; st.pmask = 255; st.plen = C;
-    st.par[0] = p0 ? p0 : m->zeros; st.par[1] = p1 ? p1 : m->zeros; st.par[2] = p2 ? p2 : m->zeros; st.par[3] = p3 ? p3 : m->zeros;
+  // row-block groups so that a step has at most one work item per worker
+  void set_groups(PStep& st) const {
+    st.mbg = cdiv(st.n_mb * ntn * st.ks, m->n_cu);
+    st.G = cdiv(st.n_mb, st.mbg);
+    while (ntn * st.G * st.ks > m->n_cu && st.mbg < st.n_mb) { ++st.mbg; st.G = cdiv(st.n_mb, st.mbg); }
+  }
+  void col_par(PStep& st, int C, const float* p0, const float* p1, const float* p2, const float* vec) {
+    st.C = C; st.plen = C;
+    st.par[0] = p0 ? p0 : m->zeros; st.par[1] = p1 ? p1 : m->zeros; st.par[2] = p2 ? p2 : m->zeros;
+    st.vec = vec;
   }
 };
 
@@ -168,11 +256,8 @@ static const ll_t* persist_encoder_layer(PBuild& b, const EncLayerW& L, const En
   st = b.blank(PK_ATT);
   st.nh = nh; st.dk = dk; st.W = W; st.qkv = qkv;
   st.ap = b.take((size_t)ntn * Tp * nh * (dk + 2));
-  if (W > 0 && L.ek && L.ev) {
-    st.pmask = 511; st.plen = (2 * W + 1) * dk;
-    st.par[0] = st.par[1] = L.ek; st.par[2] = st.par[3] = L.ev;
-    st.padd[1] = 512; st.padd[3] = 512;
-  } else st.W = 0;
+  if (W > 0 && L.ek && L.ev) { st.ek = L.ek; st.ev = L.ev; }
+  else st.W = 0;
   b.flops += 4.0 * (double)H * b.T * b.T;
   const ll_t* ap = b.push(st).ap;
   st = b.blank(PK_MERGE);
@@ -211,21 +296,165 @@ static const ll_t* persist_encoder_layer(PBuild& b, const EncLayerW& L, const En
   return b.push(st).out;
 }
 
+// ---- steps -> one record per (step, worker)
+static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, int P, int T, int Tp, std::vector<PRec>& recs, bool& bad) {
+  vits_model* m = s->m;
+  const int ntn = Tp / 16;
+  auto U = [](const void* p) { return (unsigned long long)(uintptr_t)p; };
+  PRec idle;
+  memset(&idle, 0, sizeof idle);
+  idle.kf = PK_IDLE; idle.a1 = 16;
+  for (int k = 6; k < 10; ++k) idle.p[k] = U(m->zeros);
+  recs.clear();
+  auto new_step = [&]() -> PRec* { recs.insert(recs.end(), (size_t)P, idle); return recs.data() + recs.size() - P; };
+  for (const PStep& st : steps) {
+    if (st.kind == PK_MM) {
+      const int items = ntn * st.G * st.ks;
+      if (items > P) { bad = true; return; }
+      PRec* R = new_step();
+      const int n_u = st.Cin / 16 * st.K;
+      const bool gate = st.epi == PS_EPI_GATE;
+      for (int item = 0; item < items; ++item) {
+        const int j = item % ntn, q = item / ntn, g = q % st.G, slice = q / st.G;
+        const int n0 = j * 16, mb0 = g * st.mbg, nblk = std::min(st.mbg, st.n_mb - mb0);
+        PRec& r = R[item];
+        r.kf = PK_MM | (st.relu ? PF_RELU : 0) | (st.in_mask ? PF_INMASK : 0) | (st.out_mask ? PF_OUTMASK : 0) | (gate ? PF_GATE : 0) |
+               (st.epi == PS_EPI_SPLINE ? PF_SPLINE : 0) | ((st.zinit && g == 0 && slice == 0) ? PF_ZINIT : 0) | (st.last ? PF_LAST : 0) |
+               (st.bin_plain ? PF_PLAIN_IN : 0);
+        r.a1 = st.Cin | (st.K << 16);
+        r.a2 = st.bin_plain ? st.c_sign : st.cin_pitch * st.c_sign;
+        r.a3 = n0 - st.pad;
+        const int ch0 = st.c_off + st.c_sign * slice * st.Cin;
+        if (st.bin_plain) r.p[0] = U(st.bin_plain + (size_t)ch0 * st.plain_T);
+        else r.p[0] = U(st.bin + (st.c_sign > 0 ? ch0 : ch0 - (st.Cin - 1)));
+        const int row0 = gate ? mb0 * 8 : mb0 * 16;
+        r.p[1] = st.yout ? U(st.yout + ((size_t)slice * Tp + n0) * st.ypitch + st.y_off + row0) : 0;
+        r.p[2] = st.yplain ? U(st.yplain + (size_t)row0 * st.plain_T + n0) : 0;
+        r.p[3] = st.res ? U(st.res + (size_t)n0 * st.rpitch + row0) : 0;
+        r.p[4] = U(st.z); r.p[5] = U(st.zout);
+        r.p[6] = U(st.w16 + ((size_t)mb0 * st.ks + slice) * n_u * 256);
+        r.p[7] = U(st.bias + (st.bias == m->zeros ? 0 : row0));
+        r.p[8] = U(st.cond + (st.cond == m->zeros ? 0 : row0));
+        r.b[0] = n_u | (nblk << 16);
+        r.b[1] = st.ks * n_u * 256;
+        r.b[2] = st.ypitch;
+        r.b[3] = gate ? 2 * st.gate_H : st.Cout - row0;
+        r.b[4] = st.plain_T; r.b[5] = st.rpitch;
+        r.b[6] = n0 | (st.z_row << 16) | (st.ea_row << 20);
+        r.b[7] = st.gate_H;
+      }
+    } else if (st.kind == PK_ATT) {
+      const int items = st.nh * ntn * ntn;
+      const int add[8] = {0, 512, 0, 512, 0, 0, 0, 0};
+      const float* const src[8] = {st.ek, st.ek, st.ev, st.ev, nullptr, nullptr, nullptr, nullptr};
+      const float* pack = m->zeros;
+      if (st.W > 0) {
+        // rows = thread ids: {E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]}; the two tables are packed by two calls (one length each)
+        const float* const sk[8] = {st.ek, st.ek, st.ev, st.ev, m->zeros, m->zeros, m->zeros, m->zeros};
+        (void)src;
+        pack = persist_pack(s, sk, add, (2 * st.W + 1) * st.dk, 512);
+        if (!pack) { bad = true; return; }
+      }
+      for (int i0 = 0; i0 < items; i0 += P) {
+        PRec* R = new_step();
+        for (int item = i0; item < std::min(items, i0 + P); ++item) {
+          const int kt = item % ntn, qt = (item / ntn) % ntn, hd = item / (ntn * ntn);
+          PRec& r = R[item - i0];
+          r.kf = PK_ATT;
+          r.a1 = st.dk | (st.nh << 8) | (st.W << 16);
+          r.a2 = (qt * 16) | ((kt * 16) << 16);
+          r.a3 = hd | (kt << 8);
+          r.p[0] = U(st.qkv); r.p[1] = U(st.ap); r.p[9] = U(pack);
+        }
+      }
+    } else {
+      if (Tp > P) { bad = true; return; }
+      PRec* R = new_step();
+      const float* pack = m->zeros;
+      if (st.kind != PK_MERGE && st.kind != PK_EMB) {
+        pack = persist_pack(s, st.par, st.padd, st.plen, 256);
+        if (!pack) { bad = true; return; }
+      }
+      for (int t = 0; t < Tp; ++t) {
+        PRec& r = R[t];
+        r.a1 = st.C; r.a2 = t; r.p[9] = U(pack);
+        r.p[3] = U(st.out); r.p[4] = U(st.oplain);
+        r.b[4] = st.plain_T;
+        if (st.kind == PK_DDS) {
+          r.kf = PK_DDS | (st.dw ? PF_DW : 0) | (st.fin == 1 ? PF_FIN_LN : 0) | (st.fin == 2 ? PF_FIN_PRE : 0);
+          r.a1 = st.C | (st.dil << 16);
+          r.p[0] = U(st.xin); r.p[1] = U(st.y2); r.p[2] = st.z ? U(st.z + (size_t)st.z_row * Tp) : 0; r.p[3] = U(st.xout); r.p[4] = U(st.bout);
+        } else if (st.kind == PK_LN) {
+          r.kf = PK_LN | (st.ln ? PF_LN : 0);
+          r.a3 = st.np;
+          r.p[0] = U(st.part); r.p[1] = U(st.res); r.p[2] = U(st.base);
+          r.p[8] = U(st.vec ? st.vec : m->zeros);
+          r.b[0] = (int)(unsigned)(st.part_stride & 0xffffffffll); r.b[1] = (int)(st.part_stride >> 32);
+        } else if (st.kind == PK_EMB) {
+          r.kf = PK_EMB;
+          r.p[0] = U(st.emb);
+          r.p[8] = U(st.vec ? st.vec : m->zeros);
+          memcpy(&r.b[0], &st.scale, 4);
+          r.b[1] = st.n_vocab;
+        } else if (st.kind == PK_MERGE) {
+          r.kf = PK_MERGE;
+          r.a3 = st.dk | (st.nh << 8);
+          r.p[0] = U(st.ap);
+          r.b[0] = Tp * st.nh * (st.dk + 2);
+        } else {  // PK_COUPLE
+          r.kf = PK_COUPLE | (st.u_plain ? PF_PLAIN_IN : 0);
+          r.a3 = st.np | (st.H << 16);
+          r.p[0] = U(st.part); r.p[1] = U(st.u); r.p[2] = U(st.u_plain);
+          r.b[0] = (int)(unsigned)(st.part_stride & 0xffffffffll); r.b[1] = (int)(st.part_stride >> 32);
+        }
+      }
+    }
+    if ((int)(recs.size() / P) > PS_MAX_STEPS) { bad = true; return; }
+  }
+  (void)T;
+}
+
 static void persist_upload(vits_session* s, vits_session::PersistProg& pp, PBuild& b) {
   pp.flops = b.flops;
   pp.ok = false;
   if (b.overflow) return;
+  vits_model* m = s->m;
+  const int P = m->n_cu;
+  std::vector<PRec> recs;
+  bool bad = false;
+  persist_resolve(s, *b.steps, P, b.T, b.Tp, recs, bad);
+  if (bad || recs.empty()) return;
+  const size_t bytes = recs.size() * sizeof(PRec);
+  if (bytes > pp.recs_bytes) {
+    if (pp.recs_d) { hipStreamSynchronize(s->stream); hipFree(pp.recs_d); pp.recs_d = nullptr; pp.recs_bytes = 0; }
+    if (hipMalloc((void**)&pp.recs_d, bytes) != hipSuccess) { pp.recs_d = nullptr; return; }
+    pp.recs_bytes = bytes;
+  }
   if (!pp.d && hipMalloc((void**)&pp.d, sizeof(PProgram)) != hipSuccess) { pp.d = nullptr; return; }
+  pp.h.n_steps = (int)(recs.size() / P);
+  pp.h.P = P;
+  pp.h.recs = pp.recs_d;
+  pp.kinds.clear();
+  for (int i = 0; i < pp.h.n_steps; ++i) {  // (for tools/ps_trace.py: the kind of a step = the kind of its first busy worker)
+    int k = 0;
+    for (int w = 0; w < P && !k; ++w) k = recs[(size_t)i * P + w].kf & 0xff;
+    pp.kinds.push_back(k);
+  }
+  // (pageable sources: both copies complete before persist_plan returns -- it synchronises the stream)
+  pp.recs_h.swap(recs);
+  if (hipMemcpyAsync(pp.recs_d, pp.recs_h.data(), bytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) return;
   if (hipMemcpyAsync(pp.d, &pp.h, sizeof(PProgram), hipMemcpyHostToDevice, s->stream) != hipSuccess) return;
   pp.ok = true;
 }
-static void persist_begin(vits_session* s, vits_session::PersistProg& pp, PBuild& b, int T, const int* len) {
+static void persist_begin(vits_session* s, vits_session::PersistProg& pp, PBuild& b, std::vector<PStep>& steps, int T, const int* len) {
   vits_model* m = s->m;
   memset(&pp.h, 0, sizeof(PProgram));
-  b.m = m; b.P = &pp.h; b.cur = pp.ll; b.end = pp.ll + pp.cells;
+  steps.clear();
+  steps.reserve(PS_MAX_STEPS + 1);
+  b.m = m; b.steps = &steps; b.cur = pp.ll; b.end = pp.ll + pp.cells;
   b.T = T; b.Tp = cdiv(T, 16) * 16; b.ntn = b.Tp / 16;
   PProgram& P = pp.h;
-  P.T = T; P.Tp = b.Tp; P.ntn = b.ntn;
+  P.T = T; P.Tp = b.Tp;
   P.nb = m->hp.dp_num_bins; P.bound = m->hp.dp_tail_bound; P.inv_sqrt_d = 1.0f / sqrtf((float)m->hp.dp_filter_channels);
   P.len = len; P.ea_m = m->ea_m ? m->ea_m : m->zeros; P.ea_logs = m->ea_logs ? m->ea_logs : m->zeros; P.logw = s->logw; P.err = s->d_err;
 }
@@ -236,7 +465,8 @@ static void persist_build_enc(vits_session* s) {
   const vits_hparams& hp = m->hp;
   vits_session::PersistProg& pp = s->ps_enc;
   PBuild b;
-  persist_begin(s, pp, b, s->Tx, s->len_x);
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
   const int H = hp.hidden_channels, n = (int)m->enc_p.layers.size();
   const int cond_layer = (m->use_g && m->cond_enc_off >= 0) ? hp.enc_cond_layer : -1;
   const float* vec = cond_layer >= 0 ? s->condv + m->cond_enc_off : nullptr;
@@ -261,7 +491,8 @@ static void persist_build_sdp(vits_session* s) {
   const vits_hparams& hp = m->hp;
   vits_session::PersistProg& pp = s->ps_sdp;
   PBuild b;
-  persist_begin(s, pp, b, s->Tx, s->len_x);
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
   const int D = hp.dp_filter_channels, nl = (int)m->dp_dds.pw.size(), K = hp.dp_kernel_size;
   // dp.pre (+ cond(g)) -> x0 ; z = noise * noise_scale_w          (models.py:58-60,96)
   PStep st = b.mm(m->dp_pre, nullptr, 0);
@@ -270,7 +501,7 @@ static void persist_build_sdp(vits_session* s) {
   st.zinit = 1;
   st.yout = b.take_rows(D); st.zout = b.take_rows(2);
   const ll_t* x = b.push(st).yout;
-  const ll_t* z = pp.h.steps[0].zout;
+  const ll_t* z = steps[0].zout;
   // one DDSConv stack + the 1x1 conv that consumes it (modules.py:96-108): per layer a column step (finish the previous layer,
   // depthwise conv, LN1, GELU) and a matrix step (the layer's 1x1 conv); then the last finish and the projection
   auto stack = [&](const DDSW& Wd, const ConvW& proj, bool spline, const ll_t* xin, const ll_t* zc, int z_row, const float* pw, const float* pb) -> PStep& {
@@ -279,7 +510,7 @@ static void persist_build_sdp(vits_session* s) {
     for (int i = 0; i <= nl; ++i) {
       const bool fin = i == nl;
       st = b.blank(PK_DDS);
-      st.C = D; st.pmask = 255; st.plen = D; st.dw = fin ? 0 : 1; st.dil = fin ? 0 : dil;
+      st.C = D; st.plen = D; st.dw = fin ? 0 : 1; st.dil = fin ? 0 : dil;
       st.xin = xin; st.y2 = y2;
       if (i > 0) { st.fin = 1; st.par[0] = Wd.g2[i - 1]; st.par[1] = Wd.b2[i - 1]; }
       else if (zc) { st.fin = 2; st.z = zc; st.z_row = z_row; st.par[0] = pw; st.par[1] = pb; }
@@ -294,7 +525,7 @@ static void persist_build_sdp(vits_session* s) {
       xin = col.xout;
       st = b.mm(fin ? proj : Wd.pw[i], fin ? col.xout : col.bout, D);
       if (fin) {
-        if (spline) { st.epi = PS_EPI_SPLINE; st.mbg = st.n_mb; st.G = 1; }
+        if (spline) { st.epi = PS_EPI_SPLINE; st.mbg = st.n_mb; st.G = 1; }  // all rows of a column tile in one worker: it runs the spline
         else st.out_mask = 1;  // proj(x) * x_mask (models.py:63)
         return b.push(st);
       }
@@ -302,13 +533,13 @@ static void persist_build_sdp(vits_session* s) {
       y2 = b.push(st).yout;
       dil *= K;
     }
-    return pp.h.steps[0];  // not reached
+    return steps[0];  // not reached
   };
   {
     PStep& pj = stack(m->dp_dds, m->dp_proj, false, x, nullptr, 0, nullptr, nullptr);
     pj.yout = b.take_rows(D);
   }
-  const ll_t* dc = pp.h.steps[pp.h.n_steps - 1].yout;
+  const ll_t* dc = steps.back().yout;
   int swap = 0;
   for (int k = hp.dp_n_flows - 1; k >= 1; --k) {
     swap ^= 1;  // Flip (modules.py:270-277) is a row relabel on the 2-channel z
@@ -327,7 +558,8 @@ static void persist_build_flow(vits_session* s) {
   const vits_hparams& hp = m->hp;
   vits_session::PersistProg& pp = s->ps_flow;
   PBuild b;
-  persist_begin(s, pp, b, s->Ty, s->len_y);
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Ty, s->len_y);
   const int H = hp.hidden_channels, I = hp.inter_channels, half = I / 2, L = hp.flow_wn_layers;
   const ll_t* u = nullptr;  // previous z as cells (null: the plain z_p of the first layer)
   for (int f = hp.flow_n_flows - 1; f >= 0; --f) {
@@ -346,7 +578,7 @@ static void persist_build_flow(vits_session* s) {
       st = b.mm(C.in_layers[i], fx, H);
       st.in_mask = 1; st.epi = PS_EPI_GATE; st.gate_H = H; st.blen = 2 * H;
       st.n_mb = cdiv(2 * H, 16); st.Cout = 2 * H;
-      st.mbg = cdiv(st.n_mb * b.ntn, m->n_cu); st.G = cdiv(st.n_mb, st.mbg);
+      b.set_groups(st);
       if (m->use_g) st.cond = s->condv + C.cond_off + i * 2 * H;
       st.yout = acts; st.ypitch = L * H; st.y_off = i * H;
       b.push(st);
