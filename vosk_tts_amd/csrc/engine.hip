@@ -2373,6 +2373,9 @@ static int back_get(vits_session* F, int TyB, vits_session** out) {
   s->stats = F->stats; s->cum = F->cum; s->condv = F->condv; s->len_y = F->len_y; s->len_x = F->len_x; s->ylen64 = F->ylen64;
   s->dv = reinterpret_cast<const SynthDev*>(F->io_d);
   s->item_seeds = reinterpret_cast<const unsigned long long*>(F->io_d + F->io_seeds);
+  // the persistent flow program was resolved against this session's own len_y / condv: resolve it again against the front's
+  rc = persist_plan(s);
+  if (rc != VITS_OK) { s->stream = nullptr; session_free(s); return rc; }
   s->last_use = ++F->last_use;
   F->backs[TyB] = s;
   *out = s;
