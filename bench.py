@@ -3,7 +3,13 @@
 samples/sec + real-time factor).
 
     python bench.py --gpus 1 --steps 50 --warmup 5            # default workload = BASELINE configs[1] (C2)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                              # launches its own N ranks (one process per GPU, host-side barrier)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # the driver's form: same ranks
+Ranks only meet at a host-side barrier and a max over their timings (torch.distributed, gloo on CPU tensors: no RCCL on any path,
+there is nothing to exchange -- SURVEY.md 8e).  With N > 1 the default line still leads with BASELINE's metric on configs[1] per
+replica (weak scaling) and adds "batch256_sharded": BASELINE configs[3], the 256-request list dealt to the N ranks by
+vosk_tts_amd.batching.plan_shards, value = all 256 requests' samples / slowest rank (STRONG scaling: the one place where length
+imbalance between shards can cost anything), plus "multi_device_synth": the in-process front door on the same list.
 
 A "step" is one full forward of SynthesizerTrn.infer (text encoder -> stochastic duration predictor ->
 length regulator -> flow -> decoder) over one synthetic batch whose inputs are already resident in HBM.
@@ -38,7 +44,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide; the headline figures with 2:1 sparsity are not used)
 SAMPLE_RATE = 22050
-PROFILE_ROUND = "r2"  # prefix of the committed rocprofv3 / PMC summaries under profiles/ quoted beside the live figures
+PROFILE_ROUND = "r3"  # prefix of the committed rocprofv3 / PMC summaries under profiles/ quoted beside the live figures
 # the reference's own PyTorch modules (SynthesizerTrn.infer, eager, fp32) on the survey container's 8 vCPU
 # Xeon @ 2.1 GHz for the c2 shape (50 tokens -> 150 frames, durations pinned): the only executable form of the reference.
 REFERENCE_PYTORCH_CPU = {"x_realtime": [7.0, 7.5], "samples_per_s": 1.6e5, "cores": 8, "infer_s": [0.23, 0.25],
@@ -155,17 +161,17 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
     for i in range(args.warmup):
         step(i)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         audio = step(i)
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if batched:
@@ -285,6 +291,95 @@ def vits_cpu_baseline(blob, hp, ids, lengths, dur, workload, cpu_seconds):
                     "is the faster CPU data point (reference_pytorch_cpu); neither ratio is a statement about kernel quality",
             "reference_pytorch_cpu": REFERENCE_PYTORCH_CPU}
 
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same environment
+    torch.distributed.run would set up), let rank 0 print the line, return the worst exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def dry_run(args, torch, dist, rank, world):
+    """--dry-run: no GPU and no model -- every rank runs the launch / barrier / max-over-ranks / aggregation path of the real line
+    on a pretend step (tests/test_multiproc.py runs it with 2 processes on CPU)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.0005)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))  # ranks differ on purpose: the line must carry the slowest one
+    barrier()
+    el = time.perf_counter() - t0
+    seen = 1
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        c = torch.tensor([1.0], dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        seen = int(c.item())
+    samples = 38400
+    if rank == 0:
+        print(json.dumps({"metric": "audio_samples_per_sec", "value": round(samples * world * args.steps / el, 1), "unit": "samples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": seen,
+                          "launched_by": "bench.py" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if dist is not None else "single process"),
+                          "config": {"workload": "dry run: no GPU work, launch / barrier / aggregation only"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def multi_device_synth_leg(hp, lengths_all, n_devices, reps=3):
+    """The in-process front door on BASELINE configs[3]'s request list: vosk_tts_amd.batching.MultiDeviceSynth (one Model replica and
+    one worker thread per device, plan_shards, padded solo batches of <= 32 through vits_synthesize_pcm16, int16 back in request
+    order), free-running durations.  Host-to-host: token ids on the host in, PCM on the host out."""
+    import tempfile
+
+    from vosk_tts_amd.batching import MultiDeviceSynth
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+    from vosk_tts_amd import weights as W
+
+    rng = np.random.default_rng(4321)
+    hp_t = W.default_hparams(n_vocab=len(PHONEMES))
+    hp_t.conv_precision = hp.conv_precision
+    tokens = [rng.integers(1, len(PHONEMES), size=int(n)).tolist() for n in lengths_all]
+    with tempfile.TemporaryDirectory() as d:
+        write_toy_model(d, hp_t)
+        mds = MultiDeviceSynth(model_path=d, devices=list(range(n_devices)))
+        try:
+            mds.synth_tokens(tokens[:2 * n_devices], speaker_ids=2)  # graphs / workspaces warm
+            mds.synth_tokens(tokens, speaker_ids=2)
+            times, samples = [], 0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                pcm = mds.synth_tokens(tokens, speaker_ids=2)
+                times.append(time.perf_counter() - t0)
+                samples = int(sum(len(p) for p in pcm))
+        finally:
+            mds.close()
+    el = float(np.median(times))
+    return {"requests": len(tokens), "devices": n_devices, "ms": round(el * 1e3, 2), "value": round(samples / el, 1), "unit": "samples/s",
+            "x_realtime": round(samples / SAMPLE_RATE / el, 1), "samples": samples,
+            "what": "MultiDeviceSynth.synth_tokens: 256 requests of 20..200 tokens, free-running durations, solo batches of <= 32 per device, "
+                    "token ids on the host -> int16 PCM on the host, median of %d" % reps}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,28 +395,34 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="bf16x3: model created with hparams.conv_precision = 1 (split-bf16 decoder ResBlock convs at batch size)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-to-host drop-in path leg of the default run")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch, barrier and aggregation only (CPU test of the multi-process path)")
     args = ap.parse_args()
-
-    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)  # python bench.py --gpus N: this process becomes the launcher of N ranks
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`", file=sys.stderr)
-            sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+
+    import torch
+
     dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):  # launched by torch.distributed.run
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):  # a rank of a multi-process run (ours or torchrun's)
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)  # host-side barrier + max: no RCCL
         dist = dist_mod
+    if args.dry_run:
+        return dry_run(args, torch, dist, rank, world)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # (more ranks than devices: replicas share a device)
+    torch.cuda.set_device(local_rank)
 
     from vosk_tts_amd import weights as W
     from vosk_tts_amd.capi import VitsDeviceSession, VitsLib
@@ -360,7 +461,7 @@ def main():
 
         def barrier():
             if dist is not None:
-                dist.barrier(device_ids=[local_rank])
+                dist.barrier()
 
         for _ in range(warmup):
             step()
@@ -376,28 +477,36 @@ def main():
             torch.cuda.synchronize()
             barrier()
             el = time.perf_counter() - t0
+            own_times.append(el)
             if dist is not None:
-                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                t = torch.tensor([el], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
             return el
 
         # EXACTLY `steps` steps per block; blocks repeat until the timed region spans min_seconds (all ranks agree: the
         # decision uses the max-over-ranks times), ms_per_step is the median block
+        own_times = []
         blocks = [timed_block()]
         while sum(blocks) < min_seconds and len(blocks) < 2000:
             blocks.append(timed_block())
         elapsed = float(np.median(blocks))
         timed_region_s = float(sum(blocks))
         graph_nodes = sess.graph_nodes()
-        assert os.environ.get("BENCH_SKIP_FINITE_CHECK") or torch.isfinite(d_audio).all().item(), "non-finite audio"
+        finite_checked = not os.environ.get("BENCH_SKIP_FINITE_CHECK")  # (tools/ A/B builds with garbage results set it; recorded in the line)
+        assert not finite_checked or torch.isfinite(d_audio).all().item(), "non-finite audio"
 
         ms_per_step = elapsed / steps * 1e3
         job_samples = valid_samples * world
+        rank_ms = [float(np.median(own_times)) / steps * 1e3]
         if dist is not None:
-            tt = torch.tensor([float(valid_samples)], dtype=torch.float64, device=dev)
+            tt = torch.tensor([float(valid_samples), 1.0], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            job_samples = int(tt.item())
+            job_samples = int(tt[0].item())
+            assert int(tt[1].item()) == world
+            g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(g, torch.tensor(rank_ms, dtype=torch.float64))
+            rank_ms = [round(float(x.item()), 4) for x in g]
         total_samples = job_samples * steps
         value = total_samples / elapsed
         audio_sec_per_step = job_samples / SAMPLE_RATE
@@ -500,7 +609,8 @@ def main():
         sess.close()
         return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
                     ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales,
-                    timed_region_s=timed_region_s, blocks=len(blocks), launches=graph_nodes or sum(v[0] for v in rep.values()) // nprof)
+                    timed_region_s=timed_region_s, blocks=len(blocks), launches=graph_nodes or sum(v[0] for v in rep.values()) // nprof,
+                    rank_ms=rank_ms, finite_checked=finite_checked)
 
     R = measure(args.workload, args.steps, args.warmup, args.min_seconds)
     B, Tx, Ty, lengths, ids, dur = R["B"], R["Tx"], R["Ty"], R["lengths"], R["ids"], R["dur"]
@@ -530,6 +640,26 @@ def main():
                           "timed_region_s": round(R4["timed_region_s"], 3),
                           "roofline": {k: R4["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us", "forward", "by_kernel_ms_per_forward") if k in R4["roofline"]}}
         model3.close()
+
+    # BASELINE configs[3]: the 256-request list dealt to the ranks by plan_shards (rank r runs shard r as one padded batch):
+    # STRONG scaling -- total work is fixed, value = all requests' samples / the slowest rank
+    batch256 = None
+    mds_leg = None
+    if args.workload == "c2" and not args.no_batch32:
+        R5 = measure("c4", 3, 1, 0.0)
+        batch256 = {"value": round(R5["value"], 1), "unit": "samples/s", "scaling": "strong", "ms_per_step": round(R5["ms_per_step"], 3),
+                    "x_realtime": round(1.0 / R5["rtf"], 1), "requests": 256, "ranks": world, "requests_on_rank0": R5["B"],
+                    "rank_ms": R5["rank_ms"], "imbalance": round(max(R5["rank_ms"]) / max(min(R5["rank_ms"]), 1e-9), 4),
+                    "workload": "c4: 256 ragged requests (20..200 tokens, durations pinned 3/token) sharded over the ranks by "
+                                "vosk_tts_amd.batching.plan_shards, one padded batch per rank, fp32"}
+        if rank == 0:
+            all_len = np.random.default_rng(1234).integers(20, 201, size=256)
+            try:
+                mds_leg = multi_device_synth_leg(hp, all_len, min(world, torch.cuda.device_count()))
+            except Exception as e:  # the leg must never take the line down
+                mds_leg = {"error": repr(e)}
+        if dist is not None:
+            dist.barrier()
 
     streaming = None
     if args.workload == "c5" and rank == 0:
@@ -615,7 +745,11 @@ def main():
                        "batch": B, "T_x": Tx, "T_y": Ty, "samples_per_step_per_gpu": valid_samples,
                        "parallelism": f"replicas x{world} (no collective)", "hipgraph": not args.no_graph},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_api": host_api, "batch32": batch32, "batch32_bf16x3": batch32_bf16x3, "multistream": multistream,
-            "streaming": streaming,
+            "streaming": streaming, "batch256_sharded": batch256, "multi_device_synth": mds_leg,
+            "ranks_seen": len(R["rank_ms"]), "rank_ms": R["rank_ms"], "finite_check": R["finite_checked"],
+            "launched_by": "bench.py" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if dist is not None else "single process"),
+            "value_is": "device-resident session (inputs in HBM when the timed region starts, as the bench contract requires); the drop-in host "
+                        "path (ids on the host -> int16 on the host, free-running) is host_api",
         }
         print(json.dumps(line))
     if dist is not None:

@@ -141,3 +141,33 @@ def test_bench_reads_rocprofv3_kernel_stats(tmp_path):
     assert bench.rocprof_avg_us(str(p), "conv_mfma_ks_kernel<2,1,GATE,1>") == 16.95
     assert bench.rocprof_avg_us(str(p), "conv_mfma_ks_kernel<1,1,COUPLE,1>") is None
     assert bench.rocprof_avg_us(str(tmp_path / "absent.csv"), "x") is None
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_multi_rank_entry_point_dry_run(launcher):
+    """`python bench.py --gpus 2 ...` must work PLAINLY (it starts its own ranks) and under the driver's
+    `python -m torch.distributed.run ...` form; ranks meet at a host-side (gloo) barrier and a max over their timings.  --dry-run
+    skips the GPU work and runs exactly that plumbing: 2 processes on CPU, one JSON line from rank 0 that saw both ranks and
+    carries the slower rank's time (rank r sleeps (1 + r) ms per step)."""
+    import json
+    import socket
+
+    bench = os.path.join(ROOT, "bench.py")
+    args = ["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"]
+    if launcher == "self":
+        cmd = [sys.executable, bench] + args
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), bench] + args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
+    assert d["ms_per_step"] >= 2.0  # the slower rank (2 ms per step), not the faster one
+    assert d["launched_by"] == ("bench.py" if launcher == "self" else "torch.distributed.run")

@@ -126,7 +126,13 @@ class MultiDeviceSynth:
     def synth_batch(self, texts, speaker_ids=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None, seeds=None):
         """texts: list of str -> list of int16 PCM arrays (22.05 kHz), one per request, in request order.  `seeds`: optional
         per-request noise seeds (default: a running counter), `speaker_ids`: one id or one per request."""
-        n = len(texts)
+        s0 = self.synths[0]
+        token_lists = [s0.g2p_noembed(s0.normalize(t)) for t in texts]
+        return self.synth_tokens(token_lists, speaker_ids, noise_level, speech_rate, duration_noise_level, scale, seeds)
+
+    def synth_tokens(self, token_lists, speaker_ids=0, noise_level=None, speech_rate=None, duration_noise_level=None, scale=None, seeds=None):
+        """synth_batch() behind the front end: token id lists in, int16 PCM arrays out (request order)."""
+        n = len(token_lists)
         if n == 0:
             return []
         s0 = self.synths[0]
@@ -136,7 +142,6 @@ class MultiDeviceSynth:
         duration_noise_level = inf.get("duration_noise_level", 0.8) if duration_noise_level is None else duration_noise_level
         scale = inf.get("scale", 1.0) if scale is None else scale
         scales = np.array([noise_level, 1.0 / speech_rate, duration_noise_level], np.float32)  # synth.py:106
-        token_lists = [s0.g2p_noembed(s0.normalize(t)) for t in texts]
         sids = [speaker_ids] * n if np.isscalar(speaker_ids) or speaker_ids is None else list(speaker_ids)
         sids = [0 if v is None else int(v) for v in sids]
         if seeds is None:

@@ -65,6 +65,13 @@ static int g_wn_fold = 1;
 // 1 = LayerNorm statistics of the folded encoder LayerNorms from the producer conv's epilogue (default), 0 = redone by the consumer
 static int g_ln_stats = 1;
 // single-utterance duration predictor as one persistent kernel (persist.hip.h): 1 = when eligible (default), 0 = launch path
+// A persistent kernel needs ALL its workgroups resident at once (they spin on each other's cells): two of them in flight on one
+// device could each hold half of the CUs and wait forever (the bounded poll loops turn that into an error, not a hang -- but it must
+// not happen in normal operation).  So at most ONE caller per device owns the persistent path at a time (a token); everybody else
+// takes the launch path for that call.  persist_mask() is what the stage launchers test: the owner's mask, 0 for everybody else.
+static std::mutex g_tok_mu;
+static bool g_tok_busy[64];
+static thread_local int tl_persist = -1;  // >= 0: this thread's mask for the call in progress
 static int g_persist = getenv("VITS_NO_PERSIST") ? 0 : (getenv("VITS_PERSIST") ? atoi(getenv("VITS_PERSIST")) : 7);  // mask: 1 duration predictor, 2 text encoder, 4 flow (environment switches: A/B runs of bench.py and tools/)
 
 // ------------------------------------------------------------------------------------ weights
@@ -697,6 +704,7 @@ struct vits_session {
   };
   PersistProg ps_enc, ps_sdp, ps_flow;
   PersistCtl* ps_ctl = nullptr;
+  bool ps_owner = false;   // device sessions (asynchronous entry point): this session holds the device's persistent-path token for its lifetime
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
   // session, so a steady stream of vits_synthesize calls does no hipMalloc / hipFree (both synchronise the device)
   char* stage = nullptr;
@@ -713,14 +721,14 @@ struct vits_session {
   char *io_h = nullptr, *io_d = nullptr;  // per-call inputs: pinned host mirror and device copy (SynthDev | lengths | sid | ids | forced)
   size_t io_bytes = 0, io_len = 0, io_sid = 0, io_ids = 0, io_forced = 0, io_seeds = 0;
   int64_t* h_ylen = nullptr;       // pinned [B] + one int error word behind it
-  hipGraphExec_t g1[4] = {nullptr, nullptr, nullptr, nullptr};  // [forced*2 + solo]
+  hipGraphExec_t g1[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [persist*4 + forced*2 + solo]
   std::map<int, vits_session*> backs;
   vits_session* front = nullptr;
   float* out_d = nullptr;          // back: fp32 audio [B, T_y bucket * hop] on the device
   int16_t* pcm_d = nullptr;        // back: int16 PCM, same shape
   char* out_h = nullptr;           // back: pinned host copy of whichever output the call asked for
   size_t out_elems = 0;
-  hipGraphExec_t g2[4] = {nullptr, nullptr, nullptr, nullptr};  // [solo*2 + pcm]
+  hipGraphExec_t g2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [persist*4 + solo*2 + pcm]
   uint64_t last_use = 0;
   size_t cache_bytes = 0;          // device bytes this session pins while cached (front: incl. its backs)
 };
@@ -734,6 +742,25 @@ static T* bump(vits_session* s, size_t n) {
 }
 
 #include "persist_plan.hip.h"
+
+static inline int persist_mask() { return tl_persist >= 0 ? tl_persist : 0; }
+static bool persist_token_try(int dev) {
+  std::lock_guard<std::mutex> g(g_tok_mu);
+  if (dev < 0 || dev >= 64 || g_tok_busy[dev]) return false;
+  g_tok_busy[dev] = true;
+  return true;
+}
+static void persist_token_release(int dev) {
+  std::lock_guard<std::mutex> g(g_tok_mu);
+  if (dev >= 0 && dev < 64) g_tok_busy[dev] = false;
+}
+// a host call that launches AND waits for its kernels: owns the token (when it is free) from here to its end
+struct PersistScope {
+  int dev; bool own;
+  explicit PersistScope(int dev_) : dev(dev_), own(g_persist != 0 && persist_token_try(dev_)) { tl_persist = own ? g_persist : 0; }
+  void release() { tl_persist = -1; if (own) persist_token_release(dev); own = false; }  // (the caller has waited for its kernels)
+  ~PersistScope() { release(); }
+};
 
 // lays out every activation buffer for the given capacity; with arena == nullptr only measures
 static void plan(vits_session* s, int B, int Tx, int Ty) {
@@ -865,7 +892,7 @@ static void session_free(vits_session* s) {
   drop_graphs(s);
   for (auto& kv : s->backs) session_free(kv.second);
   s->backs.clear();
-  for (int i = 0; i < 4; ++i) { if (s->g1[i]) hipGraphExecDestroy(s->g1[i]); if (s->g2[i]) hipGraphExecDestroy(s->g2[i]); }
+  for (int i = 0; i < 8; ++i) { if (s->g1[i]) hipGraphExecDestroy(s->g1[i]); if (s->g2[i]) hipGraphExecDestroy(s->g2[i]); }
   if (s->io_h) hipHostFree(s->io_h);
   if (s->io_d) hipFree(s->io_d);
   if (s->h_ylen) hipHostFree(s->h_ylen);
@@ -1527,7 +1554,7 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels;
-  if ((g_persist & PERSIST_ENC) && s->ps_enc.ok && B == 1 && Tx == s->Tx && !d_bert) {  // one persistent kernel instead of ~35 launches
+  if ((persist_mask() & PERSIST_ENC) && s->ps_enc.ok && B == 1 && Tx == s->Tx && !d_bert) {  // one persistent kernel instead of ~35 launches
     persist_launch(s, s->ps_enc, "enc.persist", nullptr, 0.f, 0, d_ids);
     return;
   }
@@ -1660,7 +1687,7 @@ static void run_duration(vits_session* s, const float* x, const float* d_noise, 
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int D = hp.dp_filter_channels;
-  if ((g_persist & PERSIST_SDP) && s->ps_sdp.ok && B == 1 && Tx == s->Tx) {  // one persistent kernel instead of ~21 launches (persist.hip.h)
+  if ((persist_mask() & PERSIST_SDP) && s->ps_sdp.ok && B == 1 && Tx == s->Tx) {  // one persistent kernel instead of ~21 launches (persist.hip.h)
     // the program reads the text-encoder output from the session's own buffer (stage-level callers bring theirs)
     if (x != s->x) hipMemcpyAsync(s->x, x, sizeof(float) * (size_t)hp.hidden_channels * Tx, hipMemcpyDeviceToDevice, s->stream);
     persist_launch(s, s->ps_sdp, "dp.persist", d_noise, nsw, seed);
@@ -1714,7 +1741,7 @@ static float* run_flow(vits_session* s, int B, int Ty) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels, I = hp.inter_channels, half = I / 2, L = hp.flow_wn_layers, K5 = hp.flow_kernel_size;
-  if ((g_persist & PERSIST_FLOW) && s->ps_flow.ok && B == 1 && Ty == s->Ty) {  // one persistent kernel instead of ~75 launches
+  if ((persist_mask() & PERSIST_FLOW) && s->ps_flow.ok && B == 1 && Ty == s->Ty) {  // one persistent kernel instead of ~75 launches
     persist_launch(s, s->ps_flow, "flow.persist");
     return s->zB;
   }
@@ -1899,7 +1926,8 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
 // ---- helpers for the host-buffer stage entry points
 struct HostStage {
   vits_model* m; vits_session* s = nullptr; std::vector<void*> tmp;
-  explicit HostStage(vits_model* m_) : m(m_) {}
+  PersistScope pscope;  // (declared last-constructed / first-destroyed relative to the stream sync in ~HostStage: see below)
+  explicit HostStage(vits_model* m_) : m(m_), pscope(m_ ? m_->device : -1) {}
   ~HostStage() {
     if (s) {
       hipStreamSynchronize(s->stream);
@@ -2409,7 +2437,7 @@ static int capture_end(vits_session* s, hipGraphExec_t* out, CaptureGuard* guard
 }
 
 static int phase1_launch(vits_session* F, bool forced, bool solo) {
-  const int gi = (forced ? 2 : 0) + (solo ? 1 : 0);
+  const int gi = (persist_mask() ? 4 : 0) + (forced ? 2 : 0) + (solo ? 1 : 0);
   if (!F->g1[gi]) {
     const int B = F->B, TxB = F->Tx;
     HIP_TRY(hipStreamBeginCapture(F->stream, hipStreamCaptureModeThreadLocal));
@@ -2436,7 +2464,7 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
 }
 
 static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm) {
-  const int gi = (solo ? 2 : 0) + (pcm ? 1 : 0);
+  const int gi = (persist_mask() ? 4 : 0) + (solo ? 2 : 0) + (pcm ? 1 : 0);
   if (!Bk->g2[gi]) {
     const int B = F->B, TxB = F->Tx, TyB = Bk->Ty;
     const long long stride = (long long)TyB * F->m->hp.hop_length;
@@ -2475,6 +2503,8 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   HIP_TRY(hipSetDevice(m->device));
   const int TxB = (Tx + 7) / 8 * 8;
   const bool forced = opts && opts->forced_durations, solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
+  // (declared before the session guard: the call's last stream synchronisation happens before this scope ends)
+  PersistScope pscope(B == 1 ? m->device : -1);  // a single utterance takes the persistent stages when no other call on this device holds them
   vits_session* F = nullptr;
   TRY(front_acquire(m, B, TxB, &F));
   struct Rel { vits_model* m; vits_session* s; ~Rel() { front_release(m, s); } } rel{m, F};
@@ -2680,6 +2710,9 @@ int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float*
     vits_stream_close(st);
     return fail(VITS_ERR_NOMEM, "stream buffers");
   }
+  // the acoustic half is done with the persistent stages: wait for them and hand the token back (the stream object lives on)
+  hipStreamSynchronize(st->hs->s->stream);
+  st->hs->pscope.release();
   rc = stream_launch(st, 0);  // first chunk is already decoding when the caller asks for it
   if (rc != VITS_OK) { vits_stream_close(st); return rc; }
   if (total_samples) *total_samples = Ty * hp.hop_length;
@@ -2743,11 +2776,17 @@ int vits_session_create(vits_model* m, int32_t max_B, int32_t max_Tx, int32_t ma
   TRY(session_new(m, &s));
   int rc = session_reserve(s, max_B, max_Tx, max_Ty);
   if (rc != VITS_OK) { session_free(s); return rc; }
+  // the asynchronous entry point cannot hand the token back per call (nobody waits for the kernels): the first device session of a
+  // device keeps it until it is destroyed; others (and host calls in the meantime) run the launch path
+  s->ps_owner = g_persist != 0 && persist_token_try(m->device);
   *out = s;
   return VITS_OK;
 }
 
-void vits_session_destroy(vits_session* s) { session_free(s); }
+void vits_session_destroy(vits_session* s) {
+  if (s && s->ps_owner) { hipStreamSynchronize(s->stream); persist_token_release(s->m->device); }
+  session_free(s);
+}
 
 int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const int64_t* d_lengths, int32_t B, int32_t Tx,
                                    const float* scales, const int64_t* d_sid, const int32_t* d_forced, int32_t Ty, uint64_t seed,
@@ -2759,9 +2798,10 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
   HIP_TRY(hipSetDevice(m->device));
   (void)stream;  // sessions run on their own stream; the argument is reserved
   TRY(session_reserve(s, B, Tx, Ty));
+  struct Mask { Mask(int v) { tl_persist = v; } ~Mask() { tl_persist = -1; } } mask(s->ps_owner ? g_persist : 0);
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
   if (s->use_graph && !s->profile) {
-    vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed, scales[0], scales[1], scales[2]);
+    vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed ^ ((uint64_t)persist_mask() << 56), scales[0], scales[1], scales[2]);
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
       if (s->graphs.size() >= 64) drop_graphs(s);  // bound the cache: a caller that varies shapes/pointers forever must not leak
