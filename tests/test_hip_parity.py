@@ -233,6 +233,41 @@ def test_stages_full_b2_ragged(hip_default, oracle_default):
     _stages_vs(hip_default, oracle_default, golden("full_b2"), STAGE_TOL)
 
 
+def test_heavy_tailed_weights_fp32_and_split_bf16(hip_lib, oracle_lib):
+    """Dynamic range: the fp32 path stage by stage against the reference's outputs on heavy-tailed weights (full_heavy.npz: per-row
+    log-normal scales, sigma 1, |z| up to 50), and the split-bf16 variant (conv_precision = 1) on a batch of 8 copies of that utterance
+    (the 128 x 128 split-bf16 kernels only run at batch size) against the same golden waveform at the north_star's 1e-3."""
+    from vosk_tts_amd import weights as W
+
+    g = golden("full_heavy")
+    hp = W.default_hparams()
+    blob = W.synthetic_blob(hp, 1234, heavy_sigma=1.0)
+    model, ref = hip_lib.create(blob, 0), oracle_lib.create(blob)
+    try:
+        _stages_vs(model, ref, g, STAGE_TOL)
+    finally:
+        model.close()
+    hp.conv_precision = 1
+    m3 = hip_lib.create(W.synthetic_blob(hp, 1234, heavy_sigma=1.0), 0)
+    try:
+        rep = lambda a: np.repeat(a, 8, axis=0)
+        args = (rep(g["ids"]), rep(g["lengths"]), g["scales"], rep(g["sid"]))
+        kw = dict(noise_dp=rep(g["noise_dp"]), noise_prior=rep(g["noise_prior"]), forced_durations=rep(g["forced_durations"]))
+        a_bf, ol = m3.synthesize(*args, **kw)
+        hip_lib.lib.vits_debug_no_bf16x3(1)
+        a_fp, _ = m3.synthesize(*args, **kw)
+        hip_lib.lib.vits_debug_no_bf16x3(0)
+        assert not np.array_equal(a_bf, a_fp)  # the split-bf16 kernels really ran
+        n = int(ol[0])
+        for b in range(8):
+            assert_close(f"heavy-tailed split-bf16 item {b} vs golden", g["audio"][0, :n], a_bf[b, :n], 1e-3)
+            assert_close(f"heavy-tailed fp32 batch item {b} vs golden", g["audio"][0, :n], a_fp[b, :n], E2E_TOL)
+        err = np.abs(a_bf[0, :n] - g["audio"][0, :n]).max() / np.abs(g["audio"]).max()
+        print(f"split-bf16 on heavy-tailed weights: rel err {err:.2e}")
+    finally:
+        m3.close()
+
+
 def test_stages_tiny_b3_ragged(hip_tiny, oracle_tiny):
     _stages_vs(hip_tiny, oracle_tiny, golden("tiny_b3"), STAGE_TOL)
 
@@ -724,6 +759,30 @@ def test_long_form_properties_at_c5_size(hip_default):
     assert_close("c5 stream vs one-shot", one, got, 2e-5)
     half, _ = hip_default.synthesize(ids[:, :1000], [1000], sc, [2], forced_durations=dur[:, :1000], seed=3)
     assert float(np.max(np.abs(half[0, :100000] - one[0, :100000]))) > 1e-3
+
+
+def test_c5_size_stages_against_the_oracle(hip_default, oracle_default):
+    """BASELINE configs[4] size AGAINST THE ORACLE at stage level (the full 70 s forward is minutes on the CPU, two of its stages are
+    seconds): the text encoder at T_x = 2000 tokens (125 key tiles of the MFMA flash kernel, relative-position band at every tile
+    edge) and the whole flow at T_y = 6000 frames (188 key tiles per pre-transformer, 4 coupling layers, WaveNet over 6000
+    columns).  The largest oracle-checked attention used to be T = 400."""
+    rng = np.random.default_rng(2000)
+    Tx = 2000
+    ids = rng.integers(1, 62, size=(1, Tx)).astype(np.int64)
+    lens = np.array([Tx - 13], np.int64)  # ragged inside the last tile
+    sid = np.array([2], np.int64)
+    want = oracle_default.text_encoder(ids, lens, sid)
+    got = hip_default.text_encoder(ids, lens, sid)
+    m = np.arange(Tx)[None, None, :] < lens[0]
+    for name, w, g in zip(("x", "m_p", "logs_p"), want, got):
+        assert_close(f"c5 text encoder {name}", w * m, g * m, STAGE_TOL)
+    Ty = 6000
+    z_p = rng.standard_normal((1, 192, Ty)).astype(np.float32)
+    ylen = np.array([Ty - 7], np.int64)
+    wz = oracle_default.flow(z_p, ylen, sid)
+    gz = hip_default.flow(z_p, ylen, sid)
+    my = np.arange(Ty)[None, None, :] < ylen[0]
+    assert_close("c5 flow z", wz * my, gz * my, STAGE_TOL)
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (2, 37), (1, 50), (3, 333), (8, 200), (16, 160)])

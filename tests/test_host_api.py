@@ -10,6 +10,8 @@ import pytest
 
 from conftest import assert_close, golden
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_g2p_known_answers():
     from vosk_tts_amd.g2p import convert
@@ -327,6 +329,71 @@ def test_device_session_graph_replay_matches_host_path(hip_default):
         for b in range(B):  # identical on every valid sample; beyond len + halo both are zeros
             assert_close(f"device session item {b}", want[b, :wl[b]], got[b, :wl[b]], 1e-6)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_driver_timed_configuration_equals_the_host_path(hip_default, workload):
+    """Exactly what bench.py times (bench.py measure()): a VitsDeviceSession with set_sdp_always(True) -- durations pinned, the
+    duration predictor executed anyway -- hipGraph on, the bench's own c2 / c3 batch built by bench.make_workload, seed 7; the audio
+    must equal the host entry point's for the same feed on every valid sample, on the first (capturing) call and on replays."""
+    import sys
+
+    import torch
+
+    from vosk_tts_amd.capi import VitsDeviceSession
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    ids, lengths, dur = bench.make_workload(workload, np.random.default_rng(1234))
+    B, Tx = ids.shape
+    Ty = int(dur.sum(1).max())
+    scales = np.array([0.8, 1.0, 0.8], np.float32)
+    sid = np.full(B, 2, np.int64)
+    want, wl = hip_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=7)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_ids, d_len, d_sid, d_dur = t(ids), t(lengths), t(sid), t(dur)
+    d_audio = torch.zeros((B, Ty * 256), dtype=torch.float32, device=dev)
+    s = VitsDeviceSession(hip_default, B, Tx, Ty)
+    s.set_options(use_graph=True, profile=False)
+    s.set_sdp_always(True)
+    for rep in range(3):
+        d_audio.zero_()
+        s.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), B, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 7, d_audio.data_ptr(), Ty * 256)
+        s.sync()
+        got = d_audio.cpu().numpy()
+        for b in range(B):
+            assert_close(f"{workload} item {b} (call {rep})", want[b, :wl[b]], got[b, :wl[b]], 2e-6)
+    assert s.graph_nodes() > 0
+    s.close()
+
+
+@pytest.mark.gpu
+def test_multi_device_synth_on_two_devices(tmp_path):
+    """MultiDeviceSynth with one replica per DEVICE (not two replicas on device 0): runs the day a box has two GPUs; the result of
+    a request must not depend on which device it landed on."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.batching import MultiDeviceSynth
+    from vosk_tts_amd.capi import VitsLib
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    if VitsLib().device_count() < 2:
+        pytest.skip("needs two visible devices")
+    d = write_toy_model(str(tmp_path / "m"), W.tiny_hparams(n_vocab=len(PHONEMES)))
+    rng = np.random.default_rng(5)
+    tokens = [rng.integers(1, len(PHONEMES), size=int(n)).tolist() for n in rng.integers(5, 40, size=12)]
+    two = MultiDeviceSynth(model_path=d, devices=[0, 1], max_batch=4)
+    one = MultiDeviceSynth(model_path=d, devices=[0], max_batch=4)
+    try:
+        seeds = list(range(100, 100 + len(tokens)))
+        a = two.synth_tokens(tokens, speaker_ids=1, seeds=seeds)
+        b = one.synth_tokens(tokens, speaker_ids=1, seeds=seeds)
+    finally:
+        two.close(); one.close()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and np.abs(x.astype(np.int32) - y.astype(np.int32)).max() <= 1, f"request {i}"
 
 
 @pytest.mark.gpu

@@ -46,6 +46,17 @@ def test_full_b2_ragged(oracle_default):
     _full(oracle_default, golden("full_b2"))
 
 
+def test_full_heavy_tailed_weights(oracle_lib):
+    """The full path on HEAVY-TAILED weights (per-row log-normal scales, sigma 1: oracle/gen_golden_heavy.py ran the reference's own
+    modules on them): |z| reaches 50, the gates and the exp() of the iSTFT heads leave the O(1) regime of the other fixtures."""
+    from vosk_tts_amd import weights as W
+
+    g = golden("full_heavy")
+    assert np.abs(g["z"]).max() > 20  # the fixture really is heavy-tailed
+    model = oracle_lib.create(W.synthetic_blob(W.default_hparams(), 1234, heavy_sigma=1.0))
+    _full(model, g)
+
+
 def test_tiny_b3_ragged(oracle_tiny):
     _full(oracle_tiny, golden("tiny_b3"))
 

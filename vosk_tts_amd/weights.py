@@ -312,12 +312,16 @@ def _rng(name, seed):
     return np.random.Generator(np.random.Philox(key=key))
 
 
-def make_synthetic_weights(hp, seed=1234):
-    """name -> float32 ndarray.  Fan-in scaled uniform so activations stay O(1)."""
-    return synthetic_from_specs(tensor_specs(hp), seed)
+def make_synthetic_weights(hp, seed=1234, heavy_sigma=0.0):
+    """name -> float32 ndarray.  Fan-in scaled uniform so activations stay O(1).
+
+    heavy_sigma > 0: the "heavy-tailed" variant for dynamic-range tests -- every weight matrix gets per-row (first-axis) scales that
+    are log-normal with that sigma, normalised to unit mean square (so the average gain of a layer is unchanged while individual
+    channels differ by an order of magnitude, as weight-normed trained layers do; tests/golden/full_heavy.npz)."""
+    return synthetic_from_specs(tensor_specs(hp), seed, heavy_sigma)
 
 
-def synthetic_from_specs(specs, seed=1234):
+def synthetic_from_specs(specs, seed=1234, heavy_sigma=0.0):
     out = {}
     for name, shape, kind, fan_in, gain in specs:
         r = _rng(name, seed)
@@ -325,6 +329,10 @@ def synthetic_from_specs(specs, seed=1234):
         if kind == "w":
             a = gain * np.sqrt(3.0 / max(fan_in, 1))
             t = u * a
+            if heavy_sigma > 0 and len(shape) >= 2 and shape[0] > 1:
+                g = np.exp(heavy_sigma * _rng(name + ":heavy", seed).standard_normal(shape[0]))
+                g /= np.sqrt(np.mean(g * g))
+                t = t * g.reshape((-1,) + (1,) * (len(shape) - 1))
         elif kind == "b":
             t = u * 0.05
         elif kind == "gamma":
@@ -428,9 +436,9 @@ def unpack_blob_generic(blob, hp_type, magic):
     return hp, tensors
 
 
-def synthetic_blob(hp=None, seed=1234):
+def synthetic_blob(hp=None, seed=1234, heavy_sigma=0.0):
     hp = hp or default_hparams()
-    return pack_blob(hp, make_synthetic_weights(hp, seed))
+    return pack_blob(hp, make_synthetic_weights(hp, seed, heavy_sigma))
 
 
 def save_blob(path, hp, tensors):
