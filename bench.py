@@ -684,7 +684,7 @@ def main():
         streaming = {"chunk_frames": chunk, "chunk_sec": round(chunk * 256 / SAMPLE_RATE, 3), "chunks": -(-Ty // chunk),
                      "time_to_first_audio_ms": round(float(np.median(ttfa)), 3), "all_chunks_ms": round(float(np.median(total)), 3),
                      "one_shot_host_call_ms": round(float(np.median(oneshot)), 3),
-                     "note": "host API incl. H2D/D2H; acoustic half once over the utterance, decoder hipGraph replayed per chunk"}
+                     "note": "host API incl. H2D/D2H; acoustic half once over the utterance; first chunk decoded alone, then one 8-chunk window per decode, double-buffered against the chunk copies"}
 
     host_api = None
     if args.workload == "c2" and rank == 0 and not args.no_host_api:

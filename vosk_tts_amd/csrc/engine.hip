@@ -654,6 +654,7 @@ struct vits_session {
   vits_model* m = nullptr;
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  hipStream_t copy_stream = nullptr;  // D2H of streamed chunks next to the decode of the following window (created on first use)
   char* arena = nullptr;
   size_t arena_bytes = 0, arena_used = 0;
   int* d_err = nullptr;
@@ -907,6 +908,7 @@ static void session_free(vits_session* s) {
   if (s->d_err) hipFree(s->d_err);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->copy_stream) hipStreamDestroy(s->copy_stream);
   if (s->stream && s->own_stream) hipStreamDestroy(s->stream);
   delete s;
 }
@@ -2641,36 +2643,34 @@ struct vits_stream {
   const float* z = nullptr;
   int Ty = 0, chunk = 0, W = 0, halo = VITS_RAGGED_HALO;  // halo is set from the model's receptive field at open
   int pos = 0;                      // first frame not yet handed to the caller
-  int win_start = -1;               // frame window currently decoded (or in flight) in d_aud
-  float *d_win = nullptr, *d_aud = nullptr, *h_pin = nullptr;
-  hipGraphExec_t graph = nullptr;
+  // The first chunk gets its own narrow window (time to first audio); after it ONE wide window of kmax chunks + halo is decoded
+  // per slot: a single 192-frame decode is latency-bound (0.6 ms per chunk) and pays the 2 x 32-frame halo per 128 frames, a
+  // wide window pays it once per kmax chunks and runs the one-shot's kernels.  Two audio slots: while the chunks of one window
+  // are copied out on the session's copy stream, the next window is decoded into the other slot on the compute stream.
+  struct Win { int lo = -1, hi = -1, start = -1; float* aud = nullptr; hipEvent_t done = nullptr; };
+  Win win[2];
+  int kmax = 8, WK = 0;
+  float *d_win = nullptr, *h_pin = nullptr;
   hipEvent_t ev = nullptr;
+  int find(int lo) const { for (int i = 0; i < 2; ++i) if (lo >= win[i].lo && lo < win[i].hi) return i; return -1; }
 };
 
-static int stream_window_start(const vits_stream* st, int lo) {
-  int start = lo - st->halo;
-  if (start > st->Ty - st->W) start = st->Ty - st->W;
-  return start < 0 ? 0 : start;
-}
-
-// enqueues the decode of the window that covers chunk [lo, ...) unless d_aud already holds it
-static int stream_launch(vits_stream* st, int lo) {
+// enqueues the decode of the window that starts with chunk `lo` into slot `slot`
+static int stream_launch(vits_stream* st, int lo, int slot) {
   vits_session* s = st->hs->s;
-  const int start = stream_window_start(st, lo);
-  if (start == st->win_start) return VITS_OK;
   const int I = st->m->hp.inter_channels;
-  hipLaunchKernelGGL(window_copy_kernel, dim3(cdiv(st->W, 256), I), dim3(256), 0, s->stream, st->z, (long long)st->Ty, start, st->W, st->d_win);
-  if (!st->graph) {
-    hipGraph_t g = nullptr;
-    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    run_decoder(s, st->d_win, false, 1, st->W, st->d_aud, (long long)st->W * st->m->hp.hop_length, nullptr);
-    HIP_TRY(hipStreamEndCapture(s->stream, &g));
-    const hipError_t ie = hipGraphInstantiate(&st->graph, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
-    if (ie != hipSuccess) return fail(VITS_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-  }
-  HIP_TRY(hipGraphLaunch(st->graph, s->stream));
-  st->win_start = start;
+  const bool wide = lo > 0 && st->WK > st->W;
+  const int width = wide ? st->WK : st->W;
+  int start = lo - st->halo;
+  if (start > st->Ty - width) start = st->Ty - width;  // at the end the window is shifted inward: the true zero padding applies
+  if (start < 0) start = 0;
+  vits_stream::Win& w = st->win[slot];
+  w.lo = lo;
+  w.hi = wide ? lo + st->kmax * st->chunk : lo + st->chunk;
+  w.start = start;
+  hipLaunchKernelGGL(window_copy_kernel, dim3(cdiv(width, 256), I), dim3(256), 0, s->stream, st->z, (long long)st->Ty, start, width, st->d_win);
+  run_decoder(s, st->d_win, false, 1, width, w.aud, (long long)width * st->m->hp.hop_length, nullptr);
+  HIP_TRY(hipEventRecord(w.done, s->stream));
   return VITS_OK;
 }
 
@@ -2678,7 +2678,8 @@ void vits_stream_close(vits_stream* st) {
   if (!st) return;
   hipSetDevice(st->m->device);
   if (st->hs && st->hs->s) hipStreamSynchronize(st->hs->s->stream);
-  if (st->graph) hipGraphExecDestroy(st->graph);
+  if (st->hs && st->hs->s && st->hs->s->copy_stream) hipStreamSynchronize(st->hs->s->copy_stream);
+  for (auto& w : st->win) if (w.done) hipEventDestroy(w.done);
   if (st->ev) hipEventDestroy(st->ev);
   if (st->h_pin) hipHostFree(st->h_pin);
   delete st->hs;  // frees d_win/d_aud and returns the session to the pool
@@ -2703,9 +2704,17 @@ int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float*
   st->chunk = chunk_frames;
   st->W = chunk_frames + 2 * st->halo;
   if (st->W > st->Ty) st->W = st->Ty;
-  st->d_win = st->hs->dev_alloc<float>((size_t)hp.inter_channels * st->W);
-  st->d_aud = st->hs->dev_alloc<float>((size_t)st->W * hp.hop_length);
-  if (!st->d_win || !st->d_aud || hipHostMalloc((void**)&st->h_pin, sizeof(float) * (size_t)chunk_frames * hp.hop_length) != hipSuccess ||
+  st->WK = st->kmax * chunk_frames + 2 * st->halo;  // the wide window of the chunks after the first
+  if (st->WK > st->Ty) st->WK = st->Ty;
+  st->d_win = st->hs->dev_alloc<float>((size_t)hp.inter_channels * st->WK);
+  for (auto& w : st->win) w.aud = st->hs->dev_alloc<float>((size_t)st->WK * hp.hop_length);
+  if (!st->hs->s->copy_stream && hipStreamCreateWithFlags(&st->hs->s->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    vits_stream_close(st);
+    return fail(VITS_ERR_DEVICE, "stream: hipStreamCreate failed");
+  }
+  if (!st->d_win || !st->win[0].aud || !st->win[1].aud ||
+      hipEventCreateWithFlags(&st->win[0].done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&st->win[1].done, hipEventDisableTiming) != hipSuccess || hipHostMalloc((void**)&st->h_pin, sizeof(float) * (size_t)chunk_frames * hp.hop_length) != hipSuccess ||
       hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) {
     vits_stream_close(st);
     return fail(VITS_ERR_NOMEM, "stream buffers");
@@ -2713,7 +2722,7 @@ int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float*
   // the acoustic half is done with the persistent stages: wait for them and hand the token back (the stream object lives on)
   hipStreamSynchronize(st->hs->s->stream);
   st->hs->pscope.release();
-  rc = stream_launch(st, 0);  // first chunk is already decoding when the caller asks for it
+  rc = stream_launch(st, 0, 0);  // first chunk is already decoding when the caller asks for it
   if (rc != VITS_OK) { vits_stream_close(st); return rc; }
   if (total_samples) *total_samples = Ty * hp.hop_length;
   *out = st;
@@ -2730,11 +2739,15 @@ int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n
   const int lo = st->pos, hi = lo + st->chunk < st->Ty ? lo + st->chunk : st->Ty;
   const int64_t n = (int64_t)(hi - lo) * hop;
   if (capacity < n) return fail(VITS_ERR_ARG, "chunk capacity %lld < %lld samples", (long long)capacity, (long long)n);
-  TRY(stream_launch(st, lo));  // no-op when decode-ahead already covered it
-  HIP_TRY(hipMemcpyAsync(st->h_pin, st->d_aud + (size_t)(lo - st->win_start) * hop, sizeof(float) * n, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipEventRecord(st->ev, s->stream));
+  int slot = st->find(lo);
+  if (slot < 0) { slot = 0; TRY(stream_launch(st, lo, slot)); }  // only the first call: later windows are decoded ahead
+  const vits_stream::Win& w = st->win[slot];
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, w.done, 0));
+  HIP_TRY(hipMemcpyAsync(st->h_pin, w.aud + (size_t)(lo - w.start) * hop, sizeof(float) * n, hipMemcpyDeviceToHost, s->copy_stream));
+  HIP_TRY(hipEventRecord(st->ev, s->copy_stream));
   st->pos = hi;
-  if (hi < st->Ty) TRY(stream_launch(st, hi));  // decode ahead; stream order keeps it behind the copy above
+  // decode ahead into the other slot: every chunk of the window it held was handed over (and waited for) before this call
+  if (w.hi < st->Ty && st->find(w.hi) < 0) TRY(stream_launch(st, w.hi, slot ^ 1));
   HIP_TRY(hipEventSynchronize(st->ev));
   memcpy(audio, st->h_pin, sizeof(float) * n);
   *n_samples = n;

@@ -1093,6 +1093,13 @@ __global__ void window_copy_kernel(const float* __restrict__ z, long long zstrid
   if (t < W) dst[(size_t)c * W + t] = z[(size_t)c * zstride + start + t];
 }
 
+// the same for a batch of windows of one utterance (streaming: k windows decoded per graph replay): item blockIdx.z starts at starts.v[z]
+struct WindowStarts { int v[8]; };
+__global__ void window_copy_batch_kernel(const float* __restrict__ z, long long zstride, WindowStarts starts, int W, int I, float* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t < W) dst[((size_t)b * I + c) * W + t] = z[(size_t)c * zstride + starts.v[b] + t];
+}
+
 // Monotonic alignment search (monotonic_align/core.pyx:7-42), one workgroup per item.
 // Forward: rows are dependent, columns of one row are not -> threads own columns, the previous row's running
 // scores live in a double-buffered LDS row, one barrier per frame row.  Instead of keeping the whole Q matrix for
