@@ -70,6 +70,14 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t T_x, const float*
                     const float* phone_duration_extra, const stts_synth_opts* opts, float** out_audio, int64_t* out_samples,
                     float** out_mel, int64_t* out_frames);
 
+/* Streaming form of stts_synthesize (the reference's transport is `stream AudioChunk`, server/tts_service.proto:46-54): the
+ * acoustic model runs once over the utterance (the estimator's attention is global), the vocoder is streamed over the mel
+ * in chunk_frames windows (vits_stream_open_latent with the clamp).  Chunks come from vits_stream_next / vits_stream_close;
+ * their concatenation equals stts_synthesize's audio for the same arguments. */
+int stts_stream_open(stts_model* m, const int64_t* ids, int32_t T_x, const float* scales, int64_t sid, const float* bert,
+                     const float* phone_duration_extra, const stts_synth_opts* opts, int32_t chunk_frames, vits_stream** out,
+                     int64_t* total_samples);
+
 /* Batch of B independent utterances (throughput; not part of the reference, whose synthesise() takes one): item b gives
  * exactly what stts_synthesize returns for ids[b][:, :lengths[b]], sid[b], bert[b], phone_duration_extra[b] and seed
  * opts->seed + b -- every kernel masks or zero-pads per item, the unmasked convs of the estimator see zeros beyond each

@@ -200,12 +200,18 @@ void vits_free_pcm16(int16_t* p);
  * currently sends the whole utterance as one chunk).  vits_stream_open runs SynthesizerTrn.infer up to the flow
  * (models.py:1680-1701) over the whole utterance -- the flow's attention is global -- and returns the total sample
  * count; each vits_stream_next returns the next chunk_frames*hop_length samples (fewer for the last chunk, 0 at the
- * end), decoded by replaying one captured hipGraph of the decoder over a frame window with a 32-frame halo, while the
- * following chunk is already decoding.  The concatenated chunks equal the one-shot vits_synthesize output (decoder
- * receptive field < 25 frames).  B = 1; opts as for vits_synthesize. */
+ * end).  The decoder runs over frame windows with a halo of the model's receptive field (>= 32 frames) either side: the
+ * first chunk alone (time to first audio), afterwards eight chunks per window, decoded one window ahead of the caller
+ * while the chunks of the previous window are copied out.  The concatenated chunks equal the one-shot vits_synthesize
+ * output (decoder receptive field < 25 frames).  B = 1; opts as for vits_synthesize.
+ * vits_stream_open_latent streams the decoder over a latent the caller holds (host float [inter_channels, T_y]): the
+ * vocoder half of a two-model voice (StableTTS mel -> vocoder, vosk_tts/synth.py:113-126); flags bit 0 clamps the audio
+ * to [-1, 1] (onnx/export.py:28-31). */
 typedef struct vits_stream vits_stream;
 int vits_stream_open(vits_model* m, const int64_t* ids, int32_t T_x, const float* scales, int64_t sid,
                      const vits_synth_opts* opts, int32_t chunk_frames, vits_stream** out, int64_t* total_samples);
+int vits_stream_open_latent(vits_model* m, const float* z, int32_t T_y, int32_t chunk_frames, uint32_t flags, vits_stream** out,
+                            int64_t* total_samples);
 int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n_samples);
 void vits_stream_close(vits_stream* st);
 

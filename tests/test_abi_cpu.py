@@ -37,7 +37,8 @@ def test_stts_header_surface_is_exported_by_product_library_and_oracle(hip_lib, 
                  "stts_stage_durations", "stts_stage_estimator", "stts_stage_cfm"):
         assert must in names
     assert not [n for n in names if not hasattr(hip_lib.lib, n)]
-    assert not [n for n in names if not hasattr(oracle_lib.lib, "sttsref_" + n[len("stts_"):])]
+    # streaming is an extension of the product library: its expected output is the oracle's one-shot audio
+    assert not [n for n in names if n != "stts_stream_open" and not hasattr(oracle_lib.lib, "sttsref_" + n[len("stts_"):])]
     from vosk_tts_amd.weights_stts import SttsHParams
 
     assert ctypes.sizeof(SttsHParams) == 26 * 4

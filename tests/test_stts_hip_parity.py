@@ -365,3 +365,32 @@ def test_stts_tiny_utterances_vs_oracle(stts_pair):
         assert m_hip.shape == (80, int(Tx * d)) and a_hip.shape == (int(Tx * d) * 256,)
         assert_close(f"mel Tx={Tx}", m_ref, m_hip, E2E_TOL)
         assert_close(f"audio Tx={Tx}", a_ref, a_hip, E2E_TOL)
+
+
+def test_stts_streamed_chunks_equal_the_one_shot_call(hip_lib):
+    """stts_stream_open / SttsSession.run_stream: the vocoder streamed over the mel in windows (first chunk alone, then 8-chunk
+    windows) gives exactly the one-shot audio, including the clamp, for chunk sizes that do and do not divide T_y and for an
+    utterance shorter than one window."""
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd import weights_stts as S
+    from vosk_tts_amd.session_stts import SttsSession
+
+    sess = SttsSession(S.synthetic_blob(S.default_hparams(40, 7), 1234), W.synthetic_blob(W.hifigan_v1_vocoder_hparams(), 1234), lib=hip_lib)
+    rng = np.random.default_rng(5)
+    for T, per, chunks in ((400, 4.0, (64, 100)), (12, 3.0, (64,))):
+        feed = {"input": rng.integers(1, 40, size=(1, 5, T)).astype(np.int64), "input_lengths": np.array([T], np.int64),
+                "scales": np.array([0.8, 1.0, 0.8], np.float32), "sid": np.array([2], np.int64),
+                "phone_duration_extra": np.full((1, T), per, np.float32), "vits.seed": 11}
+        wav, n = sess.run(None, feed)
+        assert n[0] == int(T * per) * 256
+        for cf in chunks:
+            parts = list(sess.run_stream(None, feed, chunk_frames=cf))
+            assert all(len(p) == cf * 256 for p in parts[:-1]) and len(parts) == -(-int(T * per) // cf)
+            got = np.concatenate(parts)
+            assert got.shape == wav[0].shape
+            assert_close(f"stream T={T} chunk={cf}", wav[0], got, 1e-5)  # windows of other widths run other tile shapes: summation order
+    # the vocoder alone over a caller-held mel
+    _, mel = sess._model.synthesize(feed["input"][0], feed["scales"], 2, None, feed["phone_duration_extra"][0], seed=11)
+    got = np.concatenate(list(sess._vocoder.stream_latent(mel, chunk_frames=16, clamp=True)))
+    assert_close("stream_latent", wav[0], got, 1e-5)
+    sess.close()

@@ -123,6 +123,8 @@ class VitsLib:
             f("session_last_ms").argtypes = [ctypes.c_void_p, c_f32p]
             f("stream_open").argtypes = [ctypes.c_void_p, c_i64p, ctypes.c_int32, c_f32p, ctypes.c_int64,
                                          ctypes.POINTER(SynthOpts), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), c_i64p]
+            f("stream_open_latent").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32,
+                                                ctypes.POINTER(ctypes.c_void_p), c_i64p]
             f("stream_next").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int64, c_i64p]
             f("stream_close").argtypes = [ctypes.c_void_p]
             f("stream_close").restype = None
@@ -280,6 +282,23 @@ class VitsModel:
         total = ctypes.c_int64()
         L.check(L._fn("stream_open")(self._h, _p(ids, c_i64p), Tx, _p(scales, c_f32p), int(sid), ctypes.byref(opts),
                                      int(chunk_frames), ctypes.byref(st), ctypes.byref(total)))
+        return self._drain(st, chunk_frames)
+
+    def stream_latent(self, z, chunk_frames=64, clamp=False):
+        """Streams the decoder over a latent the caller holds (vits_stream_open_latent): z float32 [inter_channels, T_y]."""
+        z = _f32(z)
+        if z.ndim != 2 or z.shape[0] != self.hp.inter_channels:
+            raise ValueError("z must be [inter_channels, T_y]")
+        L = self.lib
+        st = ctypes.c_void_p()
+        total = ctypes.c_int64()
+        L.check(L._fn("stream_open_latent")(self._h, _p(z, c_f32p), z.shape[1], int(chunk_frames), 1 if clamp else 0,
+                                            ctypes.byref(st), ctypes.byref(total)))
+        return self._drain(st, chunk_frames)
+
+    def _drain(self, st, chunk_frames):
+        """generator over an open vits_stream; closes it when exhausted or dropped"""
+        L = self.lib
         cap = int(chunk_frames) * self.hp.hop_length
         n = ctypes.c_int64()
         try:

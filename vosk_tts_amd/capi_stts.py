@@ -32,6 +32,9 @@ class SttsModel:
                                     ctypes.POINTER(c_f32p), c_i64p, ctypes.POINTER(c_f32p), c_i64p]
         f("synthesize_batch").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_f32p, c_i64p, c_f32p, c_f32p,
                                           ctypes.POINTER(SttsOpts), ctypes.POINTER(c_f32p), c_i64p, c_i64p]
+        if hasattr(L, self.prefix + "stream_open"):
+            f("stream_open").argtypes = [vp, c_i64p, ctypes.c_int32, c_f32p, ctypes.c_int64, c_f32p, c_f32p, ctypes.POINTER(SttsOpts),
+                                         ctypes.c_int32, ctypes.POINTER(vp), c_i64p]
         f("stage_encoder").argtypes = [vp, c_i64p, c_i64p, ctypes.c_int32, ctypes.c_int32, c_i64p, c_f32p, c_f32p, c_f32p]
         f("stage_durations").argtypes = [vp, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, c_i32p, c_i64p]
         f("stage_estimator").argtypes = [vp, c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p]
@@ -101,6 +104,30 @@ class SttsModel:
         if want_mel:
             melo = np.ctypeslib.as_array(mel, shape=(self.hp.n_feats, nf.value)).copy(); free(mel)
         return audio, melo
+
+    def stream(self, ids, scales, sid, bert=None, phone_duration_extra=None, seed=0, n_timesteps=0, chunk_frames=64):
+        """Streaming form of synthesize() (stts_stream_open): a generator of float32 chunks of chunk_frames*hop samples whose
+        concatenation equals synthesize()'s audio for the same arguments."""
+        if self._vocoder is None:
+            raise ValueError("no vocoder attached")
+        ids = _i64(ids)
+        if ids.ndim != 2 or ids.shape[0] != 5:
+            raise ValueError("ids must be [5, T]")
+        T = ids.shape[1]
+        scales = _f32(scales)
+        opts = SttsOpts(); opts.seed = seed; opts.n_timesteps = n_timesteps
+        b = None if bert is None else _f32(bert)
+        if b is not None and b.shape != (self.hp.bert_dim, T):
+            raise ValueError("bert must be [768, T]")
+        p = None if phone_duration_extra is None else _f32(phone_duration_extra)
+        if p is not None and p.shape != (T,):
+            raise ValueError("phone_duration_extra must be [T]")
+        st = ctypes.c_void_p()
+        total = ctypes.c_int64()
+        self.check(self._fn("stream_open")(self._h, _p(ids, c_i64p), T, _p(scales, c_f32p), int(sid), None if b is None else _p(b, c_f32p),
+                                           None if p is None else _p(p, c_f32p), ctypes.byref(opts), int(chunk_frames),
+                                           ctypes.byref(st), ctypes.byref(total)))
+        return self._vocoder._drain(st, chunk_frames)
 
     def synthesize_batch(self, ids, lengths, scales, sid, bert=None, phone_duration_extra=None, seed=0, n_timesteps=0):
         """B independent utterances in one pass (stts_synthesize_batch): ids [B,5,T], lengths [B], sid [B];

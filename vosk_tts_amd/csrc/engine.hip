@@ -1037,6 +1037,46 @@ static int ks_pick_waves(const ConvParams& P, long nblk) {
   return 4;
 }
 
+// XCD ownership of a single-utterance launch : the launch's items, ordered (group, then M-tile-major or
+// column-tile-major), are cut into 8 contiguous ranges of equal cost (cost of an item = its group's taps), one per XCD, so an
+// XCD's L2 sees one group's input (two where a cut falls inside a group) instead of all of them.  Within a group the order is
+// M-tile-major when the group's weights outweigh its input (each weight row read by one XCD, the input by the XCDs that share
+// the group) and column-major otherwise.  Returns the grid size (8 x the longest range; surplus workgroups exit at once), or 0
+// when the launch keeps the legacy order (batches, ragged tile maps, and -- the default -- VITS_XCD_MAP unset).
+// MEASURED (profiles/r3_xcd_map.txt): the ownership cuts the fabric traffic of the grouped ResBlock launches but makes them 15 %
+// SLOWER (conv_wp 0.343 -> 0.396 ms per c2 forward, same for column-major and M-major): these launches are bound by the
+// per-workgroup latency chain and by how evenly ~900 unequal workgroups spread over 256 CUs, not by L2 misses -- the legacy
+// order gives every XCD the same mix of 11/7/3-tap workgroups.  Kept as an A/B knob, off by default.
+static int g_xcd_map = 1;
+static int conv_xcd_plan(ConvParams& P) {
+  static const int env = getenv("VITS_XCD_MAP") ? atoi(getenv("VITS_XCD_MAP")) : 0;
+  P.xcd_mode = 0;
+  if (!g_xcd_map || !env || P.B != 1 || P.tile_start) return 0;
+  const long per = (long)P.ntiles_m * P.ntiles_n;
+  long taps = 0;
+  for (int g = 0; g < P.n_groups; ++g) taps += P.g[g].K;
+  const long total = per * taps;  // cost units
+  if (per * P.n_groups < 64 || total <= 0) return 0;
+  const double w_bytes = 4.0 * P.M * P.Cin * (double)taps / P.n_groups, a_bytes = 4.0 * P.Cin * (double)P.Tin;
+  const int mode = env >= 2 ? env - 1 : (w_bytes > a_bytes ? 2 : 1);  // VITS_XCD_MAP=2 / 3 force column-major / M-major (A/B)
+  int first[9];
+  for (int x = 0; x <= 8; ++x) {
+    long t = total * x / 8, item = 0;
+    int g = 0;
+    while (g < P.n_groups - 1 && t >= per * P.g[g].K) { t -= per * P.g[g].K; item += per; ++g; }
+    item += (t + P.g[g].K - 1) / P.g[g].K;
+    first[x] = (int)(item > per * P.n_groups ? per * P.n_groups : item);
+  }
+  int longest = 0;
+  for (int x = 0; x < 8; ++x) {
+    P.xcd_first[x] = first[x];
+    P.xcd_cnt[x] = first[x + 1] - first[x];
+    if (P.xcd_cnt[x] > longest) longest = P.xcd_cnt[x];
+  }
+  P.xcd_mode = mode;
+  return 8 * longest;
+}
+
 template <int MI, int NI, int EPI, int NIN, int NW>
 static void launch_ks_inst(hipStream_t st, const ConvParams& P, dim3 grid) {
   constexpr size_t lds = (size_t)NW * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
@@ -1058,7 +1098,8 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo, ProfScope* ps = 
   P.ntiles_n = cdiv(P.Tout, N_T);
   P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
-  const dim3 grid(nblk);
+  const int owned = conv_xcd_plan(P);
+  const dim3 grid(owned ? owned : nblk);
   const int nw = ks_pick_waves(P, nblk);
   if (ps) ps->add_template_arg(nw);
 #define KS_GO(MI_, NI_, EPI_, NIN_)                                                            \
@@ -1205,7 +1246,8 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
   P.ntiles_m = cdiv(P.M, 32);
   P.ntiles_n = cdiv(P.Tout, 32);
   const size_t lds = (size_t)NW * CONV_CI_T * WP_PITCH * sizeof(float);
-  const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
+  const int owned = conv_xcd_plan(P);
+  const dim3 grid(owned ? owned : P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
   ps.set_kernel("conv_wp_kernel<8>");
   hipLaunchKernelGGL(conv_wp_kernel<NW>, grid, dim3(NW * 64), lds, s->stream, P);
 }
@@ -2650,6 +2692,7 @@ struct vits_stream {
   struct Win { int lo = -1, hi = -1, start = -1; float* aud = nullptr; hipEvent_t done = nullptr; };
   Win win[2];
   int kmax = 8, WK = 0;
+  bool clamp = false;               // audio clamped to [-1, 1] (the StableTTS export, onnx/export.py:28-31)
   float *d_win = nullptr, *h_pin = nullptr;
   hipEvent_t ev = nullptr;
   int find(int lo) const { for (int i = 0; i < 2; ++i) if (lo >= win[i].lo && lo < win[i].hi) return i; return -1; }
@@ -2669,7 +2712,9 @@ static int stream_launch(vits_stream* st, int lo, int slot) {
   w.hi = wide ? lo + st->kmax * st->chunk : lo + st->chunk;
   w.start = start;
   hipLaunchKernelGGL(window_copy_kernel, dim3(cdiv(width, 256), I), dim3(256), 0, s->stream, st->z, (long long)st->Ty, start, width, st->d_win);
-  run_decoder(s, st->d_win, false, 1, width, w.aud, (long long)width * st->m->hp.hop_length, nullptr);
+  const long long S = (long long)width * st->m->hp.hop_length;
+  run_decoder(s, st->d_win, false, 1, width, w.aud, S, nullptr);
+  if (st->clamp) hipLaunchKernelGGL(clamp_kernel, dim3(cdiv((int)S, 256)), dim3(256), 0, s->stream, w.aud, S);
   HIP_TRY(hipEventRecord(w.done, s->stream));
   return VITS_OK;
 }
@@ -2686,17 +2731,10 @@ void vits_stream_close(vits_stream* st) {
   delete st;
 }
 
-int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const vits_synth_opts* opts,
-                     int32_t chunk_frames, vits_stream** out, int64_t* total_samples) {
-  if (!m || !ids || !scales || !out || Tx <= 0 || chunk_frames <= 0) return fail(VITS_ERR_ARG, "bad argument");
-  vits_stream* st = new vits_stream();
-  st->m = m;
-  st->hs = new HostStage(m);
-  std::vector<int64_t> ylen;
-  int64_t Ty = 0, len = Tx;
-  float* z = nullptr;
-  int rc = acoustic_host(*st->hs, ids, &len, 1, Tx, scales, &sid, opts, ylen, Ty, z);
-  if (rc != VITS_OK) { vits_stream_close(st); return rc; }
+// second half of every stream open: window geometry, buffers, first chunk in flight.  Closes the stream on failure.
+static int stream_start(vits_stream* st, const float* z, int Ty, int chunk_frames, vits_stream** out, int64_t* total_samples) {
+  vits_model* m = st->m;
+  int rc = VITS_OK;
   const vits_hparams& hp = m->hp;
   st->z = z;
   st->Ty = (int)Ty;
@@ -2724,9 +2762,41 @@ int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float*
   st->hs->pscope.release();
   rc = stream_launch(st, 0, 0);  // first chunk is already decoding when the caller asks for it
   if (rc != VITS_OK) { vits_stream_close(st); return rc; }
-  if (total_samples) *total_samples = Ty * hp.hop_length;
+  if (total_samples) *total_samples = (int64_t)Ty * hp.hop_length;
   *out = st;
   return VITS_OK;
+}
+
+
+int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const vits_synth_opts* opts,
+                     int32_t chunk_frames, vits_stream** out, int64_t* total_samples) {
+  if (!m || !ids || !scales || !out || Tx <= 0 || chunk_frames <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  vits_stream* st = new vits_stream();
+  st->m = m;
+  st->hs = new HostStage(m);
+  std::vector<int64_t> ylen;
+  int64_t Ty = 0, len = Tx;
+  float* z = nullptr;
+  int rc = acoustic_host(*st->hs, ids, &len, 1, Tx, scales, &sid, opts, ylen, Ty, z);
+  if (rc != VITS_OK) { vits_stream_close(st); return rc; }
+  return stream_start(st, z, (int)Ty, chunk_frames, out, total_samples);
+}
+
+// Streams the decoder over a latent the caller already holds (host, [inter_channels, T_y] row-major): the vocoder half of a
+// two-model voice (StableTTS mel -> vocoder, vosk_tts/synth.py:113-126) or a z produced elsewhere.  flags bit 0: clamp to [-1, 1].
+int vits_stream_open_latent(vits_model* m, const float* z, int32_t Ty, int32_t chunk_frames, uint32_t flags, vits_stream** out,
+                            int64_t* total_samples) {
+  if (!m || !z || !out || Ty <= 0 || chunk_frames <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  if (Ty > (1 << 18)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
+  vits_stream* st = new vits_stream();
+  st->m = m;
+  st->hs = new HostStage(m);
+  st->clamp = (flags & 1u) != 0;
+  int rc = begin_stage(*st->hs, 1, 1, Ty);
+  if (rc != VITS_OK) { vits_stream_close(st); return rc; }
+  const float* d_z = st->hs->to_dev(z, (size_t)m->hp.inter_channels * Ty);
+  if (!d_z) { vits_stream_close(st); return fail(VITS_ERR_NOMEM, "device alloc failed"); }
+  return stream_start(st, d_z, Ty, chunk_frames, out, total_samples);
 }
 
 int vits_stream_next(vits_stream* st, float* audio, int64_t capacity, int64_t* n_samples) {

@@ -1000,6 +1000,20 @@ int stts_synthesize(stts_model* m, const int64_t* ids, int32_t Tx, const float* 
   return VITS_OK;
 }
 
+int stts_stream_open(stts_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const float* bert, const float* pde,
+                     const stts_synth_opts* opts, int32_t chunk_frames, vits_stream** out, int64_t* total_samples) {
+  if (!m || !out || chunk_frames <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  if (!m->vocoder) return fail(VITS_ERR_ARG, "no vocoder attached");
+  float* mel = nullptr;
+  int64_t frames = 0;
+  TRY(stts_synthesize(m, ids, Tx, scales, sid, bert, pde, opts, nullptr, nullptr, &mel, &frames));
+  // the mel crosses the host once (80 x T_y floats): the acoustic context that produced it is cached and reused by other calls
+  int rc = frames > 0 ? vits_stream_open_latent(m->vocoder, mel, (int32_t)frames, chunk_frames, 1u, out, total_samples)
+                      : fail(VITS_ERR_ARG, "empty utterance");
+  free(mel);
+  return rc;
+}
+
 int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
                           const int64_t* sid, const float* bert, const float* pde, const stts_synth_opts* opts, float** out_audio,
                           int64_t* out_samples, int64_t* out_lengths) {

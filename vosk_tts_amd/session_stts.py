@@ -28,7 +28,7 @@ class SttsSession:
     def get_providers(self):
         return ["MI355XExecutionProvider"]
 
-    def run(self, output_names, input_feed, run_options=None):
+    def _parse(self, output_names, input_feed):
         if output_names is not None and not set(output_names) <= {"wav", "wav_lengths"}:
             raise ValueError(f"unknown output names {output_names}")
         feed = {k: v for k, v in input_feed.items() if v is not None}
@@ -55,11 +55,24 @@ class SttsSession:
         if seed is None:
             with self._seed_lock:
                 seed = next(self._seed)
-        audio, _ = self._model.synthesize(ids[0], np.asarray(feed["scales"], np.float32).reshape(-1), sid, bert, pde,
-                                          noise=feed.get("vits.noise"), seed=int(seed), n_timesteps=int(feed.get("vits.n_timesteps", 0)),
-                                          want_mel=False)
+        return feed, ids[0], np.asarray(feed["scales"], np.float32).reshape(-1), sid, bert, pde, int(seed)
+
+    def run(self, output_names, input_feed, run_options=None):
+        feed, ids, scales, sid, bert, pde, seed = self._parse(output_names, input_feed)
+        audio, _ = self._model.synthesize(ids, scales, sid, bert, pde, noise=feed.get("vits.noise"), seed=seed,
+                                          n_timesteps=int(feed.get("vits.n_timesteps", 0)), want_mel=False)
         outs = {"wav": audio[None, :], "wav_lengths": np.array([audio.shape[0]], np.int64)}
         return [outs[n] for n in (output_names or ["wav", "wav_lengths"])]
+
+    def run_stream(self, output_names, input_feed, chunk_frames=64):
+        """Streaming form of run() (extension; the reference's transport is already `stream AudioChunk`,
+        server/tts_service.proto:46-54): yields float32 [n] chunks of chunk_frames * hop samples whose concatenation equals
+        run(...)[0].squeeze() for the same feed (same "vits.seed").  The acoustic model runs once, the vocoder is streamed."""
+        feed, ids, scales, sid, bert, pde, seed = self._parse(output_names, input_feed)
+        if "vits.noise" in feed:
+            raise NotImplementedError("run_stream draws the CFM noise on the device (vits.seed)")
+        return self._model.stream(ids, scales, sid, bert, pde, seed=seed, n_timesteps=int(feed.get("vits.n_timesteps", 0)),
+                                  chunk_frames=chunk_frames)
 
     def close(self):
         self._model.close()
