@@ -473,6 +473,12 @@ def test_multistream_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
     ref = SttsModel(oracle_lib, open(os.path.join(d, "model.sttsw"), "rb").read(), vref)
     want, _ = ref.synthesize(ids[0], feed["scales"], 1, None, None, seed=5)
     assert_close("run() vs oracle", want, wav[0], 5e-4)
+    # streaming a multistream voice: the vocoder over frame windows of the mel, same audio as run() for the same seed
+    parts = list(model.onnx.run_stream(None, feed, chunk_frames=16))
+    assert all(len(p) == 16 * 256 for p in parts[:-1])
+    assert_close("run_stream vs run", wav[0], np.concatenate(parts), 1e-5)
+    pcm = list(synth.synth_stream('Прив+ет, "м+ир"!', speaker_id=2, chunk_frames=16))
+    assert all(c.dtype == np.int16 and len(c) == 16 * 256 for c in pcm[:-1]) and sum(len(c) for c in pcm) == n
     with pytest.raises(ValueError):
         model.onnx.run(None, dict(feed, input=ids[:, :3]))
     with pytest.raises(ValueError):

@@ -59,12 +59,17 @@ template <int V> struct bf3_int { static constexpr int value = V; };
 // immediate offsets.  The weight stream is read one step past its end (add_bf3_packing pads the array).
 // MI = 32-row blocks per wave: 2 -> 128 x 128 tiles, 1 -> 64 x 128 tiles (64-channel stages).  EPI: EPI_STORE, or EPI_GATE with MI == 2
 // (a wave's two row blocks are the [tanh 32 | sigmoid 32] pre-activations of the same 32 channels, commons.py:100-107)
-template <int MI, int EPI>
+// PC (producer / consumer split): the workgroup has 6 waves.  Waves 4 and 5 only stage -- each owns 8 of a chunk's 16 channels
+// (one 16-byte half of every staged column), loads them two chunks ahead, splits and stores them; waves 0..3 only stream weights,
+// read LDS and issue MFMAs.  vmcnt retires in order: in the 4-wave form every weight wait that follows the activation loads of
+// chunk c + 2 also waits for those (an HBM round trip once per chunk, measured as 26 % of the ResBlock launches' time with the
+// staging compiled out, profiles/r3_bf3_ab.txt); here the consumers' counter only ever holds weight fragments.
+template <int MI, int EPI, bool PC = false>
 static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b) {
   constexpr int N_T = 128, M_T = 64 * MI;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row / weight-block offsets stay scalar
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
   const int ROW = P.row_len;  // staged columns: 128 + the launch's largest halo
   const int n0 = nt * N_T, m0 = mt * M_T;
@@ -81,10 +86,70 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   }
   if (P.skip_len && n0 >= P.len[b]) return;
 
+  const int piece_bytes = ROW * (BF3_PITCH * 2);  // one piece (hi or lo) of one chunk buffer
+  if constexpr (PC) {
+    if (wave >= 4) {
+      // ---- producer wave pw: positions 8 pw .. 8 pw + 7 of every staged column = channels (2 pw + (i >> 2)) + 4 (i & 3), i = 0..7
+      const int pw = wave - 4;
+      float stg[8][JT], stn[8][JT];
+      const float* xb = G.x + (long long)b * P.x_bstride;
+      // leaky ReLU of the scaled input as max(s x, (s slope) x): in_scale >= 0 and 0 <= in_slope <= 1 (launcher: bf3_ok), one compare
+      // and one select less per element than conv_act_in
+      const float in_scale = P.in_scale, in_ss = P.in_scale * P.in_slope;
+      const int t_base = n0 - G.pad_l;
+      CONV_STAGE_COLS(JT)
+      unsigned tob[JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) tob[j] = (unsigned)toff[j] * 4u;
+      const __amdgpu_buffer_rsrc_t rx = bt_rsrc(xb);
+      auto load_chunk = [&](int c, float (&dst)[8][JT]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned ro = (unsigned)((long long)(c * CONV_CI_T + 2 * pw + (i >> 2) + 4 * (i & 3)) * P.Tin_stride * 4);
+#pragma unroll
+          for (int j = 0; j < JT; ++j) dst[i][j] = bt_ld(rx, tob[j], ro);
+        }
+      };
+      auto store_chunk = [&](int buf) {
+        char* dst = reinterpret_cast<char*>(lds) + buf * (2 * piece_bytes) + 16 * pw;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const int col = lane + 64 * j;
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = tok[j] ? fmaxf(stg[i][j] * in_scale, stg[i][j] * in_ss) : 0.f;  // select: stale padding may hold NaN
+            hi[i] = (__bf16)v;
+            lo[i] = (__bf16)(v - (float)hi[i]);
+          }
+          if (j < JT - 1 || col < ROW) {
+            *reinterpret_cast<bf16x8*>(dst + col * (BF3_PITCH * 2)) = hi;
+            *reinterpret_cast<bf16x8*>(dst + piece_bytes + col * (BF3_PITCH * 2)) = lo;
+          }
+        }
+      };
+      load_chunk(0, stg);
+      store_chunk(0);
+      if (nchunks > 1) load_chunk(1, stg);
+      __syncthreads();
+#pragma unroll 1
+      for (int c = 0; c < nchunks; ++c) {
+        if (c + 2 < nchunks) load_chunk(c + 2, stn);
+        if (c + 1 < nchunks) store_chunk((c + 1) & 1);  // (waits for the loads of chunk c + 1 only: the newer ones stay in flight)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < JT; ++j) stg[i][j] = stn[i][j];
+      }
+      return;
+    }
+  }
+
   // ---- staging: wave w owns chunk rows w, w+4, w+8, w+12 (coalesced along time); lanes stride over columns
   float stg[4][JT], stn[4][JT];  // staged values of chunk c + 1 (loaded one chunk earlier) and in-flight loads of chunk c + 2
   const float* xb = G.x + (long long)b * P.x_bstride;
-  const float in_scale = P.in_scale, in_slope = P.in_slope;
+  const float in_scale = P.in_scale, in_ss = P.in_scale * P.in_slope;  // (see the producer path)
   const int t_base = n0 - G.pad_l;
   CONV_STAGE_COLS(JT)
   unsigned tob[JT];  // byte offsets of the staging columns (buffer addressing: descriptor + scalar row offset + tob, conv_mfma.hip.h bt_ld)
@@ -100,7 +165,6 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     }
     // (nothing here may consume the loaded values: they ride through the tap loop and are split only in store_chunk)
   };
-  const int piece_bytes = ROW * (BF3_PITCH * 2);  // one piece (hi or lo) of one chunk buffer
   auto store_chunk = [&](int buf) {
     char* dst = reinterpret_cast<char*>(lds) + buf * (2 * piece_bytes) + 8 * wave;
 #pragma unroll
@@ -109,7 +173,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
       bf16x4 hi, lo;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float v = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;  // select: stale padding may hold NaN
+        const float v = tok[j] ? fmaxf(stg[rr][j] * in_scale, stg[rr][j] * in_ss) : 0.f;  // select: stale padding may hold NaN
         hi[rr] = (__bf16)v;
         lo[rr] = (__bf16)(v - (float)hi[rr]);
       }
@@ -141,9 +205,11 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   const unsigned lane16 = (unsigned)lane * 16u;
   auto wload = [&](__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, off, 0)); };
 
-  load_chunk(0, stg);
-  store_chunk(0);
-  if (nchunks > 1) load_chunk(1, stg);
+  if constexpr (!PC) {
+    load_chunk(0, stg);
+    store_chunk(0);
+    if (nchunks > 1) load_chunk(1, stg);
+  }
   __syncthreads();
 
   bf16x8 a[2][MI][2];  // [slot][mi][piece]
@@ -156,17 +222,27 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   // one tap: prefetch the next step into the other slot, read this tap's B fragments, 12 MFMAs
   auto tap = [&](auto slot_, const char* lk0, const char* lk1) {
     constexpr int S = decltype(slot_)::value;
+#ifndef BF3_EXP_NOW  // (time-only experiment switches, tools/ab_build.sh: results are garbage)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       a[S ^ 1][mi][0] = wload(wq[mi], ws);
       a[S ^ 1][mi][1] = wload(wq[mi], ws + 1024);
     }
     ws += 2048;
+#else
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { a[S ^ 1][mi][0] = a[S][mi][1]; a[S ^ 1][mi][1] = a[S][mi][0]; }
+#endif
     bf16x8 bh[2], bl[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
+#ifndef BF3_EXP_NOB
       bh[ni] = *reinterpret_cast<const bf16x8*>(lk0 + ni * 32 * (BF3_PITCH * 2));
       bl[ni] = *reinterpret_cast<const bf16x8*>(lk1 + ni * 32 * (BF3_PITCH * 2));
+#else
+      bh[ni] = a[S][ni % MI][0]; bl[ni] = a[S][ni % MI][1];
+      asm volatile("" : "+v"(bh[ni]), "+v"(bl[ni]));
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);  // loads of the next step and this tap's B reads in flight before the first MFMA
     // lo*hi + hi*lo + hi*hi, the four accumulators interleaved (no back-to-back dependent MFMAs)
@@ -193,7 +269,9 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     // activation loads waits for those too (conv_mfma.hip.h, same rule).  They are requested TWO chunks ahead: a chunk's taps
     // take 1.2 k (3 taps) .. 4.2 k (11 taps) MFMA cycles per wave, less than an HBM round trip under load.
     tap(bf3_int<0>{}, lk0, lk1);
-    if (c + 2 < nchunks) load_chunk(c + 2, stn);
+#if !defined(BF3_EXP_NOSTG) && !defined(BF3_EXP_NOLOAD)
+    if constexpr (!PC) { if (c + 2 < nchunks) load_chunk(c + 2, stn); }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     lk0 += dstep;
     lk1 += dstep;
@@ -213,12 +291,25 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) a[0][mi][pc] = a[1][mi][pc];
     }
-    if (c + 1 < nchunks) store_chunk((c + 1) & 1);
+#if defined(BF3_EXP_NOSTORE)
+    if constexpr (!PC) {  // keep the loads (and the wait for them) alive without the split / LDS stores
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) asm volatile("" :: "v"(stg[rr][j]));
+    }
+#elif !defined(BF3_EXP_NOSTG)
+    if constexpr (!PC) { if (c + 1 < nchunks) store_chunk((c + 1) & 1); }
+#endif
+#ifndef BF3_EXP_NOBAR
     __syncthreads();
+#endif
+    if constexpr (!PC) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+      for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-      for (int j = 0; j < JT; ++j) stg[rr][j] = stn[rr][j];
+        for (int j = 0; j < JT; ++j) stg[rr][j] = stn[rr][j];
+    }
   }
 
   // ---- epilogue (shared with the fp32 kernels).  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -251,6 +342,18 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
         for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][e0 + i];
         conv_epilogue_frag<EPI == EPI_GATE ? EPI_STORE : EPI, 4>(P, G, b, lenb, m0 + (wm * MI + mi) * 32 + 4 * h, e0, n0 + wn * 64 + ni * 32 + l31, v);
       }
+}
+
+template <int MI, int EPI>
+__global__ void __launch_bounds__(384, 2) conv_bf3pc_kernel(const ConvParams P) {
+  extern __shared__ float lds[];
+  kernarg_warm<sizeof(ConvParams)>();
+  int mt, grp, nt, b;
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
+  mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);
+  nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
+  const ConvGroup& G = P.g[grp];
+  conv_bf3_body<MI, EPI, true>(P, G, lds, mt, nt, b);
 }
 
 template <int MI, int EPI>

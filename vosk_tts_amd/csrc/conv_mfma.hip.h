@@ -176,10 +176,20 @@ __device__ __forceinline__ void kernarg_warm() {
 }
 
 // block id -> (m tile, group, column tile, batch item); returns false when the block has no work
+// Plain dispatch order with the M-tiles of one column tile on ONE XCD: workgroup L runs on XCD L % 8, so consecutive ids (the
+// M-tiles of a column tile, which stage the same activation window) would land on ntiles_m different L2s and each fetch the
+// window over the fabric.  Inside every run of 8 * ntiles_m ids, XCD x takes ids [x * ntiles_m, (x + 1) * ntiles_m) in its own
+// dispatch order; the tail that does not fill a run keeps the identity.  The spread of tiles over the XCDs is unchanged.
+__device__ __forceinline__ int conv_pair_mtiles(int ntiles_m) {
+  const int L = blockIdx.x, run = 8 * ntiles_m;
+  if (ntiles_m < 2 || L >= (int)(gridDim.x / run) * run) return L;
+  const int base = L / run * run, r = L - base, x = r & 7, w = r >> 3;  // w-th workgroup of XCD x inside this run
+  return base + x * ntiles_m + w;
+}
 __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, int& grp, int& nt, int& b) {
   if (P.tile_start) {
-    // plain dispatch order (no XCD-contiguous remap: working tiles must be spread over all XCDs)
-    int id = blockIdx.x;
+    // plain dispatch order (no XCD-contiguous remap: working tiles must be spread over all XCDs), M-tiles paired per XCD
+    int id = conv_pair_mtiles(P.ntiles_m);
     mt = id % P.ntiles_m; id /= P.ntiles_m;
     const int total = P.tile_start[P.B];
     int q;
@@ -218,7 +228,7 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
   if (P.n_groups > 1) {
     // grouped launch (k = 11/7/3 ResBlocks, sorted heaviest first by the launcher): plain dispatch order
     // with the group outermost, so the long blocks start first and the launch tail is made of short ones
-    id = blockIdx.x;
+    id = P.B > 1 ? conv_pair_mtiles(P.ntiles_m) : (int)blockIdx.x;  // (one utterance: an XCD keeps its M-tile's weight rows, profiles/r3_xcd_map.txt)
     mt = id % P.ntiles_m; id /= P.ntiles_m;
     nt = id % P.ntiles_n; id /= P.ntiles_n;
     b = id % P.B;

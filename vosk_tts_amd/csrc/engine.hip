@@ -1226,6 +1226,13 @@ static void launch_c16_dds(vits_session* s, ConvParams& P, const char* name, dou
 
 // ---- wave-pipelined kernel for the single-utterance decoder's ResBlock convs (conv_small.hip.h conv_wp_kernel)
 static int g_wp_mode = 0;  // 0 = heuristic, 1 = never, 2 = whenever eligible (tests)
+// split-bf16 kernels: VITS_BF3_PC=1 runs the producer / consumer workgroups (6 waves, conv_bf3.hip.h) instead of the 4-wave form.
+// MEASURED (profiles/r3_bf3_ab.txt): 25 % slower -- two 6-wave workgroups per CU leave two MFMA waves per SIMD instead of three, which
+// costs more than taking the staging out of their instruction streams gains.  Kept for A/B runs, off by default.
+static bool bf3_pc() {
+  static const bool on = getenv("VITS_BF3_PC") && atoi(getenv("VITS_BF3_PC")) == 1;
+  return on;
+}
 static int g_no_bf3 = 0;   // test hook: 1 = a conv_precision == 1 model runs its fp32 kernels (A/B of the split-bf16 variant)
 static bool conv_wp_ok(const ConvParams& P, int epi, int halo, bool small) {
   static const int env_mode = getenv("VITS_CONV_WP") ? atoi(getenv("VITS_CONV_WP")) : 0;
@@ -1331,6 +1338,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   if (epi == EPI_GATE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo, &ps); }
     else if (!g_no_bf3 && P.g[0].wb && P.n_groups == 1 && P.M % 128 == 0 && P.x_ch_sign == 1 && !P.x_ch_off && !P.g[0].x2 && !P.ln_g &&
+             P.in_scale >= 0.f && P.in_slope >= 0.f && P.in_slope <= 1.f &&
              (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B >= 256) {  // split-bf16 WaveNet gate conv (conv_precision == 1)
       ps.set_kernel("conv_bf3_kernel<2,GATE>");
       attach_tile_table(s, P, 128);
@@ -1338,7 +1346,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
       P.ntiles_n = cdiv(P.Tout, 128);
       P.row_len = 128 + halo;
       const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
-      hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(256), lds, s->stream, P);
+      if (bf3_pc()) hipLaunchKernelGGL((conv_bf3pc_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(384), lds, s->stream, P);
+      else hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(256), lds, s->stream, P);
     } else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
     return;
   }
@@ -1369,6 +1378,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   auto bf3_ok = [&]() {
     bool ok = !g_no_bf3 && !P.reflect && !P.x_split && P.x_ch_sign == 1 && !P.x_ch_off && !P.ln_g;
+    ok = ok && P.in_scale >= 0.f && P.in_slope >= 0.f && P.in_slope <= 1.f;  // the staging pass evaluates the leaky ReLU as a max
     if (P.ups_u && (P.ups_cout % 128 || P.n_groups != 1)) ok = false;  // a 128-row tile must lie inside one polyphase phase
     for (int g = 0; g < P.n_groups; ++g) ok = ok && P.g[g].wb && !P.g[g].x2 && !P.g[g].x3;
     return ok;
@@ -1381,7 +1391,10 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     P.row_len = 128 + halo;
     const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
     const dim3 grid(P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
-    if (mi == 2) hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
+    if (bf3_pc()) {
+      if (mi == 2) hipLaunchKernelGGL((conv_bf3pc_kernel<2, EPI_STORE>), grid, dim3(384), lds, s->stream, P);
+      else hipLaunchKernelGGL((conv_bf3pc_kernel<1, EPI_STORE>), grid, dim3(384), lds, s->stream, P);
+    } else if (mi == 2) hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
     else hipLaunchKernelGGL((conv_bf3_kernel<1, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
   };
   // 64-row outputs at batch size: 64 x 128 tiles (twice the columns per weight fragment of the 64 x 64 tile)

@@ -131,8 +131,7 @@ class Synth:
         of the single whole-utterance chunk of tts_server.py:54.  Same conversion as synth_audio per chunk."""
         args, scale = self._feed(text, speaker_id, noise_level, speech_rate, duration_noise_level, scale)
         if not hasattr(self.model.onnx, "run_stream"):
-            raise NotImplementedError("streaming synthesis is implemented for VITS voices (vits_stream_*: the decoder is replayed over "
-                                      "frame windows); multistream (StableTTS) voices synthesize one utterance per call")
+            raise NotImplementedError("this session type has no run_stream (VitsSession: vits_stream_open, SttsSession: stts_stream_open)")
         for chunk in self.model.onnx.run_stream(None, args, chunk_frames=chunk_frames):
             yield self.audio_float_to_int16(chunk * scale)
 
