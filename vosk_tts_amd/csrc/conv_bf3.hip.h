@@ -64,7 +64,10 @@ template <int V> struct bf3_int { static constexpr int value = V; };
 // read LDS and issue MFMAs.  vmcnt retires in order: in the 4-wave form every weight wait that follows the activation loads of
 // chunk c + 2 also waits for those (an HBM round trip once per chunk, measured as 26 % of the ResBlock launches' time with the
 // staging compiled out, profiles/r3_bf3_ab.txt); here the consumers' counter only ever holds weight fragments.
-template <int MI, int EPI, bool PC = false>
+// NS = weight-fragment slots: 2 (a step is requested one tap ahead) or 3 (two taps ahead, slot = (phase + tap) mod 3 with the chunk
+// body instantiated per phase; the activation loads are then requested ONE chunk ahead straight into the single staging register
+// set, at the top of the chunk, where the weight fragments of the chunk's first two taps are already older than them).
+template <int MI, int EPI, bool PC = false, int NS = 2>
 static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b) {
   constexpr int N_T = 128, M_T = 64 * MI;
   constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
@@ -212,26 +215,28 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   }
   __syncthreads();
 
-  bf16x8 a[2][MI][2];  // [slot][mi][piece]
+  bf16x8 a[NS][MI][2];  // [slot][mi][piece]
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    a[0][mi][0] = wload(wq[mi], 0);
-    a[0][mi][1] = wload(wq[mi], 1024);
-  }
-  unsigned ws = 2048;  // byte offset of the next step to fetch (2 KB per step and m-block; the packing is padded by one step for the last prefetch)
+  for (int sl = 0; sl < NS - 1; ++sl)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      a[sl][mi][0] = wload(wq[mi], sl * 2048);
+      a[sl][mi][1] = wload(wq[mi], sl * 2048 + 1024);
+    }
+  unsigned ws = (NS - 1) * 2048;  // byte offset of the next step to fetch (2 KB per step and m-block; the packing is padded by two steps for the last prefetches)
   // one tap: prefetch the next step into the other slot, read this tap's B fragments, 12 MFMAs
   auto tap = [&](auto slot_, const char* lk0, const char* lk1) {
     constexpr int S = decltype(slot_)::value;
 #ifndef BF3_EXP_NOW  // (time-only experiment switches, tools/ab_build.sh: results are garbage)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      a[S ^ 1][mi][0] = wload(wq[mi], ws);
-      a[S ^ 1][mi][1] = wload(wq[mi], ws + 1024);
+      a[(S + NS - 1) % NS][mi][0] = wload(wq[mi], ws);
+      a[(S + NS - 1) % NS][mi][1] = wload(wq[mi], ws + 1024);
     }
     ws += 2048;
 #else
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) { a[S ^ 1][mi][0] = a[S][mi][1]; a[S ^ 1][mi][1] = a[S][mi][0]; }
+    for (int mi = 0; mi < MI; ++mi) { a[(S + NS - 1) % NS][mi][0] = a[S][mi][1]; a[(S + NS - 1) % NS][mi][1] = a[S][mi][0]; }
 #endif
     bf16x8 bh[2], bl[2];
 #pragma unroll
@@ -260,6 +265,48 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][mi][0], bh[ni], acc[mi][ni], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
+  if constexpr (NS == 3) {
+    static_assert(!PC, "three weight slots: 4-wave form only");
+    const int dstep = dil * (BF3_PITCH * 2);
+    const int kmod = K % 3;
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+      // slot = tap mod 3 inside a chunk (static names); a chunk whose tap count is not a multiple of 3 ends with its successor's
+      // first two steps in slots (K mod 3) and (K mod 3) + 1: rotated back to slots 0 and 1 below (32 moves per chunk, 7- and 11-tap
+      // groups only)
+      const char* lk0 = reinterpret_cast<const char*>(lds) + (c & 1) * (2 * piece_bytes) + (wn * 64 + l31 + tap_base) * (BF3_PITCH * 2) + 16 * h;
+      const char* lk1 = lk0 + piece_bytes;
+      tap(bf3_int<0>{}, lk0, lk1);
+      lk0 += dstep; lk1 += dstep;
+      int kk = 1;
+#pragma unroll 1
+      for (; kk + 2 < K; kk += 3) {
+        tap(bf3_int<1>{}, lk0, lk1);
+        tap(bf3_int<2>{}, lk0 + dstep, lk1 + dstep);
+        tap(bf3_int<0>{}, lk0 + 2 * dstep, lk1 + 2 * dstep);
+        lk0 += 3 * dstep; lk1 += 3 * dstep;
+      }
+      if (kk < K) {
+        tap(bf3_int<1>{}, lk0, lk1);
+        if (kk + 1 < K) tap(bf3_int<2>{}, lk0 + dstep, lk1 + dstep);
+      }
+      if (kmod == 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) { a[0][mi][pc] = a[1][mi][pc]; a[1][mi][pc] = a[2][mi][pc]; }
+      } else if (kmod == 2) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) { a[1][mi][pc] = a[0][mi][pc]; a[0][mi][pc] = a[2][mi][pc]; }
+      }
+      if (c + 1 < nchunks) store_chunk((c + 1) & 1);
+      __syncthreads();
+      if (c + 2 < nchunks) load_chunk(c + 2, stg);  // one chunk ahead, into the registers the store just freed
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
     const int dstep = dil * (BF3_PITCH * 2);
@@ -356,7 +403,7 @@ __global__ void __launch_bounds__(384, 2) conv_bf3pc_kernel(const ConvParams P) 
   conv_bf3_body<MI, EPI, true>(P, G, lds, mt, nt, b);
 }
 
-template <int MI, int EPI>
+template <int MI, int EPI, int NS = 2>
 __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   extern __shared__ float lds[];
   kernarg_warm<sizeof(ConvParams)>();
@@ -365,5 +412,5 @@ __global__ void __launch_bounds__(256, 3) conv_bf3_kernel(const ConvParams P) {
   mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);  // block-uniform (see conv_mfma_kernel)
   nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
   const ConvGroup& G = P.g[grp];
-  conv_bf3_body<MI, EPI>(P, G, lds, mt, nt, b);
+  conv_bf3_body<MI, EPI, false, NS>(P, G, lds, mt, nt, b);
 }

@@ -273,7 +273,7 @@ static ConvW make_conv(vits_model* m, int M, int Cin, int K, const float* bias, 
 template <typename F>
 static void add_bf3_packing(vits_model* m, ConvW& c, F src) {
   if (!c.w || c.Mpad % 32 || c.Cin % CONV_CI_T) return;
-  std::vector<uint16_t> pk((size_t)c.Mpad * c.Cin * c.K * 2 + 128 * 8, 0);  // + one step: the kernel prefetches one step past the end
+  std::vector<uint16_t> pk((size_t)c.Mpad * c.Cin * c.K * 2 + 2 * 128 * 8, 0);  // + two steps: the kernel prefetches up to two steps past the end
   const int M = c.M;
   pack_conv_weights_bf3(pk.data(), c.Mpad, c.Cin, c.K, [&](int row, int ci, int kk) -> float { return row < M ? src(row, ci, kk) : 0.f; });
   c.wb = upload(m, reinterpret_cast<const float*>(pk.data()), pk.size() / 2);
@@ -1233,6 +1233,12 @@ static bool bf3_pc() {
   static const bool on = getenv("VITS_BF3_PC") && atoi(getenv("VITS_BF3_PC")) == 1;
   return on;
 }
+// weight-fragment slots of conv_bf3_kernel<2, STORE>: 2; VITS_BF3_SLOTS=3 runs the variant with two taps of prefetch lead and the
+// activation loads one chunk ahead (MEASURED 8 % slower, profiles/r3_bf3_ab.txt; A/B knob)
+static int bf3_slots() {
+  static const int n = getenv("VITS_BF3_SLOTS") ? atoi(getenv("VITS_BF3_SLOTS")) : 2;
+  return n == 3 ? 3 : 2;
+}
 static int g_no_bf3 = 0;   // test hook: 1 = a conv_precision == 1 model runs its fp32 kernels (A/B of the split-bf16 variant)
 static bool conv_wp_ok(const ConvParams& P, int epi, int halo, bool small) {
   static const int env_mode = getenv("VITS_CONV_WP") ? atoi(getenv("VITS_CONV_WP")) : 0;
@@ -1394,7 +1400,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     if (bf3_pc()) {
       if (mi == 2) hipLaunchKernelGGL((conv_bf3pc_kernel<2, EPI_STORE>), grid, dim3(384), lds, s->stream, P);
       else hipLaunchKernelGGL((conv_bf3pc_kernel<1, EPI_STORE>), grid, dim3(384), lds, s->stream, P);
-    } else if (mi == 2) hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
+    } else if (mi == 2 && bf3_slots() == 3) hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_STORE, 3>), grid, dim3(256), lds, s->stream, P);
+    else if (mi == 2) hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
     else hipLaunchKernelGGL((conv_bf3_kernel<1, EPI_STORE>), grid, dim3(256), lds, s->stream, P);
   };
   // 64-row outputs at batch size: 64 x 128 tiles (twice the columns per weight fragment of the 64 x 64 tile)
