@@ -242,7 +242,11 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
   return true;
 }
 #ifdef CONV_TIMING
-#define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) { P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); if ((k) == 0) P.dbg[wave * 8 + 7] = __builtin_amdgcn_s_getreg(63492); } } while (0)
+#define CONV_DBG(k) do { if (P.dbg && blockIdx.x == 0 && lane == 0) { P.dbg[wave * 8 + (k)] = __builtin_readcyclecounter(); if ((k) == 0) P.dbg[wave * 8 + 7] = __builtin_amdgcn_s_getreg(63492); } \
+    /* block trace (timing build): wall-clock start / end (100 MHz) and hardware id of every workgroup, wave 0 */ \
+    if (P.dbg && wave == 0 && lane == 0 && blockIdx.x < 4000 && ((k) == 0 || (k) == 5)) { \
+      P.dbg[128 + blockIdx.x * 4 + ((k) == 0 ? 0 : 1)] = wall_clock64(); \
+      if ((k) == 0) { P.dbg[128 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(63492); P.dbg[128 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 20); } } } while (0)
 #define CONV_DBG_DO(x) x
 #else
 #define CONV_DBG(k) do { } while (0)

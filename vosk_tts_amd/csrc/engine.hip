@@ -1298,10 +1298,13 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   static long dbg_counter = 0;
   static const long dbg_want = getenv("VITS_DBG_LAUNCH") ? atol(getenv("VITS_DBG_LAUNCH")) : -1;
   static long long* dbg_buf = nullptr;
-  const bool dbg_this = (dbg_counter++ == dbg_want);
+  // VITS_DBG_GROUPED=<n>: the n-th three-group launch of the process instead (the single-utterance decoder's ResBlock launches)
+  static long grouped_counter = 0;
+  static const long grouped_want = getenv("VITS_DBG_GROUPED") ? atol(getenv("VITS_DBG_GROUPED")) : -1;
+  const bool dbg_this = (dbg_counter++ == dbg_want) || (P.n_groups == 3 && grouped_counter++ == grouped_want);
   if (dbg_this) {
-    if (!dbg_buf) hipMalloc((void**)&dbg_buf, 128 * sizeof(long long));
-    hipMemsetAsync(dbg_buf, 0, 128 * sizeof(long long), st);
+    if (!dbg_buf) hipMalloc((void**)&dbg_buf, (128 + 4 * 4000) * sizeof(long long));
+    hipMemsetAsync(dbg_buf, 0, (128 + 4 * 4000) * sizeof(long long), st);
     P.dbg = dbg_buf;
   }
   struct DbgPrint {
@@ -1315,6 +1318,13 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
       for (int w = 0; w < 4; ++w)
         fprintf(stderr, "   wave %d: +%lld first-loads-issued  +%lld loop_done  +%lld barrier  +%lld reduced  +%lld end\n", w, h[w * 8 + 1] - h[w * 8],
                 h[w * 8 + 2] - h[w * 8], h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8]);
+      // block trace: "blk <id> <start> <end> <hw_id> <xcc_id>" (wall clock, 10 ns units, relative to the earliest start)
+      std::vector<long long> t(4 * 4000);
+      hipMemcpy(t.data(), buf + 128, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      long long t0 = 0;
+      for (int i = 0; i < 4000; ++i) if (t[4 * i] && (!t0 || t[4 * i] < t0)) t0 = t[4 * i];
+      for (int i = 0; i < 4000; ++i)
+        if (t[4 * i]) fprintf(stderr, "blk %d %lld %lld %lld %lld\n", i, t[4 * i] - t0, t[4 * i + 1] ? t[4 * i + 1] - t0 : -1, t[4 * i + 2], t[4 * i + 3]);
     }
   } dbg_print{dbg_this, st, dbg_buf, name, P.Cout, P.Cin, P.g[0].K, P.Tout, P.B};
 #endif
@@ -2370,8 +2380,17 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
 // copy out.  No hipMalloc / hipFree / re-plan in steady state.  Calls that inject noise tensors (parity tests) take the
 // eager path below (vits_synthesize_eager), which is also the A/B reference of the fast path in tests.
 static int g_fast_path = 1;
+// cap on the device memory idle fast-path sessions may pin per model: VITS_CACHE_MB, else a quarter of what was free on the device
+// when the first call asked (at most 24 GiB).  Besides the cap, an allocation failure on the request path evicts every idle
+// session and retries once (fronts_evict_all).
 static size_t fast_cache_cap() {
-  static const size_t cap = getenv("VITS_CACHE_MB") ? (size_t)atol(getenv("VITS_CACHE_MB")) << 20 : (size_t)24 << 30;
+  static const size_t cap = [] {
+    if (getenv("VITS_CACHE_MB")) return (size_t)atol(getenv("VITS_CACHE_MB")) << 20;
+    size_t fr = 0, tot = 0;
+    size_t c = (size_t)24 << 30;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 < c) c = fr / 4;
+    return c;
+  }();
   return cap;
 }
 
@@ -2431,6 +2450,19 @@ static void front_release(vits_model* m, vits_session* s) {
     }
   }
   for (vits_session* e : evict) session_free(e);
+}
+
+// frees every idle front (and its backs): the answer to a failed allocation on the request path
+static void fronts_evict_all(vits_model* m) {
+  std::vector<vits_session*> evict;
+  {
+    std::lock_guard<std::mutex> g(m->pool_mu);
+    for (auto& kv : m->fronts) evict.push_back(kv.second);
+    m->fronts.clear();
+    m->fronts_bytes = 0;
+  }
+  for (vits_session* e : evict) session_free(e);
+  (void)hipGetLastError();
 }
 
 // back session of `F` for frame bucket TyB (created on first use; at most 6 buckets stay cached per front)
@@ -2570,7 +2602,11 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   // (declared before the session guard: the call's last stream synchronisation happens before this scope ends)
   PersistScope pscope(B == 1 ? m->device : -1);  // a single utterance takes the persistent stages when no other call on this device holds them
   vits_session* F = nullptr;
-  TRY(front_acquire(m, B, TxB, &F));
+  {
+    int rc = front_acquire(m, B, TxB, &F);
+    if (rc == VITS_ERR_NOMEM) { fronts_evict_all(m); rc = front_acquire(m, B, TxB, &F); }
+    if (rc != VITS_OK) return rc;
+  }
   struct Rel { vits_model* m; vits_session* s; ~Rel() { front_release(m, s); } } rel{m, F};
   // ---- inputs -> pinned block
   SynthDev* hv = reinterpret_cast<SynthDev*>(F->io_h);
@@ -2611,7 +2647,17 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   const int TyB = (int)((Ty + 31) / 32 * 32);
   // ---- phase 2
   vits_session* Bk = nullptr;
-  TRY(back_get(F, TyB, &Bk));
+  {
+    int rc = back_get(F, TyB, &Bk);
+    if (rc == VITS_ERR_NOMEM) {  // idle fronts of other buckets and this front's other backs go first, then once more
+      fronts_evict_all(m);
+      hipStreamSynchronize(F->stream);
+      for (auto& kv : F->backs) session_free(kv.second);
+      F->backs.clear();
+      rc = back_get(F, TyB, &Bk);
+    }
+    if (rc != VITS_OK) return rc;
+  }
   TRY(phase2_launch(F, Bk, solo, pcm));
   const int64_t S = Ty * hp.hop_length, stride = (int64_t)TyB * hp.hop_length;
   const size_t esz = pcm ? sizeof(int16_t) : sizeof(float);

@@ -692,6 +692,19 @@ static void stts_front_release(stts_model* m, SttsFront* f) {
   for (SttsFront* e : evict) stts_front_free(e);
 }
 
+// frees every idle front context (with its back contexts): the answer to a failed allocation on the request path (the cache is
+// bounded by count -- 16 text buckets x 4 frame buckets -- not by bytes)
+static void stts_fronts_evict_all(stts_model* m) {
+  std::vector<SttsFront*> evict;
+  {
+    std::lock_guard<std::mutex> g(m->base.pool_mu);
+    for (auto& kv : m->fronts) evict.push_back(kv.second);
+    m->fronts.clear();
+  }
+  for (SttsFront* e : evict) stts_front_free(e);
+  (void)hipGetLastError();
+}
+
 static int stts_back_get(stts_model* m, SttsFront* F, int TB, int n, SttsBack** out) {
   const auto key = std::make_pair(TB, n);
   auto it = F->backs.find(key);
@@ -819,7 +832,11 @@ static int stts_synth_fast(stts_model* m, const int64_t* ids, int32_t Tx, const 
   HIP_TRY(hipSetDevice(m->base.device));
   const int TxB = (Tx + 7) / 8 * 8;
   SttsFront* F = nullptr;
-  TRY(stts_front_acquire(m, TxB, &F));
+  {
+    int rc = stts_front_acquire(m, TxB, &F);
+    if (rc == VITS_ERR_NOMEM) { stts_fronts_evict_all(m); rc = stts_front_acquire(m, TxB, &F); }
+    if (rc != VITS_OK) return rc;
+  }
   struct Rel { stts_model* m; SttsFront* f; ~Rel() { stts_front_release(m, f); } } rel{m, F};
   hipStream_t st = F->s->stream;
   // ---- inputs -> pinned block (rows re-strided to the bucket, padding zero)
@@ -870,7 +887,17 @@ static int stts_synth_fast(stts_model* m, const int64_t* ids, int32_t Tx, const 
   h_lenT[0] = h_lenT[1] = T4;
   // ---- phase 2
   SttsBack* Bk = nullptr;
-  TRY(stts_back_get(m, F, TB, n, &Bk));
+  {
+    int rc = stts_back_get(m, F, TB, n, &Bk);
+    if (rc == VITS_ERR_NOMEM) {
+      stts_fronts_evict_all(m);
+      hipStreamSynchronize(F->s->stream);
+      for (auto& kv : F->backs) stts_back_free(kv.second);
+      F->backs.clear();
+      rc = stts_back_get(m, F, TB, n, &Bk);
+    }
+    if (rc != VITS_OK) return rc;
+  }
   const bool audio = out_audio != nullptr;
   TRY(stts_phase2(m, F, Bk, audio));
   const int64_t S = audio ? (int64_t)ylen * m->vocoder->hp.hop_length : 0;
