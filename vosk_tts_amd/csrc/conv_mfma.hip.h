@@ -202,6 +202,27 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
     nt = q - P.tile_start[b];
     return true;
   }
+  if (P.xcd_mode == 11) {
+    // three grouped convs of one utterance, heaviest first (11 / 7 / 3 taps).  Two workgroups share a CU and run there mostly one
+    // after the other (profiles/r3_blocktrace_c2.txt), the w-th and (w + 32)-th workgroup of an XCD's stream are CU mates, and the
+    // launch lasts as long as the CU with the heaviest pair.  XCD x takes tiles x, x + 8, ... of every group in an order that puts a
+    // 3-tap tile under every 11-tap one (14 units) and 7-tap tiles under each other (14) instead of 11 + 7 (18).
+    const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+    const int per = P.ntiles_m * P.ntiles_n, n = (per - x + 7) >> 3;  // tiles of one group on this XCD
+    const int a = n < 32 ? n : 32;            // first pass over the 32 CUs: 11-tap tiles, then 7-tap ones
+    const int b7 = 32 - a < n ? 32 - a : n;   // 7-tap tiles that fit in the first pass
+    int idx;
+    if (w < a) { grp = 0; idx = w; }
+    else if (w < a + b7) { grp = 1; idx = w - a; }
+    else if (w < a + b7 + n) { grp = 2; idx = w - a - b7; }
+    else if (w < a + 2 * n) { grp = 1; idx = w - a - n; }       // the remaining 7-tap tiles
+    else { grp = 0; idx = w - 2 * n; }                          // 11-tap tiles beyond the first 32 (large launches)
+    if (idx >= n) return false;
+    const int t = idx * 8 + x;
+    mt = t % P.ntiles_m; nt = t / P.ntiles_m;
+    b = 0;
+    return true;
+  }
   if (P.xcd_mode) {
     const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
     int first = P.xcd_first[0], cnt = P.xcd_cnt[0];  // (compare chain: a dynamic index would copy the by-value struct to scratch)

@@ -1259,7 +1259,19 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
   P.ntiles_m = cdiv(P.M, 32);
   P.ntiles_n = cdiv(P.Tout, 32);
   const size_t lds = (size_t)NW * CONV_CI_T * WP_PITCH * sizeof(float);
-  const int owned = conv_xcd_plan(P);
+  int owned = conv_xcd_plan(P);
+  {
+    // a grouped launch whose workgroups are all resident at once (two per CU): choose the CU mates (conv_decode_block, mode 11).
+    // Measured on the C = 256 stage of c2 (profiles/r3_blocktrace_c2.txt): makespan 26.9 -> 23.0 us.  Launches of several rounds keep
+    // the heaviest-first order (the same mapping made the 900-workgroup C = 128 launch 14 % slower).  VITS_WP_ORDER=0: off (A/B).
+    static const int order = getenv("VITS_WP_ORDER") ? atoi(getenv("VITS_WP_ORDER")) : 1;
+    const int per_xcd = cdiv(P.ntiles_m * P.ntiles_n, 8);
+    if (order && !owned && P.B == 1 && P.n_groups == 3 && P.g[0].K >= P.g[1].K && P.g[1].K >= P.g[2].K && 3 * per_xcd <= 64 &&
+        per_xcd <= 32) {
+      P.xcd_mode = 11;
+      owned = 8 * 3 * per_xcd;
+    }
+  }
   const dim3 grid(owned ? owned : P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
   ps.set_kernel("conv_wp_kernel<8>");
   hipLaunchKernelGGL(conv_wp_kernel<NW>, grid, dim3(NW * 64), lds, s->stream, P);
