@@ -40,6 +40,13 @@ for s in range(n):
     wait = np.median(got - a[:, 0]); work = np.median(a[:, 3] - got)
     e0 = r0[s, 3] - t0 if r0[s, 3] > 0 else -1
     print(f"step {s:2d} {names[kinds[s]]:6s} workers {busy.sum():3d}  wait {wait:6.0f} (max {np.max(got - a[:, 0]):6d})  work {work:6.0f} (max {np.max(a[:, 3] - got):6d})   rank0 end {e0:8d} (+{e0 - prev if e0 >= 0 else 0:6d})")
+    if os.environ.get("PS_DETAIL"):
+        w = np.sort(a[:, 3] - got); g = np.sort(got - a[:, 0])
+        q = lambda v, f: int(v[min(len(v) - 1, int(f * len(v)))])
+        if a[:, 6].max() > 0:
+            md = lambda x: float(np.median(x))
+            print(f"        MM phases (median cycles): start->poll done {md(got - a[:, 0]):.0f} | tile+barrier {md(a[:, 2] - got):.0f} | weights wait + mfma {md(a[:, 4] - a[:, 2]):.0f} | res poll + partial tiles + barrier {md(a[:, 6] - a[:, 4]):.0f} | epilogue + stores {md(a[:, 3] - a[:, 6]):.0f}")
+        print(f"        work p10/p50/p90/max {q(w, .1)}/{q(w, .5)}/{q(w, .9)}/{int(w[-1])}   wait p10/p50/p90 {q(g, .1)}/{q(g, .5)}/{q(g, .9)}   phases(median): poll->tile {np.median(a[:, 2] - got) if a[:, 2].max() > 0 else -1:.0f}")
     if e0 >= 0: prev = e0
     tot_wait += wait; tot_work += work
 print(f"sum of medians: wait {tot_wait:.0f} work {tot_work:.0f} cycles = {(tot_wait + tot_work) / 2400:.1f} us; rank 0 timeline {prev / 2400:.1f} us")

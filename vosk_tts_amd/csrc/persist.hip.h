@@ -289,7 +289,6 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   }
   const float ea_m = ((const PS_G float*)prog->ea_m)[0], ea_is = expf(-((const PS_G float*)prog->ea_logs)[0]);  // used by the very last epilogue
   PsPre pre;
-  bool prefetched = false;
 
   for (int s = 0; s < n_steps; ++s) {
     // (opaque per step: every per-thread index below derives from this copy, so that the compiler does not hoist the address
@@ -297,17 +296,17 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const ps_i4 rv = rvA, r1 = rvB;
+    const ps_i4 rv = rvA;
     rvA = rvB;
     const int kf = PR_I(rv, 0), kind = kf & 0xff;
-    if (kind == PK_IDLE) {  // nothing to do and nothing to wait for in this step
-      rvB = load_rec(s + 2);
-      prefetched = false;
-      continue;
-    }
+    rvB = load_rec(s + 2);  // (an L2 hit; older than everything else this step requests)
+    if (kind == PK_IDLE) continue;  // nothing to do and nothing to wait for in this step
     PS_STAMP(0);
-    if (!prefetched) ps_prefetch(rv, tid, wave, lane, pre);
-    prefetched = false;
+    // This step's own operands (weight fragments, packed parameters, epilogue vectors), requested FIRST: the record decode and the
+    // poll set-up below take about as long as they need to arrive, and every poll load is younger than they are.  (They used to be
+    // requested one step ahead, after the previous step's MFMAs: as loop-carried registers written on five different paths they
+    // cost an s_waitcnt vmcnt(0) plus 40 moves at the end of every step -- the whole fetch latency, exposed: 2 k of a 12 k-cycle step.)
+    ps_prefetch(rv, tid, wave, lane, pre);
     __syncthreads();  // the previous step's readers of the LDS buffers are done
     const int L = len_raw < T ? len_raw : T;
 
@@ -321,11 +320,6 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const PS_G ll_t* zc = (kf & PF_FIN_PRE) ? PR_P(const ll_t, rv, 2) : nullptr;
       PS_G ll_t* xout = PR_P(ll_t, rv, 3);
       PS_G ll_t* bout = PR_P(ll_t, rv, 4);
-      const float par[8] = {pre.pk0[0], pre.pk0[1], pre.pk0[2], pre.pk0[3], pre.pk1[0], pre.pk1[1], pre.pk1[2], pre.pk1[3]};
-      // the next step's operands fly under this step (in-order vmcnt: they are older than every poll of the next step)
-      ps_prefetch(r1, tid, wave, lane, pre);
-      rvB = load_rec(s + 2);
-      prefetched = true;
       const int c = tid & 255, h = tid >> 8;
       const bool cok = c < D;
       {
@@ -366,6 +360,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           } while (ps_again(cx, pending));
         }
         PS_STAMP(1);
+        const float par[8] = {pre.pk0[0], pre.pk0[1], pre.pk0[2], pre.pk0[3], pre.pk1[0], pre.pk1[1], pre.pk1[2], pre.pk1[3]};
         if (zc) { x0 = par[0] * z0 + par[1] + x0; x1 = par[0] * z1 + par[1] + x1; }  // ConvFlow.pre(x0) + g  (modules.py:365-366)
         if (y2) {  // x + gelu(LN2(y2)), two-pass statistics like F.layer_norm; both slots of a half in the same reductions
           float m0 = n0 ? y0 : 0.f, m1 = n1 ? y1 : 0.f;
@@ -408,9 +403,6 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const int C = PR_I(rv, 1), t = PR_I(rv, 2), dk = PR_I(rv, 3) & 0xff, nh = PR_I(rv, 3) >> 8, dk2 = dk + 2;
       const PS_G ll_t* ap = PR_P(const ll_t, rv, 0);
       PS_G ll_t* out = PR_P(ll_t, rv, 3);
-      ps_prefetch(r1, tid, wave, lane, pre);
-      rvB = load_rec(s + 2);
-      prefetched = true;
       const int d = tid & (PS_DKP - 1), hd = tid >> 7;
       const bool ok = d < dk && hd < nh;
       const int nkt = (L + 15) >> 4;
@@ -468,10 +460,10 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const int C = PR_I(rv, 1) & 0xffff, t = PR_I(rv, 2), pT = PR_B(rv, 4);
       PS_G ll_t* out = PR_P(ll_t, rv, 3);
       PS_G float* oplain = PR_P(float, rv, 4);
-      const float par[4] = {pre.pk0[0], pre.pk0[1], pre.pk0[2], pre.ec0};  // g, b, bias, per-item vector
-      ps_prefetch(r1, tid, wave, lane, pre);
-      rvB = load_rec(s + 2);
-      prefetched = true;
+#define par_g pre.pk0[0]
+#define par_b pre.pk0[1]
+#define par_bias pre.pk0[2]
+#define par_vec pre.ec0
       const int c = tid & 255, h = tid >> 8;
       const bool cok = c < C && h == 0;  // one column per worker: the channel threads of half 0
       {
@@ -481,14 +473,14 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             // x = emb[id] * sqrt(H) (+ the speaker vector when the first layer is the conditioned one)   (models.py:318-322)
             long long id = call.ids[t];
             if (id < 0 || id >= PR_B(rv, 1)) { if (tid == 0) atomicOr((int*)prog->err, 1); id = 0; }
-            if (cok) o = PR_P(const float, rv, 0)[id * C + c] * __int_as_float(PR_B(rv, 0)) + par[3];
+            if (cok) o = PR_P(const float, rv, 0)[id * C + c] * __int_as_float(PR_B(rv, 0)) + par_vec;
           } else if (kind == PK_LN) {
             const int np = PR_I(rv, 3);
             const PS_G ll_t* part = PR_P(const ll_t, rv, 0);
             const PS_G ll_t* res = PR_P(const ll_t, rv, 1);
             const PS_G ll_t* base = PR_P(const ll_t, rv, 2);
             const long long pstr = ((long long)(unsigned)PR_B(rv, 1) << 32) | (unsigned)PR_B(rv, 0);
-            float v = par[2], bs = 0.f;
+            float v = 0.f, bs = 0.f;
             {
               unsigned o0 = (unsigned)(t * C + c) * 8u;
               bool pending;
@@ -503,7 +495,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                   if (base) qb = ll_load_off(base, o0);
                 }
                 unsigned bad = 0;
-                v = par[2];
+                v = 0.f;
                 if (cok) {
 #pragma unroll
                   for (int k = 0; k < 4; ++k)
@@ -516,6 +508,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
               } while (ps_again(cx, pending));
             }
             PS_STAMP(1);
+            v += par_bias;  // (after the poll: the packed parameters were requested at the top of the step)
             if (kf & PF_LN) {
               const float invC = 1.0f / (float)C;
               float m = cok ? v : 0.f, dummy = 0.f;
@@ -524,7 +517,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
               const float e = v - m;
               float q = cok ? e * e : 0.f;
               ps_half_sum2(q, dummy, red + 16, wave, lane);
-              o = e * (1.0f / sqrtf(q * invC + 1e-5f)) * par[0] + par[1] + par[3] + bs;
+              o = e * (1.0f / sqrtf(q * invC + 1e-5f)) * par_g + par_b + par_vec + bs;
             } else {
               o = v + bs;
             }
@@ -554,7 +547,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                 }
                 unsigned bad = 0;
                 if (cok && !up) { bad |= ll_bad(qu, epoch); uv = ll_val(qu); }
-                mv = par[2];
+                mv = 0.f;
                 if (needm) {
 #pragma unroll
                   for (int k = 0; k < 4; ++k)
@@ -564,7 +557,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
               } while (ps_again(cx, pending));
             }
             PS_STAMP(1);
-            o = c < H ? uv : uv - mv;
+            o = c < H ? uv : uv - (mv + par_bias);
           }
         }
         if (cok) {
@@ -575,6 +568,10 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       PS_STAMP(3);
       continue;
     }
+#undef par_g
+#undef par_b
+#undef par_bias
+#undef par_vec
 
     if (kind == PK_ATT) {
       // ================================================================== attention block (head, query tile, key tile)
@@ -591,18 +588,9 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       float* Ev = Ek + 9 * PS_DKP;
       float* Ss = mred;                  // [2][16][17] partial dot products of the two d-halves, then [16][17] probabilities
       const int dkp = dk + 1;
-      const float tb0 = pre.pk0[0], tb1 = pre.pk0[1], tb2 = pre.pk0[2], tb3 = pre.pk0[3];  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]
-      ps_prefetch(r1, tid, wave, lane, pre);
-      rvB = load_rec(s + 2);
-      prefetched = true;
       const float scale = 1.0f / sqrtf((float)dk);
       {
         if (i0 >= L || j0 >= L) { PS_STAMP(3); continue; }  // nothing to compute: the merge step never looks at these blocks
-        if (W > 0) {
-          const int tab = (2 * W + 1) * dk;
-          if (tid < tab) { Ek[tid] = tb0; Ev[tid] = tb2; }
-          if (tid + 512 < tab) { Ek[tid + 512] = tb1; Ev[tid + 512] = tb3; }
-        }
         // ---- gather q (16 x dk), k, v tiles: thread = (d = tid & 127, rows (tid >> 7) + 4 k)
         {
           const int d = tid & (PS_DKP - 1), r0 = tid >> 7;
@@ -639,6 +627,11 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
           PS_STAMP(1);
+          if (W > 0) {  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]
+            const int tab = (2 * W + 1) * dk;
+            if (tid < tab) { Ek[tid] = pre.pk0[0]; Ev[tid] = pre.pk0[2]; }
+            if (tid + 512 < tab) { Ek[tid + 512] = pre.pk0[1]; Ev[tid + 512] = pre.pk0[3]; }
+          }
           if (dok) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -811,7 +804,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         }
         // the weight registers are free: request the NEXT step's operands now, so that they fly under this step's reduction,
         // epilogue and the exchange
-        if (mi == nblk - 1) { ps_prefetch(r1, tid, wave, lane, pre); rvB = load_rec(s + 2); prefetched = true; }
+        if (mi == nblk - 1) PS_STAMP(4);
         // residual cells of this block (data of an older step: normally one round trip)
         float rsd = 0.f;
         const PS_G ll_t* res = PR_P(const ll_t, rv, 3);
@@ -830,6 +823,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) mred[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
         __syncthreads();
+        if (mi == nblk - 1) PS_STAMP(6);
         if (kf & PF_GATE) {
           // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8 * mb .. 8 * mb + 7 (commons.py:100-107)
           if (tid < 128) {
