@@ -43,6 +43,14 @@ for s in range(n):
     if os.environ.get("PS_DETAIL"):
         w = np.sort(a[:, 3] - got); g = np.sort(got - a[:, 0])
         q = lambda v, f: int(v[min(len(v) - 1, int(f * len(v)))])
+        if kinds[s] == 5 and a[:, 5].max() > 0:
+            ok = a[:, 5] > 0
+            b = a[ok]; g2 = got[ok]
+            md = lambda x: float(np.median(x)); mx = lambda x: float(np.max(x))
+            print(f"        ATT phases median (max): poll done->tiles in LDS {md(b[:, 2] - g2):.0f} ({mx(b[:, 2] - g2):.0f}) | scores {md(b[:, 4] - b[:, 2]):.0f} ({mx(b[:, 4] - b[:, 2]):.0f}) | softmax {md(b[:, 5] - b[:, 4]):.0f} ({mx(b[:, 5] - b[:, 4]):.0f}) | PV + stores {md(b[:, 3] - b[:, 5]):.0f} ({mx(b[:, 3] - b[:, 5]):.0f})")
+        if kinds[s] == 5 and os.environ.get("PS_ATT_ITEMS") and s == int(os.environ["PS_ATT_ITEMS"]):
+            full = st[:, s]
+            print("        PV+stores by worker:", [int(full[r, 3] - full[r, 5]) if full[r, 5] > 0 else -1 for r in range(min(P, 120))])
         if a[:, 6].max() > 0:
             md = lambda x: float(np.median(x))
             print(f"        MM phases (median cycles): start->poll done {md(got - a[:, 0]):.0f} | tile+barrier {md(a[:, 2] - got):.0f} | weights wait + mfma {md(a[:, 4] - a[:, 2]):.0f} | res poll + partial tiles + barrier {md(a[:, 6] - a[:, 4]):.0f} | epilogue + stores {md(a[:, 3] - a[:, 6]):.0f}")

@@ -210,16 +210,19 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static void* weight_alloc(vits_model* m, size_t bytes) {
   static const bool no_slab = getenv("VITS_NO_SLAB") != nullptr;  // A/B switch for tools/
   bytes = align_up(bytes ? bytes : 4, 256);
+  // every allocation is followed by >= 64 KB of mapped memory: the persistent kernel requests the weight fragments of up to
+  // PS_MAXU * PS_WAVES = 64 tap units (1 KB each) from a row block's base without clamping the unit index (ps_load_weights)
+  constexpr size_t guard = (size_t)64 << 10;
   if (no_slab) {
     void* d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    if (hipMalloc(&d, bytes + guard) != hipSuccess) return nullptr;
     m->allocs.push_back(d);
     return d;
   }
-  if (m->slab_used + bytes > m->slab_bytes) {
+  if (m->slab_used + bytes + guard > m->slab_bytes) {
     size_t want = m->blob_bytes + m->blob_bytes / 4 + ((size_t)8 << 20);  // first slab: the whole model with packing slack
     if (!m->allocs.empty()) want = (size_t)32 << 20;
-    if (want < bytes) want = bytes;
+    if (want < bytes + guard) want = bytes + guard;
     want = align_up(want, (size_t)2 << 20);
     void* d = nullptr;
     if (hipMalloc(&d, want) != hipSuccess) return nullptr;

@@ -51,6 +51,7 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 #define PS_TP 21         // LDS pitch of the MFMA operand window [C_in][16 + taps - 1] (odd: the transposing writes are conflict-free)
 #define PS_MAXROW 20     // 16 + taps - 1, taps <= 5
 #define PS_DKP 128       // attention: head-dimension slots per row of threads (d_k <= 128)
+#define PS_MKT 12        // key tiles the attention merge polls per round (3 cells each)
 #define PS_SPIN_LIMIT (1 << 18)
 #define PS_ERR_TIMEOUT 8  // bit in the session error word
 
@@ -218,11 +219,15 @@ struct PsPre {
   float eb0, eb1, ec0, ec1;  // epilogue operands of thread tid < 256 (bias, per-item bias / vector; second pair: the sigmoid row of a gate)
 };
 __device__ __forceinline__ void ps_load_weights(const PS_G float* w, int n_u, int wave, int lane, f32x4 (&a)[PS_MAXU]) {
-  const PS_G f32x4* wp = (const PS_G f32x4*)w + lane;
+  // units beyond n_u repeat the last one (an L1 hit; never used: the MFMA loop tests u < n_u).  The unit index is wave-uniform:
+  // clamp and scale on the scalar unit, one 32-bit lane offset for all eight loads.
+  const PS_G char* base = (const PS_G char*)w;
+  const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
   for (int i = 0; i < PS_MAXU; ++i) {
     const int u = wave + PS_WAVES * i;
-    a[i] = wp[(size_t)(u < n_u ? u : n_u - 1) * 64];
+    const unsigned uo = (unsigned)__builtin_amdgcn_readfirstlane(u < n_u ? u : n_u - 1) * 1024u;
+    a[i] = *(const PS_G f32x4*)(base + (uo + lane_off));
   }
 }
 // epilogue operand indices of thread tid relative to the record's bias / vector pointers
@@ -246,6 +251,8 @@ __device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, i
   const PS_G float* b = PR_P(const float, r, 7);
   const PS_G float* c = PR_P(const float, r, 8);
   pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
+  // straight-line for every kind (other kinds: unit 0 of their record's p6, always a valid pointer): behind a branch the loads
+  // cost a conservative wait in the epilogue (measured +0.5 .. 1.3 k cycles per step)
   ps_load_weights(PR_P(const float, r, 6), kind == PK_MM ? (PR_B(r, 0) & 0xffff) : 1, wave, lane, pre.a);
 }
 
@@ -253,13 +260,13 @@ __device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, i
 
 // LDS of the kernel (floats).  Matrix steps: operand window + partial tiles + spline scratch; attention blocks: Q / K / V tiles and
 // the two relative-position tables alias the operand window, scores / probabilities alias the partial tiles.
-#define PS_LDS_TILE (3 * 16 * (PS_DKP + 1) + 2 * 9 * PS_DKP)   // >= PS_MAXC * PS_TP
+#define PS_LDS_TILE (3 * 16 * (PS_DKP + 4) + (10 + 9) * (PS_DKP + 4))   // >= PS_MAXC * PS_TP
 #define PS_LDS_MRED (PS_WAVES * 256)
 static_assert(PS_LDS_TILE >= PS_MAXC * PS_TP, "operand window does not fit");
 
 __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __restrict__ prog, const PCall call) {
-  __shared__ float tile[PS_LDS_TILE];      // MFMA operand window [C_in][16 + taps - 1] (pitch 21) / attention tiles
-  __shared__ float mred[PS_LDS_MRED];      // partial tiles of the 8 waves / attention scores
+  __shared__ __attribute__((aligned(16))) float tile[PS_LDS_TILE];      // MFMA operand window [C_in][16 + taps - 1] (pitch 21) / attention tiles
+  __shared__ __attribute__((aligned(16))) float mred[PS_LDS_MRED];      // partial tiles of the 8 waves / attention scores
   __shared__ float hb[32 * 16];            // ConvFlow.proj output of the tile (spline parameters)
   __shared__ float xs[3 * PS_MAXC];        // column steps: x_in at t - d, t, t + d
   __shared__ float red[4 * 16];            // block reductions (one 16-float scratch per call site)
@@ -411,16 +418,18 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         float r = 0.f;
         if (t < L) {
           float M = -3.0e38f, num = 0.f, den = 0.f;
-          for (int k0 = 0; k0 < nkt; k0 += 4) {
-            float ov[4], mv[4], lv[4];
+          for (int k0 = 0; k0 < nkt; k0 += PS_MKT) {  // PS_MKT key tiles per poll round: one round trip for T <= 16 PS_MKT
+            float ov[PS_MKT], mv[PS_MKT], lv[PS_MKT];
             unsigned ob = (unsigned)((t * nh + (hd < nh ? hd : 0)) * dk2) * 8u, od = (unsigned)(d < dk ? d : 0) * 8u;
             bool pending;
             do {
               asm volatile("" : "+v"(ob), "+v"(od));
-              ll_t qo[4] = {0, 0, 0, 0}, qm[4] = {0, 0, 0, 0}, ql[4] = {0, 0, 0, 0};
+              ll_t qo[PS_MKT], qm[PS_MKT], ql[PS_MKT];
+#pragma unroll
+              for (int k = 0; k < PS_MKT; ++k) { qo[k] = 0; qm[k] = 0; ql[k] = 0; }
               if (ok) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < PS_MKT; ++k)
                   if (k0 + k < nkt) {
                     const PS_G ll_t* b = ap + (k0 + k) * kstr;
                     qo[k] = ll_load_off(b, ob + od);
@@ -430,14 +439,14 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
               }
               unsigned bad = 0;
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
+              for (int k = 0; k < PS_MKT; ++k) {
                 if (ok && k0 + k < nkt) bad |= ll_bad(qo[k], epoch) | ll_bad(qm[k], epoch) | ll_bad(ql[k], epoch);
                 ov[k] = ll_val(qo[k]); mv[k] = ll_val(qm[k]); lv[k] = ll_val(ql[k]);
               }
               pending = PS_PENDING(bad);
             } while (ps_again(cx, pending));
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < PS_MKT; ++k)
               if (k0 + k < nkt) {
                 const float Mn = fmaxf(M, mv[k]);
                 const float a0 = __expf(M - Mn), a1 = __expf(mv[k] - Mn);
@@ -581,13 +590,16 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const int i0 = PR_I(rv, 2) & 0xffff, j0 = PR_I(rv, 2) >> 16, hd = PR_I(rv, 3) & 0xff, kt = PR_I(rv, 3) >> 8;
       const PS_G ll_t* qkv = PR_P(const ll_t, rv, 0);
       PS_G ll_t* ap = PR_P(ll_t, rv, 1);
-      float* Qs = tile;                  // [16][dk + 1]
-      float* Ks = Qs + 16 * (PS_DKP + 1);
-      float* Vs = Ks + 16 * (PS_DKP + 1);
-      float* Ek = Vs + 16 * (PS_DKP + 1);  // [2W + 1][dk]
-      float* Ev = Ek + 9 * PS_DKP;
-      float* Ss = mred;                  // [2][16][17] partial dot products of the two d-halves, then [16][17] probabilities
-      const int dkp = dk + 1;
+      // rows of pitch dk + 4 floats: 16-byte aligned (the dot products read float4) and, at 16 bytes per lane, conflict-free for
+      // the 16 rows a lane group touches ((dk + 4) / 4 is odd for dk = 8 (2 n + 1) - 4 ... checked for dk = 96: 25)
+      float* Qs = tile;                  // [16][dk + 4]
+      float* Ks = Qs + 16 * (PS_DKP + 4);
+      float* Vs = Ks + 16 * (PS_DKP + 4);
+      float* Ek = Vs + 16 * (PS_DKP + 4);  // [2W + 1][dk + 4] + one row of zeros (row 9: what a lane outside the band adds)
+      float* Ev = Ek + 10 * (PS_DKP + 4);
+      float* Ss = mred;                  // [2][16][17] partial dot products of the two d-halves
+      float* Ps = mred + 576;            // [16][16] probabilities (16-byte aligned rows)
+      const int dkp = dk + 4;
       const float scale = 1.0f / sqrtf((float)dk);
       {
         if (i0 >= L || j0 >= L) { PS_STAMP(3); continue; }  // nothing to compute: the merge step never looks at these blocks
@@ -627,10 +639,13 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
           PS_STAMP(1);
-          if (W > 0) {  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512]
+          if (W > 0) {  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512] of the flat [2W + 1][dk] tables -> rows of pitch dk + 1:
+            // the score pass reads row (j - i + W) per LANE; at pitch dk = 96 all nine rows of a 16-lane group fell on one bank
             const int tab = (2 * W + 1) * dk;
-            if (tid < tab) { Ek[tid] = pre.pk0[0]; Ev[tid] = pre.pk0[2]; }
-            if (tid + 512 < tab) { Ek[tid + 512] = pre.pk0[1]; Ev[tid + 512] = pre.pk0[3]; }
+            const int ra = tid / dk, rb = (tid + 512) / dk;
+            if (tid < tab) { Ek[ra * dkp + (tid - ra * dk)] = pre.pk0[0]; Ev[ra * dkp + (tid - ra * dk)] = pre.pk0[2]; }
+            if (tid + 512 < tab) { Ek[rb * dkp + (tid + 512 - rb * dk)] = pre.pk0[1]; Ev[rb * dkp + (tid + 512 - rb * dk)] = pre.pk0[3]; }
+            if (tid < dkp) Ek[9 * dkp + tid] = 0.f;
           }
           if (dok) {
 #pragma unroll
@@ -643,22 +658,31 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           }
         }
         __syncthreads();
+        PS_STAMP(2);
         // ---- scores: thread = (pair (i, j) = tid & 255, d-half = tid >> 8)
         {
           const int i = (tid >> 4) & 15, j = tid & 15, dh = tid >> 8;
           const int d0 = dh * (dk >> 1), d1 = dh ? dk : (dk >> 1);
-          const float* qp = Qs + i * dkp;
-          const float* kp = Ks + j * dkp;
-          float a = 0.f;
-          for (int dd = d0; dd < d1; ++dd) a += qp[dd] * kp[dd];
+          // float4 reads with four independent partial sums: as a scalar loop this was one dependent LDS round trip per element
+          // (48 x ~100 cycles).  Inside the band k_j + E_k[j - i + W] is summed first: one pass instead of two.
+          const f32x4* qp = reinterpret_cast<const f32x4*>(Qs + i * dkp + d0);
+          const f32x4* kp = reinterpret_cast<const f32x4*>(Ks + j * dkp + d0);
           const int rel = (j0 + j) - (i0 + i);
-          if (W > 0 && rel >= -W && rel <= W) {
-            const float* ep = Ek + (rel + W) * dk;
-            for (int dd = d0; dd < d1; ++dd) a += qp[dd] * ep[dd];
+          const bool near = W > 0 && j0 - i0 <= 15 + W && i0 - j0 <= 15 + W;  // (block-uniform) the block touches the band
+          const f32x4* ep = reinterpret_cast<const f32x4*>(Ek + ((rel >= -W && rel <= W) ? rel + W : 9) * dkp + d0);  // outside the band: zeros
+          const int n4 = (d1 - d0) >> 2;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          if (near) {  // one pass for every lane of the block (a per-lane branch would run both loops)
+#pragma unroll 4
+            for (int q4 = 0; q4 < n4; ++q4) { const f32x4 qv = qp[q4], kv = kp[q4], ev = ep[q4]; acc += qv * (kv + ev); }
+          } else {
+#pragma unroll 4
+            for (int q4 = 0; q4 < n4; ++q4) { const f32x4 qv = qp[q4], kv = kp[q4]; acc += qv * kv; }
           }
-          Ss[(dh * 16 + i) * 17 + j] = a;
+          Ss[(dh * 16 + i) * 17 + j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
         __syncthreads();
+        PS_STAMP(4);
         float m_i = 0.f, l_i = 0.f;
         if (tid < 256) {  // lanes of a 16-lane row = the 16 keys of query i
           const int i = tid >> 4, j = tid & 15;
@@ -668,28 +692,47 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           m_i = ps_row_max(sc);
           const float p = kok ? __expf(sc - m_i) : 0.f;
           l_i = ps_row_sum(p);
-          Ss[(32 + i) * 17 + j] = p;
+          Ps[i * 16 + j] = p;
         }
         __syncthreads();
+        PS_STAMP(5);
         // ---- O = P V (+ the relative-value band): thread = (d = tid & 127, rows (tid >> 7) + 4 k)
         {
           const int d = tid & (PS_DKP - 1), r0 = tid >> 7;
           if (d < dk) {
+            // this thread's column of V once for its four rows; a row's probabilities as four float4 (broadcast reads)
+            float vc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vc[j] = Vs[j * dkp + d];
+            const bool near = W > 0 && j0 - i0 <= 15 + W && i0 - j0 <= 15 + W;  // (block-uniform) the block touches the band
+            float evc[9];  // this thread's column of E_v (the same for its four rows)
+            if (near) {
+#pragma unroll
+              for (int r = 0; r < 9; ++r) evc[r] = r <= 2 * W ? Ev[r * dkp + d] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int i = r0 + 4 * k;
-              if (i0 + i < L) {
-                const float* pp = Ss + (32 + i) * 17;
-                float o = 0.f;
-                for (int j = 0; j < 16; ++j) o += pp[j] * Vs[j * dkp + d];
-                if (W > 0) {
-                  for (int j = 0; j < 16; ++j) {
-                    const int rel = (j0 + j) - (i0 + i);
-                    if (rel >= -W && rel <= W) o += pp[j] * Ev[(rel + W) * dk + d];
-                  }
+              const f32x4* pp = reinterpret_cast<const f32x4*>(Ps + i * 16);
+              const f32x4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+              float o = ((p0[0] * vc[0] + p0[1] * vc[1]) + (p0[2] * vc[2] + p0[3] * vc[3])) + ((p1[0] * vc[4] + p1[1] * vc[5]) + (p1[2] * vc[6] + p1[3] * vc[7])) +
+                        (((p2[0] * vc[8] + p2[1] * vc[9]) + (p2[2] * vc[10] + p2[3] * vc[11])) + ((p3[0] * vc[12] + p3[1] * vc[13]) + (p3[2] * vc[14] + p3[3] * vc[15])));
+              if (near) {
+                // relative-value band: E_v row r = j - i + W for the keys j = r - W + (i0 + i) - j0 that fall into this tile
+                const int jb = (i0 + i) - j0 - W;
+                float pj[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {  // nine independent broadcast reads, all issued before the first use (left alone,
+                  const int j = jb + r;        // hipcc waits for each one in turn: 36 LDS round trips per thread)
+                  pj[r] = Ps[i * 16 + ((j >= 0 && j < 16) ? j : 0)];
                 }
-                ll_store(ap + (((long long)kt * Tp + i0 + i) * nh + hd) * dk2 + d, o, epoch);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 9; ++r) pj[r] = (jb + r >= 0 && jb + r < 16) ? pj[r] : 0.f;
+                o += ((pj[0] * evc[0] + pj[1] * evc[1]) + (pj[2] * evc[2] + pj[3] * evc[3])) + ((pj[4] * evc[4] + pj[5] * evc[5]) + (pj[6] * evc[6] + pj[7] * evc[7])) +
+                     pj[8] * evc[8];
               }
+              if (i0 + i < L) ll_store(ap + (((long long)kt * Tp + i0 + i) * nh + hd) * dk2 + d, o, epoch);
             }
           }
         }
