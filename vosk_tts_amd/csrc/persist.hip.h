@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     len_raw = ((const PS_G int*)prog->len)[zero];  // vector load (stays off the scalar counter), first used in step 0
   }
   const float ea_m = ((const PS_G float*)prog->ea_m)[0], ea_is = expf(-((const PS_G float*)prog->ea_logs)[0]);  // used by the very last epilogue
+  const float spline_cst = logf(expf(1.f - 1e-3f) - 1.f);  // boundary derivative parameter (transforms.py:100-103); once, not per column
   PsPre pre;
 
   for (int s = 0; s < n_steps; ++s) {
@@ -921,6 +922,18 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         // dependent chain); here the exponentials are one per thread, the two short serial scans (sum, cumulative widths / heights:
         // same order as the serial form) run on 32 threads, and 16 threads finish (bin search, quadratic).
         __syncthreads();  // h complete
+        // z of the tile's columns (cells of a much older step): requested now, checked where they are used -- one round trip under
+        // the exponentials and scans instead of behind them
+        ll_t zq0 = 0, zq1 = 0;
+        if (wave == 0) {
+          const int t = n0 + (lane & 15);
+          const int x0r = (PR_B(rv, 6) >> 16) & 1;
+          const PS_G ll_t* zin = PR_P(const ll_t, rv, 4);
+          if (lane < 16 && t < L) {
+            zq0 = ll_load_off(zin, (unsigned)(x0r * Tp + t) * 8u);
+            zq1 = ll_load_off(zin, (unsigned)((1 - x0r) * Tp + t) * 8u);
+          }
+        }
         const int nb = prog->nb;
         const float bound = prog->bound, isd = prog->inv_sqrt_d;
         float* se = mred;            // [32][16] exp(w - max): slots 0..nb-1 widths, 16..16+nb-1 heights
@@ -958,16 +971,16 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           PS_G ll_t* zout = PR_P(ll_t, rv, 5);
           const bool need = lane < 16 && t < L;
           unsigned o0 = (unsigned)(x0r * Tp + t) * 8u, o1 = (unsigned)(x1r * Tp + t) * 8u;
-          float z0 = 0.f, z1 = 0.f;
-          bool pending;
-          do {
+          float z0 = ll_val(zq0), z1 = ll_val(zq1);
+          bool pending = PS_PENDING(need ? (ll_bad(zq0, epoch) | ll_bad(zq1, epoch)) : 0u);
+          while (ps_again(cx, pending)) {  // (not yet there: poll)
             asm volatile("" : "+v"(o0), "+v"(o1));
             ll_t q0 = 0, q1 = 0;
             if (need) { q0 = ll_load_off(zin, o0); q1 = ll_load_off(zin, o1); }
             const unsigned bad = need ? (ll_bad(q0, epoch) | ll_bad(q1, epoch)) : 0u;
             z0 = ll_val(q0); z1 = ll_val(q1);
             pending = PS_PENDING(bad);
-          } while (ps_again(cx, pending));
+          }
           if (lane < 16) {
             float v0 = 0.f, v1 = 0.f;
             if (t < L) {
@@ -986,7 +999,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                 const float in_cw = cw[bin * 16], in_w = cw[(bin + 1) * 16] - in_cw;
                 const float in_ch = ch[bin * 16], in_h = ch[(bin + 1) * 16] - in_ch;
                 const float min_d = 1e-3f;
-                const float cst = logf(expf(1.f - min_d) - 1.f);
+                const float cst = spline_cst;
                 const float ud0 = (bin == 0) ? cst : hb[(2 * nb + bin - 1) * 16 + col];
                 const float ud1 = (bin == nb - 1) ? cst : hb[(2 * nb + bin) * 16 + col];
                 const float d0 = min_d + softplus_f(ud0), d1 = min_d + softplus_f(ud1);
