@@ -579,6 +579,11 @@ def main():
         # reports kernel begin -> end.  The committed summary of this workload's run is quoted beside the live figure.
         # (file-sourced fields are grouped under "committed" and say so: they are measurements of an earlier run of this command)
         committed = {"source": "committed"}
+        try:  # the git commit the committed profile files were measured at (tools/evidence_run.sh writes it; the GPU box has no .git)
+            with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_HEAD.txt")) as f:
+                committed["measured_at_git_head"] = f.read().strip()
+        except OSError:
+            committed["measured_at_git_head"] = None
         prof_csv = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{wname}_only_bench_rocprofv3_kernel_stats.csv")
         if not os.path.exists(prof_csv) and wname in ("c2", "c3"):  # the default command runs the c2 and the c3 leg
             prof_csv = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_default_bench_rocprofv3_kernel_stats.csv")

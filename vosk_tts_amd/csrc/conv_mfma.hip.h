@@ -100,11 +100,8 @@ struct ConvParams {
   int first;          // EPI_RESSKIP: first layer (store skip instead of accumulate)
   int last;           // EPI_RESSKIP: last layer (M == H, everything is skip; apply mask)
   int ntiles_m, ntiles_n;
-  // XCD-owned tile ranges of a single-utterance launch (conv_xcd_plan; 0 = the legacy orders of conv_decode_block): workgroup L
-  // runs on XCD L % 8 and takes item xcd_first[L % 8] + L / 8 of the launch's (group, tile) list, so one XCD's L2 holds ONE
-  // group's input and either a range of its weight rows (xcd_mode 2, weights > activations) or a range of its columns (1).
+  // 11: CU-mate order of a grouped single-utterance launch (conv_decode_block); 0: the plain orders
   int xcd_mode;
-  int xcd_first[8], xcd_cnt[8];
   // DDSConv prologue of the small-tile kernel (conv_small.hip.h, PRO == 1): the B operand of this 1x1 conv is computed from
   // the previous layer's raw tensors instead of being read:
   //   x_in = dds_y2 ? (x + gelu(LN(dds_y2; dds_g2, dds_b2))) * mask : x * mask          (modules.py:105-107 of the layer before)
@@ -220,21 +217,6 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
     if (idx >= n) return false;
     const int t = idx * 8 + x;
     mt = t % P.ntiles_m; nt = t / P.ntiles_m;
-    b = 0;
-    return true;
-  }
-  if (P.xcd_mode) {
-    const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
-    int first = P.xcd_first[0], cnt = P.xcd_cnt[0];  // (compare chain: a dynamic index would copy the by-value struct to scratch)
-#pragma unroll
-    for (int i = 1; i < 8; ++i) if (x == i) { first = P.xcd_first[i]; cnt = P.xcd_cnt[i]; }
-    if (w >= cnt) return false;
-    const int per = P.ntiles_m * P.ntiles_n;
-    int i = first + w;
-    grp = 0;
-    while (i >= per) { i -= per; ++grp; }
-    if (P.xcd_mode == 2) { mt = i / P.ntiles_n; nt = i - mt * P.ntiles_n; }
-    else { nt = i / P.ntiles_m; mt = i - nt * P.ntiles_m; }
     b = 0;
     return true;
   }

@@ -1040,46 +1040,6 @@ static int ks_pick_waves(const ConvParams& P, long nblk) {
   return 4;
 }
 
-// XCD ownership of a single-utterance launch : the launch's items, ordered (group, then M-tile-major or
-// column-tile-major), are cut into 8 contiguous ranges of equal cost (cost of an item = its group's taps), one per XCD, so an
-// XCD's L2 sees one group's input (two where a cut falls inside a group) instead of all of them.  Within a group the order is
-// M-tile-major when the group's weights outweigh its input (each weight row read by one XCD, the input by the XCDs that share
-// the group) and column-major otherwise.  Returns the grid size (8 x the longest range; surplus workgroups exit at once), or 0
-// when the launch keeps the legacy order (batches, ragged tile maps, and -- the default -- VITS_XCD_MAP unset).
-// MEASURED (profiles/r3_xcd_map.txt): the ownership cuts the fabric traffic of the grouped ResBlock launches but makes them 15 %
-// SLOWER (conv_wp 0.343 -> 0.396 ms per c2 forward, same for column-major and M-major): these launches are bound by the
-// per-workgroup latency chain and by how evenly ~900 unequal workgroups spread over 256 CUs, not by L2 misses -- the legacy
-// order gives every XCD the same mix of 11/7/3-tap workgroups.  Kept as an A/B knob, off by default.
-static int g_xcd_map = 1;
-static int conv_xcd_plan(ConvParams& P) {
-  static const int env = getenv("VITS_XCD_MAP") ? atoi(getenv("VITS_XCD_MAP")) : 0;
-  P.xcd_mode = 0;
-  if (!g_xcd_map || !env || P.B != 1 || P.tile_start) return 0;
-  const long per = (long)P.ntiles_m * P.ntiles_n;
-  long taps = 0;
-  for (int g = 0; g < P.n_groups; ++g) taps += P.g[g].K;
-  const long total = per * taps;  // cost units
-  if (per * P.n_groups < 64 || total <= 0) return 0;
-  const double w_bytes = 4.0 * P.M * P.Cin * (double)taps / P.n_groups, a_bytes = 4.0 * P.Cin * (double)P.Tin;
-  const int mode = env >= 2 ? env - 1 : (w_bytes > a_bytes ? 2 : 1);  // VITS_XCD_MAP=2 / 3 force column-major / M-major (A/B)
-  int first[9];
-  for (int x = 0; x <= 8; ++x) {
-    long t = total * x / 8, item = 0;
-    int g = 0;
-    while (g < P.n_groups - 1 && t >= per * P.g[g].K) { t -= per * P.g[g].K; item += per; ++g; }
-    item += (t + P.g[g].K - 1) / P.g[g].K;
-    first[x] = (int)(item > per * P.n_groups ? per * P.n_groups : item);
-  }
-  int longest = 0;
-  for (int x = 0; x < 8; ++x) {
-    P.xcd_first[x] = first[x];
-    P.xcd_cnt[x] = first[x + 1] - first[x];
-    if (P.xcd_cnt[x] > longest) longest = P.xcd_cnt[x];
-  }
-  P.xcd_mode = mode;
-  return 8 * longest;
-}
-
 template <int MI, int NI, int EPI, int NIN, int NW>
 static void launch_ks_inst(hipStream_t st, const ConvParams& P, dim3 grid) {
   constexpr size_t lds = (size_t)NW * MI * NI * 16 * 64 * sizeof(float);  // cross-wave reduction only
@@ -1101,8 +1061,7 @@ static void launch_ks(vits_session* s, ConvParams& P, int halo, ProfScope* ps = 
   P.ntiles_n = cdiv(P.Tout, N_T);
   P.row_len = 0;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
-  const int owned = conv_xcd_plan(P);
-  const dim3 grid(owned ? owned : nblk);
+  const dim3 grid(nblk);
   const int nw = ks_pick_waves(P, nblk);
   if (ps) ps->add_template_arg(nw);
 #define KS_GO(MI_, NI_, EPI_, NIN_)                                                            \
@@ -1262,14 +1221,16 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
   P.ntiles_m = cdiv(P.M, 32);
   P.ntiles_n = cdiv(P.Tout, 32);
   const size_t lds = (size_t)NW * CONV_CI_T * WP_PITCH * sizeof(float);
-  int owned = conv_xcd_plan(P);
+  int owned = 0;
   {
     // a grouped launch whose workgroups are all resident at once (two per CU): choose the CU mates (conv_decode_block, mode 11).
     // Measured on the C = 256 stage of c2 (profiles/r3_blocktrace_c2.txt): makespan 26.9 -> 23.0 us.  Launches of several rounds keep
     // the heaviest-first order (the same mapping made the 900-workgroup C = 128 launch 14 % slower).  VITS_WP_ORDER=0: off (A/B).
+    // (Tried before that, measured in profiles/r3_xcd_map.txt, removed: giving every XCD one group's input and a range of its weight
+    // rows or columns -- fabric traffic -35..44 %, launches 13-15 % slower.)
     static const int order = getenv("VITS_WP_ORDER") ? atoi(getenv("VITS_WP_ORDER")) : 1;
     const int per_xcd = cdiv(P.ntiles_m * P.ntiles_n, 8);
-    if (order && !owned && P.B == 1 && P.n_groups == 3 && P.g[0].K >= P.g[1].K && P.g[1].K >= P.g[2].K && 3 * per_xcd <= 64 &&
+    if (order && P.B == 1 && P.n_groups == 3 && P.g[0].K >= P.g[1].K && P.g[1].K >= P.g[2].K && 3 * per_xcd <= 64 &&
         per_xcd <= 32) {
       P.xcd_mode = 11;
       owned = 8 * 3 * per_xcd;
