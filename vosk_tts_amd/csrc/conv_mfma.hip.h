@@ -100,7 +100,8 @@ struct ConvParams {
   int first;          // EPI_RESSKIP: first layer (store skip instead of accumulate)
   int last;           // EPI_RESSKIP: last layer (M == H, everything is skip; apply mask)
   int ntiles_m, ntiles_n;
-  // 11: CU-mate order of a grouped single-utterance launch (conv_decode_block); 0: the plain orders
+  // 11: CU-mate order of a grouped single-utterance launch (conv_decode_block); 12: plain order without the per-XCD pairing of
+  // M-tiles (A/B: VITS_PAIR_MTILES=0); 0: the plain orders
   int xcd_mode;
   // DDSConv prologue of the small-tile kernel (conv_small.hip.h, PRO == 1): the B operand of this 1x1 conv is computed from
   // the previous layer's raw tensors instead of being read:
@@ -186,7 +187,7 @@ __device__ __forceinline__ int conv_pair_mtiles(int ntiles_m) {
 __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, int& grp, int& nt, int& b) {
   if (P.tile_start) {
     // plain dispatch order (no XCD-contiguous remap: working tiles must be spread over all XCDs), M-tiles paired per XCD
-    int id = conv_pair_mtiles(P.ntiles_m);
+    int id = P.xcd_mode == 12 ? (int)blockIdx.x : conv_pair_mtiles(P.ntiles_m);
     mt = id % P.ntiles_m; id /= P.ntiles_m;
     const int total = P.tile_start[P.B];
     int q;
@@ -231,7 +232,7 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
   if (P.n_groups > 1) {
     // grouped launch (k = 11/7/3 ResBlocks, sorted heaviest first by the launcher): plain dispatch order
     // with the group outermost, so the long blocks start first and the launch tail is made of short ones
-    id = P.B > 1 ? conv_pair_mtiles(P.ntiles_m) : (int)blockIdx.x;  // (one utterance: an XCD keeps its M-tile's weight rows, profiles/r3_xcd_map.txt)
+    id = (P.B > 1 && P.xcd_mode != 12) ? conv_pair_mtiles(P.ntiles_m) : (int)blockIdx.x;  // (one utterance: an XCD keeps its M-tile's weight rows, profiles/r3_xcd_map.txt)
     mt = id % P.ntiles_m; id /= P.ntiles_m;
     nt = id % P.ntiles_n; id /= P.ntiles_n;
     b = id % P.B;

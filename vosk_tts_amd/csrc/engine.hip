@@ -996,6 +996,8 @@ static const int* tile_table(vits_session* s, const int* len, int mul, int add, 
 }
 
 static void attach_tile_table(vits_session* s, ConvParams& P, int N_T) {
+  static const bool pair = !(getenv("VITS_PAIR_MTILES") && atoi(getenv("VITS_PAIR_MTILES")) == 0);
+  if (!pair && !P.xcd_mode) P.xcd_mode = 12;
   P.tile_start = nullptr;
   if (!s || !s->arena || s->B == 1) return;  // a single utterance in a padded bucket: the few dead tiles exit early instead
   if (P.rag) P.tile_start = tile_table(s, P.rag, P.rag_out_mul, P.rag_out_add, P.Tout, N_T);
