@@ -239,6 +239,17 @@ __device__ __forceinline__ void ps_epi_idx(int kf, int rows_left, int gate_H, in
     i1 = i0;
   }
 }
+// column / attention / merge steps: packed parameters (row tid of the pack; attention: 512 rows) and the per-item vector
+__device__ __forceinline__ void ps_prefetch_light(const ps_i4& r, int tid, PsPre& pre) {
+  const int kind = PR_I(r, 0) & 0xff;
+  const PS_G f32x4* pk = PR_P(const f32x4, r, 9);
+  const int row = tid & (kind == PK_ATT ? 511 : 255);
+  pre.pk0 = pk[row * 2];
+  pre.pk1 = pk[row * 2 + 1];
+  const int C = PR_I(r, 1) & 0xffff;
+  int i0 = tid & 255; i0 = i0 < C ? i0 : C - 1; i0 = i0 < 0 ? 0 : i0;
+  pre.ec0 = PR_P(const float, r, 8)[i0];
+}
 __device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, int lane, PsPre& pre) {
   const int kf = PR_I(r, 0), kind = kf & 0xff;
   const PS_G f32x4* pk = PR_P(const f32x4, r, 9);
@@ -314,9 +325,13 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     // poll set-up below take about as long as they need to arrive, and every poll load is younger than they are.  (They used to be
     // requested one step ahead, after the previous step's MFMAs: as loop-carried registers written on five different paths they
     // cost an s_waitcnt vmcnt(0) plus 40 moves at the end of every step -- the whole fetch latency, exposed: 2 k of a 12 k-cycle step.)
-    ps_prefetch(rv, tid, wave, lane, pre);
-    __syncthreads();  // the previous step's readers of the LDS buffers are done
+    // Two request sequences, each followed by its kinds' whole bodies (no join before the end of the step: a join right behind
+    // conditional loads costs a conservative wait): matrix steps request weight fragments + epilogue vectors + packs, the column /
+    // attention kinds only their packed parameters and per-item vector (three loads instead of fourteen).
     const int L = len_raw < T ? len_raw : T;
+    if (kind != PK_MM) {
+    ps_prefetch_light(rv, tid, pre);
+    __syncthreads();  // the previous step's readers of the LDS buffers are done
 
     if (kind == PK_DDS) {
       // ================================================================== DDSConv column step
@@ -750,7 +765,11 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       continue;
     }
 
+    continue;  // (no other kind exists)
+    }
     // ==================================================================== matrix step
+    ps_prefetch(rv, tid, wave, lane, pre);
+    __syncthreads();  // the previous step's readers of the LDS buffers are done
     {
       const int Cin = PR_I(rv, 1) & 0xffff, K = (PR_I(rv, 1) >> 16) & 0xf, ROW = 16 + K - 1;
       const int cps = PR_I(rv, 2), t0w = PR_I(rv, 3);
