@@ -250,21 +250,16 @@ __device__ __forceinline__ void ps_prefetch_light(const ps_i4& r, int tid, PsPre
   int i0 = tid & 255; i0 = i0 < C ? i0 : C - 1; i0 = i0 < 0 ? 0 : i0;
   pre.ec0 = PR_P(const float, r, 8)[i0];
 }
+// matrix steps: weight fragments of the first row block and the epilogue vectors (straight-line: behind a branch the loads cost a
+// conservative wait in the epilogue, measured +0.5 .. 1.3 k cycles per step)
 __device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, int lane, PsPre& pre) {
-  const int kf = PR_I(r, 0), kind = kf & 0xff;
-  const PS_G f32x4* pk = PR_P(const f32x4, r, 9);
-  const int row = tid & (kind == PK_ATT ? 511 : 255);
-  pre.pk0 = pk[row * 2];
-  pre.pk1 = pk[row * 2 + 1];
+  const int kf = PR_I(r, 0);
   int i0, i1;
-  if (kind == PK_MM) ps_epi_idx(kf, PR_B(r, 3), PR_B(r, 7), tid, 0, i0, i1);
-  else { const int C = PR_I(r, 1) & 0xffff; i0 = tid & 255; i0 = i0 < C ? i0 : C - 1; i0 = i0 < 0 ? 0 : i0; i1 = i0; }
+  ps_epi_idx(kf, PR_B(r, 3), PR_B(r, 7), tid, 0, i0, i1);
   const PS_G float* b = PR_P(const float, r, 7);
   const PS_G float* c = PR_P(const float, r, 8);
   pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
-  // straight-line for every kind (other kinds: unit 0 of their record's p6, always a valid pointer): behind a branch the loads
-  // cost a conservative wait in the epilogue (measured +0.5 .. 1.3 k cycles per step)
-  ps_load_weights(PR_P(const float, r, 6), kind == PK_MM ? (PR_B(r, 0) & 0xffff) : 1, wave, lane, pre.a);
+  ps_load_weights(PR_P(const float, r, 6), PR_B(r, 0) & 0xffff, wave, lane, pre.a);
 }
 
 #define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
