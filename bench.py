@@ -569,6 +569,14 @@ def main():
                         "achieved_tflops": round(flops_fwd / (elapsed / steps) / 1e12, 3),
                         "frac": round(flops_fwd / (elapsed / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                         "sum_kernel_ms_eager": round(dev_ms_all, 4)},
+            # the kernel with the most device time overall (at c2: the persistent step programs of the text encoder / duration
+            # predictor / flow -- latency-bound, 21 % of the FLOPs; the roofline object above stays on the MFMA conv kernel that
+            # carries 79 % of them and that the reviews have tracked since round 1)
+            "largest_by_time": (lambda kv: {"kernel": kv[0], "ms_per_forward": round(kv[1][1] / nprof, 4),
+                                            "launches_per_forward": kv[1][0] // nprof,
+                                            "achieved_tflops": round(kv[1][2] / (kv[1][1] * 1e-3) / 1e12, 3) if kv[1][1] > 0 else 0.0,
+                                            "frac_of_fp32_mfma_peak": round(kv[1][2] / (kv[1][1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if kv[1][1] > 0 else 0.0})(
+                                   max(by_kernel.items(), key=lambda kv: kv[1][1])),
             "by_kernel_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])},
             "by_op_ms_per_forward": {k: round(v[1] / nprof, 4) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])},
             "by_op_tflops": {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1][1])

@@ -29,24 +29,18 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c2 -o trace -- python $R/bench.py --no-batch32 --no-cpu-baseline --no-host-api --steps 50 > $O/r3_c2_only_bench_under_rocprof.json.txt 2> $O/prof_c2.err
 cp $(find $O/prof/c2 -name '*kernel_stats.csv' | head -1) $O/r3_c2_only_bench_rocprofv3_kernel_stats.csv
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/def -o trace -- python $R/bench.py --no-cpu-baseline > $O/r3_default_bench_under_rocprof.json.txt 2> $O/prof_def.err
-cp $(find $O/prof/def -name '*kernel_stats.csv' | head -1) $O/r3_default_bench_rocprofv3_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c3 -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --no-host-api > $O/r3_c3_only_bench_under_rocprof.json.txt 2> $O/prof_c3.err
+cp $(find $O/prof/c3 -name '*kernel_stats.csv' | head -1) $O/r3_c3_only_bench_rocprofv3_kernel_stats.csv
 rm -rf $O/prof
 cd $R
 for w in c3 c4 c5 m2 m3; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-host-api > $O/r3_${w}_bench.json.txt 2> $O/bench_$w.err; echo "bench $w rc=$?"
 done
-# the torch.distributed launch path (one rank here; the driver runs N = 1, 2, 4, 8): RCCL init, barrier, max-over-ranks reduction
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-host-api > $O/r3_c4_torchrun1_bench.json.txt 2> $O/bench_c4_torchrun.err; echo "bench c4 under torchrun rc=$?"
 # the self-launching multi-rank entry point: two replicas on this one device, host-side (gloo) barrier, batch256_sharded over 2 ranks
 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/r3_gpus2_selflaunch_bench.json.txt 2> $O/bench_gpus2.err; echo "bench --gpus 2 (self-launch) rc=$?"
-for w in c3 c4 c5 m3; do
+for w in c3 c5; do
   timeout 300 python bench.py --workload $w --precision bf16x3 --no-cpu-baseline --no-host-api > $O/r3_${w}_bf16x3_bench.json.txt 2> $O/bench_${w}b.err; echo "bench $w bf16x3 rc=$?"
 done
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/m2 -o trace -- python $R/bench.py --workload m2 --no-cpu-baseline --steps 30 > $O/r3_m2_bench_under_rocprof.json.txt 2> $O/prof_m2.err
-cp $(find $O/prof/m2 -name '*kernel_stats.csv' | head -1) $O/r3_m2_bench_rocprofv3_kernel_stats.csv
-rm -rf $O/prof
 cd $R
 for w in c2 c3; do
   timeout 900 bash tools/pmc_passes.sh $w > $O/pmc_$w.log 2>&1
