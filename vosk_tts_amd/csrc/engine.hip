@@ -210,8 +210,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static void* weight_alloc(vits_model* m, size_t bytes) {
   static const bool no_slab = getenv("VITS_NO_SLAB") != nullptr;  // A/B switch for tools/
   bytes = align_up(bytes ? bytes : 4, 256);
-  // every allocation is followed by >= 64 KB of mapped memory: the persistent kernel requests the weight fragments of up to
-  // PS_MAXU * PS_WAVES = 64 tap units (1 KB each) from a row block's base without clamping the unit index (ps_load_weights)
+  // every allocation is followed by >= 64 KB of mapped memory: the weight streams are prefetched past their end by design (one or
+  // two steps in the conv kernels, whose packings are padded for it); the slack makes an overrun of any of them a read of mapped
+  // memory instead of a fault
   constexpr size_t guard = (size_t)64 << 10;
   if (no_slab) {
     void* d = nullptr;
