@@ -40,6 +40,11 @@ for s in range(n):
     wait = np.median(got - a[:, 0]); work = np.median(a[:, 3] - got)
     e0 = r0[s, 3] - t0 if r0[s, 3] > 0 else -1
     print(f"step {s:2d} {names[kinds[s]]:6s} workers {busy.sum():3d}  wait {wait:6.0f} (max {np.max(got - a[:, 0]):6d})  work {work:6.0f} (max {np.max(a[:, 3] - got):6d})   rank0 end {e0:8d} (+{e0 - prev if e0 >= 0 else 0:6d})")
+    if os.environ.get("PS_DETAIL") and s + 1 < n:
+        both = busy & (st[:, s + 1, 0] > 0)
+        if both.any():
+            gap = st[both, s + 1, 0] - st[both, s, 3]
+            print(f"        end of this step -> start stamp of the next (same worker): median {np.median(gap):.0f} cycles (p90 {np.sort(gap)[int(.9 * len(gap))]:.0f})")
     if os.environ.get("PS_DETAIL"):
         w = np.sort(a[:, 3] - got); g = np.sort(got - a[:, 0])
         q = lambda v, f: int(v[min(len(v) - 1, int(f * len(v)))])

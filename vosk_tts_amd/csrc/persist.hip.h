@@ -262,6 +262,11 @@ __device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, i
   ps_load_weights(PR_P(const float, r, 6), PR_B(r, 0) & 0xffff, wave, lane, pre.a);
 }
 
+// Placed where a poll has just completed: the record of step s + 1 (requested at the top of this step, older than every poll load) is
+// certainly there -- touching it HERE makes the compiler account for its wait at a point where it costs nothing.  Without this the
+// hand-over rv = rvB at the loop's back edge is the first use, and because loads and stores share the in-order vmcnt counter the
+// compiler waits there for vmcnt(0): for the step's own output stores (an sc1 write round trip per step).
+#define PS_REC_READY() asm volatile("" : "+v"(rvB))
 #define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 // LDS of the kernel (floats).  Matrix steps: operand window + partial tiles + spline scratch; attention blocks: Q / K / V tiles and
@@ -286,7 +291,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     const PS_G ps_i4* p = (const PS_G ps_i4*)(recs + ((size_t)(s < n_steps ? s : n_steps - 1) * P + rank));
     return p[tid0 & 7];
   };
-  ps_i4 rvA = load_rec(0), rvB = load_rec(1);
+  ps_i4 rvB = load_rec(0);  // the record of the NEXT step: requested at the top of a step, touched right after that step's poll
   PsCtx cx;
   {
     unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -298,10 +303,15 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   {
     int zero = 0;
     asm volatile("" : "+v"(zero));
-    len_raw = ((const PS_G int*)prog->len)[zero];  // vector load (stays off the scalar counter), first used in step 0
+    len_raw = ((const PS_G int*)prog->len)[zero];  // vector load (stays off the scalar counter)
   }
-  const float ea_m = ((const PS_G float*)prog->ea_m)[0], ea_is = expf(-((const PS_G float*)prog->ea_logs)[0]);  // used by the very last epilogue
-  const float spline_cst = logf(expf(1.f - 1e-3f) - 1.f);  // boundary derivative parameter (transforms.py:100-103); once, not per column
+  // Loop-invariant uniform values go into SGPRs (readfirstlane): as VGPRs they are part of the block of loop-carried registers the
+  // compiler shuffles at the step loop's back edge, right behind the step's output stores -- and overwriting a register that was a
+  // store's data operand costs an s_waitcnt vmcnt(0) there, i.e. the completion of the step's sc1 stores, every step.
+  auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+  len_raw = __builtin_amdgcn_readfirstlane(len_raw);
+  const float ea_m = uni(((const PS_G float*)prog->ea_m)[0]), ea_is = uni(expf(-((const PS_G float*)prog->ea_logs)[0]));  // used by the very last epilogue
+  const float spline_cst = uni(logf(expf(1.f - 1e-3f) - 1.f));  // boundary derivative parameter (transforms.py:100-103); once, not per column
   PsPre pre;
 
   for (int s = 0; s < n_steps; ++s) {
@@ -310,10 +320,9 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const ps_i4 rv = rvA;
-    rvA = rvB;
+    const ps_i4 rv = rvB;
     const int kf = PR_I(rv, 0), kind = kf & 0xff;
-    rvB = load_rec(s + 2);  // (an L2 hit; older than everything else this step requests)
+    rvB = load_rec(s + 1);  // (an L2 hit; older than everything else this step requests)
     if (kind == PK_IDLE) continue;  // nothing to do and nothing to wait for in this step
     PS_STAMP(0);
     // This step's own operands (weight fragments, packed parameters, epilogue vectors), requested FIRST: the record decode and the
@@ -377,7 +386,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
         }
-        PS_STAMP(1);
+        PS_STAMP(1); PS_REC_READY();
         const float par[8] = {pre.pk0[0], pre.pk0[1], pre.pk0[2], pre.pk0[3], pre.pk1[0], pre.pk1[1], pre.pk1[2], pre.pk1[3]};
         if (zc) { x0 = par[0] * z0 + par[1] + x0; x1 = par[0] * z1 + par[1] + x1; }  // ConvFlow.pre(x0) + g  (modules.py:365-366)
         if (y2) {  // x + gelu(LN2(y2)), two-pass statistics like F.layer_norm; both slots of a half in the same reductions
@@ -468,7 +477,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           }
           r = den > 0.f ? num / den : 0.f;
         }
-        PS_STAMP(1);
+        PS_STAMP(1); PS_REC_READY();
         if (ok) ll_store(out + (long long)t * C + hd * dk + d, r, epoch);
       }
       PS_STAMP(3);
@@ -527,7 +536,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                 pending = PS_PENDING(bad);
               } while (ps_again(cx, pending));
             }
-            PS_STAMP(1);
+            PS_STAMP(1); PS_REC_READY();
             v += par_bias;  // (after the poll: the packed parameters were requested at the top of the step)
             if (kf & PF_LN) {
               const float invC = 1.0f / (float)C;
@@ -576,7 +585,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                 pending = PS_PENDING(bad);
               } while (ps_again(cx, pending));
             }
-            PS_STAMP(1);
+            PS_STAMP(1); PS_REC_READY();
             o = c < H ? uv : uv - (mv + par_bias);
           }
         }
@@ -649,7 +658,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             }
             pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
-          PS_STAMP(1);
+          PS_STAMP(1); PS_REC_READY();
           if (W > 0) {  // E_k[tid], E_k[tid + 512], E_v[tid], E_v[tid + 512] of the flat [2W + 1][dk] tables -> rows of pitch dk + 1:
             // the score pass reads row (j - i + W) per LANE; at pitch dk = 96 all nine rows of a 16-lane group fell on one bank
             const int tab = (2 * W + 1) * dk;
@@ -812,7 +821,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
         }
-        PS_STAMP(1);
+        PS_STAMP(1); PS_REC_READY();
         if (cok) {
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
