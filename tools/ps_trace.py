@@ -58,7 +58,7 @@ for s in range(n):
             print("        PV+stores by worker:", [int(full[r, 3] - full[r, 5]) if full[r, 5] > 0 else -1 for r in range(min(P, 120))])
         if a[:, 6].max() > 0:
             md = lambda x: float(np.median(x))
-            print(f"        MM phases (median cycles): start->poll done {md(got - a[:, 0]):.0f} | tile+barrier {md(a[:, 2] - got):.0f} | weights wait + mfma {md(a[:, 4] - a[:, 2]):.0f} | res poll + partial tiles + barrier {md(a[:, 6] - a[:, 4]):.0f} | epilogue + stores {md(a[:, 3] - a[:, 6]):.0f}")
+            print(f"        MM phases (median cycles): start->poll done {md(got - a[:, 0]):.0f} | tile+barrier {md(a[:, 2] - got):.0f} | to MFMA loop {md(a[:, 7] - a[:, 2]):.0f} | MFMA loop {md(a[:, 4] - a[:, 7]):.0f} | res poll + partial tiles + barrier {md(a[:, 6] - a[:, 4]):.0f} | epilogue + stores {md(a[:, 3] - a[:, 6]):.0f}")
         print(f"        work p10/p50/p90/max {q(w, .1)}/{q(w, .5)}/{q(w, .9)}/{int(w[-1])}   wait p10/p50/p90 {q(g, .1)}/{q(g, .5)}/{q(g, .9)}   phases(median): poll->tile {np.median(a[:, 2] - got) if a[:, 2].max() > 0 else -1:.0f}")
     if e0 >= 0: prev = e0
     tot_wait += wait; tot_work += work

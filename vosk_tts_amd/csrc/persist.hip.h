@@ -852,6 +852,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           // unit u = chunk * K + tap for u = wave + 8 i: (chunk, tap) advance by (8 / K, 8 % K); K in {1, 3, 5} without a division
           const int kmul = K == 1 ? 64 : (K == 3 ? 22 : (K == 5 ? 13 : 0));
           int uc = kmul ? (wave * kmul) >> 6 : wave / K, uk = wave - uc * K;
+          if (mi == nblk - 1) PS_STAMP(7);
           const int step_c = kmul ? (PS_WAVES * kmul) >> 6 : PS_WAVES / K, step_k = PS_WAVES - step_c * K;
 #pragma unroll
           for (int i = 0; i < PS_MAXU; ++i) {
