@@ -2623,7 +2623,13 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   for (int b = 0; b < B; ++b) if (F->h_ylen[b] > Ty) Ty = F->h_ylen[b];
   if (opts && opts->max_frames > 0 && Ty > opts->max_frames) return fail(VITS_ERR_ARG, "T_y %lld exceeds max_frames %d", (long long)Ty, opts->max_frames);
   if (Ty > (1 << 24)) return fail(VITS_ERR_ARG, "T_y unreasonably large");
-  const int TyB = (int)((Ty + 31) / 32 * 32);
+  // frame bucket: multiples of 32 for one utterance; batches round up in steps of 1/8 of the power of two below T_y (64 frames
+  // at 512..1023): with free-running durations the longest item of a batch lands on a different multiple of 32 almost every
+  // call, and every new bucket is a workspace + a graph capture on the request path.  The padding is not computed (ragged tile
+  // maps skip dead tiles); it costs the D2H of the padded rows only.
+  int ty_step = 32;
+  if (B > 1) { int p2 = 32; while (p2 * 2 <= Ty) p2 *= 2; if (p2 / 8 > ty_step) ty_step = p2 / 8; }
+  const int TyB = (int)((Ty + ty_step - 1) / ty_step * ty_step);
   // ---- phase 2
   vits_session* Bk = nullptr;
   {
