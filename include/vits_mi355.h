@@ -307,6 +307,10 @@ void vits_debug_ln_stats(int on);
  * exchange between their steps (csrc/persist.hip.h): 1 duration predictor, 2 text encoder, 4 flow.  Default 7; 0: the launch-per-layer
  * path everywhere (the A/B reference, and the batch path). */
 void vits_debug_persist(int mask);
+/* Test hook: poll rounds after which a worker of a persistent program gives up (0 = the default bound, 2^18).  A timeout
+ * switches the persistent programs off for the process and the host entry points run the call again on the launch path
+ * (the caller sees a slower call, not an error); an asynchronous device session reports VITS_ERR_DEVICE once. */
+void vits_debug_persist_spin(int limit);
 /* Test hook: 1 (default) = WaveNet tail of the coupling layers in folded form (gate outputs of all layers kept, one conv =
  * post o sum of skip halves), 0 = per-layer res/skip accumulation + post as the reference executes it.  Same results to rounding. */
 void vits_debug_wn_fold(int on);

@@ -1006,3 +1006,33 @@ def test_pcm16_output_equals_numpy_conversion(hip_lib, hip_default):
             assert np.array_equal(want, p)
             if scale > 1:
                 assert (np.abs(p) == 32767).any()
+
+
+def test_persistent_timeout_falls_back_to_launches_without_failing_the_call(hip_lib, hip_default):
+    """A poll of a persistent program that does not complete within its bound (workgroups not co-resident: another process on the
+    device) must not cost the request: the host entry point switches the persistent programs off and runs the call again on
+    launches.  Forced here by shrinking the bound to one round (vits_debug_persist_spin): the call succeeds, returns what the
+    launch path returns, and later calls stay on launches until the switch is set again."""
+    rng = np.random.default_rng(77)
+    ids = rng.integers(1, 62, size=(1, 40)).astype(np.int64)
+    lens = np.array([40], np.int64)
+    sc = np.array([0.667, 1.0, 0.8], np.float32)
+    sid = np.array([1], np.int64)
+    lib = hip_lib.lib
+    lib.vits_debug_persist(0)
+    want, wl = hip_default.synthesize(ids, lens, sc, sid, seed=9)
+    try:
+        lib.vits_debug_persist(7)
+        lib.vits_debug_persist_spin(1)
+        got, gl = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # times out inside, retried on launches
+        assert np.array_equal(wl, gl)
+        assert_close("timeout fallback", want, got, 1e-6)
+        pcm, _ = hip_default.synthesize_pcm16(ids, lens, sc, sid, seed=9)  # persistent programs are off now: plain launch path
+        assert pcm.shape[-1] == got.shape[-1]
+        chunks = list(hip_default.stream(ids[:, :40], sc, 1, chunk_frames=32, seed=9))
+        assert sum(len(c) for c in chunks) == int(gl[0])
+    finally:
+        lib.vits_debug_persist_spin(0)
+        lib.vits_debug_persist(7)
+    again, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # and back on the persistent programs
+    assert_close("persistent again", want, again, 2e-4)

@@ -662,6 +662,7 @@ struct vits_session {
   char* arena = nullptr;
   size_t arena_bytes = 0, arena_used = 0;
   int* d_err = nullptr;
+  int* h_err = nullptr;  // back sessions of the fast path: pinned copy of d_err, written by the phase-2 graph
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   bool profile = false;
@@ -910,6 +911,7 @@ static void session_free(vits_session* s) {
   for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow}) { if (pp->d) hipFree(pp->d); if (pp->recs_d) hipFree(pp->recs_d); }
   if (s->stage) hipFree(s->stage);
   if (s->d_err) hipFree(s->d_err);
+  if (s->h_err) hipHostFree(s->h_err);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->copy_stream) hipStreamDestroy(s->copy_stream);
@@ -951,6 +953,7 @@ struct ProfScope {
 
 // ---- one persistent step program (persist.hip.h) as ONE launch of P = #CUs workgroups
 static bool big_lds_needed(std::atomic<unsigned long long>& done);
+static int g_ps_spin_limit = 0;  // test hook (vits_debug_persist_spin): poll rounds before a worker gives up; 0 = PS_SPIN_LIMIT
 static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const char* name, const float* d_noise = nullptr, float nsw = 0.f,
                            uint64_t seed = 0, const int64_t* d_ids = nullptr) {
   vits_model* m = s->m;
@@ -958,6 +961,7 @@ static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const
   PCall c;
   c.ctl = s->ps_ctl; c.ids = reinterpret_cast<const long long*>(d_ids); c.noise = d_noise; c.nsw = nsw; c.seed = seed;
   c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds; c.trace = nullptr;
+  c.spin_limit = g_ps_spin_limit > 0 ? g_ps_spin_limit : PS_SPIN_LIMIT;
   static const char* trace_path = getenv("VITS_PS_TRACE");  // tools/ps_trace.py: per-worker, per-step cycle stamps of an EAGER forward
   static const char* trace_name = getenv("VITS_PS_TRACE_PROG");  // which program ("dp.persist" by default)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1570,6 +1574,17 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
   (void)F;
 }
 
+// A bounded poll of a persistent program ran out (its workgroups were not all co-resident: another process on the device, a
+// partitioned GPU): the launch path stays available.  Persistent programs are switched off for the process and the host entry
+// points run the call again on launches (synth_dispatch / vits_stream_open look at tl_ps_timed_out) -- the caller sees a slower
+// call, not an error; asynchronous device sessions report VITS_ERR_DEVICE once.
+static thread_local bool tl_ps_timed_out = false;
+static int persist_timed_out() {
+  g_persist = 0;
+  tl_ps_timed_out = true;
+  return fail(VITS_ERR_DEVICE, "persistent kernel: exchange timed out (workgroups not co-resident?); disabled for this process");
+}
+
 static int check_err(vits_session* s) {
   int e = 0;
   HIP_TRY(hipMemcpyAsync(&e, s->d_err, sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -1581,10 +1596,7 @@ static int check_err(vits_session* s) {
     if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
     if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
     if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
-    if (e & PS_ERR_TIMEOUT) {
-      g_persist = 0;  // the launch path stays available: do not try again in this process
-      return fail(VITS_ERR_DEVICE, "persistent kernel: exchange timed out (workgroups not co-resident?); disabled for this process");
-    }
+    if (e & PS_ERR_TIMEOUT) return persist_timed_out();
   }
   return VITS_OK;
 }
@@ -2469,8 +2481,10 @@ static int back_get(vits_session* F, int TyB, vits_session** out) {
   s->out_elems = (size_t)F->B * TyB * m->hp.hop_length;
   if (rc == VITS_OK && (hipMalloc((void**)&s->out_d, s->out_elems * sizeof(float)) != hipSuccess ||
                         hipMalloc((void**)&s->pcm_d, s->out_elems * sizeof(int16_t)) != hipSuccess ||
-                        hipHostMalloc((void**)&s->out_h, s->out_elems * sizeof(float)) != hipSuccess))
+                        hipHostMalloc((void**)&s->out_h, s->out_elems * sizeof(float)) != hipSuccess ||
+                        hipHostMalloc((void**)&s->h_err, 64) != hipSuccess))
     rc = fail(VITS_ERR_NOMEM, "fast-path output buffers (%zu samples)", s->out_elems);
+  if (s->h_err) *s->h_err = 0;
   if (rc != VITS_OK) { s->stream = nullptr; session_free(s); return rc; }
   // phase 2 reads the front's phase-1 results in place
   s->stats = F->stats; s->cum = F->cum; s->condv = F->condv; s->len_y = F->len_y; s->len_x = F->len_x; s->ylen64 = F->ylen64;
@@ -2557,6 +2571,7 @@ static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm)
     } else {
       hipMemcpyAsync(Bk->out_h, Bk->out_d, Bk->out_elems * sizeof(float), hipMemcpyDeviceToHost, F->stream);
     }
+    hipMemcpyAsync(Bk->h_err, Bk->d_err, sizeof(int), hipMemcpyDeviceToHost, F->stream);  // (the flow program's error bits)
     Bk->ragged = false; Bk->solo = false;
     TRY(capture_end(F, &Bk->g2[gi], &cg));
   }
@@ -2568,7 +2583,8 @@ static int device_error_word(int e) {
   if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
   if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
   if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
-  return VITS_OK;
+  if (e & PS_ERR_TIMEOUT) return persist_timed_out();
+  return e ? fail(VITS_ERR_DEVICE, "device error word %d", e) : VITS_OK;
 }
 
 static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
@@ -2651,6 +2667,13 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   HIP_TRY(hipStreamSynchronize(F->stream));
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { free(h_out); return fail(VITS_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(le)); }
+  if (*Bk->h_err) {
+    const int e2 = *Bk->h_err;
+    *Bk->h_err = 0;
+    hipMemsetAsync(Bk->d_err, 0, sizeof(int), F->stream);
+    free(h_out);
+    return device_error_word(e2);
+  }
   for (int b = 0; b < B; ++b) memcpy(h_out + esz * (size_t)b * S, Bk->out_h + esz * (size_t)b * stride, esz * (size_t)S);
   *out = h_out;
   *out_samples = S;
@@ -2703,8 +2726,13 @@ static int synth_dispatch(vits_model* m, const int64_t* ids, const int64_t* leng
   for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
   static const bool env_off = getenv("VITS_NO_FASTPATH") != nullptr;
   const bool injected = (opts && (opts->noise_dp || opts->noise_prior || opts->bert)) || m->hp.bert_dim > 0;
-  if (g_fast_path && !env_off && !injected) return synth_fast(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
-  return synth_eager(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
+  for (int attempt = 0;; ++attempt) {
+    tl_ps_timed_out = false;
+    const int rc = (g_fast_path && !env_off && !injected)
+                       ? synth_fast(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths)
+                       : synth_eager(m, ids, lengths, B, Tx, scales, sid, opts, pcm, pcm_scale, out, out_samples, out_lengths);
+    if (rc == VITS_OK || !tl_ps_timed_out || attempt) return rc;  // a persistent program timed out: once more, on launches
+  }
 }
 
 int vits_synthesize(vits_model* m, const int64_t* ids, const int64_t* lengths, int32_t B, int32_t Tx, const float* scales,
@@ -2822,15 +2850,19 @@ static int stream_start(vits_stream* st, const float* z, int Ty, int chunk_frame
 int vits_stream_open(vits_model* m, const int64_t* ids, int32_t Tx, const float* scales, int64_t sid, const vits_synth_opts* opts,
                      int32_t chunk_frames, vits_stream** out, int64_t* total_samples) {
   if (!m || !ids || !scales || !out || Tx <= 0 || chunk_frames <= 0) return fail(VITS_ERR_ARG, "bad argument");
-  vits_stream* st = new vits_stream();
-  st->m = m;
-  st->hs = new HostStage(m);
-  std::vector<int64_t> ylen;
-  int64_t Ty = 0, len = Tx;
-  float* z = nullptr;
-  int rc = acoustic_host(*st->hs, ids, &len, 1, Tx, scales, &sid, opts, ylen, Ty, z);
-  if (rc != VITS_OK) { vits_stream_close(st); return rc; }
-  return stream_start(st, z, (int)Ty, chunk_frames, out, total_samples);
+  for (int attempt = 0;; ++attempt) {
+    vits_stream* st = new vits_stream();
+    st->m = m;
+    st->hs = new HostStage(m);
+    std::vector<int64_t> ylen;
+    int64_t Ty = 0, len = Tx;
+    float* z = nullptr;
+    tl_ps_timed_out = false;
+    const int rc = acoustic_host(*st->hs, ids, &len, 1, Tx, scales, &sid, opts, ylen, Ty, z);
+    if (rc == VITS_OK) return stream_start(st, z, (int)Ty, chunk_frames, out, total_samples);
+    vits_stream_close(st);
+    if (!tl_ps_timed_out || attempt) return rc;  // a persistent program timed out: once more, on launches
+  }
 }
 
 // Streams the decoder over a latent the caller already holds (host, [inter_channels, T_y] row-major): the vocoder half of a
@@ -2975,6 +3007,7 @@ void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
 void vits_debug_ln_stats(int on) { g_ln_stats = on; }
 void vits_debug_persist(int on) { g_persist = on; }
+void vits_debug_persist_spin(int limit) { g_ps_spin_limit = limit; }
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
 void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }

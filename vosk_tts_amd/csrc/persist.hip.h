@@ -115,6 +115,7 @@ struct PCall {                          // per-call values (by value: a captured
   const SynthDev* dv;
   const unsigned long long* item_seeds;
   long long* trace;                     // tools only (VITS_PS_TRACE): [P][PS_MAX_STEPS][8] cycle stamps, null in production
+  int spin_limit;                       // poll rounds before a worker gives up (PS_SPIN_LIMIT; tests shrink it to force the fallback)
 };
 
 #define PS_G __attribute__((address_space(1)))
@@ -148,6 +149,7 @@ struct PsCtx {
   unsigned epoch;
   int aborted;        // this wave gave up (or saw ctl->abort): polls return at once
   int spins;
+  int limit;
   PersistCtl* ctl;
 };
 // one more round of a poll loop: true = keep polling.  `pending` is wave-uniform (a ballot).
@@ -158,7 +160,7 @@ __device__ __forceinline__ bool ps_again(PsCtx& cx, bool pending) {
   if (!pending || cx.aborted) { cx.spins = 0; return false; }
   ++cx.spins;
   if ((cx.spins & 1023) == 0 && __hip_atomic_load(&cx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { cx.aborted = 1; return false; }
-  if (cx.spins >= PS_SPIN_LIMIT) {
+  if (cx.spins >= cx.limit) {
     cx.aborted = 1;
     if ((threadIdx.x & 63) == 0) {
       __hip_atomic_store(&cx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     cx.epoch = __builtin_amdgcn_readfirstlane(e ? e : 1u);  // 0 marks "never written"
   }
-  cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl;
+  cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl; cx.limit = call.spin_limit;
   const unsigned epoch = cx.epoch;
   int len_raw;
   {
