@@ -395,6 +395,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="bf16x3: model created with hparams.conv_precision = 1 (split-bf16 decoder ResBlock convs at batch size)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-to-host drop-in path leg of the default run")
+    ap.add_argument("--no-extras", action="store_true", help="skip the streaming (c5) and concurrency legs of the default run")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch, barrier and aggregation only (CPU test of the multi-process path)")
     args = ap.parse_args()
 

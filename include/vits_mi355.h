@@ -311,6 +311,9 @@ void vits_debug_persist(int mask);
  * switches the persistent programs off for the process and the host entry points run the call again on the launch path
  * (the caller sees a slower call, not an error); an asynchronous device session reports VITS_ERR_DEVICE once. */
 void vits_debug_persist_spin(int limit);
+/* Test hook: persistent-program launches of this model that ran to completion (no timeout) since vits_create; -1 on error.
+ * (The bound of vits_debug_persist_spin is a device word the kernel reads at run time: captured graphs follow it.) */
+int vits_debug_persist_runs(vits_model* m);
 /* Test hook: 1 (default) = WaveNet tail of the coupling layers in folded form (gate outputs of all layers kept, one conv =
  * post o sum of skip halves), 0 = per-layer res/skip accumulation + post as the reference executes it.  Same results to rounding. */
 void vits_debug_wn_fold(int on);

@@ -5,6 +5,8 @@ Tolerances (relative to the tensor's max magnitude, see conftest.assert_close):
   north_star demands 1e-3 relative fp32 on mel(z)/waveform; we hold the HIP path to 1e-4 per stage
   and 5e-4 end to end so a real indexing bug (errors of O(1e-1)) can never hide behind the budget.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -1019,20 +1021,32 @@ def test_persistent_timeout_falls_back_to_launches_without_failing_the_call(hip_
     sc = np.array([0.667, 1.0, 0.8], np.float32)
     sid = np.array([1], np.int64)
     lib = hip_lib.lib
+    lib.vits_debug_persist_runs.restype = ctypes.c_int
+    lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
+    runs = lambda: int(lib.vits_debug_persist_runs(hip_default._h))
     lib.vits_debug_persist(0)
     want, wl = hip_default.synthesize(ids, lens, sc, sid, seed=9)
+    r0 = runs()
     try:
         lib.vits_debug_persist(7)
-        lib.vits_debug_persist_spin(1)
+        warm, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # captures this bucket's graphs WITH the persistent kernels
+        assert runs() == r0 + 3, "text encoder, duration predictor and flow each as one completed persistent launch"
+        assert_close("persistent", want, warm, 2e-4)
+        lib.vits_debug_persist_spin(1)  # (a device word: the graphs captured above follow it)
+        r1 = runs()
         got, gl = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # times out inside, retried on launches
+        assert runs() == r1, "no persistent launch may have completed under a one-round bound"
         assert np.array_equal(wl, gl)
         assert_close("timeout fallback", want, got, 1e-6)
         pcm, _ = hip_default.synthesize_pcm16(ids, lens, sc, sid, seed=9)  # persistent programs are off now: plain launch path
         assert pcm.shape[-1] == got.shape[-1]
         chunks = list(hip_default.stream(ids[:, :40], sc, 1, chunk_frames=32, seed=9))
         assert sum(len(c) for c in chunks) == int(gl[0])
+        assert runs() == r1
     finally:
         lib.vits_debug_persist_spin(0)
         lib.vits_debug_persist(7)
-    again, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # and back on the persistent programs
+    r2 = runs()
+    again, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # and back on the persistent programs: the SAME captured graphs
+    assert runs() == r2 + 3, "the last call must have run the three persistent kernels to completion"
     assert_close("persistent again", want, again, 2e-4)

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -64,6 +65,7 @@ static int g_tail_impl = 0;
 static int g_wn_fold = 1;
 // 1 = LayerNorm statistics of the folded encoder LayerNorms from the producer conv's epilogue (default), 0 = redone by the consumer
 static int g_ln_stats = 1;
+static int g_ps_spin_limit = 0;  // test hook (vits_debug_persist_spin): poll rounds before a persistent worker gives up; 0 = PS_SPIN_LIMIT
 // single-utterance duration predictor as one persistent kernel (persist.hip.h): 1 = when eligible (default), 0 = launch path
 // A persistent kernel needs ALL its workgroups resident at once (they spin on each other's cells): two of them in flight on one
 // device could each hold half of the CUs and wait forever (the bounded poll loops turn that into an error, not a hang -- but it must
@@ -158,6 +160,7 @@ struct vits_model {
   float *istft_basis = nullptr, *pqmf = nullptr;
   bool use_g = false;
   float* zeros = nullptr;  // 4096 zeros: the "unused" parameter pointers of persistent-kernel steps (persist.hip.h)
+  int* ps_dbg = nullptr;   // device words read / written by persist_kernel: [0] poll-round limit (0 = default), [1] completed persistent launches
   std::mutex pack_mu;      // packed per-thread parameter vectors of persistent steps, keyed by their sources (persist_plan.hip.h)
   std::map<std::vector<long long>, const float*> packs;
   int n_cu = 0;       // compute units of the device = workgroups of a persistent kernel (persist.hip.h)
@@ -170,6 +173,10 @@ struct vits_model {
   uint64_t use_clock = 0;
   size_t fronts_bytes = 0;
 };
+
+// live models (vits_debug_persist_spin writes the poll limit into each model's device word)
+static std::mutex g_models_mu;
+static std::vector<vits_model*> g_models;
 
 static const float* tget(vits_model* m, int ndim, int d0, int d1, int d2, const char* fmt, ...) {
   char name[160];
@@ -668,7 +675,7 @@ struct vits_session {
   bool profile = false;
   std::vector<ProfRec> prof;
   // graph cache for the device entry point
-  typedef std::tuple<const void*, const void*, const void*, const void*, void*, int, int, int, uint64_t, float, float, float> GKey;
+  typedef std::tuple<const void*, const void*, const void*, const void*, void*, int, int, int, uint64_t, float, float, float, int> GKey;  // (last: persist mask)
   std::map<GKey, hipGraphExec_t> graphs;
   bool use_graph = true;
   const SynthDev* dv = nullptr;  // device parameter block of the graph-replayed fast path (null: scalars by value)
@@ -709,6 +716,9 @@ struct vits_session {
     double flops = 0;
   };
   PersistProg ps_enc, ps_sdp, ps_flow;
+  int ps_roles = 7;        // PERSIST_* mask of the programs this session can ever launch: fronts of the fast path run the text encoder and the
+                           // duration predictor, their backs the flow -- cells and records are only laid out / built for those
+  bool ps_defer = false;   // the owner calls persist_plan itself after re-pointing shared tensors (backs): session_reserve skips it
   PersistCtl* ps_ctl = nullptr;
   bool ps_owner = false;   // device sessions (asynchronous entry point): this session holds the device's persistent-path token for its lifetime
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
@@ -795,11 +805,11 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->dc = bump<float>(s, B * D * Tx); s->dfh = bump<float>(s, B * D * Tx);
   s->dq1 = bump<float>(s, B * D * Tx); s->dq2 = bump<float>(s, B * D * Tx);
   s->dz = bump<float>(s, (size_t)B * 2 * Tx); s->dpr = bump<float>(s, (size_t)B * 32 * Tx); s->logw = bump<float>(s, (size_t)B * Tx);
-  s->ps_enc.cells = persist_enc_cells(s->m, B, Tx);
+  s->ps_enc.cells = (s->ps_roles & PERSIST_ENC) ? persist_enc_cells(s->m, B, Tx) : 0;
   s->ps_enc.ll = bump<ll_t>(s, s->ps_enc.cells);
-  s->ps_sdp.cells = persist_sdp_cells(s->m, B, Tx);
+  s->ps_sdp.cells = (s->ps_roles & PERSIST_SDP) ? persist_sdp_cells(s->m, B, Tx) : 0;
   s->ps_sdp.ll = bump<ll_t>(s, s->ps_sdp.cells);
-  s->ps_flow.cells = persist_flow_cells(s->m, B, Ty);
+  s->ps_flow.cells = (s->ps_roles & PERSIST_FLOW) ? persist_flow_cells(s->m, B, Ty) : 0;
   s->ps_flow.ll = bump<ll_t>(s, s->ps_flow.cells);
   s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
   s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
@@ -872,7 +882,8 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);
     hipStreamSynchronize(s->stream);
   }
-  return persist_plan(s);
+  if (!s->ps_defer) persist_plan(s);  // never fails the reserve: a program that cannot be built leaves its stage on the launch path
+  return VITS_OK;
 }
 
 static int session_new(vits_model* m, vits_session** out) {
@@ -953,7 +964,6 @@ struct ProfScope {
 
 // ---- one persistent step program (persist.hip.h) as ONE launch of P = #CUs workgroups
 static bool big_lds_needed(std::atomic<unsigned long long>& done);
-static int g_ps_spin_limit = 0;  // test hook (vits_debug_persist_spin): poll rounds before a worker gives up; 0 = PS_SPIN_LIMIT
 static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const char* name, const float* d_noise = nullptr, float nsw = 0.f,
                            uint64_t seed = 0, const int64_t* d_ids = nullptr) {
   vits_model* m = s->m;
@@ -961,7 +971,9 @@ static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const
   PCall c;
   c.ctl = s->ps_ctl; c.ids = reinterpret_cast<const long long*>(d_ids); c.noise = d_noise; c.nsw = nsw; c.seed = seed;
   c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds; c.trace = nullptr;
-  c.spin_limit = g_ps_spin_limit > 0 ? g_ps_spin_limit : PS_SPIN_LIMIT;
+  c.dbg = m->ps_dbg;
+  static const int tune = getenv("VITS_PS_TUNE") ? atoi(getenv("VITS_PS_TUNE")) : PS_TUNE_DEFAULT;  // experiment switches (persist.hip.h)
+  c.tune = tune;
   static const char* trace_path = getenv("VITS_PS_TRACE");  // tools/ps_trace.py: per-worker, per-step cycle stamps of an EAGER forward
   static const char* trace_name = getenv("VITS_PS_TRACE_PROG");  // which program ("dp.persist" by default)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1593,10 +1605,12 @@ static int check_err(vits_session* s) {
   if (le != hipSuccess) return fail(VITS_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(le));
   if (e) {
     hipMemsetAsync(s->d_err, 0, sizeof(int), s->stream);
+    // an aborted persistent program leaves stale logw / x behind: every other bit may be a consequence of it (a garbage duration
+    // sum raises bit 4), so the timeout is reported first -- the retry on launches surfaces the real argument errors
+    if (e & PS_ERR_TIMEOUT) return persist_timed_out();
     if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
     if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
     if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
-    if (e & PS_ERR_TIMEOUT) return persist_timed_out();
   }
   return VITS_OK;
 }
@@ -2100,16 +2114,21 @@ int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
     std::vector<float> z(4096, 0.f);
     m->zeros = upload(m, z.data(), z.size());
     if (!m->zeros) rc = VITS_ERR_NOMEM;
+    m->ps_dbg = reinterpret_cast<int*>(upload(m, z.data(), 16));
+    if (!m->ps_dbg) rc = VITS_ERR_NOMEM;
+    else if (g_ps_spin_limit > 0) hipMemcpy(m->ps_dbg, &g_ps_spin_limit, sizeof(int), hipMemcpyHostToDevice);
   }
   m->blob = nullptr; m->entries = nullptr;
   if (rc != VITS_OK) { for (void* a : m->allocs) hipFree(a); delete m; return rc; }
   hipDeviceSynchronize();
+  { std::lock_guard<std::mutex> g(g_models_mu); g_models.push_back(m); }
   *out = m;
   return VITS_OK;
 }
 
 void vits_destroy(vits_model* m) {
   if (!m) return;
+  { std::lock_guard<std::mutex> g(g_models_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
   hipSetDevice(m->device);
   for (vits_session* s : m->pool) session_free(s);
   for (auto& kv : m->fronts) session_free(kv.second);
@@ -2404,6 +2423,7 @@ static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
   }
   vits_session* s = nullptr;
   TRY(session_new(m, &s));
+  s->ps_roles = PERSIST_ENC | PERSIST_SDP;
   int rc = session_reserve(s, B, TxB, 1);
   if (rc != VITS_OK) { session_free(s); return rc; }
   // per-call input block: [SynthDev | lengths int64 [B] | sid int64 [B] | ids int64 [B,TxB] | forced int32 [B,TxB]]
@@ -2477,6 +2497,8 @@ static int back_get(vits_session* F, int TyB, vits_session** out) {
   int rc = VITS_OK;
   if (hipMalloc((void**)&s->d_err, sizeof(int)) != hipSuccess || hipMemsetAsync(s->d_err, 0, sizeof(int), s->stream) != hipSuccess)
     rc = fail(VITS_ERR_NOMEM, "back session");
+  s->ps_roles = PERSIST_FLOW;
+  s->ps_defer = true;  // planned below, once the shared tensors point into the front
   if (rc == VITS_OK) rc = session_reserve(s, F->B, F->Tx, TyB);
   s->out_elems = (size_t)F->B * TyB * m->hp.hop_length;
   if (rc == VITS_OK && (hipMalloc((void**)&s->out_d, s->out_elems * sizeof(float)) != hipSuccess ||
@@ -2491,8 +2513,7 @@ static int back_get(vits_session* F, int TyB, vits_session** out) {
   s->dv = reinterpret_cast<const SynthDev*>(F->io_d);
   s->item_seeds = reinterpret_cast<const unsigned long long*>(F->io_d + F->io_seeds);
   // the persistent flow program was resolved against this session's own len_y / condv: resolve it again against the front's
-  rc = persist_plan(s);
-  if (rc != VITS_OK) { s->stream = nullptr; session_free(s); return rc; }
+  persist_plan(s);
   s->last_use = ++F->last_use;
   F->backs[TyB] = s;
   *out = s;
@@ -2580,10 +2601,10 @@ static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm)
 }
 
 static int device_error_word(int e) {
+  if (e & PS_ERR_TIMEOUT) return persist_timed_out();  // first: a timeout invalidates every bit derived from computed data (check_err)
   if (e & 1) return fail(VITS_ERR_ARG, "token id out of range");
   if (e & 2) return fail(VITS_ERR_ARG, "speaker id out of range");
   if (e & 4) return fail(VITS_ERR_ARG, "T_y exceeds frame capacity");
-  if (e & PS_ERR_TIMEOUT) return persist_timed_out();
   return e ? fail(VITS_ERR_DEVICE, "device error word %d", e) : VITS_OK;
 }
 
@@ -2967,7 +2988,7 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
   struct Mask { Mask(int v) { tl_persist = v; } ~Mask() { tl_persist = -1; } } mask(s->ps_owner ? g_persist : 0);
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
   if (s->use_graph && !s->profile) {
-    vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed ^ ((uint64_t)persist_mask() << 56), scales[0], scales[1], scales[2]);
+    vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed, scales[0], scales[1], scales[2], persist_mask());
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
       if (s->graphs.size() >= 64) drop_graphs(s);  // bound the cache: a caller that varies shapes/pointers forever must not leak
@@ -3007,7 +3028,25 @@ void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
 void vits_debug_ln_stats(int on) { g_ln_stats = on; }
 void vits_debug_persist(int on) { g_persist = on; }
-void vits_debug_persist_spin(int limit) { g_ps_spin_limit = limit; }
+// The limit lives in a device word the kernel reads at run time, so graphs captured before or after the call follow it alike.
+void vits_debug_persist_spin(int limit) {
+  g_ps_spin_limit = limit > 0 ? limit : 0;
+  std::lock_guard<std::mutex> g(g_models_mu);
+  for (vits_model* m : g_models) {
+    hipSetDevice(m->device);
+    hipDeviceSynchronize();
+    hipMemcpy(m->ps_dbg, &g_ps_spin_limit, sizeof(int), hipMemcpyHostToDevice);
+  }
+}
+// persistent launches of this model that ran to completion (no timeout) since it was created
+int vits_debug_persist_runs(vits_model* m) {
+  if (!m) return -1;
+  int v[2] = {0, 0};
+  hipSetDevice(m->device);
+  hipDeviceSynchronize();
+  if (hipMemcpy(v, m->ps_dbg, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v[1];
+}
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
 void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }

@@ -53,6 +53,8 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 #define PS_DKP 128       // attention: head-dimension slots per row of threads (d_k <= 128)
 #define PS_MKT 12        // key tiles the attention merge polls per round (3 cells each)
 #define PS_SPIN_LIMIT (1 << 18)
+#define PS_TUNE_TOUCH 1   // PCall.tune bits
+#define PS_TUNE_DEFAULT (PS_TUNE_TOUCH)
 #define PS_ERR_TIMEOUT 8  // bit in the session error word
 
 struct PersistCtl {
@@ -80,7 +82,9 @@ enum {
 // PK_MM    a1 = Cs | K << 16 ; a2 = cell pitch of the operand * channel direction (signed; plain operands: +-1); a3 = t0 (first window column)
 //          p0 operand (cells: (column 0, LOWEST channel of the slice); plain: the row of the slice's first channel),
 //          p1 yout tile (cell (n0, first row)), p2 yplain (first row, column n0), p3 res tile, p4 z, p5 zout
-//          b0 = n_u | nblk << 16; b1 = floats between consecutive row blocks of the weights; b2 = ypitch; b3 = rows left (Cout - first row);
+//          p9 = weight fragments of this worker's NEXT matrix item (first row block; 0: none)
+//          b0 = n_u | nblk << 7 | next item's (n_u << 11 | nblk << 18 | KB between its row blocks << 22);
+//          b1 = floats between consecutive row blocks of the weights; b2 = ypitch; b3 = rows left (Cout - first row);
 //          b4 = pT; b5 = rpitch; b6 = n0 | z_row << 16 | ea_row << 20; b7 = gate_H
 // PK_DDS   a1 = C | dil << 16; a2 = t; p0 xin, p1 y2, p2 z row, p3 xout, p4 bout
 // PK_LN    a1 = C; a2 = t; a3 = np; p0 part, p1 res, p2 base, p3 out, p4 oplain; b0/b1 = part stride (cells, 64 bit); b4 = pT
@@ -115,7 +119,9 @@ struct PCall {                          // per-call values (by value: a captured
   const SynthDev* dv;
   const unsigned long long* item_seeds;
   long long* trace;                     // tools only (VITS_PS_TRACE): [P][PS_MAX_STEPS][8] cycle stamps, null in production
-  int spin_limit;                       // poll rounds before a worker gives up (PS_SPIN_LIMIT; tests shrink it to force the fallback)
+  int tune;                             // experiment switches (VITS_PS_TUNE; default PS_TUNE_DEFAULT): bit 0 = pull the next matrix step's weights into L2 ahead of time
+  int* dbg;                             // device words of the model: [0] poll rounds before a worker gives up (0 = PS_SPIN_LIMIT; tests shrink it to
+                                        // force the fallback -- read at run time, so captured graphs follow the hook), [1] completed persistent launches
 };
 
 #define PS_G __attribute__((address_space(1)))
@@ -261,7 +267,30 @@ __device__ __forceinline__ void ps_prefetch(const ps_i4& r, int tid, int wave, i
   const PS_G float* b = PR_P(const float, r, 7);
   const PS_G float* c = PR_P(const float, r, 8);
   pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
-  ps_load_weights(PR_P(const float, r, 6), PR_B(r, 0) & 0xffff, wave, lane, pre.a);
+  ps_load_weights(PR_P(const float, r, 6), PR_B(r, 0) & 0x7f, wave, lane, pre.a);
+}
+
+// LDS-DMA load of one dword per lane into a scratch slot of the LDS: a load WITHOUT a register destination.  Used to pull lines into
+// this XCD's L2 ahead of time.  The compiler does not see it (inline asm): it is absent from its s_waitcnt bookkeeping, which is
+// what is wanted here -- nothing ever waits for it -- and harmless for the loads the compiler does count (vmcnt retires in order:
+// a counted wait can only wait longer, never shorter).  M0 holds the LDS destination and is restored (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void ps_glds_dword(const PS_G char* g, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+// the weight fragments wave `wave` will stream in a later matrix step (units u = wave + 8 i of nblk row blocks, 1 KiB each): one dword
+// per 64 bytes, four units per instruction
+__device__ __forceinline__ void ps_touch_weights(const PS_G char* w, int n_u, int nblk, unsigned stride_bytes, int wave, int lane, unsigned lds_dst) {
+  const unsigned lo = (unsigned)(lane & 15) * 64u;
+  for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int u = wave + PS_WAVES * (h * 4 + (lane >> 4));
+      u = u < n_u ? u : n_u - 1;  // (beyond the last unit: a line that is fetched anyway)
+      ps_glds_dword(w + ((unsigned)u * 1024u + lo), lds_dst);
+    }
+    w += stride_bytes;
+  }
 }
 
 // Placed where a poll has just completed: the record of step s + 1 (requested at the top of this step, older than every poll load) is
@@ -283,6 +312,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   __shared__ float hb[32 * 16];            // ConvFlow.proj output of the tile (spline parameters)
   __shared__ float xs[3 * PS_MAXC];        // column steps: x_in at t - d, t, t + d
   __shared__ float red[4 * 16];            // block reductions (one 16-float scratch per call site)
+  __shared__ float dma_sink[64];           // destination of the L2 pre-touch loads (never read)
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int rank = blockIdx.x, P = gridDim.x;
@@ -299,7 +329,11 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     unsigned e = __hip_atomic_load(&call.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     cx.epoch = __builtin_amdgcn_readfirstlane(e ? e : 1u);  // 0 marks "never written"
   }
-  cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl; cx.limit = call.spin_limit;
+  cx.aborted = 0; cx.spins = 0; cx.ctl = call.ctl;
+  {
+    const int lim = __builtin_amdgcn_readfirstlane(__hip_atomic_load(call.dbg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    cx.limit = lim > 0 ? lim : PS_SPIN_LIMIT;
+  }
   const unsigned epoch = cx.epoch;
   int len_raw;
   {
@@ -779,7 +813,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     {
       const int Cin = PR_I(rv, 1) & 0xffff, K = (PR_I(rv, 1) >> 16) & 0xf, ROW = 16 + K - 1;
       const int cps = PR_I(rv, 2), t0w = PR_I(rv, 3);
-      const int n_u = PR_B(rv, 0) & 0xffff, nblk = PR_B(rv, 0) >> 16, wstride = PR_B(rv, 1), ypitch = PR_B(rv, 2), rows_left = PR_B(rv, 3);
+      const int n_u = PR_B(rv, 0) & 0x7f, nblk = (PR_B(rv, 0) >> 7) & 0xf, wstride = PR_B(rv, 1), ypitch = PR_B(rv, 2), rows_left = PR_B(rv, 3);
       const int pT = PR_B(rv, 4), n0 = PR_B(rv, 6) & 0xffff, gate_H = PR_B(rv, 7);
       // ---- operand window [Cin][ROW] -> LDS (transposed: cells are column-major); thread = (channel c = tid & 255, columns 2 k + (tid >> 8))
       {
@@ -824,6 +858,17 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           } while (ps_again(cx, pending));
         }
         PS_STAMP(1); PS_REC_READY();
+        // The poll has completed: this CU's memory queue is empty and ~4 k cycles of LDS and matrix work follow.  The moment to pull
+        // the weights of this worker's NEXT matrix item towards it (into the XCD's L2; the workers of the other column tiles that
+        // stream the same fragments sit on the same XCD, persist_plan.hip.h): requested at the top of that step they come from the
+        // fabric, ahead of its poll loads in the in-order queue -- MI355X_MICROARCH.md prices a hand-off at 1.1 us into an unloaded
+        // consumer CU against 2.5 into a streaming one.
+        if (call.tune & PS_TUNE_TOUCH) {
+          const int nx = PR_B(rv, 0) >> 11;
+          if (nx & 0x7f)
+            ps_touch_weights(PR_P(const char, rv, 9), nx & 0x7f, (nx >> 7) & 0xf, (unsigned)((nx >> 11) & 0x1ff) << 10, wave, lane,
+                             __builtin_amdgcn_readfirstlane((unsigned)(size_t)dma_sink));
+        }
         if (cok) {
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
@@ -839,15 +884,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const float* bl = tile + (lane >> 4) * PS_TP + (lane & 15);
       const PS_G float* wbase = PR_P(const float, rv, 6);
       for (int mi = 0; mi < nblk; ++mi) {
-        if (mi > 0) {
-          __syncthreads();  // mred of the previous block has been read
-          int i0, i1;
-          ps_epi_idx(kf, rows_left, gate_H, tid, mi, i0, i1);
-          const PS_G float* b = PR_P(const float, rv, 7);
-          const PS_G float* c = PR_P(const float, rv, 8);
-          pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
-          ps_load_weights(wbase + (size_t)mi * wstride, n_u, wave, lane, pre.a);
-        }
+        if (mi > 0) __syncthreads();  // mred of the previous block has been read
         const float eb0 = pre.eb0, eb1 = pre.eb1, ec0 = pre.ec0, ec1 = pre.ec1;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         {
@@ -872,8 +909,6 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             uk -= uk >= K ? K : 0;
           }
         }
-        // the weight registers are free: request the NEXT step's operands now, so that they fly under this step's reduction,
-        // epilogue and the exchange
         if (mi == nblk - 1) PS_STAMP(4);
         // residual cells of this block (data of an older step: normally one round trip)
         float rsd = 0.f;
@@ -889,6 +924,16 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             rsd = ll_val(q);
             pending = PS_PENDING(rok ? ll_bad(q, epoch) : 0u);
           } while (ps_again(cx, pending));
+        }
+        // the weight registers are free: the NEXT row block's fragments and epilogue vectors fly under this block's reduction and
+        // epilogue (requested at the top of the next iteration -- behind the epilogue and a barrier -- their whole latency was exposed)
+        if (mi + 1 < nblk) {
+          int i0, i1;
+          ps_epi_idx(kf, rows_left, gate_H, tid, mi + 1, i0, i1);
+          const PS_G float* b = PR_P(const float, rv, 7);
+          const PS_G float* c = PR_P(const float, rv, 8);
+          pre.eb0 = b[i0]; pre.eb1 = b[i1]; pre.ec0 = c[i0]; pre.ec1 = c[i1];
+          ps_load_weights(wbase + (size_t)(mi + 1) * wstride, n_u, wave, lane, pre.a);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) mred[(wave * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
@@ -1056,9 +1101,11 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   // ---- the last worker to finish publishes the epoch (every worker read it before doing anything else)
   __syncthreads();
   if (tid0 == 0) {
-    if (cx.aborted || __hip_atomic_load(&call.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr((int*)prog->err, PS_ERR_TIMEOUT);
+    const bool timed_out = cx.aborted || __hip_atomic_load(&call.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (timed_out) atomicOr((int*)prog->err, PS_ERR_TIMEOUT);
     const unsigned old = atomicAdd(&call.ctl->done, 1u);
     if (old == gridDim.x - 1) {
+      if (!timed_out) atomicAdd(call.dbg + 1, 1);  // (diagnostics: tests assert that a call really took the persistent path)
       __hip_atomic_store(&call.ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&call.ctl->abort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&call.ctl->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -178,6 +178,9 @@ static const float* persist_pack(vits_session* s, const float* const (&src)[8], 
   PsPackArgs a;
   for (int k = 0; k < 8; ++k) { a.src[k] = src[k] == m->zeros ? nullptr : src[k]; a.add[k] = add[k]; a.len[k] = len; }
   hipLaunchKernelGGL(ps_pack_kernel, dim3(cdiv(rows * 8, 256)), dim3(256), 0, s->stream, dst, a, rows);
+  // published only once it is written: another thread planning a session on ITS stream would otherwise find the entry and launch a
+  // program that reads the pack before this stream has run the kernel (once per distinct pack per model)
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return nullptr;
   m->packs[key] = dst;
   return dst;
 }
@@ -307,6 +310,32 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
   for (int k = 6; k < 10; ++k) idle.p[k] = U(m->zeros);
   recs.clear();
   auto new_step = [&]() -> PRec* { recs.insert(recs.end(), (size_t)P, idle); return recs.data() + recs.size() - P; };
+  // Which worker runs which matrix item.  The ntn column tiles of one (row-block group, K-slice) stream the SAME weight fragments;
+  // in dispatch order (worker = item) they sit on ntn different XCDs -- block b runs on XCD b % 8 (MI355X_MICROARCH.md; a
+  // placement for speed only, nothing depends on it) -- and every XCD's L2 fetches every fragment of the step from the fabric
+  // (round 3 PMC: 200 MB per launch against 26 MB of weights).  Placement by weight group: group q -> XCD q % 8, its tiles on
+  // consecutive workers of that XCD; groups beyond 8 * floor(P / 8 / ntn) fill the workers left over.  VITS_PS_XCD=0: dispatch order.
+  static const bool xcd_place = !(getenv("VITS_PS_XCD") && atoi(getenv("VITS_PS_XCD")) == 0);
+  std::vector<int> rank_of, used;
+  auto place = [&](int Q) {
+    const int items = Q * ntn;
+    rank_of.assign(items, -1);
+    if (!xcd_place || P % 8 || P / 8 < ntn) { for (int i = 0; i < items; ++i) rank_of[i] = i; return; }
+    used.assign(P, 0);
+    const int per = P / 8, cap = per / ntn;
+    for (int q = 0; q < Q && q < 8 * cap; ++q)
+      for (int j = 0; j < ntn; ++j) {
+        const int rk = (q % 8) + 8 * ((q / 8) * ntn + j);
+        rank_of[q * ntn + j] = rk;
+        used[rk] = 1;
+      }
+    int nx = 0;
+    for (int i = 8 * cap * ntn; i < items; ++i) {
+      while (used[nx]) ++nx;
+      rank_of[i] = nx;
+      used[nx] = 1;
+    }
+  };
   for (const PStep& st : steps) {
     if (st.kind == PK_MM) {
       const int items = ntn * st.G * st.ks;
@@ -314,10 +343,12 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
       PRec* R = new_step();
       const int n_u = st.Cin / 16 * st.K;
       const bool gate = st.epi == PS_EPI_GATE;
+      if (n_u > 127 || st.mbg > 15) { bad = true; return; }  // (field widths of record dword b0)
+      place(st.G * st.ks);
       for (int item = 0; item < items; ++item) {
         const int j = item % ntn, q = item / ntn, g = q % st.G, slice = q / st.G;
         const int n0 = j * 16, mb0 = g * st.mbg, nblk = std::min(st.mbg, st.n_mb - mb0);
-        PRec& r = R[item];
+        PRec& r = R[rank_of[q * ntn + j]];
         r.kf = PK_MM | (st.relu ? PF_RELU : 0) | (st.in_mask ? PF_INMASK : 0) | (st.out_mask ? PF_OUTMASK : 0) | (gate ? PF_GATE : 0) |
                (st.epi == PS_EPI_SPLINE ? PF_SPLINE : 0) | ((st.zinit && g == 0 && slice == 0) ? PF_ZINIT : 0) | (st.last ? PF_LAST : 0) |
                (st.bin_plain ? PF_PLAIN_IN : 0);
@@ -335,7 +366,7 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
         r.p[6] = U(st.w16 + ((size_t)mb0 * st.ks + slice) * n_u * 256);
         r.p[7] = U(st.bias + (st.bias == m->zeros ? 0 : row0));
         r.p[8] = U(st.cond + (st.cond == m->zeros ? 0 : row0));
-        r.b[0] = n_u | (nblk << 16);
+        r.b[0] = n_u | (nblk << 7);  // (+ the next matrix item of this worker: chained below)
         r.b[1] = st.ks * n_u * 256;
         r.b[2] = st.ypitch;
         r.b[3] = gate ? 2 * st.gate_H : st.Cout - row0;
@@ -410,6 +441,22 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
       }
     }
     if ((int)(recs.size() / P) > PS_MAX_STEPS) { bad = true; return; }
+  }
+  // chain: every matrix record says where the same worker's NEXT matrix item streams its weights from (the kernel pulls them into L2
+  // while it computes this one)
+  const int nst = (int)(recs.size() / P);
+  for (int w = 0; w < P; ++w) {
+    unsigned long long nw = 0;
+    int nx = 0;
+    for (int si = nst - 1; si >= 0; --si) {
+      PRec& r = recs[(size_t)si * P + w];
+      if ((r.kf & 0xff) != PK_MM) continue;
+      const int n_u = r.b[0] & 0x7f, nblk = (r.b[0] >> 7) & 0xf, kb = r.b[1] / 256;  // b1 = floats between row blocks = ks * n_u KiB
+      r.p[9] = nw;
+      r.b[0] |= nx << 11;
+      nw = r.p[6];
+      nx = (kb < 512 && n_u < 128) ? (n_u | (nblk << 7) | (kb << 11)) : 0;
+    }
   }
   (void)T;
 }
@@ -608,18 +655,20 @@ static void persist_build_flow(vits_session* s) {
 
 // Called at every re-plan, outside any capture.  The exchange cells are zeroed (epoch 0 = "never written": whatever the arena held
 // before must not look like a cell of a later forward); the epoch block survives re-plans, so epochs only ever grow.
-static int persist_plan(vits_session* s) {
+// A failure here (allocation, upload) is not an error of the call: the affected programs stay !ok and their stages run on launches.
+static void persist_plan(vits_session* s) {
   s->ps_enc.ok = s->ps_sdp.ok = s->ps_flow.ok = false;
-  if (!s->ps_enc.cells && !s->ps_sdp.cells && !s->ps_flow.cells) return VITS_OK;
+  if (!s->ps_enc.cells && !s->ps_sdp.cells && !s->ps_flow.cells) return;
+  auto give_up = [&]() { s->ps_enc.ok = s->ps_sdp.ok = s->ps_flow.ok = false; (void)hipGetLastError(); };
   if (!s->ps_ctl) {
-    HIP_TRY(hipMalloc((void**)&s->ps_ctl, sizeof(PersistCtl)));
-    HIP_TRY(hipMemsetAsync(s->ps_ctl, 0, sizeof(PersistCtl), s->stream));
+    if (hipMalloc((void**)&s->ps_ctl, sizeof(PersistCtl)) != hipSuccess) { s->ps_ctl = nullptr; return give_up(); }
+    if (hipMemsetAsync(s->ps_ctl, 0, sizeof(PersistCtl), s->stream) != hipSuccess) return give_up();
   }
   for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow})
-    if (pp->cells && pp->ll) HIP_TRY(hipMemsetAsync(pp->ll, 0, pp->cells * sizeof(ll_t), s->stream));
+    if (pp->cells && pp->ll && hipMemsetAsync(pp->ll, 0, pp->cells * sizeof(ll_t), s->stream) != hipSuccess) return give_up();
   if (s->ps_enc.cells && s->ps_enc.ll) persist_build_enc(s);
   if (s->ps_sdp.cells && s->ps_sdp.ll) persist_build_sdp(s);
   if (s->ps_flow.cells && s->ps_flow.ll) persist_build_flow(s);
-  HIP_TRY(hipStreamSynchronize(s->stream));  // the programs live in pageable memory of the session: the copies must not outlive this call's view
-  return VITS_OK;
+  // the programs live in pageable memory of the session: the copies must not outlive this call's view
+  if (hipStreamSynchronize(s->stream) != hipSuccess) give_up();
 }
