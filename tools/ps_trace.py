@@ -12,7 +12,8 @@ os.environ["VITS_PS_TRACE_PROG"] = prog + ".persist"
 import torch  # noqa
 from vosk_tts_amd import weights as W
 from vosk_tts_amd.capi import VitsLib
-lib = VitsLib()
+# the product library carries no stamps: the tracing build (make -C vosk_tts_amd/csrc libvits_mi355_pstrace.so)
+lib = VitsLib(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vosk_tts_amd", "csrc", "libvits_mi355_pstrace.so"))
 m = lib.create(W.synthetic_blob(W.default_hparams(), 1234), 0)
 rng = np.random.default_rng(0)
 for _ in range(3):

@@ -268,7 +268,7 @@ class VitsModel:
             self.lib._fn("free_pcm16")(out)
         return pcm, olen
 
-    def stream(self, ids, scales, sid, chunk_frames=64, noise_dp=None, noise_prior=None, forced_durations=None, seed=0):
+    def stream(self, ids, scales, sid, chunk_frames=64, noise_dp=None, noise_prior=None, forced_durations=None, seed=0, bert=None):
         """Streaming synthesis of ONE utterance (vits_stream_*): a generator of float32 chunks of
         chunk_frames*hop_length samples (the last one shorter); their concatenation equals synthesize()."""
         if not self.lib.has("stream_open"):
@@ -276,7 +276,7 @@ class VitsModel:
         ids = _i64(ids).reshape(1, -1)
         Tx = ids.shape[1]
         scales = _f32(scales)
-        opts, keep = self._opts(1, Tx, noise_dp, noise_prior, forced_durations, seed, 0)
+        opts, keep = self._opts(1, Tx, noise_dp, noise_prior, forced_durations, seed, 0, bert=bert)
         L = self.lib
         st = ctypes.c_void_p()
         total = ctypes.c_int64()

@@ -54,7 +54,7 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 #define PS_MKT 12        // key tiles the attention merge polls per round (3 cells each)
 #define PS_SPIN_LIMIT (1 << 18)
 #define PS_TUNE_TOUCH 1   // PCall.tune bits
-#define PS_TUNE_DEFAULT (PS_TUNE_TOUCH)
+#define PS_TUNE_DEFAULT 0
 #define PS_ERR_TIMEOUT 8  // bit in the session error word
 
 struct PersistCtl {
@@ -163,10 +163,15 @@ __device__ __forceinline__ bool ps_again(PsCtx& cx, bool pending) {
 #ifdef PS_EXP_NOPOLL
   return false;
 #endif
-  if (!pending || cx.aborted) { cx.spins = 0; return false; }
-  ++cx.spins;
-  if ((cx.spins & 1023) == 0 && __hip_atomic_load(&cx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { cx.aborted = 1; return false; }
-  if (cx.spins >= cx.limit) {
+  // The poll state is wave-uniform by construction, but hipcc's uniformity analysis gives up on it (it is carried around the step
+  // loop through every kind's control flow) and kept `aborted` / `spins` as per-lane values: the exit test of every poll loop was a
+  // vector compare under an exec mask.  readfirstlane at the point of use puts the test back on the scalar unit.
+  if (!pending || __builtin_amdgcn_readfirstlane(cx.aborted)) { cx.spins = 0; return false; }
+  const int spins = __builtin_amdgcn_readfirstlane(cx.spins) + 1;
+  cx.spins = spins;
+  if ((spins & 1023) == 0 &&
+      __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { cx.aborted = 1; return false; }
+  if (spins >= cx.limit) {
     cx.aborted = 1;
     if ((threadIdx.x & 63) == 0) {
       __hip_atomic_store(&cx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -226,6 +231,22 @@ struct PsPre {
   f32x4 pk0, pk1;     // packed per-thread parameters: 8 floats of row (tid & 255) -- attention: row tid of the table pack
   float eb0, eb1, ec0, ec1;  // epilogue operands of thread tid < 256 (bias, per-item bias / vector; second pair: the sigmoid row of a gate)
 };
+// LDS byte offset of tap unit u = wave + 8 i inside the operand window [C_in][PS_TP] for K = 1 / 3 / 5 taps: unit u = (16-channel
+// chunk u / K, tap u % K) -> (chunk * 16 * PS_TP + tap) * 4.  One s_load_dwordx8 per step instead of a division-free but
+// 8-instruction (chunk, tap) update per unit per wave.
+struct PsUnitTab { int off[3][PS_WAVES][PS_MAXU]; };
+static constexpr PsUnitTab ps_make_unit_tab() {
+  PsUnitTab t{};
+  for (int ki = 0; ki < 3; ++ki)
+    for (int w = 0; w < PS_WAVES; ++w)
+      for (int i = 0; i < PS_MAXU; ++i) {
+        const int K = 2 * ki + 1, u = w + PS_WAVES * i;
+        t.off[ki][w][i] = ((u / K) * 16 * PS_TP + (u % K)) * 4;
+      }
+  return t;
+}
+__constant__ PsUnitTab ps_unit_tab = ps_make_unit_tab();
+
 __device__ __forceinline__ void ps_load_weights(const PS_G float* w, int n_u, int wave, int lane, f32x4 (&a)[PS_MAXU]) {
   // units beyond n_u repeat the last one (an L1 hit; never used: the MFMA loop tests u < n_u).  The unit index is wave-uniform:
   // clamp and scale on the scalar unit, one 32-bit lane offset for all eight loads.
@@ -298,7 +319,13 @@ __device__ __forceinline__ void ps_touch_weights(const PS_G char* w, int n_u, in
 // hand-over rv = rvB at the loop's back edge is the first use, and because loads and stores share the in-order vmcnt counter the
 // compiler waits there for vmcnt(0): for the step's own output stores (an sc1 write round trip per step).
 #define PS_REC_READY() asm volatile("" : "+v"(rvB))
+// cycle stamps for tools/ps_trace.py: only in the -DPS_TRACE build (libvits_mi355_pstrace.so) -- at 2 waves per SIMD every instruction
+// of a step is on its critical path, and eight guarded stamps per step were ~40 of them
+#ifdef PS_TRACE
 #define PS_STAMP(k) do { if (call.trace && tid0 == 0) call.trace[((long long)rank * PS_MAX_STEPS + s) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PS_STAMP(k) do { } while (0)
+#endif
 
 // LDS of the kernel (floats).  Matrix steps: operand window + partial tiles + spline scratch; attention blocks: Q / K / V tiles and
 // the two relative-position tables alias the operand window, scores / probabilities alias the partial tiles.
@@ -808,6 +835,12 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     continue;  // (no other kind exists)
     }
     // ==================================================================== matrix step
+    // Written for INSTRUCTION COUNT: with two waves per SIMD that run the same code, a wave issues one instruction per ~8 cycles, and
+    // the round-3 form of this step was ~1100 instructions per wave -- its 10 k cycles were issue time, not memory time (the round-4
+    // trace: 1.06 k cycles between the staging barrier and the first MFMA without a single memory access in between).  Everything that
+    // does not depend on the lane is kept on the scalar unit: the window column a thread gathers depends only on its WAVE (waves 0-3
+    // take the even columns, 4-7 the odd ones), so the validity of a column is a scalar compare and a scalar branch, and the column's
+    // address is a scalar base plus ONE lane offset shared by all ten loads.
     ps_prefetch(rv, tid, wave, lane, pre);
     __syncthreads();  // the previous step's readers of the LDS buffers are done
     {
@@ -815,54 +848,74 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const int cps = PR_I(rv, 2), t0w = PR_I(rv, 3);
       const int n_u = PR_B(rv, 0) & 0x7f, nblk = (PR_B(rv, 0) >> 7) & 0xf, wstride = PR_B(rv, 1), ypitch = PR_B(rv, 2), rows_left = PR_B(rv, 3);
       const int pT = PR_B(rv, 4), n0 = PR_B(rv, 6) & 0xffff, gate_H = PR_B(rv, 7);
-      // ---- operand window [Cin][ROW] -> LDS (transposed: cells are column-major); thread = (channel c = tid & 255, columns 2 k + (tid >> 8))
+      // LDS byte offsets of this wave's tap units (one scalar load of eight dwords; K is 1, 3 or 5: persist_slice)
+      int uoff[PS_MAXU];
+#pragma unroll
+      for (int i = 0; i < PS_MAXU; ++i) uoff[i] = ps_unit_tab.off[K >> 1][wave][i];
+      const int cnt = n_u > wave ? (n_u - wave + PS_WAVES - 1) >> 3 : 0;  // tap units of this wave
+      float rsd0 = 0.f;  // residual cell of row block 0 (polled with the window)
+      // ---- operand window [Cin][ROW] -> LDS (transposed: cells are column-major); thread = (channel c, window columns jh + 2 k)
       {
-        const int c = tid & 255, jh = tid >> 8;
+        const int jh = wave >> 2;                // (wave-uniform)
+        const int c = (wave & 3) * 64 + lane;    // == tid & 255
         const bool cok = c < Cin;
         const int lim = (kf & PF_INMASK) ? L : Tp;
         constexpr int NG = PS_MAXROW / 2;
+        const int nk = (ROW - jh + 1) >> 1;      // columns of this wave: jh + 2 k < ROW
+        const int tj = t0w + jh;
         float v[NG];
-        bool need[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) v[k] = 0.f;
         if (kf & PF_PLAIN_IN) {
           // plain floats [channels][pT] written by an earlier kernel; cps = +-1 (channel direction)
-          const PS_G float* bp = PR_P(const float, rv, 0);
+          const PS_G float* bp = PR_P(const float, rv, 0) + (long long)(cok ? c : 0) * cps * pT;
           const int limp = lim < pT ? lim : pT;
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
-            const int jj = 2 * k + jh, t = t0w + jj;
-            need[k] = cok && jj < ROW && t >= 0 && t < limp;
-            v[k] = bp[(long long)(cok ? c : 0) * cps * pT + (need[k] ? t : 0)];
+            const int t = tj + 2 * k;
+            if (k < nk && t >= 0 && t < limp) v[k] = bp[t];  // (uniform condition)
           }
+#pragma unroll
+          for (int k = 0; k < NG; ++k) v[k] = cok ? v[k] : 0.f;
         } else {
           const PS_G ll_t* bin = PR_P(const ll_t, rv, 0);
           const int acp = cps < 0 ? -cps : cps;
           const int cc = cok ? (cps < 0 ? Cin - 1 - c : c) : 0;  // (negative direction: the record's base points at the slice's LOWEST channel)
-          unsigned off[NG];
+          unsigned lo = (unsigned)cc * 8u;
+          const PS_G ll_t* res = PR_P(const ll_t, rv, 3);
+          const bool rok = res != nullptr && wave < 4 && (tid & 15) < rows_left;
+          unsigned ro = (unsigned)((tid >> 4) * PR_B(rv, 5) + (tid & 15)) * 8u;
+          // cells that are not requested read as {0.0f, this epoch}: the check pass below needs no conditions (and every load of a
+          // round is issued before the first check -- a check inside the load's own branch made hipcc wait for each load in turn)
+          const ll_t zero_cell = (ll_t)epoch << 32;
+          ll_t q[NG], qr = zero_cell;
 #pragma unroll
-          for (int k = 0; k < NG; ++k) {
-            const int jj = 2 * k + jh, t = t0w + jj;
-            need[k] = cok && jj < ROW && t >= 0 && t < lim;
-            off[k] = (unsigned)((need[k] ? t : 0) * acp + cc) * 8u;
-          }
+          for (int k = 0; k < NG; ++k) q[k] = zero_cell;
           bool pending;
           do {
+            asm volatile("" : "+v"(lo), "+v"(ro));  // (addresses stay inside the loop body: no hoisted 64-bit pairs)
+            if (cok) {
 #pragma unroll
-            for (int k = 0; k < NG; ++k) asm volatile("" : "+v"(off[k]));
-            ll_t q[NG];
+              for (int k = 0; k < NG; ++k) {
+                const int t = tj + 2 * k;
+                if (k < nk && t >= 0 && t < lim) q[k] = ll_load_off(bin + (long long)t * acp, lo);  // wave-uniform condition: a scalar branch
+              }
+            }
+            if (rok) qr = ll_load_off(res, ro);
+            unsigned bad = ll_bad(qr, epoch);
 #pragma unroll
-            for (int k = 0; k < NG; ++k) { q[k] = 0; if (need[k]) q[k] = ll_load_off(bin, off[k]); }
-            unsigned bad = 0;
-#pragma unroll
-            for (int k = 0; k < NG; ++k) { if (need[k]) bad |= ll_bad(q[k], epoch); v[k] = ll_val(q[k]); }
+            for (int k = 0; k < NG; ++k) bad |= ll_bad(q[k], epoch);
             pending = PS_PENDING(bad);
           } while (ps_again(cx, pending));
+#pragma unroll
+          for (int k = 0; k < NG; ++k) v[k] = ll_val(q[k]);
+          rsd0 = ll_val(qr);
         }
         PS_STAMP(1); PS_REC_READY();
         // The poll has completed: this CU's memory queue is empty and ~4 k cycles of LDS and matrix work follow.  The moment to pull
         // the weights of this worker's NEXT matrix item towards it (into the XCD's L2; the workers of the other column tiles that
-        // stream the same fragments sit on the same XCD, persist_plan.hip.h): requested at the top of that step they come from the
-        // fabric, ahead of its poll loads in the in-order queue -- MI355X_MICROARCH.md prices a hand-off at 1.1 us into an unloaded
-        // consumer CU against 2.5 into a streaming one.
+        // stream the same fragments sit on the same XCD, persist_plan.hip.h).  Measured neutral to slightly negative at c2 (round 4,
+        // profiles/r4_persist_ab.txt): off by default, kept as a switch (VITS_PS_TUNE bit 0).
         if (call.tune & PS_TUNE_TOUCH) {
           const int nx = PR_B(rv, 0) >> 11;
           if (nx & 0x7f)
@@ -870,52 +923,44 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                              __builtin_amdgcn_readfirstlane((unsigned)(size_t)dma_sink));
         }
         if (cok) {
+          float* tp = tile + c * PS_TP + jh;
 #pragma unroll
-          for (int k = 0; k < NG; ++k) {
-            const int jj = 2 * k + jh;
-            if (jj < ROW) tile[c * PS_TP + jj] = need[k] ? v[k] : 0.f;
-          }
+          for (int k = 0; k < NG; ++k)
+            if (k < nk) tp[2 * k] = v[k];
         }
       }
       __syncthreads();
       PS_STAMP(2);
 
       // ---- MFMA tiles of this item's 16-row blocks + epilogues
-      const float* bl = tile + (lane >> 4) * PS_TP + (lane & 15);
+      const char* blb = reinterpret_cast<const char*>(tile + (lane >> 4) * PS_TP + (lane & 15));
       const PS_G float* wbase = PR_P(const float, rv, 6);
       for (int mi = 0; mi < nblk; ++mi) {
         if (mi > 0) __syncthreads();  // mred of the previous block has been read
         const float eb0 = pre.eb0, eb1 = pre.eb1, ec0 = pre.ec0, ec1 = pre.ec1;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        {
-          // unit u = chunk * K + tap for u = wave + 8 i: (chunk, tap) advance by (8 / K, 8 % K); K in {1, 3, 5} without a division
-          const int kmul = K == 1 ? 64 : (K == 3 ? 22 : (K == 5 ? 13 : 0));
-          int uc = kmul ? (wave * kmul) >> 6 : wave / K, uk = wave - uc * K;
-          if (mi == nblk - 1) PS_STAMP(7);
-          const int step_c = kmul ? (PS_WAVES * kmul) >> 6 : PS_WAVES / K, step_k = PS_WAVES - step_c * K;
-#pragma unroll
-          for (int i = 0; i < PS_MAXU; ++i) {
-            const int u = wave + PS_WAVES * i;
-            if (u < n_u) {  // wave-uniform
-              const float* bp = bl + uc * (16 * PS_TP) + uk;
-              const float b0 = bp[0], b1 = bp[4 * PS_TP], b2 = bp[8 * PS_TP], b3 = bp[12 * PS_TP];
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][0], b0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][1], b1, acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][2], b2, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][3], b3, acc1, 0, 0, 0);
-            }
-            uk += step_k;
-            uc += step_c + (uk >= K ? 1 : 0);
-            uk -= uk >= K ? K : 0;
+        if (mi == nblk - 1) PS_STAMP(7);
+        do {  // this wave's tap units, leaving at the first one it does not have (one scalar compare per unit)
+#define PS_UNIT(i)                                                                                              \
+          if (cnt <= (i)) break;                                                                                \
+          {                                                                                                     \
+            const float* bp = reinterpret_cast<const float*>(blb + uoff[i]);                                    \
+            const float b0 = bp[0], b1 = bp[4 * PS_TP], b2 = bp[8 * PS_TP], b3 = bp[12 * PS_TP];                \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][0], b0, acc0, 0, 0, 0);                        \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][1], b1, acc1, 0, 0, 0);                        \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][2], b2, acc0, 0, 0, 0);                        \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pre.a[i][3], b3, acc1, 0, 0, 0);                        \
           }
-        }
+          PS_UNIT(0) PS_UNIT(1) PS_UNIT(2) PS_UNIT(3) PS_UNIT(4) PS_UNIT(5) PS_UNIT(6) PS_UNIT(7)
+#undef PS_UNIT
+        } while (0);
         if (mi == nblk - 1) PS_STAMP(4);
-        // residual cells of this block (data of an older step: normally one round trip)
-        float rsd = 0.f;
+        // residual cells of this block: block 0's came with the window; later blocks (data of an older step: normally one round trip)
+        float rsd = rsd0;
         const PS_G ll_t* res = PR_P(const ll_t, rv, 3);
-        if (res && tid < 256) {
+        if (mi > 0 && res) {  // (every wave runs the loop -- a poll loop under a per-lane condition makes the poll state per-lane values)
           unsigned ro = (unsigned)((tid >> 4) * PR_B(rv, 5) + mi * 16 + (tid & 15)) * 8u;
-          const bool rok = mi * 16 + (tid & 15) < rows_left;
+          const bool rok = wave < 4 && mi * 16 + (tid & 15) < rows_left;
           bool pending;
           do {
             asm volatile("" : "+v"(ro));

@@ -10,7 +10,7 @@
 // contraction channels of one K-slice of a conv with C_in channels and K taps: the largest divisor of C_in (multiple of 16) that
 // keeps a worker's operand window <= PS_MAXC channels and its weights within PS_MAXU tap units per wave; 0 = does not fit
 static int persist_slice(int Cin, int K) {
-  if (Cin % 16 || K < 1 || K > 5) return 0;
+  if (Cin % 16 || (K != 1 && K != 3 && K != 5)) return 0;  // (1, 3 or 5 taps: the kernel's tap-unit table, persist.hip.h)
   for (int ks = 1; ks <= 4; ++ks) {
     if (Cin % ks) continue;
     const int cs = Cin / ks;

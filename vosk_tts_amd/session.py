@@ -18,6 +18,89 @@ import numpy as np
 
 from .capi import VitsLib
 
+
+class _Pending:
+    """one request waiting in the coalescer: its owner sleeps on `event` until a result (or an exception) is posted, or until it
+    is handed a batch to lead"""
+    __slots__ = ("key", "ids", "sid", "seed", "event", "result", "error", "lead")
+
+    def __init__(self, key, ids, sid, seed):
+        self.key, self.ids, self.sid, self.seed = key, ids, sid, seed
+        self.event = threading.Event()
+        self.result = self.error = self.lead = None
+
+
+class RequestCoalescer:
+    """Merges concurrent single-utterance requests into solo batches (server shape: one Synth shared by a thread pool,
+    server/tts_server.py:35-57 -- N threads each calling .run() for ONE utterance).
+
+    Natural batching, no timer: a request that finds the engine idle runs at once, alone (the persistent single-utterance path,
+    nothing added to its latency).  Requests that arrive while a call is in flight queue up; when that call returns, its thread
+    hands the queue's compatible requests (same scales / output kind / conversion scale, at most `max_batch`) to the first waiter,
+    which runs them as ONE padded VITS_FLAG_SOLO_BATCH call with per-request item seeds -- every item of a solo batch is its own
+    single-utterance synthesis (own Philox streams, zeros beyond its own end), so what a request gets does not depend on what it was
+    batched with -- and scatters the results.  Without this, N concurrent calls run N - 1 of them on the launch-per-layer path
+    (one persistent program owner per device) and the GPU executes N small forwards one after the other."""
+
+    def __init__(self, run_batch, max_batch=32):
+        self._run_batch = run_batch  # (key, [(ids, sid, seed), ...]) -> list of per-request results
+        self.max_batch = int(max_batch)
+        self._lock = threading.Lock()
+        self._busy = False
+        self._queue = []
+        self.calls = 0        # engine calls issued
+        self.requests = 0     # requests served
+        self.largest = 0      # largest batch so far
+
+    def submit(self, key, ids, sid, seed):
+        me = _Pending(key, ids, sid, seed)
+        with self._lock:
+            if self._busy:
+                self._queue.append(me)
+                batch = None
+            else:
+                self._busy = True
+                batch = [me]
+        if batch is None:
+            me.event.wait()
+            if me.lead is None:  # somebody else ran it
+                if me.error is not None:
+                    raise me.error
+                return me.result
+            batch = me.lead
+        # this thread leads `batch` (which contains its own request)
+        try:
+            try:
+                outs = self._run_batch(batch[0].key, [(p.ids, p.sid, p.seed) for p in batch])
+                for p, o in zip(batch, outs):
+                    p.result = o
+            except BaseException as e:  # every member of the batch sees the failure
+                for p in batch:
+                    p.error = e
+        finally:
+            with self._lock:
+                self.calls += 1
+                self.requests += len(batch)
+                self.largest = max(self.largest, len(batch))
+                nxt = None
+                if self._queue:
+                    head = self._queue[0]
+                    take = [p for p in self._queue if p.key == head.key][:self.max_batch]
+                    taken = set(map(id, take))
+                    self._queue = [p for p in self._queue if id(p) not in taken]
+                    head.lead = take
+                    nxt = head
+                else:
+                    self._busy = False
+            for p in batch:
+                if p is not me:
+                    p.event.set()
+            if nxt is not None:
+                nxt.event.set()
+        if me.error is not None:
+            raise me.error
+        return me.result
+
 _GRAPH_INPUTS = ("input", "input_lengths", "scales", "sid")
 _OPTIONAL_NONE = ("bert", "phone_duration_extra")
 # extension feeds (not part of the ONNX graph) used by parity tests
@@ -30,12 +113,42 @@ class _Arg:
 
 
 class VitsSession:
-    def __init__(self, blob, device=0, lib=None):
+    def __init__(self, blob, device=0, lib=None, coalesce=True, max_batch=32):
         self._lib = lib or VitsLib()
         self._model = self._lib.create(blob, device)
         self.hp = self._model.hp
         self._seed = itertools.count(1)
         self._seed_lock = threading.Lock()
+        # concurrent single-utterance run() / run_pcm16() calls are merged into solo batches (RequestCoalescer); coalesce=False:
+        # every call goes to the engine on its own, as in rounds 1-3
+        self.coalescer = RequestCoalescer(self._run_solo_batch, max_batch) if coalesce else None
+
+    def _coalescable(self, feed, ids):
+        """plain single-utterance requests only: no injected tensors, no pinned durations, no caller-chosen batch semantics"""
+        return (self.coalescer is not None and ids.shape[0] == 1 and self.hp.bert_dim == 0 and
+                not any(k in feed for k in ("vits.noise_dp", "vits.noise_prior", "vits.forced_durations", "vits.solo", "vits.item_seeds", "bert")))
+
+    def _run_solo_batch(self, key, reqs):
+        """reqs: [(ids [1,T] int64, sid, seed)] -> per request (audio-or-pcm [1,S_b], lengths [1]); one request: the plain call"""
+        kind, scales, scale = key
+        scales = np.array(scales, np.float32)
+        if len(reqs) == 1:
+            ids, sid, seed = reqs[0]
+            lens = np.array([ids.shape[1]], np.int64)
+            if kind == "pcm":
+                return [self._model.synthesize_pcm16(ids, lens, scales, np.array([sid], np.int64), pcm_scale=scale, seed=seed)]
+            return [self._model.synthesize(ids, lens, scales, np.array([sid], np.int64), seed=seed)]
+        lens = np.array([r[0].shape[1] for r in reqs], np.int64)
+        batch = np.zeros((len(reqs), int(lens.max())), np.int64)
+        for b, r in enumerate(reqs):
+            batch[b, :lens[b]] = r[0][0]
+        sids = np.array([r[1] for r in reqs], np.int64)
+        seeds = np.array([r[2] for r in reqs], np.uint64)
+        if kind == "pcm":
+            out, ol = self._model.synthesize_pcm16(batch, lens, scales, sids, pcm_scale=scale, seed=int(seeds[0]), solo=True, item_seeds=seeds)
+        else:
+            out, ol = self._model.synthesize(batch, lens, scales, sids, seed=int(seeds[0]), solo=True, item_seeds=seeds)
+        return [(out[b:b + 1, :int(ol[b])].copy(), ol[b:b + 1].copy()) for b in range(len(reqs))]
 
     # -- onnxruntime.InferenceSession surface used by the reference ------------------------
     def get_inputs(self):
@@ -84,6 +197,12 @@ class VitsSession:
 
     def run(self, output_names, input_feed, run_options=None):
         feed, ids, sid, seed = self._validated(output_names, input_feed)
+        if self._coalescable(feed, ids):
+            n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
+            key = ("f32", tuple(float(v) for v in np.asarray(feed["scales"], np.float32).reshape(-1)), 1.0)
+            audio, lengths = self.coalescer.submit(key, np.ascontiguousarray(ids[:, :n], np.int64), int(sid[0]), int(seed))
+            self.last_lengths = lengths
+            return [audio[:, None, None, :]]
         audio, lengths = self._model.synthesize(
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
@@ -98,6 +217,12 @@ class VitsSession:
         float output with numpy, half the bytes over PCIe.  return_lengths: also return the per-item sample counts
         (concurrent callers must take them from the call, not from the shared `last_lengths` attribute)."""
         feed, ids, sid, seed = self._validated(None, input_feed)
+        if self._coalescable(feed, ids):
+            n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
+            key = ("pcm", tuple(float(v) for v in np.asarray(feed["scales"], np.float32).reshape(-1)), float(scale))
+            pcm, lengths = self.coalescer.submit(key, np.ascontiguousarray(ids[:, :n], np.int64), int(sid[0]), int(seed))
+            self.last_lengths = lengths
+            return (pcm, lengths) if return_lengths else pcm
         pcm, lengths = self._model.synthesize_pcm16(
             ids, np.asarray(feed["input_lengths"]).reshape(-1), np.asarray(feed["scales"], np.float32).reshape(-1), sid,
             pcm_scale=float(scale), noise_dp=feed.get("vits.noise_dp"), noise_prior=feed.get("vits.noise_prior"),
@@ -113,15 +238,15 @@ class VitsSession:
         feed, ids, sid, seed = self._validated(output_names, input_feed)
         if ids.shape[0] != 1:
             raise ValueError("run_stream takes one utterance")
-        if "bert" in feed:
-            raise NotImplementedError("streaming of BERT-conditioned voices: vits_stream_open takes no bert feed yet")
         n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
         fd = feed.get("vits.forced_durations")
         nd = feed.get("vits.noise_dp")
+        bert = feed.get("bert")  # BERT-conditioned flavour (synth.py:88-99): vits_stream_open takes it through opts->bert
         return self._model.stream(
             ids[:, :n], np.asarray(feed["scales"], np.float32).reshape(-1), int(sid[0]), chunk_frames=chunk_frames,
             noise_dp=None if nd is None else np.asarray(nd)[:, :, :n], noise_prior=feed.get("vits.noise_prior"),
-            forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed)
+            forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed,
+            bert=None if bert is None else np.ascontiguousarray(np.asarray(bert, np.float32)[:, :, :n]))
 
     def close(self):
         self._model.close()
