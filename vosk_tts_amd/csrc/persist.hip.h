@@ -135,6 +135,9 @@ __device__ __forceinline__ ll_t ll_load(const PS_G ll_t* p) {
 __device__ __forceinline__ ll_t ll_load_off(const PS_G ll_t* base, unsigned byte_off) {
   return ll_load((const PS_G ll_t*)((const PS_G char*)base + byte_off));
 }
+__device__ __forceinline__ void ll_store_off(PS_G ll_t* base, unsigned byte_off, float v, unsigned e) {  // uniform base + 32-bit lane offset
+  ll_store((PS_G ll_t*)((PS_G char*)base + byte_off), v, e);
+}
 __device__ __forceinline__ float ll_val(ll_t q) { return __uint_as_float((unsigned)q); }
 __device__ __forceinline__ unsigned ll_bad(ll_t q, unsigned epoch) { return (unsigned)(q >> 32) ^ epoch; }
 
@@ -863,6 +866,9 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         constexpr int NG = PS_MAXROW / 2;
         const int nk = (ROW - jh + 1) >> 1;      // columns of this wave: jh + 2 k < ROW
         const int tj = t0w + jh;
+        // which of this wave's columns exist: bit k set <=> k < nk and 0 <= tj + 2 k < lim  (one scalar bit test per column below)
+        const int klo = tj < 0 ? (1 - tj) >> 1 : 0, khi_t = lim > tj ? (lim - tj + 1) >> 1 : 0, khi = khi_t < nk ? khi_t : nk;
+        const unsigned kmask = khi > klo ? ((1u << khi) - 1u) & ~((1u << klo) - 1u) : 0u;
         float v[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) v[k] = 0.f;
@@ -873,7 +879,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
             const int t = tj + 2 * k;
-            if (k < nk && t >= 0 && t < limp) v[k] = bp[t];  // (uniform condition)
+            if (k < nk && t >= 0 && t < limp) v[k] = bp[t];  // (uniform condition; limp, not lim: kmask does not apply)
           }
 #pragma unroll
           for (int k = 0; k < NG; ++k) v[k] = cok ? v[k] : 0.f;
@@ -882,6 +888,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           const int acp = cps < 0 ? -cps : cps;
           const int cc = cok ? (cps < 0 ? Cin - 1 - c : c) : 0;  // (negative direction: the record's base points at the slice's LOWEST channel)
           unsigned lo = (unsigned)cc * 8u;
+          const unsigned colb = (unsigned)acp * 8u;                 // bytes per window column
+          const unsigned col0 = (unsigned)tj * colb;                // (wraps for tj < 0: those columns are never requested)
           const PS_G ll_t* res = PR_P(const ll_t, rv, 3);
           const bool rok = res != nullptr && wave < 4 && (tid & 15) < rows_left;
           unsigned ro = (unsigned)((tid >> 4) * PR_B(rv, 5) + (tid & 15)) * 8u;
@@ -896,10 +904,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             asm volatile("" : "+v"(lo), "+v"(ro));  // (addresses stay inside the loop body: no hoisted 64-bit pairs)
             if (cok) {
 #pragma unroll
-              for (int k = 0; k < NG; ++k) {
-                const int t = tj + 2 * k;
-                if (k < nk && t >= 0 && t < lim) q[k] = ll_load_off(bin + (long long)t * acp, lo);  // wave-uniform condition: a scalar branch
-              }
+              for (int k = 0; k < NG; ++k)  // wave-uniform condition: a scalar bit test and branch; 32-bit offsets (a cell array is < 4 GiB)
+                if (kmask & (1u << k)) q[k] = ll_load_off(bin, lo + (col0 + 2u * k * colb));
             }
             if (rok) qr = ll_load_off(res, ro);
             unsigned bad = ll_bad(qr, epoch);
@@ -996,7 +1002,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             }
             const float tv = tanhf(at + eb0 + ec0);
             const float sv = 1.0f / (1.0f + __expf(-(as + eb1 + ec1)));
-            ll_store(PR_P(ll_t, rv, 1) + (long long)col * ypitch + mi * 8 + ch, tv * sv, epoch);  // (p1 points at channel 8 * first block)
+            ll_store_off(PR_P(ll_t, rv, 1), (unsigned)(col * ypitch + mi * 8 + ch) * 8u, tv * sv, epoch);  // (p1 points at channel 8 * first block)
           }
         } else if (tid < 256) {
           const int row = tid & 15, col = tid >> 4;  // rows fastest: a column's 16 cells are one 128-byte segment
@@ -1014,8 +1020,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             else {
               PS_G ll_t* yo = PR_P(ll_t, rv, 1);
               PS_G float* yp = PR_P(float, rv, 2);
-              if (yo) ll_store(yo + (long long)col * ypitch + rl, v, epoch);
-              if (yp && t < pT) yp[(long long)rl * pT + col] = v;
+              if (yo) ll_store_off(yo, (unsigned)(col * ypitch + rl) * 8u, v, epoch);
+              if (yp && t < pT) *(PS_G float*)((PS_G char*)yp + (unsigned)(rl * pT + col) * 4u) = v;
             }
           }
         }
