@@ -1,9 +1,9 @@
 #!/bin/bash
-# Builds alternative libraries for tools/bigtile_ab.py into tools/bt/ (git-ignored, travels to the GPU box):
+# Builds alternative product libraries into tools/bt/ (git-ignored, travels to the GPU box) for A/B runs on one lease:
 #   tools/ab_build.sh base                       working tree as is            -> tools/bt/bt_base.so
 #   tools/ab_build.sh exp:-DSOME_SWITCH          working tree with extra flags -> tools/bt/bt_exp.so
-#   tools/ab_build.sh epi@exp/bf3-fast-epilogue  sources of a git ref          -> tools/bt/bt_epi.so
-# then:  gpurun -- 'BT_LIBS="$(ls tools/bt/*.so | tr "\n" " ")" python tools/bigtile_ab.py'
+#   tools/ab_build.sh old@<git ref>              sources of a git ref          -> tools/bt/bt_old.so
+# then on the GPU box:  VITS_MI355_LIB=tools/bt/bt_exp.so python bench.py ...   (tools/gpu_r4.sh libs)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/tools/bt $R/gpurun_out

@@ -18,6 +18,10 @@ ab)
     x=${cfg%%:*}; t=${cfg##*:}
     echo "VITS_PS_XCD=$x VITS_PS_TUNE=$t: $(VITS_PS_XCD=$x VITS_PS_TUNE=$t c2)" | tee -a $O/ab.txt
   done;;
+libs)  # A/B of alternative builds (tools/ab_build.sh): every tools/bt/bt_*.so, twice each, interleaved
+  for rep in 1 2; do for so in tools/bt/bt_*.so; do
+    echo "$so: $(VITS_MI355_LIB=$R/$so c2)" | tee -a $O/libs.txt
+  done; done;;
 trace)
   for p in enc dp flow; do PS_DETAIL=1 timeout 200 python tools/ps_trace.py $p > $O/trace_$p.txt 2>&1; tail -2 $O/trace_$p.txt; done;;
 pmc)

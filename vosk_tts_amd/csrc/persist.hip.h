@@ -209,6 +209,10 @@ __device__ __forceinline__ float ps_row_max(float v) {
   v = ps_dpp_max<0x140>(v);
   return v;
 }
+template <int N>
+__device__ __forceinline__ float ps_row_shr(float v) {  // lane k <- lane k - N of its 16-lane row (0 where the row has no such lane)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float ps_wave_sum(float v) {  // sum over the 64 lanes, in every lane
   v = ps_row_sum(v);
   v = ps_dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
@@ -332,7 +336,7 @@ __device__ __forceinline__ void ps_touch_weights(const PS_G char* w, int n_u, in
 
 // LDS of the kernel (floats).  Matrix steps: operand window + partial tiles + spline scratch; attention blocks: Q / K / V tiles and
 // the two relative-position tables alias the operand window, scores / probabilities alias the partial tiles.
-#define PS_LDS_TILE (3 * 16 * (PS_DKP + 4) + (10 + 9) * (PS_DKP + 4))   // >= PS_MAXC * PS_TP
+#define PS_LDS_TILE (3 * 16 * (PS_DKP + 4) + (10 + 12) * (PS_DKP + 4))   // >= PS_MAXC * PS_TP
 #define PS_LDS_MRED (PS_WAVES * 256)
 static_assert(PS_LDS_TILE >= PS_MAXC * PS_TP, "operand window does not fit");
 
@@ -343,6 +347,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   __shared__ float xs[3 * PS_MAXC];        // column steps: x_in at t - d, t, t + d
   __shared__ float red[4 * 16];            // block reductions (one 16-float scratch per call site)
   __shared__ float dma_sink[64];           // destination of the L2 pre-touch loads (never read)
+  __shared__ __attribute__((aligned(16))) float att_r[PS_WAVES * 256];  // attention blocks: partial q E_k^T tiles of the 8 waves
+  __shared__ float att_p[16 * 17];         // attention blocks: probabilities [query][key], pitch 17 (conflict-free MFMA A reads)
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int rank = blockIdx.x, P = gridDim.x;
@@ -413,7 +419,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const PS_G ll_t* zc = (kf & PF_FIN_PRE) ? PR_P(const ll_t, rv, 2) : nullptr;
       PS_G ll_t* xout = PR_P(ll_t, rv, 3);
       PS_G ll_t* bout = PR_P(ll_t, rv, 4);
-      const int c = tid & 255, h = tid >> 8;
+      const int c = (wave & 3) * 64 + lane, h = wave >> 2;  // (== tid & 255, tid >> 8; the half is wave-uniform: scalar conditions)
       const bool cok = c < D;
       {
         if (t >= L) {  // padding column (worker-uniform): zeros, nothing to wait for
@@ -496,7 +502,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       const int C = PR_I(rv, 1), t = PR_I(rv, 2), dk = PR_I(rv, 3) & 0xff, nh = PR_I(rv, 3) >> 8, dk2 = dk + 2;
       const PS_G ll_t* ap = PR_P(const ll_t, rv, 0);
       PS_G ll_t* out = PR_P(ll_t, rv, 3);
-      const int d = tid & (PS_DKP - 1), hd = tid >> 7;
+      const int d = (wave & 1) * 64 + lane, hd = wave >> 1;  // (== tid & 127, tid >> 7; the head is wave-uniform)
       const bool ok = d < dk && hd < nh;
       const int nkt = (L + 15) >> 4;
       const long long kstr = PR_B(rv, 0);
@@ -559,7 +565,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
 #define par_b pre.pk0[1]
 #define par_bias pre.pk0[2]
 #define par_vec pre.ec0
-      const int c = tid & 255, h = tid >> 8;
+      const int c = (wave & 3) * 64 + lane, h = wave >> 2;  // (== tid & 255, tid >> 8)
       const bool cok = c < C && h == 0;  // one column per worker: the channel threads of half 0
       {
         float o = 0.f;
@@ -681,17 +687,18 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       float* Qs = tile;                  // [16][dk + 4]
       float* Ks = Qs + 16 * (PS_DKP + 4);
       float* Vs = Ks + 16 * (PS_DKP + 4);
-      float* Ek = Vs + 16 * (PS_DKP + 4);  // [2W + 1][dk + 4] + one row of zeros (row 9: what a lane outside the band adds)
-      float* Ev = Ek + 10 * (PS_DKP + 4);
-      float* Ss = mred;                  // [2][16][17] partial dot products of the two d-halves
-      float* Ps = mred + 576;            // [16][16] probabilities (16-byte aligned rows)
+      float* Ek = Vs + 16 * (PS_DKP + 4);  // [2W + 1][dk + 4] (+ row 9 zeroed)
+      float* Ev = Ek + 10 * (PS_DKP + 4);  // [12][dk + 4]: rows 2W + 1 .. 11 zero (the band product runs over 12 relative positions)
+      float* Sp = mred;                  // [8 waves][4][64] partial q k^T tiles (MFMA accumulator layout)
+      float* Rp = att_r;                 // the same for q E_k^T
+      float* Ps = att_p;                 // [16][17] probabilities
       const int dkp = dk + 4;
       const float scale = 1.0f / sqrtf((float)dk);
       {
         if (i0 >= L || j0 >= L) { PS_STAMP(3); continue; }  // nothing to compute: the merge step never looks at these blocks
         // ---- gather q (16 x dk), k, v tiles: thread = (d = tid & 127, rows (tid >> 7) + 4 k)
         {
-          const int d = tid & (PS_DKP - 1), r0 = tid >> 7;
+          const int d = (wave & 1) * 64 + lane, r0 = wave >> 1;  // (== tid & 127, tid >> 7; the row group is wave-uniform)
           const bool dok = d < dk;
           unsigned oq[4], okv[4];
           bool nq[4], nk[4];
@@ -732,6 +739,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             if (tid < tab) { Ek[ra * dkp + (tid - ra * dk)] = pre.pk0[0]; Ev[ra * dkp + (tid - ra * dk)] = pre.pk0[2]; }
             if (tid + 512 < tab) { Ek[rb * dkp + (tid + 512 - rb * dk)] = pre.pk0[1]; Ev[rb * dkp + (tid + 512 - rb * dk)] = pre.pk0[3]; }
             if (tid < dkp) Ek[9 * dkp + tid] = 0.f;
+            if (tid < 3 * dkp && 2 * W + 1 <= 9) Ev[(9 * dkp) + tid] = 0.f;                                   // rows 9 .. 11
+            for (int r = 2 * W + 1; r < 9; ++r) if (tid < dkp) Ev[r * dkp + tid] = 0.f;                        // (W < 4)
           }
           if (dok) {
 #pragma unroll
@@ -745,84 +754,73 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         }
         __syncthreads();
         PS_STAMP(2);
-        // ---- scores: thread = (pair (i, j) = tid & 255, d-half = tid >> 8)
+        // ---- scores on the matrix cores (round 4; the float4 dot products this replaces were 2.2 k + 3.9 k cycles of VALU and LDS
+        // issue per block).  S = Q K^T and, for blocks that touch the band, R = Q E_k^T (R[i][r] = q_i . E_k[r]; s_ij += R[i][j - i + W]):
+        // the 8 waves split the contraction over d (k-steps of 4), partial tiles meet in LDS.  A = Q[i = lane & 15][d], B = K[j = lane & 15][d]
+        // (rows of pitch dk + 4: (dk + 4) mod 64 is a multiple of 4 and odd / 4 -> the 16 rows of a lane group and the 4 d of a k-step
+        // hit 64 different banks).
+        const bool near = W > 0 && j0 - i0 <= 15 + W && i0 - j0 <= 15 + W;  // (block-uniform) the block touches the band
         {
-          const int i = (tid >> 4) & 15, j = tid & 15, dh = tid >> 8;
-          const int d0 = dh * (dk >> 1), d1 = dh ? dk : (dk >> 1);
-          // float4 reads with four independent partial sums: as a scalar loop this was one dependent LDS round trip per element
-          // (48 x ~100 cycles).  Inside the band k_j + E_k[j - i + W] is summed first: one pass instead of two.
-          const f32x4* qp = reinterpret_cast<const f32x4*>(Qs + i * dkp + d0);
-          const f32x4* kp = reinterpret_cast<const f32x4*>(Ks + j * dkp + d0);
-          const int rel = (j0 + j) - (i0 + i);
-          const bool near = W > 0 && j0 - i0 <= 15 + W && i0 - j0 <= 15 + W;  // (block-uniform) the block touches the band
-          const f32x4* ep = reinterpret_cast<const f32x4*>(Ek + ((rel >= -W && rel <= W) ? rel + W : 9) * dkp + d0);  // outside the band: zeros
-          const int n4 = (d1 - d0) >> 2;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          if (near) {  // one pass for every lane of the block (a per-lane branch would run both loops)
-#pragma unroll 4
-            for (int q4 = 0; q4 < n4; ++q4) { const f32x4 qv = qp[q4], kv = kp[q4], ev = ep[q4]; acc += qv * (kv + ev); }
-          } else {
-#pragma unroll 4
-            for (int q4 = 0; q4 < n4; ++q4) { const f32x4 qv = qp[q4], kv = kp[q4]; acc += qv * kv; }
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, racc = {0.f, 0.f, 0.f, 0.f};
+          const int ro = (lane & 15) * dkp + (lane >> 4);
+          const int nks = dk >> 2;
+          for (int ks = wave; ks < nks; ks += PS_WAVES) {
+            const float qa = Qs[ro + 4 * ks], kb = Ks[ro + 4 * ks];
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, kb, sacc, 0, 0, 0);
+            if (near) racc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, Ek[ro + 4 * ks], racc, 0, 0, 0);  // (rows >= 2W + 1: never read)
           }
-          Ss[(dh * 16 + i) * 17 + j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { Sp[(wave * 4 + r) * 64 + lane] = sacc[r]; Rp[(wave * 4 + r) * 64 + lane] = racc[r]; }
         }
         __syncthreads();
         PS_STAMP(4);
         float m_i = 0.f, l_i = 0.f;
-        if (tid < 256) {  // lanes of a 16-lane row = the 16 keys of query i
+        if (wave < 4) {  // (tid < 256) thread = (query i = tid >> 4, key j = tid & 15): the 16 lanes of a DPP row = the keys of query i
           const int i = tid >> 4, j = tid & 15;
-          float sc = Ss[i * 17 + j] + Ss[(16 + i) * 17 + j];
+          float sc = 0.f;
+#pragma unroll
+          for (int w = 0; w < PS_WAVES; ++w) sc += Sp[(w * 4 + (i & 3)) * 64 + (i >> 2) * 16 + j];
+          const int rel = (j0 + j) - (i0 + i) + W;  // relative position index
+          if (near) {
+            const int rc = rel < 0 ? 0 : (rel > 15 ? 15 : rel);
+            float rs = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_WAVES; ++w) rs += Rp[(w * 4 + (i & 3)) * 64 + (i >> 2) * 16 + rc];
+            sc += (rel >= 0 && rel <= 2 * W) ? rs : 0.f;
+          }
           const bool kok = j0 + j < L;
           sc = kok ? sc : -3.0e38f;
           m_i = ps_row_max(sc);
           const float p = kok ? __expf(sc - m_i) : 0.f;
           l_i = ps_row_sum(p);
-          Ps[i * 16 + j] = p;
+          Ps[i * 17 + j] = p;
         }
         __syncthreads();
         PS_STAMP(5);
-        // ---- O = P V (+ the relative-value band): thread = (d = tid & 127, rows (tid >> 7) + 4 k)
-        {
-          const int d = tid & (PS_DKP - 1), r0 = tid >> 7;
-          if (d < dk) {
-            // this thread's column of V once for its four rows; a row's probabilities as four float4 (broadcast reads)
-            float vc[16];
+        // ---- O = P V (+ the relative-value band P_rel E_v, P_rel[i][r] = p_{i, j = i + r - W + i0 - j0}): wave w owns the 16 head
+        // dimensions d0 = 16 w; A = P[i = lane & 15][j], B = V[j][d0 + (lane & 15)]
+        if (wave * 16 < dk) {
+          const int d0 = wave * 16, n = lane & 15, kk = lane >> 4;
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) vc[j] = Vs[j * dkp + d];
-            const bool near = W > 0 && j0 - i0 <= 15 + W && i0 - j0 <= 15 + W;  // (block-uniform) the block touches the band
-            float evc[9];  // this thread's column of E_v (the same for its four rows)
-            if (near) {
+          for (int ks = 0; ks < 4; ++ks)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(Ps[n * 17 + 4 * ks + kk], Vs[(4 * ks + kk) * dkp + d0 + n], o, 0, 0, 0);
+          if (near) {
+            const int jb = n + (i0 - j0) - W + kk;  // key (tile-local) of relative position r = kk for query i = n; + 4 per k-step
 #pragma unroll
-              for (int r = 0; r < 9; ++r) evc[r] = r <= 2 * W ? Ev[r * dkp + d] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int i = r0 + 4 * k;
-              const f32x4* pp = reinterpret_cast<const f32x4*>(Ps + i * 16);
-              const f32x4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
-              float o = ((p0[0] * vc[0] + p0[1] * vc[1]) + (p0[2] * vc[2] + p0[3] * vc[3])) + ((p1[0] * vc[4] + p1[1] * vc[5]) + (p1[2] * vc[6] + p1[3] * vc[7])) +
-                        (((p2[0] * vc[8] + p2[1] * vc[9]) + (p2[2] * vc[10] + p2[3] * vc[11])) + ((p3[0] * vc[12] + p3[1] * vc[13]) + (p3[2] * vc[14] + p3[3] * vc[15])));
-              if (near) {
-                // relative-value band: E_v row r = j - i + W for the keys j = r - W + (i0 + i) - j0 that fall into this tile
-                const int jb = (i0 + i) - j0 - W;
-                float pj[9];
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {  // nine independent broadcast reads, all issued before the first use (left alone,
-                  const int j = jb + r;        // hipcc waits for each one in turn: 36 LDS round trips per thread)
-                  pj[r] = Ps[i * 16 + ((j >= 0 && j < 16) ? j : 0)];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 9; ++r) pj[r] = (jb + r >= 0 && jb + r < 16) ? pj[r] : 0.f;
-                o += ((pj[0] * evc[0] + pj[1] * evc[1]) + (pj[2] * evc[2] + pj[3] * evc[3])) + ((pj[4] * evc[4] + pj[5] * evc[5]) + (pj[6] * evc[6] + pj[7] * evc[7])) +
-                     pj[8] * evc[8];
-              }
-              if (i0 + i < L) ll_store(ap + (((long long)kt * Tp + i0 + i) * nh + hd) * dk2 + d, o, epoch);
+            for (int ks = 0; ks < 3; ++ks) {
+              const int j = jb + 4 * ks, r = 4 * ks + kk;
+              const float pr = Ps[n * 17 + (j < 0 ? 0 : (j > 15 ? 15 : j))];
+              o = __builtin_amdgcn_mfma_f32_16x16x4f32((j >= 0 && j < 16 && r <= 2 * W) ? pr : 0.f, Ev[r * dkp + d0 + n], o, 0, 0, 0);
             }
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {  // accumulator row 4 (lane >> 4) + r, column lane & 15
+            const int i = 4 * kk + r;
+            if (i0 + i < L) ll_store_off(ap, (unsigned)((((kt * Tp + i0 + i) * nh + hd) * dk2) + d0 + n) * 8u, o[r], epoch);
+          }
         }
-        if (tid < 256 && (tid & 15) == 0) {
+        if (wave < 4 && (tid & 15) == 0) {
           const int i = tid >> 4;
           if (i0 + i < L) {
             PS_G ll_t* dst = ap + (((long long)kt * Tp + i0 + i) * nh + hd) * dk2 + dk;
@@ -856,6 +854,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
 #pragma unroll
       for (int i = 0; i < PS_MAXU; ++i) uoff[i] = ps_unit_tab.off[K >> 1][wave][i];
       const int cnt = n_u > wave ? (n_u - wave + PS_WAVES - 1) >> 3 : 0;  // tap units of this wave
+      const unsigned umask = (1u << cnt) - 1u;                             // bit i: unit i exists (one scalar bit test per unit)
       float rsd0 = 0.f;  // residual cell of row block 0 (polled with the window)
       // ---- operand window [Cin][ROW] -> LDS (transposed: cells are column-major); thread = (channel c, window columns jh + 2 k)
       {
@@ -899,8 +898,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           ll_t q[NG], qr = zero_cell;
 #pragma unroll
           for (int k = 0; k < NG; ++k) q[k] = zero_cell;
-          bool pending;
-          do {
+          auto issue = [&]() {
             asm volatile("" : "+v"(lo), "+v"(ro));  // (addresses stay inside the loop body: no hoisted 64-bit pairs)
             if (cok) {
 #pragma unroll
@@ -908,10 +906,20 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
                 if (kmask & (1u << k)) q[k] = ll_load_off(bin, lo + (col0 + 2u * k * colb));
             }
             if (rok) qr = ll_load_off(res, ro);
+          };
+          auto check = [&]() -> bool {
             unsigned bad = ll_bad(qr, epoch);
 #pragma unroll
             for (int k = 0; k < NG; ++k) bad |= ll_bad(q[k], epoch);
-            pending = PS_PENDING(bad);
+            return PS_PENDING(bad);
+          };
+          // (the first poll round BEFORE this step's own operand requests -- weights and epilogue vectors flying under its round trip --
+          //  was measured again in round 4: c2 0.917 against 0.890 ms; the store -> visible latency of the producers is longer than the
+          //  bookkeeping in front of the poll, so an earlier poll only adds a failed round)
+          bool pending;
+          do {
+            issue();
+            pending = check();
           } while (ps_again(cx, pending));
 #pragma unroll
           for (int k = 0; k < NG; ++k) v[k] = ll_val(q[k]);
@@ -948,7 +956,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         if (mi == nblk - 1) PS_STAMP(7);
         do {  // this wave's tap units, leaving at the first one it does not have (one scalar compare per unit)
 #define PS_UNIT(i)                                                                                              \
-          if (cnt <= (i)) break;                                                                                \
+          if (!(umask & (1u << (i)))) break;                                                                    \
           {                                                                                                     \
             const float* bp = reinterpret_cast<const float*>(blb + uoff[i]);                                    \
             const float b0 = bp[0], b1 = bp[4 * PS_TP], b2 = bp[8 * PS_TP], b3 = bp[12 * PS_TP];                \
@@ -992,7 +1000,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         if (mi == nblk - 1) PS_STAMP(6);
         if (kf & PF_GATE) {
           // packed 16-row block = [8 tanh rows | 8 sigmoid rows] of channels 8 * mb .. 8 * mb + 7 (commons.py:100-107)
-          if (tid < 128) {
+          if (wave < 2) {  // (tid < 128)
             const int ch = tid & 7, col = tid >> 3;
             float at = 0.f, as = 0.f;
 #pragma unroll
@@ -1004,7 +1012,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             const float sv = 1.0f / (1.0f + __expf(-(as + eb1 + ec1)));
             ll_store_off(PR_P(ll_t, rv, 1), (unsigned)(col * ypitch + mi * 8 + ch) * 8u, tv * sv, epoch);  // (p1 points at channel 8 * first block)
           }
-        } else if (tid < 256) {
+        } else if (wave < 4) {  // (tid < 256)
           const int row = tid & 15, col = tid >> 4;  // rows fastest: a column's 16 cells are one 128-byte segment
           float v = 0.f;
 #pragma unroll
@@ -1026,7 +1034,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
           }
         }
       }
-      if ((kf & PF_ZINIT) && tid < 32) {
+      if ((kf & PF_ZINIT) && wave == 0 && lane < 32) {
         // z = randn * noise_scale_w (models.py:96): injected noise or the Philox stream of dp_init_z_kernel
         const int c = tid >> 4, t = n0 + (tid & 15);
         float nsw = call.nsw;
@@ -1041,8 +1049,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
       if (kf & PF_SPLINE) {
         // Inverse rational-quadratic spline of the tile's 16 columns (transforms.py:55-177), the arithmetic of spline_inverse_elem
         // (kernels_misc.hip.h) spread over the workgroup: one thread per column ran ~23 k cycles (20 expf and 20 divisions in a
-        // dependent chain); here the exponentials are one per thread, the two short serial scans (sum, cumulative widths / heights:
-        // same order as the serial form) run on 32 threads, and 16 threads finish (bin search, quadratic).
+        // dependent chain); here the exponentials are one per thread, the bin softmax / cumulative sums are DPP row operations, and 16
+        // threads finish (bin search, quadratic).
         __syncthreads();  // h complete
         // z of the tile's columns (cells of a much older step): requested now, checked where they are used -- one round trip under
         // the exponentials and scans instead of behind them
@@ -1058,32 +1066,27 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         }
         const int nb = prog->nb;
         const float bound = prog->bound, isd = prog->inv_sqrt_d;
-        float* se = mred;            // [32][16] exp(w - max): slots 0..nb-1 widths, 16..16+nb-1 heights
-        float* sc = mred + 32 * 16;  // [2][17][16] cumulative widths / heights (knots)
+        float* sc = mred;  // [2][17][16] cumulative widths / heights (knots)
         {
-          const int col = tid & 15, slot = tid >> 4, which = slot >> 4, i = slot & 15;
-          if (i < nb) {
-            const float* src = hb + (which * nb) * 16 + col;
-            float mx = -3.0e38f;
-            for (int k = 0; k < nb; ++k) mx = fmaxf(mx, src[k * 16] * isd);
-            se[slot * 16 + col] = expf(src[i * 16] * isd - mx);
-          }
-        }
-        __syncthreads();
-        if (tid < 32) {
-          const int col = tid & 15, which = tid >> 4;
-          const float* e = se + which * 256 + col;
-          float* cdst = sc + which * 17 * 16 + col;
+          // softmax over the bins, cumulative sum and knots (transforms.py:96-131) with the 16 lanes of a DPP row = the bins of ONE
+          // column: thread = (which = wave >> 2: widths / heights, column = 4 (wave & 3) + (lane >> 4), bin k = lane & 15).  Row
+          // maximum, row sum and the inclusive prefix are DPP row operations (no LDS, no loop): the serial form this replaces (32
+          // threads walking the bins: two dependent LDS reads per bin, then a 16-thread bin search) took 11 k cycles per spline step.
+          const int which = wave >> 2, col = 4 * (wave & 3) + (lane >> 4), k = lane & 15;
+          const bool kok = k < nb;
+          const float u = kok ? hb[(which * nb + k) * 16 + col] * isd : -3.0e38f;
+          const float mx = ps_row_max(u);
+          const float e = kok ? expf(u - mx) : 0.f;
+          const float sum = ps_row_sum(e);
           const float mn = 1e-3f;  // min_bin_width == min_bin_height
-          float sum = 0.f;
-          for (int k = 0; k < nb; ++k) sum += e[k * 16];
-          float acc = 0.f;
-          cdst[0] = -bound;
-          for (int k = 0; k < nb; ++k) {
-            acc += mn + (1.f - mn * nb) * (e[k * 16] / sum);
-            cdst[(k + 1) * 16] = 2.f * bound * acc - bound;
-          }
-          cdst[nb * 16] = bound;
+          float c = kok ? mn + (1.f - mn * nb) * (e / sum) : 0.f;
+          c += ps_row_shr<1>(c);
+          c += ps_row_shr<2>(c);
+          c += ps_row_shr<4>(c);
+          c += ps_row_shr<8>(c);
+          float* cdst = sc + which * 17 * 16 + col;
+          if (k == 0) cdst[0] = -bound;
+          if (kok) cdst[(k + 1) * 16] = k == nb - 1 ? bound : 2.f * bound * c - bound;
         }
         __syncthreads();
         if (wave == 0) {  // one column per lane (lanes >= 16 ride along in the wave-uniform poll)

@@ -24,7 +24,7 @@ static bool persist_encoder_ok(const vits_model* m, const EncoderW& E) {
   const vits_hparams& hp = m->hp;
   if (E.layers.empty() || E.H % 16 || E.H > PS_MAXC || hp.n_heads < 1 || hp.n_heads > 4 || E.H % hp.n_heads) return false;
   const int dk = E.H / hp.n_heads;
-  if (dk > PS_DKP || dk % 8 || hp.window_size < 0 || hp.window_size > 4 || (2 * hp.window_size + 1) * dk > 1024) return false;
+  if (dk > PS_DKP || dk % 16 || hp.window_size < 0 || hp.window_size > 4 || (2 * hp.window_size + 1) * dk > 1024) return false;  // (dk % 16: the PV tiles of the MFMA attention blocks)
   for (const EncLayerW& L : E.layers)
     if (!persist_conv_ok(L.qkv) || !persist_conv_ok(L.o) || !persist_conv_ok(L.f1) || !persist_conv_ok(L.f2) || L.qkv.K != 1 || L.o.K != 1) return false;
   return true;
