@@ -716,6 +716,11 @@ struct vits_session {
     double flops = 0;
   };
   PersistProg ps_enc, ps_sdp, ps_flow;
+  // programs of the graph-replayed paths (persist_plan.hip.h): front = text encoder [+ duration predictor] + durations, back = prior
+  // sample + flow, full = both in ONE launch (device sessions: the caller brings the frame capacity); index = duration predictor included.
+  // They work in the exchange regions of the three programs above plus ps_x (only its ll / cells are used)
+  PersistProg ps_front[2], ps_back, ps_full[2], ps_x;
+  ll_t *ps_x_stats = nullptr, *ps_x_logw = nullptr, *ps_x_cum = nullptr, *ps_x_leny = nullptr, *ps_x_zp = nullptr;
   int ps_roles = 7;        // PERSIST_* mask of the programs this session can ever launch: fronts of the fast path run the text encoder and the
                            // duration predictor, their backs the flow -- cells and records are only laid out / built for those
   bool ps_defer = false;   // the owner calls persist_plan itself after re-pointing shared tensors (backs): session_reserve skips it
@@ -811,6 +816,18 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   s->ps_sdp.ll = bump<ll_t>(s, s->ps_sdp.cells);
   s->ps_flow.cells = (s->ps_roles & PERSIST_FLOW) ? persist_flow_cells(s->m, B, Ty) : 0;
   s->ps_flow.ll = bump<ll_t>(s, s->ps_flow.cells);
+  {
+    // cells of the multi-stage programs: stats [Tp_x][2I], logw [Tp_x], cum [Tp_x], frame count, z_p [Tp_y][I]
+    const size_t Tpx = (size_t)cdiv(Tx, 16) * 16, Tpy = (size_t)cdiv(Ty, 16) * 16;
+    s->ps_x.cells = (s->ps_enc.cells || s->ps_flow.cells) ? Tpx * 2 * I + Tpx + Tpx + 16 + Tpy * I : 0;
+    s->ps_x.ll = bump<ll_t>(s, s->ps_x.cells);
+    ll_t* p = s->ps_x.ll;
+    s->ps_x_stats = p; p += Tpx * 2 * I;
+    s->ps_x_logw = p; p += Tpx;
+    s->ps_x_cum = p; p += Tpx;
+    s->ps_x_leny = p; p += 16;
+    s->ps_x_zp = p;
+  }
   s->zA = bump<float>(s, B * I * Ty); s->zB = bump<float>(s, B * I * Ty);
   s->fh = bump<float>(s, B * H * Ty); s->fx = bump<float>(s, B * H * Ty);
   s->facts = bump<float>(s, B * H * Ty * (size_t)(hp.flow_wn_layers > 0 ? hp.flow_wn_layers : 1));  // gate outputs of all WN layers, stacked
@@ -919,7 +936,10 @@ static void session_free(vits_session* s) {
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
   if (s->ps_ctl) hipFree(s->ps_ctl);
-  for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow}) { if (pp->d) hipFree(pp->d); if (pp->recs_d) hipFree(pp->recs_d); }
+  for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow, &s->ps_front[0], &s->ps_front[1], &s->ps_back, &s->ps_full[0], &s->ps_full[1]}) {
+    if (pp->d) hipFree(pp->d);
+    if (pp->recs_d) hipFree(pp->recs_d);
+  }
   if (s->stage) hipFree(s->stage);
   if (s->d_err) hipFree(s->d_err);
   if (s->h_err) hipHostFree(s->h_err);
@@ -965,13 +985,15 @@ struct ProfScope {
 // ---- one persistent step program (persist.hip.h) as ONE launch of P = #CUs workgroups
 static bool big_lds_needed(std::atomic<unsigned long long>& done);
 static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const char* name, const float* d_noise = nullptr, float nsw = 0.f,
-                           uint64_t seed = 0, const int64_t* d_ids = nullptr) {
+                           uint64_t seed = 0, const int64_t* d_ids = nullptr, const int* d_forced = nullptr, float length_scale = 1.f,
+                           float noise_scale = 0.f) {
   vits_model* m = s->m;
   ProfScope ps(s, name, pp.flops, "persist_kernel");
   PCall c;
   c.ctl = s->ps_ctl; c.ids = reinterpret_cast<const long long*>(d_ids); c.noise = d_noise; c.nsw = nsw; c.seed = seed;
   c.solo = s->solo ? 1 : 0; c.dv = s->dv; c.item_seeds = s->item_seeds; c.trace = nullptr;
   c.dbg = m->ps_dbg;
+  c.forced = d_forced; c.length_scale = length_scale; c.noise_scale = noise_scale; c.noise_prior = nullptr; c.noise_stride = 0;
   static const int tune = getenv("VITS_PS_TUNE") ? atoi(getenv("VITS_PS_TUNE")) : PS_TUNE_DEFAULT;  // experiment switches (persist.hip.h)
   c.tune = tune;
   static const char* trace_path = getenv("VITS_PS_TRACE");  // tools/ps_trace.py: per-worker, per-step cycle stamps of an EAGER forward
@@ -2062,11 +2084,20 @@ static void forward_device(vits_session* s, const int64_t* d_ids, const int64_t*
   s->ragged = B > 1 && !no_ragged;
   s->tile_keys.clear();
   run_cond(s, d_sid, B, d_len, s->len_x, Tx);
-  run_text_encoder(s, d_ids, B, Tx);
-  if (!d_forced || s->sdp_always) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx, true);  // logw unused when durations are pinned
-  run_durations(s, d_forced, scales[1], B, Tx, Ty);
-  run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
-  float* z = run_flow(s, B, Ty);
+  const bool with_sdp = !d_forced || s->sdp_always;  // (logw unused when durations are pinned)
+  float* z;
+  if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && Tx == s->Tx && Ty == s->Ty && s->ps_full[with_sdp].ok) {
+    // text encoder .. flow of a single utterance as ONE persistent launch (the frame capacity T_y is the caller's)
+    persist_launch(s, s->ps_full[with_sdp], "acoustic.persist", nullptr, scales[2], seed, d_ids, d_forced, scales[1], scales[0]);
+    s->ea_pending = false;
+    z = s->zB;
+  } else {
+    run_text_encoder(s, d_ids, B, Tx);
+    if (with_sdp) run_duration(s, s->x, nullptr, scales[2], seed, B, Tx, true);
+    run_durations(s, d_forced, scales[1], B, Tx, Ty);
+    run_expand(s, nullptr, Ty, scales[0], seed, s->zA, B, Tx, Ty);
+    z = run_flow(s, B, Ty);
+  }
   run_decoder(s, z, true, B, Ty, d_audio, cap, nullptr, true);
   s->ragged = false;
 }
@@ -2561,9 +2592,15 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
     const int64_t* d_ids = reinterpret_cast<const int64_t*>(F->io_d + F->io_ids);
     const int32_t* d_forced = reinterpret_cast<const int32_t*>(F->io_d + F->io_forced);
     run_cond(F, d_sid, B, d_len, F->len_x, TxB);
-    run_text_encoder(F, d_ids, B, TxB);
-    if (!forced) run_duration(F, F->x, nullptr, 0.f, 0, B, TxB, true);
-    run_durations(F, forced ? d_forced : nullptr, 1.f, B, TxB, 0);
+    if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && F->ps_front[forced ? 0 : 1].ok) {
+      // text encoder [+ duration predictor] + durations as one persistent launch
+      persist_launch(F, F->ps_front[forced ? 0 : 1], "front.persist", nullptr, 0.f, 0, d_ids, forced ? d_forced : nullptr, 1.f, 0.f);
+      F->ea_pending = false;
+    } else {
+      run_text_encoder(F, d_ids, B, TxB);
+      if (!forced) run_duration(F, F->x, nullptr, 0.f, 0, B, TxB, true);
+      run_durations(F, forced ? d_forced : nullptr, 1.f, B, TxB, 0);
+    }
     hipMemcpyAsync(F->h_ylen, F->ylen64, sizeof(int64_t) * B, hipMemcpyDeviceToHost, F->stream);
     hipMemcpyAsync(F->h_ylen + B, F->d_err, sizeof(int), hipMemcpyDeviceToHost, F->stream);
     F->ragged = false; F->solo = false;
@@ -2581,8 +2618,14 @@ static int phase2_launch(vits_session* F, vits_session* Bk, bool solo, bool pcm)
     HIP_TRY(hipStreamBeginCapture(F->stream, hipStreamCaptureModeThreadLocal));
     CaptureGuard cg(F->stream);
     Bk->ragged = true; Bk->solo = solo; Bk->rag_b1 = true; Bk->tile_keys.clear();
-    run_expand(Bk, nullptr, TyB, 0.f, 0, Bk->zA, B, TxB, TyB);
-    float* z = run_flow(Bk, B, TyB);
+    float* z;
+    if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && Bk->ps_back.ok) {  // prior sample + flow as one persistent launch
+      persist_launch(Bk, Bk->ps_back, "back.persist");
+      z = Bk->zB;
+    } else {
+      run_expand(Bk, nullptr, TyB, 0.f, 0, Bk->zA, B, TxB, TyB);
+      z = run_flow(Bk, B, TyB);
+    }
     // a lone utterance decodes as the exact-size run does (zeros beyond its end); batches keep the reference's padded-batch
     // continuation over the halo unless the caller asked for independent items
     run_decoder(Bk, z, true, B, TyB, Bk->out_d, stride, nullptr, true, (solo || B == 1) ? 0 : F->m->rag_halo);

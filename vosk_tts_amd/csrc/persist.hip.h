@@ -45,7 +45,7 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 
 #define PS_THREADS 512
 #define PS_WAVES 8
-#define PS_MAX_STEPS 128
+#define PS_MAX_STEPS 192
 #define PS_MAXC 256      // channels of a column step / contraction channels of one K-slice
 #define PS_MAXU 8        // tap units (16 channels x 1 tap) per wave
 #define PS_TP 21         // LDS pitch of the MFMA operand window [C_in][16 + taps - 1] (odd: the transposing writes are conflict-free)
@@ -64,7 +64,7 @@ struct PersistCtl {
   unsigned timeouts;  // diagnostics
 };
 
-enum { PK_IDLE = 0, PK_MM = 1, PK_DDS = 2, PK_LN = 3, PK_EMB = 4, PK_ATT = 5, PK_MERGE = 6, PK_COUPLE = 7 };
+enum { PK_IDLE = 0, PK_MM = 1, PK_DDS = 2, PK_LN = 3, PK_EMB = 4, PK_ATT = 5, PK_MERGE = 6, PK_COUPLE = 7, PK_DUR = 8, PK_EXPAND = 9 };
 // flags (record dword 0, bits 8..)
 enum {
   PF_RELU = 1 << 8, PF_INMASK = 1 << 9, PF_OUTMASK = 1 << 10, PF_GATE = 1 << 11, PF_SPLINE = 1 << 12, PF_ZINIT = 1 << 13, PF_LAST = 1 << 14,
@@ -92,6 +92,10 @@ enum {
 // PK_ATT   a1 = dk | nh << 8 | W << 16; a2 = i0 | j0 << 16; a3 = head | key tile << 8; p0 qkv, p1 ap
 // PK_MERGE a1 = C; a2 = t; a3 = dk | nh << 8; p0 ap, p3 out; b0 = cells per key tile
 // PK_COUPLE a1 = C (= 2H); a2 = t; a3 = np | H << 16; p0 part, p1 u cells, p2 u plain, p3 out, p4 oplain; b0/b1 = part stride; b4 = pT
+// PK_DUR   (one worker) a1 = T_x; a2 = frame capacity (0: none); flag PF_PLAIN_IN: logw is not waited for (no duration predictor in this
+//          program); p0 logw cells [T_x], p1 dur (plain int), p2 cum (plain int), p3 cum cells, p4 y_len int32, p5 y_len int64, p6 y_len cell
+// PK_EXPAND a1 = I; a2 = frame f; a3 = T_x; flag PF_PLAIN_IN: stats / cum are plain arrays of an earlier launch; p0 stats cells [T_x][2I] or
+//          plain [2I][T_x], p1 cum cells or plain int [T_x], p3 out cells [T_y][I], p4 oplain [I][pT]; b4 = pT
 struct alignas(16) PRec {
   int kf, a1, a2, a3;
   unsigned long long p[10];
@@ -107,6 +111,11 @@ struct PProgram {
   float* logw;                          // duration predictor result [T] (plain floats)
   int* err;
   const PRec* recs;                     // [n_steps][P]
+  // programs that cover both halves of the forward (text side laid out for T_x, frame side for T_y): from step seg_step on the kernel
+  // works with (T2, Tp2) and the utterance's frame count, which the PK_DUR step of the SAME launch publishes in the cell len2 (-1: one half only)
+  int seg_step, T2, Tp2;
+  const ll_t* len2;
+  ll_t* logw_cells;                     // duration predictor result as cells for PK_DUR (null: plain only)
 };
 
 struct PCall {                          // per-call values (by value: a captured graph re-reads `dv`, not these, when dv != null)
@@ -119,6 +128,10 @@ struct PCall {                          // per-call values (by value: a captured
   const SynthDev* dv;
   const unsigned long long* item_seeds;
   long long* trace;                     // tools only (VITS_PS_TRACE): [P][PS_MAX_STEPS][8] cycle stamps, null in production
+  const int* forced;                    // PK_DUR: pinned durations [T_x] (null: from logw)
+  float length_scale, noise_scale;      // PK_DUR / PK_EXPAND (overridden by dv)
+  const float* noise_prior;             // PK_EXPAND: injected prior noise [I][noise_stride] or null (Philox stream 2)
+  long long noise_stride;
   int tune;                             // experiment switches (VITS_PS_TUNE; default PS_TUNE_DEFAULT): bit 0 = pull the next matrix step's weights into L2 ahead of time
   int* dbg;                             // device words of the model: [0] poll rounds before a worker gives up (0 = PS_SPIN_LIMIT; tests shrink it to
                                         // force the fallback -- read at run time, so captured graphs follow the hook), [1] completed persistent launches
@@ -172,6 +185,9 @@ __device__ __forceinline__ bool ps_again(PsCtx& cx, bool pending) {
   if (!pending || __builtin_amdgcn_readfirstlane(cx.aborted)) { cx.spins = 0; return false; }
   const int spins = __builtin_amdgcn_readfirstlane(cx.spins) + 1;
   cx.spins = spins;
+  // a poll that has failed a few rounds is waiting for something that is far away (another stage of the program, a slow worker): back
+  // off instead of hammering the fabric next to the workers that are computing (MI355X_MICROARCH.md "polling-cost")
+  if (spins > 8) __builtin_amdgcn_s_sleep(8);
   if ((spins & 1023) == 0 &&
       __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { cx.aborted = 1; return false; }
   if (spins >= cx.limit) {
@@ -352,7 +368,8 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int rank = blockIdx.x, P = gridDim.x;
-  const int n_steps = prog->n_steps, T = prog->T, Tp = prog->Tp;
+  const int n_steps = prog->n_steps, seg_step = prog->seg_step;
+  int T = prog->T, Tp = prog->Tp;
   const PS_G PRec* recs = (const PS_G PRec*)prog->recs;
   // record of step s for this worker: lanes 0..7 read its eight dwordx4 (the other lanes read along: same lines)
   auto load_rec = [&](int s) -> ps_i4 {
@@ -395,6 +412,20 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     const ps_i4 rv = rvB;
     const int kf = PR_I(rv, 0), kind = kf & 0xff;
     rvB = load_rec(s + 1);  // (an L2 hit; older than everything else this step requests)
+    if (s == seg_step) {
+      // second half of a two-halves program: from here on the frame-side geometry, and the frame count this launch's PK_DUR step
+      // publishes.  EVERY worker passes here (also the ones that idle in this step), so it sits in front of the idle test; a worker
+      // that has been idle through the whole duration predictor waits here for ~100 us -- ps_again backs off (s_sleep) after a few rounds.
+      const PS_G ll_t* lc = (const PS_G ll_t*)prog->len2;
+      ll_t q;
+      bool pending;
+      do {
+        q = ll_load(lc);
+        pending = PS_PENDING(ll_bad(q, epoch));
+      } while (ps_again(cx, pending));
+      len_raw = __builtin_amdgcn_readfirstlane((int)(unsigned)q);  // (the cell's value field holds the integer)
+      T = prog->T2; Tp = prog->Tp2;
+    }
     if (kind == PK_IDLE) continue;  // nothing to do and nothing to wait for in this step
     PS_STAMP(0);
     // This step's own operands (weight fragments, packed parameters, epilogue vectors), requested FIRST: the record decode and the
@@ -551,6 +582,135 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
         }
         PS_STAMP(1); PS_REC_READY();
         if (ok) ll_store(out + (long long)t * C + hd * dk + d, r, epoch);
+      }
+      PS_STAMP(3);
+      continue;
+    }
+
+    if (kind == PK_DUR) {
+      // ================================================================== durations, cumulative sums, frame count (one worker)
+      // w = ceil(exp(logw) * length_scale) * mask, cumsum, y_length = max(sum, 1)   (models.py:1689-1694; durations_kernel); thread = token
+      const int Tx = PR_I(rv, 1), Tcap = PR_I(rv, 2);
+      const PS_G ll_t* lwc = PR_P(const ll_t, rv, 0);
+      int* redi = reinterpret_cast<int*>(red);
+      float length_scale = call.length_scale;
+      if (call.dv) length_scale = call.dv->scales[1];
+      const bool tok = tid < Tx;
+      float lw = 0.f;
+      if (!(kf & PF_PLAIN_IN)) {  // wait for the duration predictor of THIS launch (also when the durations are pinned: the benchmark's
+        // dependency chain is the production one)
+        unsigned o = (unsigned)(tok ? tid : 0) * 8u;
+        bool pending;
+        do {
+          asm volatile("" : "+v"(o));
+          ll_t q = (ll_t)epoch << 32;
+          if (tok) q = ll_load_off(lwc, o);
+          lw = ll_val(q);
+          pending = PS_PENDING(ll_bad(q, epoch));
+        } while (ps_again(cx, pending));
+      }
+      PS_STAMP(1); PS_REC_READY();
+      int d = 0;
+      if (tok && tid < L) d = call.forced ? call.forced[tid] : (int)ceilf(expf(lw) * length_scale);
+      if (d < 0) d = 0;
+      // inclusive scan: DPP inside a wave, wave totals through LDS
+      int v = d;
+#define PS_IDPP(x, CTRL, RM) __builtin_amdgcn_update_dpp(0, (x), (CTRL), (RM), 0xF, false)
+      v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+      v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+      v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+      v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+      v += PS_IDPP(v, 0x142, 0xA);                                    // row_bcast:15 -> rows 1 and 3
+      v += PS_IDPP(v, 0x143, 0xC);                                    // row_bcast:31 -> rows 2 and 3
+#undef PS_IDPP
+      if (lane == 63) redi[wave] = v;
+      __syncthreads();
+      int base = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < PS_WAVES; ++w) { const int x = redi[w]; total += x; base += w < wave ? x : 0; }
+      const int cum = base + v;
+      int yl = total < 1 ? 1 : total;
+      if (Tcap > 0 && yl > Tcap) { if (tid == 0) atomicOr((int*)prog->err, 4); yl = Tcap; }
+      if (tok) {
+        PR_P(int, rv, 1)[tid] = d;
+        PR_P(int, rv, 2)[tid] = cum;
+        ll_store(PR_P(ll_t, rv, 3) + tid, __int_as_float(cum), epoch);
+      }
+      if (tid == 0) {
+        PR_P(int, rv, 4)[0] = yl;
+        if (PR_P(long long, rv, 5)) PR_P(long long, rv, 5)[0] = yl;
+        ll_store(PR_P(ll_t, rv, 6), __int_as_float(yl), epoch);
+      }
+      PS_STAMP(3);
+      continue;
+    }
+
+    if (kind == PK_EXPAND) {
+      // ================================================================== length regulator + prior sample, frame f:
+      // z_p[:, f] = m_p[:, tok] + eps * exp(logs_p[:, tok]) * noise_scale, tok = the token whose span holds f   (models.py:1696-1700 as a
+      // gather, expand_prior_kernel); thread = channel
+      const int I = PR_I(rv, 1), f = PR_I(rv, 2), Tx = PR_I(rv, 3), pT = PR_B(rv, 4);
+      const bool plain = (kf & PF_PLAIN_IN) != 0;
+      PS_G ll_t* out = PR_P(ll_t, rv, 3);
+      PS_G float* oplain = PR_P(float, rv, 4);
+      int* redi = reinterpret_cast<int*>(red);
+      const int c = (wave & 3) * 64 + lane, h = wave >> 2;
+      const bool cok = c < I && h == 0;
+      float o = 0.f;
+      if (f < L) {  // (worker-uniform) frames beyond the utterance: zeros, nothing to wait for
+        // tok = number of tokens whose cumulative duration is <= f (= first j with cum[j] > f; f < y_length <= cum[Tx - 1])
+        const bool iok = tid < Tx;
+        int cv = 0;
+        if (plain) { if (iok) cv = PR_P(const int, rv, 1)[tid]; }
+        else {
+          const PS_G ll_t* cc = PR_P(const ll_t, rv, 1);
+          unsigned oc = (unsigned)(iok ? tid : 0) * 8u;
+          bool pending;
+          do {
+            asm volatile("" : "+v"(oc));
+            ll_t q = (ll_t)epoch << 32;
+            if (iok) q = ll_load_off(cc, oc);
+            cv = (int)(unsigned)q;
+            pending = PS_PENDING(ll_bad(q, epoch));
+          } while (ps_again(cx, pending));
+        }
+        const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(iok && cv <= f));
+        if (lane == 0) redi[wave] = cnt;
+        __syncthreads();
+        int tk = 0;
+#pragma unroll
+        for (int w = 0; w < PS_WAVES; ++w) tk += redi[w];
+        tk = tk < Tx ? tk : Tx - 1;
+        float mu = 0.f, ls = 0.f;
+        if (plain) {
+          const PS_G float* st = PR_P(const float, rv, 0);
+          if (cok) { mu = st[c * Tx + tk]; ls = st[(I + c) * Tx + tk]; }
+        } else {
+          const PS_G ll_t* st = PR_P(const ll_t, rv, 0);
+          unsigned om = (unsigned)(tk * 2 * I + (cok ? c : 0)) * 8u;
+          bool pending;
+          do {
+            asm volatile("" : "+v"(om));
+            ll_t q0 = (ll_t)epoch << 32, q1 = q0;
+            if (cok) { q0 = ll_load_off(st, om); q1 = ll_load_off(st, om + (unsigned)I * 8u); }
+            mu = ll_val(q0); ls = ll_val(q1);
+            pending = PS_PENDING(ll_bad(q0, epoch) | ll_bad(q1, epoch));
+          } while (ps_again(cx, pending));
+        }
+        PS_STAMP(1);
+        float noise_scale = call.noise_scale;
+        unsigned long long seed = call.seed;
+        if (call.dv) { noise_scale = call.dv->scales[0]; seed = call.dv->seed; }
+        if (call.solo && call.item_seeds) seed = call.item_seeds[0];
+        if (cok) {
+          const float e = call.noise_prior ? call.noise_prior[(long long)c * call.noise_stride + f] : philox_normal(seed, 2, (uint32_t)c, (uint32_t)f);
+          o = mu + e * expf(ls) * noise_scale;
+        }
+      }
+      PS_REC_READY();
+      if (cok) {
+        if (out) ll_store(out + (long long)f * I + c, o, epoch);
+        if (oplain && f < pT) oplain[(long long)c * pT + f] = o;
       }
       PS_STAMP(3);
       continue;
@@ -1144,7 +1304,9 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
             }
             if ((kf & PF_LAST) && t < T) {
               const float zz = ea_row == x0r ? v0 : v1;
-              ((PS_G float*)prog->logw)[t] = t < L ? (zz - ea_m) * ea_is : 0.f;
+              const float lw = t < L ? (zz - ea_m) * ea_is : 0.f;
+              ((PS_G float*)prog->logw)[t] = lw;
+              if (prog->logw_cells) ll_store((PS_G ll_t*)prog->logw_cells + t, lw, epoch);
             }
           }
         }

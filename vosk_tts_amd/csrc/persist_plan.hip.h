@@ -105,6 +105,7 @@ static size_t persist_flow_cells(const vits_model* m, int B, int Ty) {
 enum { PS_EPI_STORE = 0, PS_EPI_SPLINE = 1, PS_EPI_GATE = 2 };
 struct PStep {
   int kind;
+  int Tp;                  // padded column count of the segment the step belongs to (set by PBuild::push)
   // ---- PK_MM: y[Cout x 16-column tile] (+)= W[Cout x ks*Cin*K] * window(B)
   int Cin;                 // contraction channels of ONE K-slice (multiple of 16, <= PS_MAXC)
   int cin_pitch;           // channel pitch of the operand cells
@@ -214,6 +215,7 @@ struct PBuild {
   PStep& push(const PStep& st) {
     if ((int)steps->size() >= PS_MAX_STEPS) { overflow = true; return steps->back(); }
     steps->push_back(st);
+    steps->back().Tp = Tp;
     return steps->back();
   }
   // matrix step skeleton for conv W over cells `bin` (channel pitch cin_pitch, first channel c_off, direction c_sign)
@@ -300,9 +302,10 @@ static const ll_t* persist_encoder_layer(PBuild& b, const EncLayerW& L, const En
 }
 
 // ---- steps -> one record per (step, worker)
-static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, int P, int T, int Tp, std::vector<PRec>& recs, bool& bad) {
+static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, int P, int seg_pstep, int& seg_step, std::vector<PRec>& recs, bool& bad) {
   vits_model* m = s->m;
-  const int ntn = Tp / 16;
+  int Tp = 16, ntn = 1;  // (per step: a two-halves program changes geometry at seg_pstep)
+  seg_step = -1;
   auto U = [](const void* p) { return (unsigned long long)(uintptr_t)p; };
   PRec idle;
   memset(&idle, 0, sizeof idle);
@@ -336,8 +339,30 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
       used[nx] = 1;
     }
   };
-  for (const PStep& st : steps) {
-    if (st.kind == PK_MM) {
+  for (size_t si = 0; si < steps.size(); ++si) {
+    const PStep& st = steps[si];
+    Tp = st.Tp; ntn = Tp / 16;
+    if ((int)si == seg_pstep) seg_step = (int)(recs.size() / P);
+    if (st.kind == PK_DUR) {
+      PRec* R = new_step();
+      PRec& r = R[0];
+      r.kf = PK_DUR | (st.dw ? 0 : PF_PLAIN_IN);
+      r.a1 = st.C; r.a2 = st.dil;
+      r.p[0] = U(s->ps_x_logw); r.p[1] = U(s->dur); r.p[2] = U(s->cum); r.p[3] = U(s->ps_x_cum);
+      r.p[4] = U(s->len_y); r.p[5] = U(s->ylen64); r.p[6] = U(s->ps_x_leny);
+    } else if (st.kind == PK_EXPAND) {
+      if (Tp > P) { bad = true; return; }
+      PRec* R = new_step();
+      for (int t = 0; t < Tp; ++t) {
+        PRec& r = R[t];
+        r.kf = PK_EXPAND | (st.dw ? 0 : PF_PLAIN_IN);
+        r.a1 = st.C; r.a2 = t; r.a3 = s->Tx;
+        r.p[0] = st.dw ? U(s->ps_x_stats) : U(s->stats);
+        r.p[1] = st.dw ? U(s->ps_x_cum) : U(s->cum);
+        r.p[3] = U(st.out); r.p[4] = U(st.oplain);
+        r.b[4] = st.plain_T;
+      }
+    } else if (st.kind == PK_MM) {
       const int items = ntn * st.G * st.ks;
       if (items > P) { bad = true; return; }
       PRec* R = new_step();
@@ -458,7 +483,6 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
       nx = (kb < 512 && n_u < 128) ? (n_u | (nblk << 7) | (kb << 11)) : 0;
     }
   }
-  (void)T;
 }
 
 static void persist_upload(vits_session* s, vits_session::PersistProg& pp, PBuild& b) {
@@ -469,8 +493,10 @@ static void persist_upload(vits_session* s, vits_session::PersistProg& pp, PBuil
   const int P = m->n_cu;
   std::vector<PRec> recs;
   bool bad = false;
-  persist_resolve(s, *b.steps, P, b.T, b.Tp, recs, bad);
-  if (bad || recs.empty()) return;
+  int seg_step = -1;
+  persist_resolve(s, *b.steps, P, pp.h.seg_step, seg_step, recs, bad);
+  if (bad || recs.empty() || (pp.h.seg_step >= 0 && seg_step < 0)) return;
+  pp.h.seg_step = seg_step;
   const size_t bytes = recs.size() * sizeof(PRec);
   if (bytes > pp.recs_bytes) {
     if (pp.recs_d) { hipStreamSynchronize(s->stream); hipFree(pp.recs_d); pp.recs_d = nullptr; pp.recs_bytes = 0; }
@@ -493,27 +519,30 @@ static void persist_upload(vits_session* s, vits_session::PersistProg& pp, PBuil
   if (hipMemcpyAsync(pp.d, &pp.h, sizeof(PProgram), hipMemcpyHostToDevice, s->stream) != hipSuccess) return;
   pp.ok = true;
 }
+// geometry / exchange region of the segment that is being built
+static void seg_geom(PBuild& b, int T) { b.T = T; b.Tp = cdiv(T, 16) * 16; b.ntn = b.Tp / 16; }
+static void seg_cells(PBuild& b, vits_session::PersistProg& region) { b.cur = region.ll; b.end = region.ll + region.cells; }
+
 static void persist_begin(vits_session* s, vits_session::PersistProg& pp, PBuild& b, std::vector<PStep>& steps, int T, const int* len) {
   vits_model* m = s->m;
   memset(&pp.h, 0, sizeof(PProgram));
   steps.clear();
   steps.reserve(PS_MAX_STEPS + 1);
   b.m = m; b.steps = &steps; b.cur = pp.ll; b.end = pp.ll + pp.cells;
-  b.T = T; b.Tp = cdiv(T, 16) * 16; b.ntn = b.Tp / 16;
+  seg_geom(b, T);
   PProgram& P = pp.h;
   P.T = T; P.Tp = b.Tp;
   P.nb = m->hp.dp_num_bins; P.bound = m->hp.dp_tail_bound; P.inv_sqrt_d = 1.0f / sqrtf((float)m->hp.dp_filter_channels);
   P.len = len; P.ea_m = m->ea_m ? m->ea_m : m->zeros; P.ea_logs = m->ea_logs ? m->ea_logs : m->zeros; P.logw = s->logw; P.err = s->d_err;
+  P.seg_step = -1;
 }
 
-// text encoder (models.py:317-326): embedding, n_layers encoder layers, proj -> s->x (plain, masked) and s->stats (plain)
-static void persist_build_enc(vits_session* s) {
+// ---- segments (a program is one segment, or several laid one after the other: persist_build_front / _back / _full)
+// text encoder (models.py:317-326): embedding, n_layers encoder layers, proj -> s->x (plain, masked) and s->stats (plain); with
+// stats_cells also as cells [Tp][2I] for a PK_EXPAND step of the same launch.  Returns the encoder output as cells [Tp][H].
+static const ll_t* seg_enc(vits_session* s, PBuild& b, ll_t* stats_cells) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
-  vits_session::PersistProg& pp = s->ps_enc;
-  PBuild b;
-  std::vector<PStep> steps;
-  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
   const int H = hp.hidden_channels, n = (int)m->enc_p.layers.size();
   const int cond_layer = (m->use_g && m->cond_enc_off >= 0) ? hp.enc_cond_layer : -1;
   const float* vec = cond_layer >= 0 ? s->condv + m->cond_enc_off : nullptr;
@@ -528,27 +557,27 @@ static void persist_build_enc(vits_session* s) {
   st = b.mm(m->enc_proj, x, H);
   st.in_mask = 1; st.out_mask = 1;
   st.yplain = s->stats;
+  st.yout = stats_cells;
   b.push(st);
-  persist_upload(s, pp, b);
+  return x;
 }
 
-// stochastic duration predictor, reverse (models.py:56-63,93-101)
-static void persist_build_sdp(vits_session* s) {
+// stochastic duration predictor, reverse (models.py:56-63,93-101); x_cells: the text encoder output of the SAME launch (null: the plain
+// s->x an earlier launch left)
+static void seg_sdp(vits_session* s, PBuild& b, const ll_t* x_cells) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
-  vits_session::PersistProg& pp = s->ps_sdp;
-  PBuild b;
-  std::vector<PStep> steps;
-  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
-  const int D = hp.dp_filter_channels, nl = (int)m->dp_dds.pw.size(), K = hp.dp_kernel_size;
+  std::vector<PStep>& steps = *b.steps;
+  const int D = hp.dp_filter_channels, nl = (int)m->dp_dds.pw.size(), K = hp.dp_kernel_size, H = hp.hidden_channels;
   // dp.pre (+ cond(g)) -> x0 ; z = noise * noise_scale_w          (models.py:58-60,96)
-  PStep st = b.mm(m->dp_pre, nullptr, 0);
-  st.bin_plain = s->x;
+  PStep st = b.mm(m->dp_pre, x_cells, H);
+  if (!x_cells) st.bin_plain = s->x;
   if (m->use_g && m->cond_dp_off >= 0) st.cond = s->condv + m->cond_dp_off;
   st.zinit = 1;
   st.yout = b.take_rows(D); st.zout = b.take_rows(2);
+  const size_t first = steps.size();
   const ll_t* x = b.push(st).yout;
-  const ll_t* z = steps[0].zout;
+  const ll_t* z = steps[first].zout;
   // one DDSConv stack + the 1x1 conv that consumes it (modules.py:96-108): per layer a column step (finish the previous layer,
   // depthwise conv, LN1, GELU) and a matrix step (the layer's 1x1 conv); then the last finish and the projection
   auto stack = [&](const DDSW& Wd, const ConvW& proj, bool spline, const ll_t* xin, const ll_t* zc, int z_row, const float* pw, const float* pb) -> PStep& {
@@ -580,7 +609,7 @@ static void persist_build_sdp(vits_session* s) {
       y2 = b.push(st).yout;
       dil *= K;
     }
-    return steps[0];  // not reached
+    return steps[first];  // not reached
   };
   {
     PStep& pj = stack(m->dp_dds, m->dp_proj, false, x, nullptr, 0, nullptr, nullptr);
@@ -596,19 +625,14 @@ static void persist_build_sdp(vits_session* s) {
     if (k > 1) { pj.zout = b.take_rows(2); z = pj.zout; }
     else { pj.last = 1; pj.ea_row = swap ^ 1; }
   }
-  persist_upload(s, pp, b);
 }
 
-// flow, reverse (models.py:750-757, 374-393): z_p (plain, s->zA) -> z (plain, s->zB)
-static void persist_build_flow(vits_session* s) {
+// flow, reverse (models.py:750-757, 374-393): z_p -> z (plain, s->zB); zp_cells: the prior sample of the SAME launch (null: plain s->zA)
+static void seg_flow(vits_session* s, PBuild& b, const ll_t* zp_cells) {
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
-  vits_session::PersistProg& pp = s->ps_flow;
-  PBuild b;
-  std::vector<PStep> steps;
-  persist_begin(s, pp, b, steps, s->Ty, s->len_y);
   const int H = hp.hidden_channels, I = hp.inter_channels, half = I / 2, L = hp.flow_wn_layers;
-  const ll_t* u = nullptr;  // previous z as cells (null: the plain z_p of the first layer)
+  const ll_t* u = zp_cells;  // previous z as cells (null: the plain z_p of the first layer)
   for (int f = hp.flow_n_flows - 1; f >= 0; --f) {
     const CouplingW& C = m->flow[f];
     // h = pre(x0) * mask, x0[c] = u[I-1-c]  (models.py:375-376 after Flip)
@@ -650,6 +674,80 @@ static void persist_build_flow(vits_session* s) {
     if (f == 0) st.oplain = s->zB;
     u = b.push(st).out;
   }
+}
+
+// PK_DUR: durations / cumsum / frame count of the utterance (one worker).  with_logw: wait for the duration predictor of this launch
+static void seg_dur(vits_session* s, PBuild& b, bool with_logw, int Tcap) {
+  PStep st = b.blank(PK_DUR);
+  st.C = s->Tx; st.dil = Tcap; st.dw = with_logw ? 1 : 0;
+  b.push(st);
+}
+// PK_EXPAND: z_p of every frame.  cells: stats / cum / frame count come from THIS launch (else: the plain arrays an earlier launch left)
+static const ll_t* seg_expand(vits_session* s, PBuild& b, bool cells) {
+  PStep st = b.blank(PK_EXPAND);
+  st.C = s->m->hp.inter_channels; st.dw = cells ? 1 : 0;
+  st.out = s->ps_x_zp;
+  st.oplain = s->zA;
+  return b.push(st).out;
+}
+
+static void persist_build_enc(vits_session* s) {
+  vits_session::PersistProg& pp = s->ps_enc;
+  PBuild b;
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
+  seg_enc(s, b, nullptr);
+  persist_upload(s, pp, b);
+}
+static void persist_build_sdp(vits_session* s) {
+  vits_session::PersistProg& pp = s->ps_sdp;
+  PBuild b;
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
+  seg_sdp(s, b, nullptr);
+  persist_upload(s, pp, b);
+}
+static void persist_build_flow(vits_session* s) {
+  vits_session::PersistProg& pp = s->ps_flow;
+  PBuild b;
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Ty, s->len_y);
+  seg_flow(s, b, nullptr);
+  persist_upload(s, pp, b);
+}
+
+// ---- programs of the graph-replayed paths: the stages of one forward in ONE launch each side of the host's T_y round trip, or in one
+// launch altogether where the caller brings the frame capacity (device sessions).  They use the exchange regions of the single-stage
+// programs (a session never runs two programs at once) plus the small region ps_x (stats / logw / cum / frame count / z_p cells).
+//   front = text encoder [+ duration predictor] + PK_DUR            (phase 1 of vits_synthesize*)
+//   back  = PK_EXPAND + flow                                          (phase 2)
+//   full  = front + back, frame capacity = the session's T_y          (vits_session_synthesize_device)
+static void persist_build_front(vits_session* s, vits_session::PersistProg& pp, bool with_sdp, int Tcap, bool and_back) {
+  PBuild b;
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Tx, s->len_x);
+  pp.h.logw_cells = s->ps_x_logw;
+  seg_cells(b, s->ps_enc);
+  const ll_t* x = seg_enc(s, b, and_back ? s->ps_x_stats : nullptr);
+  if (with_sdp) { seg_cells(b, s->ps_sdp); seg_sdp(s, b, x); }
+  seg_dur(s, b, with_sdp, Tcap);
+  if (and_back) {
+    pp.h.seg_step = (int)steps.size();  // (= its index among the resolved steps as long as no earlier step splits: checked in persist_resolve)
+    pp.h.T2 = s->Ty; pp.h.Tp2 = cdiv(s->Ty, 16) * 16; pp.h.len2 = s->ps_x_leny;
+    seg_geom(b, s->Ty);
+    const ll_t* zp = seg_expand(s, b, true);
+    seg_cells(b, s->ps_flow);
+    seg_flow(s, b, zp);
+  }
+  persist_upload(s, pp, b);
+}
+static void persist_build_back(vits_session* s, vits_session::PersistProg& pp) {
+  PBuild b;
+  std::vector<PStep> steps;
+  persist_begin(s, pp, b, steps, s->Ty, s->len_y);
+  const ll_t* zp = seg_expand(s, b, false);
+  seg_cells(b, s->ps_flow);
+  seg_flow(s, b, zp);
   persist_upload(s, pp, b);
 }
 
@@ -666,9 +764,24 @@ static void persist_plan(vits_session* s) {
   }
   for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow})
     if (pp->cells && pp->ll && hipMemsetAsync(pp->ll, 0, pp->cells * sizeof(ll_t), s->stream) != hipSuccess) return give_up();
+  if (s->ps_x.cells && s->ps_x.ll && hipMemsetAsync(s->ps_x.ll, 0, s->ps_x.cells * sizeof(ll_t), s->stream) != hipSuccess) return give_up();
   if (s->ps_enc.cells && s->ps_enc.ll) persist_build_enc(s);
   if (s->ps_sdp.cells && s->ps_sdp.ll) persist_build_sdp(s);
   if (s->ps_flow.cells && s->ps_flow.ll) persist_build_flow(s);
+  for (int k = 0; k < 2; ++k) { s->ps_front[k].ok = false; s->ps_full[k].ok = false; }
+  s->ps_back.ok = false;
+  if (s->ps_x.cells && s->ps_x.ll) {
+    const bool enc = s->ps_enc.ok, sdp = s->ps_sdp.ok, flow = s->ps_flow.ok;
+    if (enc) {
+      persist_build_front(s, s->ps_front[0], false, 0, false);
+      if (sdp) persist_build_front(s, s->ps_front[1], true, 0, false);
+    }
+    if (flow) persist_build_back(s, s->ps_back);
+    if (enc && flow && s->Ty > 1) {
+      persist_build_front(s, s->ps_full[0], false, s->Ty, true);
+      if (sdp) persist_build_front(s, s->ps_full[1], true, s->Ty, true);
+    }
+  }
   // the programs live in pageable memory of the session: the copies must not outlive this call's view
   if (hipStreamSynchronize(s->stream) != hipSuccess) give_up();
 }
