@@ -57,6 +57,8 @@ typedef struct stts_synth_opts {
   uint64_t seed;         /* Philox seed when noise == NULL */
   int32_t n_timesteps;   /* 0 = hparams.n_timesteps */
   int32_t flags;
+  const uint64_t* item_seeds; /* stts_synthesize_batch only: [B] Philox seed of every item (NULL: seed + b), so that what a request
+                               * gets does not depend on what it was batched with (MultiDeviceSynth) */
 } stts_synth_opts;
 
 /* The hot path for ONE utterance: MatchaTTS.synthesise (matcha_tts.py:93-211) -> denormalised mel ->
@@ -80,7 +82,7 @@ int stts_stream_open(stts_model* m, const int64_t* ids, int32_t T_x, const float
 
 /* Batch of B independent utterances (throughput; not part of the reference, whose synthesise() takes one): item b gives
  * exactly what stts_synthesize returns for ids[b][:, :lengths[b]], sid[b], bert[b], phone_duration_extra[b] and seed
- * opts->seed + b -- every kernel masks or zero-pads per item, the unmasked convs of the estimator see zeros beyond each
+ * opts->item_seeds[b] (opts->seed + b without item seeds) -- every kernel masks or zero-pads per item, the unmasked convs of the estimator see zeros beyond each
  * item's own padded length, the vocoder decodes every item as if alone.  ids [B,5,T_x], lengths [B], sid [B],
  * bert [B,768,T_x] or NULL, phone_duration_extra [B,T_x] or NULL; opts->noise must be NULL.
  * out_audio: library-owned float [B, *out_samples], zero beyond out_lengths[b] samples. */

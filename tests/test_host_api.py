@@ -396,6 +396,208 @@ def test_multi_device_synth_on_two_devices(tmp_path):
         assert x.shape == y.shape and np.abs(x.astype(np.int32) - y.astype(np.int32)).max() <= 1, f"request {i}"
 
 
+def test_request_coalescer_batches_concurrent_requests_and_routes_results():
+    """RequestCoalescer (session.py; no GPU needed): a lone request runs at once and alone; requests that arrive while a call is in
+    flight are handed to ONE waiter as one batch (same key only, at most max_batch), every caller gets its own result, and an
+    exception of a batch reaches every member of it."""
+    import threading
+    import time
+
+    from vosk_tts_amd.session import RequestCoalescer
+
+    seen = []
+    gate = threading.Event()
+
+    def run_batch(key, reqs):
+        seen.append((key, [r[2] for r in reqs]))
+        if key == "boom":
+            raise RuntimeError("engine failure")
+        if len(seen) == 1:
+            gate.wait(5)  # the first call stays in flight until the others have queued up
+        return [("out", key, r[2]) for r in reqs]
+
+    co = RequestCoalescer(run_batch, max_batch=4)
+    assert co.submit("a", None, 0, 100) == ("out", "a", 100) and seen == [("a", [100])]  # idle engine: alone, immediately
+    seen.clear()
+    results, errors = {}, {}
+
+    def call(key, seed):
+        try:
+            results[seed] = co.submit(key, None, 0, seed)
+        except RuntimeError as e:
+            errors[seed] = str(e)
+
+    first = threading.Thread(target=call, args=("a", 1))
+    first.start()
+    while not seen:
+        time.sleep(0.001)
+    rest = [threading.Thread(target=call, args=("a" if k < 7 else "boom", k)) for k in range(2, 10)]
+    for t in rest:
+        t.start()
+    while len(co._queue) < 8:
+        time.sleep(0.001)
+    gate.set()
+    for t in [first] + rest:
+        t.join(10)
+    assert (set(results) | set(errors)) == set(range(1, 10))
+    keys = [k for k, _ in seen]
+    sizes = [len(v) for _, v in seen]
+    assert seen[0] == ("a", [1]) and max(sizes) <= 4 and sum(sizes) == 9
+    assert all(len({kk}) == 1 for kk in keys)  # one key per engine call
+    for key, seeds in seen:
+        assert all((sd >= 7) == (key == "boom") for sd in seeds)
+    assert set(errors) == {7, 8, 9} and all(results[k] == ("out", "a", k) for k in range(1, 7))
+    assert co.calls == len(seen) + 1 and co.requests == 10 and co.largest == max(sizes) and not co._busy and not co._queue
+
+
+@pytest.mark.gpu
+def test_concurrent_single_requests_are_coalesced_and_equal_their_solo_calls(tmp_path):
+    """The reference's serving shape (one Synth shared by a thread pool, server/tts_server.py:35-57): 12 threads call run_pcm16 for one
+    utterance each at the same moment.  The coalescer merges the ones that queue up behind the first call into solo batches with
+    per-request seeds; every request gets, to one LSB, what it gets when it is the only call (coalescer off)."""
+    import threading
+
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), W.default_hparams(n_vocab=len(PHONEMES)))
+    model = Model(model_path=d, device=0)
+    synth = Synth(model)
+    sess = model.onnx
+    texts = ["прив+ет, м+ир!", "м+ир", "прив+ет прив+ет прив+ет м+ир, м+ир.", "м+ир прив+ет?", "прив+ет", "м+ир, м+ир, м+ир; прив+ет!"] * 2
+    feeds = []
+    for i, t in enumerate(texts):
+        ids = np.array([synth.g2p_noembed(t)], np.int64)
+        feeds.append({"input": ids, "input_lengths": np.array([ids.shape[1]], np.int64), "scales": np.array([0.8, 1.0, 0.8], np.float32),
+                      "sid": np.array([i % 7], np.int64), "bert": None, "phone_duration_extra": None, "vits.seed": 500 + i})
+    co = sess.coalescer
+    assert co is not None
+    sess.coalescer = None
+    solo = [sess.run_pcm16(f, 0.9, return_lengths=True) for f in feeds]
+    sess.coalescer = co
+    for rounds in range(2):
+        got = [None] * len(feeds)
+        start = threading.Barrier(len(feeds))
+
+        def work(k):
+            start.wait()
+            got[k] = sess.run_pcm16(feeds[k], 0.9, return_lengths=True)
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(feeds))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for k, ((pa, la), (pb, lb)) in enumerate(zip(solo, got)):
+            assert np.array_equal(la, lb) and pa.shape == pb.shape and pb.dtype == np.int16, f"request {k}"
+            assert np.abs(pa.astype(np.int32) - pb.astype(np.int32)).max() <= 1, f"request {k}"
+    assert co.requests == 2 * len(feeds) and co.calls < co.requests and co.largest >= 2
+    # the float entry point goes through the same door
+    a = sess.run(None, feeds[0])[0]
+    assert a.shape[:3] == (1, 1, 1) and a.shape[3] == solo[0][0].shape[1]
+    sess.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_blank", [0, 1])
+def test_bert_conditioned_vits_voice_streams_and_batches_over_replicas(tmp_path, no_blank):
+    """The remaining doors of a BERT-conditioned VITS voice (vosk_tts/synth.py:88-99): run_stream takes the `bert` feed (vits_stream_open
+    reads it through opts->bert) and its chunks concatenate to run()'s audio; MultiDeviceSynth front-ends such a voice (get_word_bert
+    + g2p / g2p_noblank, padded `bert` feed) over two replicas on device 0 and every request equals its own solo call."""
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd.batching import MultiDeviceSynth
+    from vosk_tts_amd.toymodel import write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), bert=True, no_blank=no_blank)
+    model = Model(model_path=d, device=0)
+    synth = Synth(model)
+    feed, _ = synth._feed("прив+ет, м+ир! прив+ет м+ир.", 3, None, None, None, None)
+    feed = dict(feed, **{"vits.seed": 11})
+    whole = model.onnx.run(None, feed)[0].reshape(-1)
+    chunks = list(model.onnx.run_stream(None, feed, chunk_frames=16))
+    assert len(chunks) > 1
+    assert_close("streamed BERT voice", whole, np.concatenate(chunks), 1e-4)
+    texts = ["прив+ет, м+ир!", "м+ир", "прив+ет прив+ет м+ир, м+ир.", "м+ир прив+ет?", "прив+ет"]
+    sids, seeds = [2, 0, 5, 1, 3], [101, 7, 33, 58, 4]
+    mds = MultiDeviceSynth(d, devices=[0, 0], max_batch=2)
+    try:
+        assert mds.family == "vits_bert"
+        got = mds.synth_batch(texts, speaker_ids=sids, seeds=seeds)
+        for i, t in enumerate(texts):
+            f, _ = synth._feed(t, sids[i], None, None, None, None)
+            want = model.onnx.run_pcm16(dict(f, **{"vits.seed": seeds[i]}), 1.0)[0]
+            assert got[i].dtype == np.int16 and got[i].shape == want.shape, i
+            assert np.abs(got[i].astype(np.int32) - want.astype(np.int32)).max() <= 1, i
+    finally:
+        mds.close()
+    model.onnx.close()
+
+
+@pytest.mark.gpu
+def test_multistream_voice_batches_over_replicas(tmp_path):
+    """MultiDeviceSynth on a multistream (StableTTS / Matcha) voice: the five-stream front end per request, stts_synthesize_batch per
+    replica with per-request seeds (stts_synth_opts.item_seeds), two replicas on device 0 -- every request equals Synth.synth_audio's
+    samples for the same seed (float -> int16: at most one LSB apart; the batch runs other conv kernels)."""
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd.batching import MultiDeviceSynth
+    from vosk_tts_amd.toymodel import write_toy_multistream_model
+
+    d = write_toy_multistream_model(str(tmp_path / "ms"))
+    model = Model(model_path=d, device=0)
+    synth = Synth(model)
+    texts = ["прив+ет, м+ир!", "м+ир.", "прив+ет прив+ет м+ир, м+ир.", "м+ир прив+ет?"]
+    sids, seeds = [1, 0, 2, 1], [21, 22, 23, 24]
+    mds = MultiDeviceSynth(d, devices=[0, 0], max_batch=2)
+    try:
+        assert mds.family == "multistream"
+        got = mds.synth_batch(texts, speaker_ids=sids, seeds=seeds)
+        for i, t in enumerate(texts):
+            f, sc = synth._feed(t, sids[i], None, None, None, None)
+            wav = model.onnx.run(None, dict(f, **{"vits.seed": seeds[i]}))[0][0]
+            want = synth.audio_float_to_int16(wav * sc)
+            assert got[i].shape == want.shape, (i, got[i].shape, want.shape)
+            assert np.abs(got[i].astype(np.int32) - want.astype(np.int32)).max() <= 2, i
+        with pytest.raises(NotImplementedError):
+            mds.synth_tokens([[1, 2, 3]])
+    finally:
+        mds.close()
+    model.onnx.close()
+
+
+@pytest.mark.gpu
+def test_two_replicas_on_one_device_arbitrate_the_persistent_programs(tmp_path):
+    """What an 8-GPU node runs per device, exercised on one: two Model replicas on device 0 (MultiDeviceSynth devices=[0, 0]) serving
+    single-utterance batches at the same time.  One persistent program may own a device at a time (a per-device token): whoever does
+    not get it runs the launch path -- no timeout, no error, and the samples do not depend on who won."""
+    import ctypes
+
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.batching import MultiDeviceSynth
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), W.default_hparams(n_vocab=len(PHONEMES)))
+    rng = np.random.default_rng(9)
+    tokens = [rng.integers(1, len(PHONEMES), size=int(n)).tolist() for n in rng.integers(20, 60, size=16)]
+    seeds = list(range(300, 316))
+    two = MultiDeviceSynth(model_path=d, devices=[0, 0], max_batch=1)   # batches of ONE: the persistent single-utterance path
+    one = MultiDeviceSynth(model_path=d, devices=[0], max_batch=1)
+    try:
+        lib = two.models[0].onnx._lib.lib
+        lib.vits_debug_persist_runs.restype = ctypes.c_int
+        lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
+        runs = lambda mds: [int(lib.vits_debug_persist_runs(m.onnx._model._h)) for m in mds.models]
+        b = one.synth_tokens(tokens, speaker_ids=1, seeds=seeds)
+        assert runs(one)[0] == 2 * len(tokens)  # alone on the device: front + back persistent launch per request
+        r0 = runs(two)
+        a = two.synth_tokens(tokens, speaker_ids=1, seeds=seeds)
+        r1 = runs(two)
+        took = [y - x for x, y in zip(r0, r1)]
+        assert sum(took) > 0 and all(t % 2 == 0 for t in took) and sum(took) <= 2 * len(tokens)
+    finally:
+        two.close(); one.close()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and np.abs(x.astype(np.int32) - y.astype(np.int32)).max() <= 1, f"request {i}"
+
+
 @pytest.mark.gpu
 def test_synth_stream_matches_synth_audio(tmp_path):
     """Synth.synth_stream: int16 chunks whose concatenation is synth_audio's PCM for the same seed."""

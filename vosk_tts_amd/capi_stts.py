@@ -11,7 +11,7 @@ from .weights_stts import SttsHParams
 
 class SttsOpts(ctypes.Structure):
     _fields_ = [("noise", c_f32p), ("noise_stride", ctypes.c_int64), ("seed", ctypes.c_uint64),
-                ("n_timesteps", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("n_timesteps", ctypes.c_int32), ("flags", ctypes.c_int32), ("item_seeds", ctypes.POINTER(ctypes.c_uint64))]
 
 
 class SttsModel:
@@ -129,15 +129,20 @@ class SttsModel:
                                            ctypes.byref(st), ctypes.byref(total)))
         return self._vocoder._drain(st, chunk_frames)
 
-    def synthesize_batch(self, ids, lengths, scales, sid, bert=None, phone_duration_extra=None, seed=0, n_timesteps=0):
+    def synthesize_batch(self, ids, lengths, scales, sid, bert=None, phone_duration_extra=None, seed=0, n_timesteps=0, item_seeds=None):
         """B independent utterances in one pass (stts_synthesize_batch): ids [B,5,T], lengths [B], sid [B];
         returns (audio float32 [B,S] zero-padded, out_lengths int64 [B] in samples).  Item b equals
-        synthesize(ids[b][:, :lengths[b]], ..., seed=seed + b)."""
+        synthesize(ids[b][:, :lengths[b]], ..., seed=item_seeds[b]) (seed + b without item seeds)."""
         ids = _i64(ids); lengths = _i64(lengths); sid = _i64(sid); scales = _f32(scales)
         B, five, T = ids.shape
         b = None if bert is None else _f32(bert)
         p = None if phone_duration_extra is None else _f32(phone_duration_extra)
         opts = SttsOpts(); opts.seed = seed; opts.n_timesteps = n_timesteps
+        if item_seeds is not None:
+            sd = np.ascontiguousarray(item_seeds, dtype=np.uint64)
+            if sd.shape != (B,):
+                raise ValueError("item_seeds must be [B]")
+            opts.item_seeds = sd.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
         au = c_f32p(); ns = ctypes.c_int64(); ol = np.zeros(B, np.int64)
         self.check(self._fn("synthesize_batch")(self._h, _p(ids, c_i64p), _p(lengths, c_i64p), B, T, _p(scales, c_f32p), _p(sid, c_i64p),
                                                 None if b is None else _p(b, c_f32p), None if p is None else _p(p, c_f32p),

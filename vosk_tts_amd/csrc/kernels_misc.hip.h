@@ -1205,11 +1205,12 @@ __global__ void copy_rows_kernel(const float* src, long long sb, float* dst, lon
 // graph serves every request of its shape bucket
 struct SttsDev { float temperature; float pad; unsigned long long seed; };
 __global__ void cfm_init_kernel(float* cat, long long cat_b, const float* noise, long long nstride, float temperature, uint64_t seed,
-                                int NF, int T, int B, int cfg, const SttsDev* dv) {
+                                int NF, int T, int B, int cfg, const SttsDev* dv, const unsigned long long* item_seeds = nullptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   if (dv) { temperature = dv->temperature; seed = dv->seed; }
-  const float v = (noise ? noise[(long long)c * nstride + t] : philox_normal(seed + (uint64_t)b, 3u, (uint32_t)c, (uint32_t)t)) * temperature;
+  const float v = (noise ? noise[(long long)c * nstride + t]
+                         : philox_normal(item_seeds ? item_seeds[b] : seed + (uint64_t)b, 3u, (uint32_t)c, (uint32_t)t)) * temperature;
   cat[(long long)b * cat_b + (long long)c * T + t] = v;
   if (cfg) cat[(long long)(B + b) * cat_b + (long long)c * T + t] = v;
 }

@@ -427,14 +427,14 @@ static void stts_durations_host(const stts_hparams& hp, const float* mu_dp, int 
 // B utterances; E.nb = B (no guidance) or 2B (items [B,2B) = the unconditional branch of items [0,B))
 static void stts_run_cfm(vits_session* s, const stts_model* m, SttsEst& E, const float* d_c, const float* d_mu2, const int* d_len, const float* d_noise,
                          long long nstride, float temperature, uint64_t seed, int B = 1, const int* d_lenT = nullptr, const SttsDev* dv = nullptr,
-                         bool setup_only = false) {
+                         bool setup_only = false, const unsigned long long* d_item_seeds = nullptr) {
   const stts_hparams& hp = m->hp;
   const int NF = hp.n_feats, H = hp.dec_hidden, T = E.T, cfg = E.nb > B ? 1 : 0;
   std::vector<float> tv, dtv;
   stts_time_grid(E.n_steps, tv, dtv);
   stts_est_setup(s, m, E, d_c, d_mu2, d_len, tv.data(), d_lenT);
   if (setup_only) return;
-  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, B, cfg, dv);
+  hipLaunchKernelGGL(cfm_init_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, d_noise, nstride, temperature, seed, NF, T, B, cfg, dv, d_item_seeds);
   for (int k = 0; k < E.n_steps; ++k) {
     stts_est_step(s, m, E, k);
     hipLaunchKernelGGL(cfm_euler_kernel, dim3(cdiv(T, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, E.dphi, dtv[k], hp.guidance_scale, NF, T, B, cfg);
@@ -1110,7 +1110,12 @@ int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* leng
   s->B = nb;
   s->ragged = B > 1;
   struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->tile_tabs = nullptr; s->tile_keys.clear(); } } ragged_off{s};
-  stts_run_cfm(s, m, E, d_c, d_mu2, d_len, nullptr, T, temperature, opts ? opts->seed : 0, B, d_lenT);
+  const unsigned long long* d_seeds = nullptr;
+  if (opts && opts->item_seeds) {
+    d_seeds = call.up(reinterpret_cast<const unsigned long long*>(opts->item_seeds), (size_t)B);
+    if (!d_seeds) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  }
+  stts_run_cfm(s, m, E, d_c, d_mu2, d_len, nullptr, T, temperature, opts ? opts->seed : 0, B, d_lenT, nullptr, false, d_seeds);
   hipLaunchKernelGGL(stts_mel_kernel, dim3(cdiv(Tm, 64), NF, B), dim3(64), 0, s->stream, E.cat, (long long)(NF + H) * T, T, d_pau, d_mel, NF, Tm, d_len,
                      hp.mel_std, hp.mel_mean);
   // ---- vocoder over the ragged batch, every item decoded as if alone (rag halo 0)
