@@ -441,13 +441,26 @@ def concurrency_leg(hp, device, seconds=0.4):
         lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
         runs = lambda: int(lib.vits_debug_persist_runs(sess._model._h))
 
-        def leg(n_threads, coalesce):
+        def leg(n_threads, coalesce, inflight=None):
             co = sess.coalescer
             if not coalesce:
                 sess.coalescer = None
+            keep_inflight = co.max_inflight if co is not None else 1
+            if co is not None and inflight is not None:
+                co.max_inflight = inflight
             try:
                 for _ in range(4):
                     synth.synth_audio(text, speaker_id=2)
+                if n_threads > 1:  # the same traffic untimed first: every batch-size / length bucket it produces gets its workspace and graphs
+                    wstop = time.perf_counter() + 0.5
+
+                    def warm():
+                        while time.perf_counter() < wstop:
+                            synth.synth_audio(text, speaker_id=2)
+
+                    wt = [threading.Thread(target=warm) for _ in range(n_threads)]
+                    [t.start() for t in wt]
+                    [t.join() for t in wt]
                 lat, samples = [[] for _ in range(n_threads)], [0] * n_threads
                 stop = time.perf_counter() + seconds
                 c0 = (co.calls, co.requests) if co is not None else (0, 0)
@@ -478,9 +491,13 @@ def concurrency_leg(hp, device, seconds=0.4):
                 return res
             finally:
                 sess.coalescer = co
+                if co is not None:
+                    co.max_inflight = keep_inflight
 
         out["coalesced"] = [leg(n, True) for n in (1, 4, 16)]
         out["uncoalesced_16_threads"] = leg(16, False)
+        if os.environ.get("BENCH_COALESCE_SWEEP"):  # tools: engine calls allowed in flight at once
+            out["inflight_sweep_16_threads"] = {str(k): leg(16, True, k) for k in (2, 3, 4, 8)}
         one = out["coalesced"][0]["requests_per_s"]
         out["speedup_16_threads_over_1"] = round(out["coalesced"][2]["requests_per_s"] / max(one, 1e-9), 2)
         sess.close()

@@ -447,7 +447,7 @@ def test_request_coalescer_batches_concurrent_requests_and_routes_results():
     for key, seeds in seen:
         assert all((sd >= 7) == (key == "boom") for sd in seeds)
     assert set(errors) == {7, 8, 9} and all(results[k] == ("out", "a", k) for k in range(1, 7))
-    assert co.calls == len(seen) + 1 and co.requests == 10 and co.largest == max(sizes) and not co._busy and not co._queue
+    assert co.calls == len(seen) + 1 and co.requests == 10 and co.largest == max(sizes) and co._busy == 0 and not co._queue
 
 
 @pytest.mark.gpu

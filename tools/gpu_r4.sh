@@ -22,6 +22,9 @@ libs)  # A/B of alternative builds (tools/ab_build.sh): every tools/bt/bt_*.so, 
   for rep in 1 2; do for so in tools/bt/bt_*.so; do
     echo "$so: $(VITS_MI355_LIB=$R/$so c2)" | tee -a $O/libs.txt
   done; done;;
+bench)  # the default driver line
+  timeout 900 python bench.py > $O/default_bench.json.txt 2> $O/default_bench.err; echo "bench rc=$?"; tail -c 300 $O/default_bench.err
+  python tools/bench_summary.py $O/default_bench.json.txt;;
 trace)
   for p in enc dp flow; do PS_DETAIL=1 timeout 200 python tools/ps_trace.py $p > $O/trace_$p.txt 2>&1; tail -2 $O/trace_$p.txt; done;;
 pmc)

@@ -12,6 +12,7 @@ is no CPU path.  Thread-safe: the gRPC server shares one Synth across worker thr
 (server/tts_server.py:39-40) and ctypes releases the GIL during the call.
 """
 import itertools
+import os
 import threading
 
 import numpy as np
@@ -34,19 +35,20 @@ class RequestCoalescer:
     """Merges concurrent single-utterance requests into solo batches (server shape: one Synth shared by a thread pool,
     server/tts_server.py:35-57 -- N threads each calling .run() for ONE utterance).
 
-    Natural batching, no timer: a request that finds the engine idle runs at once, alone (the persistent single-utterance path,
-    nothing added to its latency).  Requests that arrive while a call is in flight queue up; when that call returns, its thread
-    hands the queue's compatible requests (same scales / output kind / conversion scale, at most `max_batch`) to the first waiter,
+    Natural batching, no timer: a request that finds fewer than `max_inflight` engine calls running runs at once, alone (the first of
+    them on the persistent single-utterance path; nothing added to its latency).  Requests that arrive while `max_inflight` calls are in
+    flight queue up; when one of those calls returns, its thread hands the queue's compatible requests (same scales / output kind / conversion scale, at most `max_batch`) to the first waiter,
     which runs them as ONE padded VITS_FLAG_SOLO_BATCH call with per-request item seeds -- every item of a solo batch is its own
     single-utterance synthesis (own Philox streams, zeros beyond its own end), so what a request gets does not depend on what it was
     batched with -- and scatters the results.  Without this, N concurrent calls run N - 1 of them on the launch-per-layer path
     (one persistent program owner per device) and the GPU executes N small forwards one after the other."""
 
-    def __init__(self, run_batch, max_batch=32):
+    def __init__(self, run_batch, max_batch=32, max_inflight=1):
         self._run_batch = run_batch  # (key, [(ids, sid, seed), ...]) -> list of per-request results
         self.max_batch = int(max_batch)
+        self.max_inflight = max(1, int(max_inflight))  # engine calls that may run at the same time (the GPU overlaps a few small forwards)
         self._lock = threading.Lock()
-        self._busy = False
+        self._busy = 0
         self._queue = []
         self.calls = 0        # engine calls issued
         self.requests = 0     # requests served
@@ -55,11 +57,11 @@ class RequestCoalescer:
     def submit(self, key, ids, sid, seed):
         me = _Pending(key, ids, sid, seed)
         with self._lock:
-            if self._busy:
+            if self._busy >= self.max_inflight:
                 self._queue.append(me)
                 batch = None
             else:
-                self._busy = True
+                self._busy += 1
                 batch = [me]
         if batch is None:
             me.event.wait()
@@ -91,7 +93,7 @@ class RequestCoalescer:
                     head.lead = take
                     nxt = head
                 else:
-                    self._busy = False
+                    self._busy -= 1
             for p in batch:
                 if p is not me:
                     p.event.set()
@@ -113,7 +115,7 @@ class _Arg:
 
 
 class VitsSession:
-    def __init__(self, blob, device=0, lib=None, coalesce=True, max_batch=32):
+    def __init__(self, blob, device=0, lib=None, coalesce=True, max_batch=32, max_inflight=None):
         self._lib = lib or VitsLib()
         self._model = self._lib.create(blob, device)
         self.hp = self._model.hp
@@ -121,7 +123,12 @@ class VitsSession:
         self._seed_lock = threading.Lock()
         # concurrent single-utterance run() / run_pcm16() calls are merged into solo batches (RequestCoalescer); coalesce=False:
         # every call goes to the engine on its own, as in rounds 1-3
-        self.coalescer = RequestCoalescer(self._run_solo_batch, max_batch) if coalesce else None
+        if max_inflight is None:
+            # measured on MI355X (16 threads, 47-token requests, bench.py host_api.concurrent): 1 call in flight 1520 requests/s, 2-4: ~2000,
+            # 8: 2200, no coalescing: 2110 -- the device overlaps a handful of single-utterance forwards (one of them on the persistent
+            # programs); merging only starts beyond that, which also bounds the workspaces and streams a burst can pin
+            max_inflight = int(os.environ.get("VITS_COALESCE_INFLIGHT", "8"))
+        self.coalescer = RequestCoalescer(self._run_solo_batch, max_batch, max_inflight) if coalesce else None
 
     def _coalescable(self, feed, ids):
         """plain single-utterance requests only: no injected tensors, no pinned durations, no caller-chosen batch semantics"""
@@ -138,6 +145,14 @@ class VitsSession:
             if kind == "pcm":
                 return [self._model.synthesize_pcm16(ids, lens, scales, np.array([sid], np.int64), pcm_scale=scale, seed=seed)]
             return [self._model.synthesize(ids, lens, scales, np.array([sid], np.int64), seed=seed)]
+        # batch sizes come in powers of two (filled up with one-token dummies, whose padding tiles the ragged solo batch never
+        # computes): every (batch size, length bucket) is a workspace and two captured graphs inside the engine, and a thread pool
+        # produces every batch size between 1 and its own size
+        n_real = len(reqs)
+        n_pad = 1
+        while n_pad < n_real:
+            n_pad *= 2
+        reqs = list(reqs) + [(np.ones((1, 1), np.int64), 0, 0)] * (n_pad - n_real)
         lens = np.array([r[0].shape[1] for r in reqs], np.int64)
         batch = np.zeros((len(reqs), int(lens.max())), np.int64)
         for b, r in enumerate(reqs):
@@ -148,7 +163,7 @@ class VitsSession:
             out, ol = self._model.synthesize_pcm16(batch, lens, scales, sids, pcm_scale=scale, seed=int(seeds[0]), solo=True, item_seeds=seeds)
         else:
             out, ol = self._model.synthesize(batch, lens, scales, sids, seed=int(seeds[0]), solo=True, item_seeds=seeds)
-        return [(out[b:b + 1, :int(ol[b])].copy(), ol[b:b + 1].copy()) for b in range(len(reqs))]
+        return [(out[b:b + 1, :int(ol[b])].copy(), ol[b:b + 1].copy()) for b in range(n_real)]
 
     # -- onnxruntime.InferenceSession surface used by the reference ------------------------
     def get_inputs(self):
