@@ -91,7 +91,7 @@ def assert_close(name, ref, got, rtol, atol_frac=None):
 
 def load_reference_mas():
     """the reference's own compiled MAS core (oracle/_ref/mas/, built by __graft_entry__.build() where /root/reference exists;
-    the .so travels to the GPU box) or None"""
+    it does not travel to the GPU box) or None"""
     import glob
     import importlib.util
 

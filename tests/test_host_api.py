@@ -473,6 +473,7 @@ def test_concurrent_single_requests_are_coalesced_and_equal_their_solo_calls(tmp
                       "sid": np.array([i % 7], np.int64), "bert": None, "phone_duration_extra": None, "vits.seed": 500 + i})
     co = sess.coalescer
     assert co is not None
+    co.max_inflight = 1  # (one engine call at a time: everything behind the first call must come back from a batch)
     sess.coalescer = None
     solo = [sess.run_pcm16(f, 0.9, return_lengths=True) for f in feeds]
     sess.coalescer = co

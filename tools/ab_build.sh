@@ -3,7 +3,7 @@
 #   tools/ab_build.sh base                       working tree as is            -> tools/bt/bt_base.so
 #   tools/ab_build.sh exp:-DSOME_SWITCH          working tree with extra flags -> tools/bt/bt_exp.so
 #   tools/ab_build.sh old@<git ref>              sources of a git ref          -> tools/bt/bt_old.so
-# then on the GPU box:  VITS_MI355_LIB=tools/bt/bt_exp.so python bench.py ...   (tools/gpu_r4.sh libs)
+# then on the GPU box:  VITS_MI355_LIB=tools/bt/bt_exp.so python bench.py ...   (tools/gpu_lease.sh libs)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/tools/bt $R/gpurun_out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 measurement call (one lease): persistent-path parity subset, A/B of the persistent-program switches on the c2 bench,
-# stage timelines, quick FETCH_SIZE comparison.  Usage: gpurun -- 'bash tools/gpu_r4.sh [tests] [ab] [trace] [pmc]'
+# stage timelines, quick FETCH_SIZE comparison.  Usage: gpurun -- 'bash tools/gpu_lease.sh [tests] [ab] [trace] [pmc]'
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4; mkdir -p $O; cd $R
 c2() {  # one c2-only bench line -> "ms_per_step {persist ops}"
   BENCH_SKIP_FINITE_CHECK=1 timeout 300 python bench.py --no-batch32 --no-cpu-baseline --no-host-api --no-extras --steps 50 2>$O/bench_err.txt | python -c "
@@ -25,6 +25,14 @@ libs)  # A/B of alternative builds (tools/ab_build.sh): every tools/bt/bt_*.so, 
 bench)  # the default driver line
   timeout 900 python bench.py > $O/default_bench.json.txt 2> $O/default_bench.err; echo "bench rc=$?"; tail -c 300 $O/default_bench.err
   python tools/bench_summary.py $O/default_bench.json.txt;;
+c3ab)  # c3 (batch 32) under environment variants: C3_ENVS="A=1 B=2|A=3" (| separates variants)
+  IFS='|' read -ra VARS <<< "${C3_ENVS:-}"
+  for v in "" "${VARS[@]}"; do
+    echo "c3 [$v]: $(env $v timeout 300 python bench.py --workload c3 --no-cpu-baseline --no-host-api --no-extras 2>$O/c3_err.txt | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(d['ms_per_step'], r['kernel'], r['frac'], {k:round(v,3) for k,v in list(r['by_kernel_ms_per_forward'].items())[:9]})")" | tee -a $O/c3ab.txt
+  done;;
 trace)
   for p in enc dp flow; do PS_DETAIL=1 timeout 200 python tools/ps_trace.py $p > $O/trace_$p.txt 2>&1; tail -2 $O/trace_$p.txt; done;;
 pmc)

@@ -1444,6 +1444,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   // 64-row multiples at batch size (encoder / flow STORE convs: 192, 576, 768 rows) of a conv_precision == 1 model
   if (P.M % 64 == 0 && (long)cdiv(P.M, 64) * cdiv(P.Tout, 128) * P.B * P.n_groups >= 256 && bf3_ok()) { bf3_go(1); return; }
+  // (64 x 128 fp32 tiles for these convs were measured on the c3 batch in round 4: 2.21 - 2.42 ms against 2.17 ms per forward for the
+  //  64 x 64 tiles -- profiles/r4_c3_tile_ab.txt; not a tile-shape problem)
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
   launch_cfg<2, 2, 1, 1, EPI_STORE>(s, P, halo);
 }
