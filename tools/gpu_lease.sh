@@ -25,6 +25,11 @@ libs)  # A/B of alternative builds (tools/ab_build.sh): every tools/bt/bt_*.so, 
 bench)  # the default driver line
   timeout 900 python bench.py > $O/default_bench.json.txt 2> $O/default_bench.err; echo "bench rc=$?"; tail -c 300 $O/default_bench.err
   python tools/bench_summary.py $O/default_bench.json.txt;;
+c2ab)  # c2 under environment variants: C2_ENVS="A=1 B=2|A=3" (| separates variants), each twice, interleaved
+  IFS='|' read -ra VARS <<< "${C2_ENVS:-}"
+  for rep in 1 2; do for v in "" "${VARS[@]}"; do
+    echo "c2 [$v]: $(env $v bash -c "$(declare -f c2); R=$R; O=$O; c2")" | tee -a $O/c2ab.txt
+  done; done;;
 c3ab)  # c3 (batch 32) under environment variants: C3_ENVS="A=1 B=2|A=3" (| separates variants)
   IFS='|' read -ra VARS <<< "${C3_ENVS:-}"
   for v in "" "${VARS[@]}"; do

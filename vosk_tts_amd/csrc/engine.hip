@@ -1381,7 +1381,9 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
       const size_t lds = (size_t)2 * 2 * P.row_len * (BF3_PITCH * 2);
       if (bf3_pc()) hipLaunchKernelGGL((conv_bf3pc_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(384), lds, s->stream, P);
       else hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(256), lds, s->stream, P);
-    } else { ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo); }
+    } else {  // (128 x 128 tiles for the gate conv: 2.30 against 1.77 ms per c3 forward, round 4, profiles/r4_c3_tile_ab.txt)
+      ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo);
+    }
     return;
   }
   if (epi == EPI_RESSKIP) {
@@ -1953,6 +1955,9 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     C = Co; T = To; rate *= U.u;
     // MRF: 3 ResBlock1 chains in grouped launches (modules.py:210-223)
     const int nk = hp.n_resk;
+    // (Round 4 experiment, removed: the three chains as three branches of the captured graph -- one stream each, forked and joined
+    //  with events -- so that a chain's per-launch fixed cost runs under the other chains' matrix work: c2 0.856 -> 0.921 ms, 19 -> 43
+    //  graph nodes; the cross-queue dependencies cost more than the overlap returns.  profiles/r4_decoder_split.txt)
     for (int d = 0; d < hp.n_resd; ++d) {
       memset(&P, 0, sizeof P);
       P.n_groups = nk;
