@@ -19,6 +19,19 @@ bf16x3_profiles() {
   rm -rf $R/gpurun_out/pmc_c3_bf16x3
 }
 if [ "$1" == "bf16x3_only" ]; then bf16x3_profiles; ls -la $O; exit 0; fi
+if [ "$1" == "c2_profiles_only" ]; then  # the c2 kernel stats + counter passes again (e.g. after a change to the single-utterance path)
+  cd /tmp && export TMPDIR=/tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c2 -o trace -- python $R/bench.py --no-batch32 --no-cpu-baseline --no-host-api --no-extras --steps 50 > $O/${RD}_c2_only_bench_under_rocprof.json.txt 2> $O/prof_c2.err
+  cp $(find $O/prof/c2 -name '*kernel_stats.csv' | head -1) $O/${RD}_c2_only_bench_rocprofv3_kernel_stats.csv
+  rm -rf $O/prof
+  cd $R
+  timeout 900 bash tools/pmc_passes.sh c2 > $O/pmc_c2.log 2>&1
+  cp $R/gpurun_out/pmc_c2/pmc_c2.json $O/${RD}_pmc_c2.json
+  timeout 600 python bench.py > $O/${RD}_default_bench.json.txt 2> $O/bench_default.err; echo "bench rc=$?"
+  python tools/bench_summary.py $O/${RD}_default_bench.json.txt | head -4
+  head -8 $O/${RD}_c2_only_bench_rocprofv3_kernel_stats.csv | cut -c1-150
+  exit 0
+fi
 if [ "$1" != "noprof_tests" ]; then
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $O/${RD}_gpu_tests.log 2>&1; echo "pytest rc=$?" | tee -a $O/${RD}_gpu_tests.log
 tail -5 $O/${RD}_gpu_tests.log
@@ -28,7 +41,7 @@ timeout 600 python bench.py > $O/${RD}_default_bench.json.txt 2> $O/bench_defaul
 tail -c 600 $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c2 -o trace -- python $R/bench.py --no-batch32 --no-cpu-baseline --no-host-api --steps 50 > $O/${RD}_c2_only_bench_under_rocprof.json.txt 2> $O/prof_c2.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c2 -o trace -- python $R/bench.py --no-batch32 --no-cpu-baseline --no-host-api --no-extras --steps 50 > $O/${RD}_c2_only_bench_under_rocprof.json.txt 2> $O/prof_c2.err
 cp $(find $O/prof/c2 -name '*kernel_stats.csv' | head -1) $O/${RD}_c2_only_bench_rocprofv3_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/c3 -o trace -- python $R/bench.py --workload c3 --no-cpu-baseline --no-host-api > $O/${RD}_c3_only_bench_under_rocprof.json.txt 2> $O/prof_c3.err
 cp $(find $O/prof/c3 -name '*kernel_stats.csv' | head -1) $O/${RD}_c3_only_bench_rocprofv3_kernel_stats.csv

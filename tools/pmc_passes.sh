@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$W$SUF
 mkdir -p $OUT
-CMD="python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-batch32 --no-host-api --min-seconds 0 --no-graph $EXTRA"
+CMD="python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-batch32 --no-host-api --no-extras --min-seconds 0 --no-graph $EXTRA"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq1 -- $CMD > /dev/null 2>&1 || echo pass1 failed
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT -o sq2 -- $CMD > /dev/null 2>&1 || echo pass2 failed
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $CMD > /dev/null 2>&1 || echo pass3 failed
