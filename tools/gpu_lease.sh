@@ -19,9 +19,9 @@ ab)
     echo "VITS_PS_XCD=$x VITS_PS_TUNE=$t: $(VITS_PS_XCD=$x VITS_PS_TUNE=$t c2)" | tee -a $O/ab.txt
   done;;
 libs)  # A/B of alternative builds (tools/ab_build.sh): every tools/bt/bt_*.so, twice each, interleaved
-  for rep in 1 2; do for so in tools/bt/bt_*.so; do
-    echo "$so: $(VITS_MI355_LIB=$R/$so c2)" | tee -a $O/libs.txt
-  done; done;;
+  for rep in 1 2; do for so in tools/bt/bt_*.so; do for tune in ${LIB_TUNES:-0}; do
+    echo "$so VITS_PS_TUNE=$tune: $(VITS_MI355_LIB=$R/$so VITS_PS_TUNE=$tune c2)" | tee -a $O/libs.txt
+  done; done; done;;
 bench)  # the default driver line
   timeout 900 python bench.py > $O/default_bench.json.txt 2> $O/default_bench.err; echo "bench rc=$?"; tail -c 300 $O/default_bench.err
   python tools/bench_summary.py $O/default_bench.json.txt;;
