@@ -721,6 +721,7 @@ struct vits_session {
   // They work in the exchange regions of the three programs above plus ps_x (only its ll / cells are used)
   PersistProg ps_front[2], ps_back, ps_full[2], ps_x;
   ll_t *ps_x_stats = nullptr, *ps_x_logw = nullptr, *ps_x_cum = nullptr, *ps_x_leny = nullptr, *ps_x_zp = nullptr;
+  int ps_planned_roles = -1;  // ps_roles of the current layout (a change of roles re-plans like a change of shape)
   int ps_roles = 7;        // PERSIST_* mask of the programs this session can ever launch: fronts of the fast path run the text encoder and the
                            // duration predictor, their backs the flow -- cells and records are only laid out / built for those
   bool ps_defer = false;   // the owner calls persist_plan itself after re-pointing shared tensors (backs): session_reserve skips it
@@ -863,7 +864,7 @@ static void drop_graphs(vits_session* s) {
 // (re)lays the workspace out for exactly (B,Tx,Ty) so every [B,C,T] tensor is dense; grows the
 // arena when needed.  Captured graphs hold raw workspace pointers, so a re-plan drops them.
 static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
-  if (s->arena && B == s->B && Tx == s->Tx && Ty == s->Ty) return VITS_OK;
+  if (s->arena && B == s->B && Tx == s->Tx && Ty == s->Ty && s->ps_planned_roles == s->ps_roles) return VITS_OK;
   {
     // the batch-size conv kernels address one item's [C, T] tensor with 32-bit byte offsets (buffer loads, conv_mfma.hip.h bt_ld):
     // every per-item tensor must stay below 2 GiB.  The widest are the decoder stages, C_i x T_y x prod(rates[0..i]).
@@ -895,6 +896,7 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     s->arena_bytes = want;
   }
   plan(s, B, Tx, Ty);
+  s->ps_planned_roles = s->ps_roles;
   if (g_poison) {  // 0xFFFFFFFF = NaN; synchronised: stts_synthesize runs the decoder of this session on ITS stream
     hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);
     hipStreamSynchronize(s->stream);
@@ -2072,10 +2074,13 @@ struct HostStage {
   template <typename T> T* dev_alloc(size_t n) { return static_cast<T*>(raw_alloc(n * sizeof(T))); }
 };
 
-static int begin_stage(HostStage& hs, int B, int Tx, int Ty) {
+// roles: the persistent programs the caller will launch on this layout (pooled sessions are shared by callers with different needs:
+// the mask is part of the layout key, session_reserve)
+static int begin_stage(HostStage& hs, int B, int Tx, int Ty, int roles = 7) {
   hipError_t e = hipSetDevice(hs.m->device);
   if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
   TRY(pool_acquire(hs.m, &hs.s));
+  hs.s->ps_roles = roles;
   TRY(session_reserve(hs.s, B, Tx, Ty));
   return VITS_OK;
 }
@@ -2219,7 +2224,7 @@ int vits_stage_text_encoder(vits_model* m, const int64_t* ids, const int64_t* le
   if (!m || !ids || !lengths || !x || !m_p || !logs_p || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
   for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
   HostStage hs(m);
-  TRY(begin_stage(hs, B, Tx, 1));
+  TRY(begin_stage(hs, B, Tx, 1, PERSIST_ENC));
   vits_session* s = hs.s;
   const int H = m->hp.hidden_channels, I = m->hp.inter_channels;
   int64_t* d_ids = hs.to_dev(ids, (size_t)B * Tx);
@@ -2242,7 +2247,7 @@ int vits_stage_duration(vits_model* m, const float* x, const int64_t* lengths, i
   if (m && !m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!m || !x || !lengths || !noise || !logw || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
   HostStage hs(m);
-  TRY(begin_stage(hs, B, Tx, 1));
+  TRY(begin_stage(hs, B, Tx, 1, PERSIST_SDP));
   vits_session* s = hs.s;
   const int H = m->hp.hidden_channels;
   float* d_x = hs.to_dev(x, (size_t)B * H * Tx);
@@ -2264,7 +2269,7 @@ int vits_stage_regulate(vits_model* m, const float* logw, const int32_t* forced,
   if (!m || !lengths || !durations || !y_lengths || (!logw && !forced) || B <= 0 || Tx <= 0) return fail(VITS_ERR_ARG, "bad argument");
   if (z_p && (!m_p || !logs_p || Tcap <= 0)) return fail(VITS_ERR_ARG, "m_p/logs_p/T_cap required");
   HostStage hs(m);
-  TRY(begin_stage(hs, B, Tx, Tcap > 0 ? Tcap : 1));
+  TRY(begin_stage(hs, B, Tx, Tcap > 0 ? Tcap : 1, 0));
   vits_session* s = hs.s;
   const int I = m->hp.inter_channels;
   int64_t* d_len = hs.to_dev(lengths, B);
@@ -2297,7 +2302,7 @@ int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, i
   if (m && !m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   if (!m || !z_p || !y_lengths || !z || B <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
   HostStage hs(m);
-  TRY(begin_stage(hs, B, 1, Ty));
+  TRY(begin_stage(hs, B, 1, Ty, PERSIST_FLOW));
   vits_session* s = hs.s;
   const int I = m->hp.inter_channels;
   int64_t* d_len = hs.to_dev(y_lengths, B);
@@ -2313,7 +2318,7 @@ int vits_stage_flow(vits_model* m, const float* z_p, const int64_t* y_lengths, i
 int vits_stage_decoder(vits_model* m, const float* z, int32_t B, int32_t Ty, const int64_t* sid, float* audio, float* audio_mb) {
   if (!m || !z || !audio || B <= 0 || Ty <= 0) return fail(VITS_ERR_ARG, "bad argument");
   HostStage hs(m);
-  TRY(begin_stage(hs, B, 1, Ty));
+  TRY(begin_stage(hs, B, 1, Ty, 0));
   vits_session* s = hs.s;
   const vits_hparams& hp = m->hp;
   const int I = hp.inter_channels;
@@ -2340,7 +2345,7 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   const int I = hp.inter_channels;
   const float noise_scale = scales[0], length_scale = scales[1], noise_scale_w = scales[2];
   const uint64_t seed = opts ? opts->seed : 0;
-  TRY(begin_stage(hs, B, Tx, 1));
+  TRY(begin_stage(hs, B, Tx, 1, PERSIST_ENC | PERSIST_SDP));  // (text side first: no flow program for a one-frame layout)
   vits_session* s = hs.s;
   int64_t* d_ids = hs.to_dev(ids, (size_t)B * Tx);
   int64_t* d_len = hs.to_dev(lengths, B);
@@ -2389,6 +2394,7 @@ static int acoustic_host(HostStage& hs, const int64_t* ids, const int64_t* lengt
   HIP_TRY(hipMemcpyAsync(keep_stats, s->stats, sizeof(float) * (size_t)B * 2 * I * Tx, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(keep_cum, s->cum, sizeof(int) * (size_t)B * Tx, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  s->ps_roles = PERSIST_FLOW;  // (frame side: the text-side programs are not built again)
   TRY(session_reserve(s, B, Tx, (int)Ty));
   s->tile_keys.clear();  // the tile tables live in the (re-planned) workspace
   HIP_TRY(hipMemcpyAsync(s->stats, keep_stats, sizeof(float) * (size_t)B * 2 * I * Tx, hipMemcpyDeviceToDevice, s->stream));
@@ -2946,7 +2952,7 @@ int vits_stream_open_latent(vits_model* m, const float* z, int32_t Ty, int32_t c
   st->m = m;
   st->hs = new HostStage(m);
   st->clamp = (flags & 1u) != 0;
-  int rc = begin_stage(*st->hs, 1, 1, Ty);
+  int rc = begin_stage(*st->hs, 1, 1, Ty, 0);
   if (rc != VITS_OK) { vits_stream_close(st); return rc; }
   const float* d_z = st->hs->to_dev(z, (size_t)m->hp.inter_channels * Ty);
   if (!d_z) { vits_stream_close(st); return fail(VITS_ERR_NOMEM, "device alloc failed"); }
