@@ -27,7 +27,7 @@ raw = open(path, "rb").read()
 P, MS, n, Tx = struct.unpack("4i", raw[:16])
 kinds = struct.unpack(f"{n}i", raw[16:16 + 4 * n])
 st = np.frombuffer(raw[16 + 4 * n:], dtype=np.int64).reshape(P, MS, 8)[:, :n]
-names = {0: "IDLE", 1: "MM", 2: "DDS", 3: "LN", 4: "EMB", 5: "ATT", 6: "MERGE", 7: "COUPLE"}
+names = {0: "IDLE", 1: "MM", 2: "DDS", 3: "LN", 4: "EMB", 5: "ATT", 6: "MERGE", 7: "COUPLE", 8: "DUR", 9: "EXPAND", 10: "DDSL"}
 print(f"{prog}: T={Tx} workers={P} steps={n}; 2400 cycles = 1 us")
 # the timeline of ONE worker that is busy in most steps: rank 0
 r0 = st[0]
