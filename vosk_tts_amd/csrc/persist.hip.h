@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
   __shared__ __attribute__((aligned(16))) float att_r[PS_WAVES * 256];  // attention blocks: partial q E_k^T tiles of the 8 waves
   __shared__ float att_p[16 * 17];         // attention blocks: probabilities [query][key], pitch 17 (conflict-free MFMA A reads)
   const int tid0 = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int rank = blockIdx.x, P = gridDim.x;
   const int n_steps = prog->n_steps, seg_step = prog->seg_step;
   int T = prog->T, Tp = prog->Tp;
@@ -409,6 +409,10 @@ __global__ void __launch_bounds__(PS_THREADS) persist_kernel(const PProgram* __r
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
+    // (the same for the wave index: hipcc hoists every wave-derived scalar expression of every step kind out of the step loop --
+    //  ~140 of them -- spills them to VGPR lanes in the prologue and reads them back with v_readlane where one SALU instruction would do)
+    int wave = wave0;
+    asm volatile("" : "+s"(wave));
     const ps_i4 rv = rvB;
     const int kf = PR_I(rv, 0), kind = kf & 0xff;
     rvB = load_rec(s + 1);  // (an L2 hit; older than everything else this step requests)
