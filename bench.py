@@ -75,6 +75,8 @@ def make_workload(name, rng, rank=0, world=1):
         lengths = np.full(8, 47, np.int64)
     elif name == "s16":
         lengths = np.full(16, 47, np.int64)
+    elif name[0] == "u" and name[1:].isdigit():  # one utterance of N tokens (kernel-selection sweeps between c2 and c5)
+        lengths = np.array([int(name[1:])], np.int64)
     else:
         raise ValueError(name)
     B, Tx = len(lengths), int(lengths.max())
@@ -513,7 +515,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "m2", "m3", "s8", "s16"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "m2", "m3", "s8", "s16"] + ["u%d" % n for n in range(100, 2001, 100)],
                     help="c1..c5: BASELINE configs on the VITS2 graph; m2 / m3: the configs[1] / configs[2] shapes on the StableTTS (multistream) family")
     ap.add_argument("--no-batch32", action="store_true", help="skip the extra c3 (batch=32) measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")

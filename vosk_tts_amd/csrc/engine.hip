@@ -1284,10 +1284,22 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
   hipLaunchKernelGGL(conv_wp_kernel<NW>, grid, dim3(NW * 64), lds, s->stream, P);
 }
 
+// Column counts (B x T) up to which the 16-column-tile kernels run.  Round 4, measured on single utterances of 300 - 1000 tokens and on
+// batches of 8 / 16 short requests (profiles/r4_c16_threshold.txt): beyond ~256 columns the K-split / wave-pipelined kernels win the
+// plain convolutions (although the LayerNorm is then a launch of its own), the gate conv to ~512, the fused DDSConv layer to ~640.
+// VITS_C16_COLS overrides both, VITS_C16_DDS_COLS the second.
+static long c16_cols_conv(int epi) {  // (the WaveNet gate conv -- 5 taps, 2H rows, tanh * sigmoid epilogue -- crosses over at ~500 columns)
+  static const long v = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 0;
+  return v ? v : (epi == EPI_GATE ? 512 : 256);
+}
+static long c16_cols_dds() {
+  static const long v = getenv("VITS_C16_DDS_COLS") ? atol(getenv("VITS_C16_DDS_COLS")) : (getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 640);
+  return v;
+}
 // would launch_conv route this launch to the small-tile kernel?  (callers that fold a LayerNorm into the consumer's staging
 // must know before they drop the LayerNorm launch: only that kernel has the prologue)
 static bool conv_takes_c16(const ConvParams& P, int epi) {
-  static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
+  const long c16_cols = c16_cols_conv(epi);
   if (!(g_force_tile == 3 || (g_force_tile == 0 && (long)P.B * P.Tout <= c16_cols))) return false;
   // (launch_conv hands 200..1000-column convs with C_in >= 256 to the wave-pipelined kernel first, unless they carry a prologue or
   // write LayerNorm statistics)
@@ -1356,7 +1368,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   // few-column regime (a single utterance's encoder / duration predictor / flow): many small workgroups, LDS-staged B
-  static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
+  const long c16_cols = c16_cols_conv(epi);
   // between ~200 and ~1000 columns the 16-column tiles re-read every weight once per column tile (19 times at 304 columns: the
   // StableTTS estimator, 20 us per conv): the wave-pipelined 32x32 kernel takes those when it can
   const bool wp_first = g_force_tile == 0 && (long)P.B * P.Tout > 192 && P.Cin >= 256 && !P.ln_g && !P.dds_y2 && conv_wp_ok(P, epi, halo, small);
@@ -1740,7 +1752,7 @@ static void run_dds_proj(vits_session* s, const DDSW& W, float* h, const ConvW& 
   const vits_hparams& hp = s->m->hp;
   const int D = hp.dp_filter_channels, K = hp.dp_kernel_size;
   static const bool no_c16 = getenv("VITS_NO_DDS_C16") != nullptr;  // A/B switch for tools/ and tests
-  static const long c16_cols = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 1024;
+  const long c16_cols = c16_cols_dds();
   {
     ConvParams P = conv_params(proj, h, out, B, T, 1, 0);
     P.len = s->len_x;
