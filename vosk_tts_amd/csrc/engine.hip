@@ -1286,14 +1286,14 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
 
 // Column counts (B x T) up to which the 16-column-tile kernels run.  Round 4, measured on single utterances of 300 - 1000 tokens and on
 // batches of 8 / 16 short requests (profiles/r4_c16_threshold.txt): beyond ~256 columns the K-split / wave-pipelined kernels win the
-// plain convolutions (although the LayerNorm is then a launch of its own), the gate conv to ~512, the fused DDSConv layer to ~640.
+// plain convolutions (although the LayerNorm is then a launch of its own), the gate conv to ~512, the fused DDSConv layer to ~800.
 // VITS_C16_COLS overrides both, VITS_C16_DDS_COLS the second.
 static long c16_cols_conv(int epi) {  // (the WaveNet gate conv -- 5 taps, 2H rows, tanh * sigmoid epilogue -- crosses over at ~500 columns)
   static const long v = getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 0;
   return v ? v : (epi == EPI_GATE ? 512 : 256);
 }
 static long c16_cols_dds() {
-  static const long v = getenv("VITS_C16_DDS_COLS") ? atol(getenv("VITS_C16_DDS_COLS")) : (getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 640);
+  static const long v = getenv("VITS_C16_DDS_COLS") ? atol(getenv("VITS_C16_DDS_COLS")) : (getenv("VITS_C16_COLS") ? atol(getenv("VITS_C16_COLS")) : 800);
   return v;
 }
 // would launch_conv route this launch to the small-tile kernel?  (callers that fold a LayerNorm into the consumer's staging
@@ -1366,6 +1366,9 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   const long blocks64 = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
   static const long ks_threshold = getenv("VITS_KS_THRESHOLD") ? atol(getenv("VITS_KS_THRESHOLD")) : 512;
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
+  // (the polyphase upsamplers and the 32-row conv_post leave the K-split kernel earlier: 300-token utterance ups 0.20 -> 0.135 ms,
+  //  conv_post 0.092 -> 0.046 ms -- profiles/r4_c16_threshold.txt)
+  if (small && g_force_tile == 0 && epi == EPI_STORE && (P.ups_u || P.M % 64 == 32) && blocks64 >= ks_threshold / 2) small = false;
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   // few-column regime (a single utterance's encoder / duration predictor / flow): many small workgroups, LDS-staged B
   const long c16_cols = c16_cols_conv(epi);
@@ -1454,7 +1457,8 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   const long big_blocks = (long)cdiv(P.M, 128) * cdiv(P.Tout, 128) * P.B * P.n_groups;
   const bool m_fits = (P.M % 128 == 0) && (!P.ups_u || P.ups_cout % 128 == 0);
-  if (m_fits && big_blocks >= 512) {
+  static const long big_min = getenv("VITS_BIG_BLOCKS") ? atol(getenv("VITS_BIG_BLOCKS")) : 512;
+  if (m_fits && big_blocks >= big_min) {
     if (bf3_ok()) { bf3_go(2); return; }
     ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return;
   }
@@ -1497,8 +1501,12 @@ static void launch_attention_raw(vits_session* s, const float* qkv, const float*
                                  int H, int T, int nh, int W) {
   const int dk = H / nh;
   struct { const float* ek; const float* ev; } L{ek, ev};
-  static const int t16_max = getenv("VITS_ATT16_MAXT") ? atoi(getenv("VITS_ATT16_MAXT")) : 512;
-  const bool use16 = g_attn_impl == 3 || (g_attn_impl == 0 && T <= t16_max);
+  // 16-query tiles (more, smaller workgroups) while the 32-query MFMA kernel's grid would not fill the chip: measured round 4
+  // (profiles/r4_c16_threshold.txt) single utterances of 200 - 600 tokens (T_y 600 - 1800) -15..-35 % attention time against the old rule
+  // (T <= 512), the 32-item batch c3 -6 % (its 200-token text side now runs the MFMA kernel).  VITS_ATT16_MAXT=<T> restores a pure T rule.
+  static const int t16_max = getenv("VITS_ATT16_MAXT") ? atoi(getenv("VITS_ATT16_MAXT")) : 0;
+  const bool small_grid = (long)cdiv(T, 32) * nh * B < 256;
+  const bool use16 = g_attn_impl == 3 || (g_attn_impl == 0 && (t16_max ? T <= t16_max : (T <= 64 || (small_grid && T <= 4096))));
   ProfScope ps(s, "attention", 4.0 * (double)B * H * T * T,
                use16 ? "relpos_attention16_kernel" : (g_attn_impl == 1 ? "relpos_attention_kernel" : "relpos_attention_mfma_kernel"));
   if (use16) {  // short sequences: 16-query tiles, more and smaller workgroups
