@@ -536,6 +536,47 @@ def test_c3_full_size_batch_parity(hip_default, oracle_default):
     _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 4, seed=7)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 120), (1, 300), (8, 47), (16, 47)])
+def test_mid_size_shapes_against_the_oracle(hip_default, oracle_default, B, T):
+    """The shapes between the single short utterance and the 32-item batch -- one utterance of 120 / 300 tokens, a coalesced batch of
+    8 / 16 short requests (bench.py s8 / s16) -- where round 4 changed which kernel runs (DESIGN.md "Kernel selection in the mid-size
+    regime": conv16 up to 256 / 512 / 800 columns, attention by grid size): every stage against the oracle, the duration predictor
+    executed with injected noise, then the end-to-end call."""
+    rng = np.random.default_rng(1000 * B + T)
+    lengths = np.full(B, T, np.int64)
+    if B > 1:
+        lengths[1] = T - 7; lengths[-1] = T - 16  # ragged
+    ids = rng.integers(1, 62, size=(B, T)).astype(np.int64)
+    ids *= (np.arange(T)[None] < lengths[:, None])
+    sid = np.full(B, 2, np.int64)
+    scales = np.array([0.667, 1.0, 0.8], np.float32)
+    x, m_p, logs_p = hip_default.text_encoder(ids, lengths, sid)
+    xr, mr, lr = oracle_default.text_encoder(ids, lengths, sid)
+    assert_close("x", xr, x, STAGE_TOL); assert_close("m_p", mr, m_p, STAGE_TOL); assert_close("logs_p", lr, logs_p, STAGE_TOL)
+    noise_dp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    logw = hip_default.duration(xr, lengths, sid, noise_dp, 0.8)
+    assert_close("logw", oracle_default.duration(xr, lengths, sid, noise_dp, 0.8), logw, 2 * STAGE_TOL)
+    dur = np.where(np.arange(T)[None] < lengths[:, None], 3, 0).astype(np.int32)
+    Ty = 3 * T
+    noise = rng.standard_normal((B, 192, Ty)).astype(np.float32)
+    _, ylen, z_p = hip_default.regulate(None, dur, lengths, 1.0, mr, lr, noise, 0.667, Ty)
+    _, ylr, zpr = oracle_default.regulate(None, dur, lengths, 1.0, mr, lr, noise, 0.667, Ty)
+    assert np.array_equal(ylen, ylr)
+    assert_close("z_p", zpr, z_p, STAGE_TOL)
+    z = hip_default.flow(zpr, ylen, sid)
+    zr = oracle_default.flow(zpr, ylen, sid)
+    assert_close("z", zr, z, STAGE_TOL)
+    mask = (np.arange(Ty)[None, :] < ylen[:, None])[:, None, :]
+    audio, _ = hip_default.decoder(zr * mask)
+    audio_r, _ = oracle_default.decoder(zr * mask)
+    assert_close("audio (decoder stage)", audio_r, audio, STAGE_TOL)
+    a_hip, l_hip = hip_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+    a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+    assert np.array_equal(l_hip, l_ref)
+    assert_close("waveform", _valid(a_ref, l_ref), _valid(a_hip, l_hip), E2E_TOL)
+
+
 def test_bf16x3_decoder_variant(hip_lib, oracle_default):
     """hparams.conv_precision = 1 (BASELINE configs[2]'s reduced-precision variant in its accuracy-preserving form): the decoder's
     ResBlock convs at batch size run as 3 bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulation, conv_bf3_kernel).
