@@ -510,12 +510,19 @@ def concurrency_leg(hp, device, seconds=0.4):
     return out
 
 
+def _workload_name(v):
+    import argparse
+    if v in ("c1", "c2", "c3", "c4", "c5", "m2", "m3", "s8", "s16") or (v[:1] == "u" and v[1:].isdigit() and 1 <= int(v[1:]) <= 4000):
+        return v
+    raise argparse.ArgumentTypeError("c1..c5, m2, m3, s8, s16 or u<N> (one utterance of N tokens)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "m2", "m3", "s8", "s16"] + ["u%d" % n for n in range(100, 2001, 100)],
+    ap.add_argument("--workload", default="c2", type=_workload_name,
                     help="c1..c5: BASELINE configs on the VITS2 graph; m2 / m3: the configs[1] / configs[2] shapes on the StableTTS (multistream) family")
     ap.add_argument("--no-batch32", action="store_true", help="skip the extra c3 (batch=32) measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")

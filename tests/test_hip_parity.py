@@ -847,7 +847,16 @@ def test_duration_predictor_both_dds_paths(hip_default, oracle_default, B, T):
     assert_close("logw", want * m, got * m, STAGE_TOL)
 
 
-@pytest.mark.parametrize("T", [1, 3, 15, 16, 17, 33, 50, 64, 100, 128])
+def _persist_runs(hip_lib, model):
+    """completed persistent launches of `model` so far (vits_debug_persist_runs): a stage that silently fell back to launches adds none"""
+    lib = hip_lib.lib
+    lib.vits_debug_persist_runs.restype = ctypes.c_int
+    lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
+    return int(lib.vits_debug_persist_runs(model._h))
+
+
+
+@pytest.mark.parametrize("T", [1, 3, 15, 16, 17, 33, 50, 64, 100, 128, 257, 300, 512])
 def test_persistent_duration_predictor(hip_lib, hip_default, oracle_default, T):
     """The single-utterance duration predictor as ONE persistent kernel (csrc/persist.hip.h: steps exchange 8-byte {value, epoch}
     cells, no launches and no barriers in between) against the launch-per-layer path (vits_debug_persist(0)) and the oracle;
@@ -862,8 +871,10 @@ def test_persistent_duration_predictor(hip_lib, hip_default, oracle_default, T):
         noise = rng.standard_normal((1, 2, T)).astype(np.float32)
         want = oracle_default.duration(x, lens, sid, noise, 0.8)
         hip_lib.lib.vits_debug_persist(7)
+        r0 = _persist_runs(hip_lib, hip_default)
         got = hip_default.duration(x, lens, sid, noise, 0.8)
         got2 = hip_default.duration(x, lens, sid, noise, 0.8)
+        assert _persist_runs(hip_lib, hip_default) == r0 + 2, "the persistent program did not run (columns beyond the worker count are further rounds of a step)"
         hip_lib.lib.vits_debug_persist(0)
         base = hip_default.duration(x, lens, sid, noise, 0.8)
         hip_lib.lib.vits_debug_persist(7)
@@ -874,7 +885,7 @@ def test_persistent_duration_predictor(hip_lib, hip_default, oracle_default, T):
         assert np.all(got[~m] == 0)
 
 
-@pytest.mark.parametrize("T", [1, 5, 16, 17, 50, 64, 100, 130, 200])
+@pytest.mark.parametrize("T", [1, 5, 16, 17, 50, 64, 100, 130, 200, 257, 300, 512])
 def test_persistent_text_encoder(hip_lib, hip_default, oracle_default, T):
     """TextEncoder (models.py:317-326; attentions.py:48-65) of a single utterance as ONE persistent step program (embedding, per layer
     q|k|v, 16 x 16 attention blocks + merge, conv_o + residual, LayerNorm, FFN in K-slices, LayerNorm, then proj) against the
@@ -886,8 +897,10 @@ def test_persistent_text_encoder(hip_lib, hip_default, oracle_default, T):
         sid = np.array([it + 3], np.int64)
         want = oracle_default.text_encoder(ids, lens, sid)
         hip_lib.lib.vits_debug_persist(7)
+        r0 = _persist_runs(hip_lib, hip_default)
         got = hip_default.text_encoder(ids, lens, sid)
         got2 = hip_default.text_encoder(ids, lens, sid)
+        assert _persist_runs(hip_lib, hip_default) == r0 + 2, "the persistent program did not run"
         hip_lib.lib.vits_debug_persist(0)
         base = hip_default.text_encoder(ids, lens, sid)
         hip_lib.lib.vits_debug_persist(7)
@@ -899,7 +912,7 @@ def test_persistent_text_encoder(hip_lib, hip_default, oracle_default, T):
             assert np.all((g * ~m) == 0), f"{name}: padding columns must be zero"
 
 
-@pytest.mark.parametrize("T", [1, 16, 33, 150, 160, 250])
+@pytest.mark.parametrize("T", [1, 16, 33, 150, 160, 250, 257, 272, 400, 512])
 def test_persistent_flow(hip_lib, hip_default, oracle_default, T):
     """ResidualCouplingTransformersBlock reverse (models.py:750-757, 374-393) of a single utterance as ONE persistent step program
     (per coupling layer: pre with the Flip folded into the read, the pre-transformer layer, WaveNet gates / residual updates,
@@ -911,8 +924,10 @@ def test_persistent_flow(hip_lib, hip_default, oracle_default, T):
         sid = np.array([it + 5], np.int64)
         want = oracle_default.flow(z_p, lens, sid)
         hip_lib.lib.vits_debug_persist(7)
+        r0 = _persist_runs(hip_lib, hip_default)
         got = hip_default.flow(z_p, lens, sid)
         got2 = hip_default.flow(z_p, lens, sid)
+        assert _persist_runs(hip_lib, hip_default) == r0 + 2, "the persistent program did not run"
         hip_lib.lib.vits_debug_persist(0)
         base = hip_default.flow(z_p, lens, sid)
         hip_lib.lib.vits_debug_persist(7)

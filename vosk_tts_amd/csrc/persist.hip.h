@@ -45,7 +45,8 @@ typedef unsigned long long ll_t;  // {float value (bits 0..31), u32 epoch (bits 
 
 #define PS_THREADS 512
 #define PS_WAVES 8
-#define PS_MAX_STEPS 192
+#define PS_MAX_STEPS 320
+#define PS_MAX_T 512         // longest sequence of a program (columns beyond the worker count run as further rounds of a step)
 #define PS_MAXC 256      // channels of a column step / contraction channels of one K-slice
 #define PS_MAXU 8        // tap units (16 channels x 1 tap) per wave
 #define PS_TP 21         // LDS pitch of the MFMA operand window [C_in][16 + taps - 1] (odd: the transposing writes are conflict-free)

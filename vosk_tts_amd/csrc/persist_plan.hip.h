@@ -30,8 +30,15 @@ static bool persist_encoder_ok(const vits_model* m, const EncoderW& E) {
   return true;
 }
 
+// Longest sequence a program is built for.  Up to P columns every column kind is one step (worker t = column t); beyond, the resolver
+// cuts a column step into rounds of P columns and an attention step into rounds of P blocks (the kernel does not know: a step is
+// whatever records it finds).  VITS_PS_MAX_T overrides (A/B of the launch path against the program at a given length).
+static int persist_max_t() {
+  static const int v = getenv("VITS_PS_MAX_T") ? atoi(getenv("VITS_PS_MAX_T")) : PS_MAX_T;
+  return v < 16 ? 16 : (v > PS_MAX_T ? PS_MAX_T : v);
+}
 static bool persist_common_ok(const vits_model* m, int B, int T) {
-  return m->acoustic && B == 1 && T >= 1 && T <= 256 && m->n_cu >= 16 && m->zeros;
+  return m->acoustic && B == 1 && T >= 1 && T <= persist_max_t() && m->n_cu >= 16 && m->zeros;
 }
 
 // ---- stochastic duration predictor
@@ -351,10 +358,10 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
       r.p[0] = U(s->ps_x_logw); r.p[1] = U(s->dur); r.p[2] = U(s->cum); r.p[3] = U(s->ps_x_cum);
       r.p[4] = U(s->len_y); r.p[5] = U(s->ylen64); r.p[6] = U(s->ps_x_leny);
     } else if (st.kind == PK_EXPAND) {
-      if (Tp > P) { bad = true; return; }
-      PRec* R = new_step();
+      PRec* R = nullptr;
       for (int t = 0; t < Tp; ++t) {
-        PRec& r = R[t];
+        if (t % P == 0) R = new_step();  // (a round of P columns per step)
+        PRec& r = R[t % P];
         r.kf = PK_EXPAND | (st.dw ? 0 : PF_PLAIN_IN);
         r.a1 = st.C; r.a2 = t; r.a3 = s->Tx;
         r.p[0] = st.dw ? U(s->ps_x_stats) : U(s->stats);
@@ -424,15 +431,15 @@ static void persist_resolve(vits_session* s, const std::vector<PStep>& steps, in
         }
       }
     } else {
-      if (Tp > P) { bad = true; return; }
-      PRec* R = new_step();
+      PRec* R = nullptr;
       const float* pack = m->zeros;
       if (st.kind != PK_MERGE && st.kind != PK_EMB) {
         pack = persist_pack(s, st.par, st.padd, st.plen, 256);
         if (!pack) { bad = true; return; }
       }
       for (int t = 0; t < Tp; ++t) {
-        PRec& r = R[t];
+        if (t % P == 0) R = new_step();  // (a round of P columns per step)
+        PRec& r = R[t % P];
         r.a1 = st.C; r.a2 = t; r.p[9] = U(pack);
         r.p[3] = U(st.out); r.p[4] = U(st.oplain);
         r.b[4] = st.plain_T;
