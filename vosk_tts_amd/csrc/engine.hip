@@ -1368,7 +1368,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   bool small = g_force_tile == 2 || (g_force_tile == 0 && blocks64 < ks_threshold);
   // (the polyphase upsamplers and the 32-row conv_post leave the K-split kernel earlier: 300-token utterance ups 0.20 -> 0.135 ms,
   //  conv_post 0.092 -> 0.046 ms -- profiles/r4_c16_threshold.txt)
-  if (small && g_force_tile == 0 && epi == EPI_STORE && (P.ups_u || P.M % 64 == 32) && blocks64 >= ks_threshold / 2) small = false;
+  if (small && g_force_tile == 0 && epi == EPI_STORE && (P.ups_u || P.M % 64 == 32) && blocks64 >= 256) small = false;
   if (!P.g[0].x2 && P.in_scale != 1.0f) small = false;  // the K-split kernel folds in_scale into the multi-input sum only
   // few-column regime (a single utterance's encoder / duration predictor / flow): many small workgroups, LDS-staged B
   const long c16_cols = c16_cols_conv(epi);
