@@ -601,9 +601,15 @@ def main():
             if dist is not None:
                 dist.barrier()
 
+        import ctypes
+        _runs_fn = model.lib.lib.vits_debug_persist_runs
+        _runs_fn.restype = ctypes.c_int
+        _runs_fn.argtypes = [ctypes.c_void_p]
+        persist_runs = lambda: int(_runs_fn(model._h))
         for _ in range(warmup):
             step()
         sess.sync()
+        persist_r0, persist_steps = persist_runs(), 0
 
         def timed_block():
             barrier()
@@ -631,6 +637,12 @@ def main():
         elapsed = float(np.median(blocks))
         timed_region_s = float(sum(blocks))
         graph_nodes = sess.graph_nodes()
+        # did the single-utterance persistent programs run?  (one owner per device -- a token inside the process, a lock file across
+        # processes: a second process on the device silently takes the launch path, ~1.5 x slower at c2 -- so the line says which it was)
+        persistent_per_step = (persist_runs() - persist_r0) / max(steps * len(blocks), 1)
+        if B == 1 and persistent_per_step == 0 and not os.environ.get("VITS_NO_PERSIST"):
+            print(f"bench.py: rank {rank}: no persistent-program launches in the timed region (another process owns this device's programs, "
+                  "or the shape is not eligible): this is the launch path", file=sys.stderr)
         finite_checked = not os.environ.get("BENCH_SKIP_FINITE_CHECK")  # (tools/ A/B builds with garbage results set it; recorded in the line)
         assert not finite_checked or torch.isfinite(d_audio).all().item(), "non-finite audio"
 
@@ -768,7 +780,7 @@ def main():
         return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
                     ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales,
                     timed_region_s=timed_region_s, blocks=len(blocks), launches=graph_nodes or sum(v[0] for v in rep.values()) // nprof,
-                    rank_ms=rank_ms, finite_checked=finite_checked)
+                    rank_ms=rank_ms, finite_checked=finite_checked, persistent_per_step=persistent_per_step)
 
     R = measure(args.workload, args.steps, args.warmup, args.min_seconds)
     B, Tx, Ty, lengths, ids, dur = R["B"], R["Tx"], R["Ty"], R["lengths"], R["ids"], R["dur"]
@@ -891,6 +903,7 @@ def main():
             "scaling": "strong" if args.workload == "c4" else "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
             "rtf": round(rtf, 6), "x_realtime": round(1.0 / rtf, 1),
             "timed_region_s": round(R["timed_region_s"], 3), "timed_blocks": R["blocks"], "launches_per_forward": R["launches"],
+            "persistent_launches_per_forward": round(R["persistent_per_step"], 3),
             "config": {"workload": f"{args.workload}: MB-iSTFT-VITS2 (ru-0.9-multi-shaped, SEEDED SYNTHETIC weights: timings are shape-exact, "
                                    f"dynamic range of a trained voice untested), B={B} T_x={Tx} (lengths {int(lengths.min())}..{int(lengths.max())}), "
                                    f"durations pinned 3/token -> T_y={Ty} with the duration predictor executed, "

@@ -773,3 +773,77 @@ def test_model_loads_the_reference_file_layout_of_a_multistream_voice_on_gpu(tmp
     wa = ma.onnx.run(None, dict(fa, **{"vits.seed": 9}))[0]
     wb = mb.onnx.run(None, dict(fb, **{"vits.seed": 9}))[0]
     assert np.array_equal(wa, wb) and wa.size > 0
+
+
+
+_CHILD_PROCESS = r"""
+import ctypes, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from vosk_tts_amd import weights as W
+from vosk_tts_amd.capi import VitsLib
+lib = VitsLib()
+m = lib.create(W.synthetic_blob(W.default_hparams(), 1234), 0)
+lib.lib.vits_debug_persist_runs.restype = ctypes.c_int
+lib.lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
+rng = np.random.default_rng(5)
+ids = rng.integers(1, 62, size=(1, 40)).astype(np.int64)
+args = (ids, np.array([40], np.int64), np.array([0.667, 1.0, 0.8], np.float32), np.array([2], np.int64))
+a, l = m.synthesize(*args, seed=77)
+a2, _ = m.synthesize(*args, seed=77)
+assert np.array_equal(a, a2)
+np.save(sys.argv[2], a)
+print("RUNS", int(lib.lib.vits_debug_persist_runs(m._h)), flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "hold":   # keep the model (and with it the device's lock) until told to let go
+    sys.stdin.readline()
+    m.close()
+    print("RELEASED", flush=True)
+    sys.stdin.readline()
+"""
+
+
+@pytest.mark.gpu
+def test_a_second_process_on_the_device_leaves_the_persistent_programs_to_the_first(tmp_path):
+    """Two PROCESSES on one device (two bench ranks on a one-GPU box, a server with several workers per GPU): the persistent programs
+    need all their workgroups co-resident, so only the process that holds the device's lock (flock on a file named after the PCI bus
+    id, engine.hip persist_process_owns) runs them; the other one takes the launch path -- same samples, no timeout -- and gets the
+    programs once the first process has destroyed its last model on the device.  (Own lock directory: independent of what this
+    test process itself holds.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD_PROCESS)
+    env = dict(os.environ, VITS_PERSIST_LOCK_DIR=str(tmp_path))
+
+    def run_child(tag):
+        out = tmp_path / f"{tag}.npy"
+        r = subprocess.run([sys.executable, str(script), root, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return int([x for x in r.stdout.splitlines() if x.startswith("RUNS")][-1].split()[1]), np.load(out)
+
+    first = subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "first.npy"), "hold"], env=env, stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        line = first.stdout.readline()
+        while line and not line.startswith("RUNS"):
+            line = first.stdout.readline()
+        assert line.startswith("RUNS") and int(line.split()[1]) > 0, (line, first.stderr.read()[-2000:] if not line else "")
+        mine = np.load(tmp_path / "first.npy")
+        runs_b, audio_b = run_child("while_owned")
+        assert runs_b == 0, "the second process ran persistent programs on a device another process owns"
+        assert audio_b.shape == mine.shape and np.abs(audio_b - mine).max() <= 5e-4 * np.abs(mine).max()
+        first.stdin.write("\n"); first.stdin.flush()
+        line = first.stdout.readline()
+        while line and not line.startswith("RELEASED"):
+            line = first.stdout.readline()
+        assert line.startswith("RELEASED")
+        runs_c, audio_c = run_child("after_release")
+        assert runs_c > 0, "the lock was not released with the first process's last model"
+        assert np.abs(audio_c - mine).max() <= 5e-4 * np.abs(mine).max()
+    finally:
+        try:
+            first.stdin.write("\n"); first.stdin.flush()
+        except Exception:
+            pass
+        first.wait(timeout=60)

@@ -14,6 +14,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -766,9 +769,38 @@ static T* bump(vits_session* s, size_t n) {
 #include "persist_plan.hip.h"
 
 static inline int persist_mask() { return tl_persist >= 0 ? tl_persist : 0; }
+// ... and across PROCESSES: two processes that run the persistent programs on one device at the same time starve each other into the
+// poll timeout just the same (seen with two bench ranks on one device: "exchange timed out").  The first process that wants the programs
+// on a device takes an advisory lock -- flock on a file named after the device's PCI bus id, kept while the process has a model on
+// that device -- and every other process runs the launch path there.  Processes that do not share the lock directory (containers
+// with their own /tmp) are not covered; the bounded poll loops and the launch-path fallback still are.
+// VITS_PERSIST_LOCK=0: no lock; VITS_PERSIST_LOCK_DIR: directory of the lock files (default /tmp).
+static int g_proc_lock[64];     // 0 = not tried, 1 = this process owns the device's programs (or no lock is used), -1 = another process does
+static int g_proc_lock_fd[64];
+static bool persist_process_owns(int dev) {  // (g_tok_mu held)
+  if (g_proc_lock[dev]) return g_proc_lock[dev] > 0;
+  g_proc_lock_fd[dev] = -1;
+  if (getenv("VITS_PERSIST_LOCK") && atoi(getenv("VITS_PERSIST_LOCK")) == 0) { g_proc_lock[dev] = 1; return true; }
+  char bus[64] = "dev";
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+  for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+  char path[512];
+  snprintf(path, sizeof path, "%s/vits_mi355_persist_%s.lock", getenv("VITS_PERSIST_LOCK_DIR") ? getenv("VITS_PERSIST_LOCK_DIR") : "/tmp", bus);
+  const int fd = open(path, O_CREAT | O_RDONLY | O_CLOEXEC, 0644);  // (read-only: another user's process can open it too; flock does not care)
+  if (fd < 0) { g_proc_lock[dev] = 1; return true; }                // no lock directory: as before
+  if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); g_proc_lock[dev] = -1; return false; }
+  g_proc_lock[dev] = 1; g_proc_lock_fd[dev] = fd;
+  return true;
+}
+static void persist_process_release(int dev) {  // the last model of this process on `dev` is gone
+  std::lock_guard<std::mutex> g(g_tok_mu);
+  if (dev < 0 || dev >= 64) return;
+  if (g_proc_lock[dev] > 0 && g_proc_lock_fd[dev] >= 0) { flock(g_proc_lock_fd[dev], LOCK_UN); close(g_proc_lock_fd[dev]); }
+  g_proc_lock[dev] = 0; g_proc_lock_fd[dev] = -1;  // (a process that was denied asks again with its next model)
+}
 static bool persist_token_try(int dev) {
   std::lock_guard<std::mutex> g(g_tok_mu);
-  if (dev < 0 || dev >= 64 || g_tok_busy[dev]) return false;
+  if (dev < 0 || dev >= 64 || g_tok_busy[dev] || !persist_process_owns(dev)) return false;
   g_tok_busy[dev] = true;
   return true;
 }
@@ -2191,12 +2223,19 @@ int vits_create(const void* blob, size_t bytes, int device, vits_model** out) {
 
 void vits_destroy(vits_model* m) {
   if (!m) return;
-  { std::lock_guard<std::mutex> g(g_models_mu); g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end()); }
+  bool last_on_device = true;
+  {
+    std::lock_guard<std::mutex> g(g_models_mu);
+    g_models.erase(std::remove(g_models.begin(), g_models.end(), m), g_models.end());
+    for (vits_model* o : g_models) if (o->device == m->device) last_on_device = false;
+  }
   hipSetDevice(m->device);
   for (vits_session* s : m->pool) session_free(s);
   for (auto& kv : m->fronts) session_free(kv.second);
   for (void* a : m->allocs) hipFree(a);
+  const int dev = m->device;
   delete m;
+  if (last_on_device) { hipDeviceSynchronize(); persist_process_release(dev); }  // (nothing of this process runs a program there any more)
 }
 
 int vits_get_hparams(const vits_model* m, vits_hparams* out) {
