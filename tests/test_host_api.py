@@ -332,11 +332,15 @@ def test_device_session_graph_replay_matches_host_path(hip_default):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["c2", "c3"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "u100", "u170"])
 def test_driver_timed_configuration_equals_the_host_path(hip_default, workload):
     """Exactly what bench.py times (bench.py measure()): a VitsDeviceSession with set_sdp_always(True) -- durations pinned, the
     duration predictor executed anyway -- hipGraph on, the bench's own c2 / c3 batch built by bench.make_workload, seed 7; the audio
-    must equal the host entry point's for the same feed on every valid sample, on the first (capturing) call and on replays."""
+    must equal the host entry point's for the same feed on every valid sample, on the first (capturing) call and on replays.
+    u100 / u170: one utterance of 100 / 170 tokens (300 / 510 frames) -- the merged persistent program beyond 256 columns (column and
+    attention steps in rounds of 256 records); it must have run (one launch per call)."""
+    import ctypes
+
     import sys
 
     import torch
@@ -359,6 +363,10 @@ def test_driver_timed_configuration_equals_the_host_path(hip_default, workload):
     s = VitsDeviceSession(hip_default, B, Tx, Ty)
     s.set_options(use_graph=True, profile=False)
     s.set_sdp_always(True)
+    runs_fn = hip_default.lib.lib.vits_debug_persist_runs
+    runs_fn.restype = ctypes.c_int
+    runs_fn.argtypes = [ctypes.c_void_p]
+    r0 = int(runs_fn(hip_default._h))
     for rep in range(3):
         d_audio.zero_()
         s.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), B, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 7, d_audio.data_ptr(), Ty * 256)
@@ -367,6 +375,8 @@ def test_driver_timed_configuration_equals_the_host_path(hip_default, workload):
         for b in range(B):
             assert_close(f"{workload} item {b} (call {rep})", want[b, :wl[b]], got[b, :wl[b]], 2e-6)
     assert s.graph_nodes() > 0
+    if B == 1:  # (the first device session of a device owns its persistent programs; this suite runs one process per device)
+        assert int(runs_fn(hip_default._h)) - r0 == 3, "the merged persistent program did not run for every call"
     s.close()
 
 
