@@ -32,6 +32,9 @@
 //     into K-slices whose partial sums the consuming LayerNorm / coupling column step adds up;
 //   * attention = 16 x 16 (query tile, key tile) block steps (each gathers three 16 x d_k tiles, partial softmax with the banded
 //     relative-position terms of attentions.py:165-260) + a merge column step.
+//   * a step is whatever records the resolver wrote for it: sequences longer than the worker count (T up to PS_MAX_T = 512 with
+//     P = 256 workers) run a column step as two rounds of P columns and an attention step as rounds of P blocks -- the kernel is
+//     the same (round 4; DESIGN.md "Programs beyond 256 columns").
 // (v1 of the duration predictor ran a whole DDSConv layer per step like conv16_kernel's PRO == 1: every one of the 16 workgroups of
 // a column tile pulled the full 256-channel x 34-column window of two tensors and redid its LayerNorms and 8 k erf evaluations:
 // 12 us per step, 208 us for the predictor against 265 us of launches.)
