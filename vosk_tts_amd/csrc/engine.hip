@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -777,8 +778,13 @@ static inline int persist_mask() { return tl_persist >= 0 ? tl_persist : 0; }
 // VITS_PERSIST_LOCK=0: no lock; VITS_PERSIST_LOCK_DIR: directory of the lock files (default /tmp).
 static int g_proc_lock[64];     // 0 = not tried, 1 = this process owns the device's programs (or no lock is used), -1 = another process does
 static int g_proc_lock_fd[64];
+static std::chrono::steady_clock::time_point g_proc_lock_tried[64];
 static bool persist_process_owns(int dev) {  // (g_tok_mu held)
-  if (g_proc_lock[dev]) return g_proc_lock[dev] > 0;
+  if (g_proc_lock[dev] > 0) return true;
+  const auto now = std::chrono::steady_clock::now();
+  // denied: ask again once a second (the owner may have exited; one non-blocking flock)
+  if (g_proc_lock[dev] < 0 && now - g_proc_lock_tried[dev] < std::chrono::seconds(1)) return false;
+  g_proc_lock_tried[dev] = now;
   g_proc_lock_fd[dev] = -1;
   if (getenv("VITS_PERSIST_LOCK") && atoi(getenv("VITS_PERSIST_LOCK")) == 0) { g_proc_lock[dev] = 1; return true; }
   char bus[64] = "dev";
