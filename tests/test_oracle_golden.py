@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/vits_oracle.c) against fixtures produced by the
 reference's own PyTorch modules (oracle/gen_golden.py).  CPU-only, fast."""
+import os
+
 import numpy as np
 import pytest
 
@@ -208,3 +210,25 @@ def test_bench_cpu_baseline_leg_runs_without_a_gpu(tiny_blob):
     import json
 
     json.dumps(out)  # the bench prints it as part of its one JSON line
+
+
+def test_bench_workload_names_and_shapes():
+    """bench.py --workload: the BASELINE configs, the serving-shaped batches (s8 / s16) and u<N> (one utterance of N tokens, the
+    kernel-selection / program-length sweeps of round 4); durations pinned to 3 frames per valid token."""
+    import argparse
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name, B, Tx in (("c2", 1, 50), ("s8", 8, 47), ("s16", 16, 47), ("u120", 1, 120), ("u512", 1, 512), ("c5", 1, 2000)):
+        assert bench._workload_name(name) == name
+        ids, lengths, dur = bench.make_workload(name, np.random.default_rng(1234))
+        assert ids.shape == (B, Tx) and lengths.shape == (B,) and int(lengths.max()) == Tx
+        assert np.array_equal(dur.sum(1), 3 * lengths) and ids.min() >= 1
+    ids, lengths, dur = bench.make_workload("c3", np.random.default_rng(1234))
+    assert ids.shape[0] == 32 and 20 <= lengths.min() and lengths.max() <= 200
+    for bad in ("u0", "u", "x3", "u99999"):
+        with pytest.raises(argparse.ArgumentTypeError):
+            bench._workload_name(bad)
