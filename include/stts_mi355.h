@@ -56,10 +56,13 @@ typedef struct stts_synth_opts {
   int64_t noise_stride;  /* >= T_y rounded up to a multiple of 4 (fix_len_compatibility, utils/model.py:14-20) */
   uint64_t seed;         /* Philox seed when noise == NULL */
   int32_t n_timesteps;   /* 0 = hparams.n_timesteps */
-  int32_t flags;
-  const uint64_t* item_seeds; /* stts_synthesize_batch only: [B] Philox seed of every item (NULL: seed + b), so that what a request
-                               * gets does not depend on what it was batched with (MultiDeviceSynth) */
+  int32_t flags;         /* STTS_FLAG_* */
+  const uint64_t* item_seeds; /* stts_synthesize_batch only, and only read when flags & STTS_FLAG_ITEM_SEEDS: [B] Philox seed of every
+                               * item (otherwise seed + b), so that what a request gets does not depend on what it was batched with
+                               * (MultiDeviceSynth).  The field was appended after the first release of this struct: a caller built
+                               * against the shorter struct never sets the flag, so the library never reads past what it passed */
 } stts_synth_opts;
+#define STTS_FLAG_ITEM_SEEDS 1
 
 /* The hot path for ONE utterance: MatchaTTS.synthesise (matcha_tts.py:93-211) -> denormalised mel ->
  * vocoder.decode(mel).clamp(-1,1) (onnx/export.py:28-31).

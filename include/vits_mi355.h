@@ -305,12 +305,29 @@ void vits_debug_ks_waves(int nw);
 void vits_debug_ln_stats(int on);
 /* Bit mask of the single-utterance stages (B = 1, T <= 256) that run as ONE persistent kernel each, with in-band ("LL cell")
  * exchange between their steps (csrc/persist.hip.h): 1 duration predictor, 2 text encoder, 4 flow.  Default 7; 0: the launch-per-layer
- * path everywhere (the A/B reference, and the batch path). */
+ * path everywhere (the A/B reference, and the batch path).  Setting the mask also ends a timeout's off interval at once. */
 void vits_debug_persist(int mask);
 /* Test hook: poll rounds after which a worker of a persistent program gives up (0 = the default bound, 2^18).  A timeout
- * switches the persistent programs off for the process and the host entry points run the call again on the launch path
- * (the caller sees a slower call, not an error); an asynchronous device session reports VITS_ERR_DEVICE once. */
+ * switches the persistent programs off for a bounded interval (below) and the host entry points run the call again on the launch
+ * path (the caller sees a slower call, not an error); an asynchronous device session reports VITS_ERR_DEVICE once. */
 void vits_debug_persist_spin(int limit);
+/* State of the persistent programs in this process.  A poll timeout (the program's workgroups were not all co-resident: another
+ * process on the device, a transient) turns them off for VITS_PERSIST_REARM_MS (environment, default 1000) and they are re-armed
+ * by the first call after that; the interval doubles (up to 64 x) while timeouts keep following the re-arms.  A server logs this
+ * (vosk_tts_amd.session.VitsSession does, at WARNING, whenever `timeouts` grows). */
+typedef struct vits_persist_info {
+  int32_t configured_mask;     /* vits_debug_persist / VITS_PERSIST: 1 duration predictor, 2 text encoder, 4 flow */
+  int32_t active_mask;         /* what a call would use now: 0 while switched off after a timeout */
+  int32_t off_for_ms;          /* milliseconds until the re-arm (0 = armed) */
+  int32_t timeouts;            /* poll timeouts since the library was loaded */
+  int32_t rearms;              /* re-arms since the library was loaded */
+  int32_t launches;            /* persistent launches of `m` that ran to completion (-1 without a model) */
+  int32_t process_owns_device; /* this process holds the cross-process lock of m's device: 1 yes, -1 another process does, 0 not asked yet */
+  int32_t reserved;
+} vits_persist_info;
+int vits_persist_state(vits_model* m, vits_persist_info* out);
+/* Test hook: base re-arm interval in milliseconds (0 = VITS_PERSIST_REARM_MS or 1000). */
+void vits_debug_persist_rearm_ms(int ms);
 /* Test hook: persistent-program launches of this model that ran to completion (no timeout) since vits_create; -1 on error.
  * (The bound of vits_debug_persist_spin is a device word the kernel reads at run time: captured graphs follow it.) */
 int vits_debug_persist_runs(vits_model* m);

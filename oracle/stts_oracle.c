@@ -514,8 +514,8 @@ int SAPI(synthesize_batch)(stts_model* m, const int64_t* ids, const int64_t* len
     if (bb) for (int c = 0; c < m->hp.bert_dim; ++c) memcpy(bb + (size_t)c * L, bert + ((size_t)b * m->hp.bert_dim + c) * Tx, sizeof(float) * L);
     stts_synth_opts o = {0};
     if (opts) o = *opts;
-    o.seed = (opts && opts->item_seeds) ? opts->item_seeds[b] : (opts ? opts->seed : 0) + (uint64_t)b;
-    o.item_seeds = NULL;
+    o.seed = (opts && (opts->flags & STTS_FLAG_ITEM_SEEDS) && opts->item_seeds) ? opts->item_seeds[b] : (opts ? opts->seed : 0) + (uint64_t)b;
+    o.item_seeds = NULL; o.flags &= ~STTS_FLAG_ITEM_SEEDS;
     int64_t ns = 0;
     rc = SAPI(synthesize)(m, idb, L, scales, sid ? sid[b] : 0, bb, pde ? pde + (size_t)b * Tx : NULL, &o, &wav[b], &ns, NULL, NULL);
     out_lengths[b] = ns;

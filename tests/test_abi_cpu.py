@@ -92,7 +92,7 @@ def test_every_ctypes_mirror_has_the_layout_of_its_header_struct(tmp_path):
 
     from vosk_tts_amd import capi, capi_stts, weights, weights_bert, weights_stts
 
-    pairs = [(weights.HParams, "vits_hparams"), (weights.BlobEntry, "vits_blob_entry"), (capi.SynthOpts, "vits_synth_opts"),
+    pairs = [(weights.HParams, "vits_hparams"), (weights.BlobEntry, "vits_blob_entry"), (capi.SynthOpts, "vits_synth_opts"), (capi.PersistInfo, "vits_persist_info"),
              (weights_stts.SttsHParams, "stts_hparams"), (capi_stts.SttsOpts, "stts_synth_opts"), (weights_bert.BertHParams, "bert_hparams")]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "vits_mi355.h"', '#include "stts_mi355.h"', 'int main(void) {']

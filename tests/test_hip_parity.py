@@ -1066,11 +1066,14 @@ def test_pcm16_output_equals_numpy_conversion(hip_lib, hip_default):
                 assert (np.abs(p) == 32767).any()
 
 
-def test_persistent_timeout_falls_back_to_launches_without_failing_the_call(hip_lib, hip_default):
+def test_persistent_timeout_falls_back_to_launches_and_rearms(hip_lib, hip_default):
     """A poll of a persistent program that does not complete within its bound (workgroups not co-resident: another process on the
-    device) must not cost the request: the host entry point switches the persistent programs off and runs the call again on
-    launches.  Forced here by shrinking the bound to one round (vits_debug_persist_spin): the call succeeds, returns what the
-    launch path returns, and later calls stay on launches until the switch is set again."""
+    device) must not cost the request, and must not cost the process its programs for good: the host entry point runs the call again
+    on launches, the programs stay off for a bounded interval (vits_persist_state says so) and the first call after it runs them
+    again -- the SAME model, the same captured graphs.  Forced here by shrinking the poll bound to one round
+    (vits_debug_persist_spin).  A timeout that follows a re-arm closely doubles the interval."""
+    import time
+
     rng = np.random.default_rng(77)
     ids = rng.integers(1, 62, size=(1, 40)).astype(np.int64)
     lens = np.array([40], np.int64)
@@ -1080,29 +1083,102 @@ def test_persistent_timeout_falls_back_to_launches_without_failing_the_call(hip_
     lib.vits_debug_persist_runs.restype = ctypes.c_int
     lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
     runs = lambda: int(lib.vits_debug_persist_runs(hip_default._h))
+    state = hip_default.persist_state
     lib.vits_debug_persist(0)
     want, wl = hip_default.synthesize(ids, lens, sc, sid, seed=9)
+    assert state()["active_mask"] == 0 and state()["configured_mask"] == 0
     r0 = runs()
     try:
         lib.vits_debug_persist(7)
+        lib.vits_debug_persist_rearm_ms(400)
         warm, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # captures this bucket's graphs WITH the persistent kernels
         assert runs() == r0 + 2, "front (text encoder + duration predictor + durations) and back (prior + flow): two completed persistent launches"
         assert_close("persistent", want, warm, 2e-4)
+        s0 = state()
+        assert s0["active_mask"] == 7 and s0["off_for_ms"] == 0 and s0["launches"] == r0 + 2 and s0["process_owns_device"] == 1
         lib.vits_debug_persist_spin(1)  # (a device word: the graphs captured above follow it)
         r1 = runs()
         got, gl = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # times out inside, retried on launches
+        t_off = time.monotonic()
         assert runs() == r1, "no persistent launch may have completed under a one-round bound"
         assert np.array_equal(wl, gl)
         assert_close("timeout fallback", want, got, 1e-6)
-        pcm, _ = hip_default.synthesize_pcm16(ids, lens, sc, sid, seed=9)  # persistent programs are off now: plain launch path
+        s1 = state()
+        assert s1["timeouts"] == s0["timeouts"] + 1 and s1["active_mask"] == 0 and 0 < s1["off_for_ms"] <= 400 and s1["configured_mask"] == 7
+        lib.vits_debug_persist_spin(0)  # the cause is gone, but the interval has not passed: launch path
+        pcm, _ = hip_default.synthesize_pcm16(ids, lens, sc, sid, seed=9)
         assert pcm.shape[-1] == got.shape[-1]
         chunks = list(hip_default.stream(ids[:, :40], sc, 1, chunk_frames=32, seed=9))
         assert sum(len(c) for c in chunks) == int(gl[0])
-        assert runs() == r1
+        if time.monotonic() - t_off < 0.35:
+            assert runs() == r1
+        time.sleep(max(0.0, 0.45 - (time.monotonic() - t_off)))
+        again, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # re-armed: the same captured graphs, the same model
+        assert runs() == r1 + 2, "the first call after the interval must have run the two persistent launches to completion"
+        assert_close("persistent again", want, again, 2e-4)
+        s2 = state()
+        assert s2["rearms"] == s1["rearms"] + 1 and s2["active_mask"] == 7 and s2["off_for_ms"] == 0
+        lib.vits_debug_persist_spin(1)  # and a timeout right after a re-arm backs off: twice the interval
+        hip_default.synthesize(ids, lens, sc, sid, seed=9)
+        s3 = state()
+        assert s3["timeouts"] == s2["timeouts"] + 1 and 400 < s3["off_for_ms"] <= 800
     finally:
         lib.vits_debug_persist_spin(0)
-        lib.vits_debug_persist(7)
+        lib.vits_debug_persist_rearm_ms(0)
+        lib.vits_debug_persist(7)  # (arms at once)
     r2 = runs()
-    again, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)  # and back on the persistent programs: the SAME captured graphs
-    assert runs() == r2 + 2, "the last call must have run the two persistent launches to completion"
-    assert_close("persistent again", want, again, 2e-4)
+    last, _ = hip_default.synthesize(ids, lens, sc, sid, seed=9)
+    assert runs() == r2 + 2
+    assert_close("persistent, armed by the switch", want, last, 2e-4)
+
+
+def test_batch_on_another_stream_does_not_starve_the_persistent_programs(hip_lib, hip_default):
+    """A c3-sized batch (32 ragged items) running on its own session / stream from another thread while single utterances run the
+    persistent programs: the programs' workgroups must all become co-resident in time (no poll timeout, no fallback), and both
+    callers get what they get alone."""
+    import threading
+
+    rng = np.random.default_rng(5)
+    sc = np.array([0.667, 1.0, 0.8], np.float32)
+    B, T = 32, 200
+    lens_b = rng.integers(20, T + 1, size=B).astype(np.int64); lens_b[0] = T
+    ids_b = np.zeros((B, T), np.int64)
+    for b in range(B):
+        ids_b[b, :lens_b[b]] = rng.integers(1, 62, size=lens_b[b])
+    sid_b = rng.integers(0, 7, size=B).astype(np.int64)
+    ids1 = rng.integers(1, 62, size=(1, 50)).astype(np.int64)
+    lens1 = np.array([50], np.int64); sid1 = np.array([2], np.int64)
+    lib = hip_lib.lib
+    lib.vits_debug_persist(7)
+    want1, _ = hip_default.synthesize(ids1, lens1, sc, sid1, seed=3)
+    wantb, wl = hip_default.synthesize(ids_b, lens_b, sc, sid_b, seed=4)
+    st0 = hip_default.persist_state()
+    stop = threading.Event()
+    errs, nb = [], [0]
+
+    def batches():
+        try:
+            while not stop.is_set():
+                a, l = hip_default.synthesize(ids_b, lens_b, sc, sid_b, seed=4)
+                nb[0] += 1
+                if nb[0] == 1:
+                    assert np.array_equal(l, wl)
+                    assert_close("batch under contention", wantb, a, 1e-5)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=batches)
+    th.start()
+    try:
+        n1 = 0
+        while (nb[0] < 3 or n1 < 40) and not errs and n1 < 4000:
+            got1, _ = hip_default.synthesize(ids1, lens1, sc, sid1, seed=3)
+            assert_close("single utterance under contention", want1, got1, 2e-4)
+            n1 += 1
+    finally:
+        stop.set()
+        th.join(120)
+    assert not errs, errs
+    st1 = hip_default.persist_state()
+    assert st1["timeouts"] == st0["timeouts"], "a persistent program timed out next to a batch on another stream"
+    assert st1["launches"] >= st0["launches"] + 2 * n1, "every single-utterance call must have completed its two persistent launches"

@@ -408,8 +408,8 @@ def test_multi_device_synth_on_two_devices(tmp_path):
 
 def test_request_coalescer_batches_concurrent_requests_and_routes_results():
     """RequestCoalescer (session.py; no GPU needed): a lone request runs at once and alone; requests that arrive while a call is in
-    flight are handed to ONE waiter as one batch (same key only, at most max_batch), every caller gets its own result, and an
-    exception of a batch reaches every member of it."""
+    flight are handed to ONE waiter as one batch (same key only, at most max_batch), every caller gets its own result, and a merged
+    batch that fails is re-run member by member: only the offending request sees an exception (its own object)."""
     import threading
     import time
 
@@ -420,8 +420,8 @@ def test_request_coalescer_batches_concurrent_requests_and_routes_results():
 
     def run_batch(key, reqs):
         seen.append((key, [r[2] for r in reqs]))
-        if key == "boom":
-            raise RuntimeError("engine failure")
+        if any(r[2] == 8 for r in reqs):
+            raise RuntimeError(f"token id out of range (batch of {len(reqs)})")
         if len(seen) == 1:
             gate.wait(5)  # the first call stays in flight until the others have queued up
         return [("out", key, r[2]) for r in reqs]
@@ -435,13 +435,13 @@ def test_request_coalescer_batches_concurrent_requests_and_routes_results():
         try:
             results[seed] = co.submit(key, None, 0, seed)
         except RuntimeError as e:
-            errors[seed] = str(e)
+            errors[seed] = e
 
     first = threading.Thread(target=call, args=("a", 1))
     first.start()
     while not seen:
         time.sleep(0.001)
-    rest = [threading.Thread(target=call, args=("a" if k < 7 else "boom", k)) for k in range(2, 10)]
+    rest = [threading.Thread(target=call, args=("a" if k < 7 else "b", k)) for k in range(2, 10)]
     for t in rest:
         t.start()
     while len(co._queue) < 8:
@@ -452,12 +452,37 @@ def test_request_coalescer_batches_concurrent_requests_and_routes_results():
     assert (set(results) | set(errors)) == set(range(1, 10))
     keys = [k for k, _ in seen]
     sizes = [len(v) for _, v in seen]
-    assert seen[0] == ("a", [1]) and max(sizes) <= 4 and sum(sizes) == 9
+    merged = [(k, v) for k, v in seen if len(v) > 1]
+    assert seen[0] == ("a", [1]) and max(sizes) <= 4
     assert all(len({kk}) == 1 for kk in keys)  # one key per engine call
     for key, seeds in seen:
-        assert all((sd >= 7) == (key == "boom") for sd in seeds)
-    assert set(errors) == {7, 8, 9} and all(results[k] == ("out", "a", k) for k in range(1, 7))
-    assert co.calls == len(seen) + 1 and co.requests == 10 and co.largest == max(sizes) and co._busy == 0 and not co._queue
+        assert all((sd >= 7) == (key == "b") for sd in seeds)
+    # the batch (7, 8, 9) failed as a whole and was re-run as three single calls: 7 and 9 are served, only 8 fails
+    assert ("b", [7, 8, 9]) in merged and [("b", [k]) in seen for k in (7, 8, 9)] == [True] * 3
+    assert set(errors) == {8} and "batch of 1" in str(errors[8]) and co.split_retries == 1
+    assert all(results[k] == ("out", "a" if k < 7 else "b", k) for k in (1, 2, 3, 4, 5, 6, 7, 9))
+    assert co.requests == 10 and co.largest == max(sizes) and co._busy == 0 and not co._queue
+
+
+def test_session_does_not_slice_by_an_unvalidated_length():
+    """VitsSession._coalescable (no GPU needed): input_lengths outside (0, T] must not be used to slice the ids -- such a request is
+    not merged and takes the direct call, whose C-side check answers VITS_ERR_ARG."""
+    from vosk_tts_amd.session import RequestCoalescer, VitsSession
+
+    class HP:
+        bert_dim = 0
+
+    s = VitsSession.__new__(VitsSession)
+    s.hp = HP()
+    s.coalescer = RequestCoalescer(lambda k, r: [], 4)
+    ids = np.ones((1, 5), np.int64)
+    f = lambda n: {"input": ids, "input_lengths": np.array(n, np.int64).reshape(-1), "scales": np.ones(3, np.float32)}
+    assert s._coalescable(f(5), ids) == 5 and s._coalescable(f(3), ids) == 3
+    assert s._coalescable(f(6), ids) == 0 and s._coalescable(f(0), ids) == 0 and s._coalescable(f(-2), ids) == 0
+    assert s._coalescable(f([3, 3]), ids) == 0
+    assert s._coalescable(dict(f(5), **{"vits.solo": True}), ids) == 0
+    s.coalescer = None
+    assert s._coalescable(f(5), ids) == 0
 
 
 @pytest.mark.gpu

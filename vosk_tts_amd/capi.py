@@ -37,6 +37,13 @@ class SynthOpts(ctypes.Structure):
     ]
 
 
+class PersistInfo(ctypes.Structure):
+    """mirror of `struct vits_persist_info` (vits_persist_state)"""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("configured_mask", "active_mask", "off_for_ms", "timeouts", "rearms", "launches",
+                                               "process_owns_device", "reserved")]
+
+
 class VitsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"vits error {code}: {msg}")
@@ -128,6 +135,7 @@ class VitsLib:
             f("stream_next").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int64, c_i64p]
             f("stream_close").argtypes = [ctypes.c_void_p]
             f("stream_close").restype = None
+            f("persist_state").argtypes = [ctypes.c_void_p, ctypes.POINTER(PersistInfo)]
 
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -175,6 +183,13 @@ class VitsModel:
         self.hp = HParams()
         lib.check(lib._fn("get_hparams")(self._h, ctypes.byref(self.hp)))
         self.device = device
+
+    def persist_state(self, with_device=True):
+        """vits_persist_state: dict of the persistent-program state of this process (masks, timeouts, re-arms, completed launches).
+        with_device=False: process-wide counters only (no device synchronisation; `launches` / `process_owns_device` are -1)."""
+        info = PersistInfo()
+        self.lib.check(self.lib._fn("persist_state")(self._h if with_device else None, ctypes.byref(info)))
+        return {n: int(getattr(info, n)) for n, _ in PersistInfo._fields_ if n != "reserved"}
 
     def close(self):
         if self._h:

@@ -9,6 +9,9 @@ from .capi import VitsError, VitsLib, _f32, _i32, _i64, _p, c_f32p, c_i32p, c_i6
 from .weights_stts import SttsHParams
 
 
+STTS_FLAG_ITEM_SEEDS = 1  # include/stts_mi355.h
+
+
 class SttsOpts(ctypes.Structure):
     _fields_ = [("noise", c_f32p), ("noise_stride", ctypes.c_int64), ("seed", ctypes.c_uint64),
                 ("n_timesteps", ctypes.c_int32), ("flags", ctypes.c_int32), ("item_seeds", ctypes.POINTER(ctypes.c_uint64))]
@@ -143,6 +146,7 @@ class SttsModel:
             if sd.shape != (B,):
                 raise ValueError("item_seeds must be [B]")
             opts.item_seeds = sd.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+            opts.flags |= STTS_FLAG_ITEM_SEEDS  # (the trailing field is only read under this flag: include/stts_mi355.h)
         au = c_f32p(); ns = ctypes.c_int64(); ol = np.zeros(B, np.int64)
         self.check(self._fn("synthesize_batch")(self._h, _p(ids, c_i64p), _p(lengths, c_i64p), B, T, _p(scales, c_f32p), _p(sid, c_i64p),
                                                 None if b is None else _p(b, c_f32p), None if p is None else _p(p, c_f32p),

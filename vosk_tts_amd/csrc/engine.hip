@@ -79,6 +79,27 @@ static std::mutex g_tok_mu;
 static bool g_tok_busy[64];
 static thread_local int tl_persist = -1;  // >= 0: this thread's mask for the call in progress
 static int g_persist = getenv("VITS_NO_PERSIST") ? 0 : (getenv("VITS_PERSIST") ? atoi(getenv("VITS_PERSIST")) : 7);  // mask: 1 duration predictor, 2 text encoder, 4 flow (environment switches: A/B runs of bench.py and tools/)
+// A poll timeout (persist_timed_out) switches the programs off for a BOUNDED interval, not for the life of the process: a server that
+// once lost co-residency (another process on the device, a transient) gets them back.  The interval starts at VITS_PERSIST_REARM_MS
+// (default 1000) and doubles with every timeout that follows a re-arm within 10 intervals (cap: 64 x), so a device that is shared for
+// good costs one failed forward per minute, not one per second.  persist_cfg() is the mask in effect now; vits_persist_state reports.
+static long long g_ps_rearm_base_ns = (getenv("VITS_PERSIST_REARM_MS") ? atoll(getenv("VITS_PERSIST_REARM_MS")) : 1000) * 1000000LL;
+static std::atomic<long long> g_ps_off_until_ns{0};  // steady-clock ns; 0 = armed
+static std::atomic<long long> g_ps_rearmed_at_ns{0};
+static std::atomic<long long> g_ps_rearm_ns{0};      // current interval (0 = base)
+static std::atomic<int> g_ps_timeouts{0}, g_ps_rearms{0};
+static inline long long steady_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static int persist_cfg() {
+  if (!g_persist) return 0;
+  long long until = g_ps_off_until_ns.load(std::memory_order_relaxed);
+  if (!until) return g_persist;
+  const long long now = steady_ns();
+  if (now < until) return 0;
+  if (g_ps_off_until_ns.compare_exchange_strong(until, 0)) { g_ps_rearms.fetch_add(1); g_ps_rearmed_at_ns.store(now); }
+  return g_persist;
+}
 
 // ------------------------------------------------------------------------------------ weights
 struct ConvW {
@@ -792,15 +813,27 @@ static bool persist_process_owns(int dev) {  // (g_tok_mu held)
   for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
   char path[512];
   snprintf(path, sizeof path, "%s/vits_mi355_persist_%s.lock", getenv("VITS_PERSIST_LOCK_DIR") ? getenv("VITS_PERSIST_LOCK_DIR") : "/tmp", bus);
-  const int fd = open(path, O_CREAT | O_RDONLY | O_CLOEXEC, 0644);  // (read-only: another user's process can open it too; flock does not care)
+  // read-only: another user's process can open it too (flock does not care); O_NOFOLLOW: a symlink planted under the predictable name
+  // in a shared directory is refused, not followed (then: no lock, as without a lock directory)
+  const int fd = open(path, O_CREAT | O_RDONLY | O_CLOEXEC | O_NOFOLLOW, 0644);
   if (fd < 0) { g_proc_lock[dev] = 1; return true; }                // no lock directory: as before
-  if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); g_proc_lock[dev] = -1; return false; }
+  if (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+    close(fd);
+    if (g_proc_lock[dev] == 0 && !getenv("VITS_QUIET"))  // once per (process, device, model generation)
+      fprintf(stderr, "[vits_mi355] device %d: another process owns the persistent programs (%s): single utterances run the launch path here\n", dev, path);
+    g_proc_lock[dev] = -1;
+    return false;
+  }
   g_proc_lock[dev] = 1; g_proc_lock_fd[dev] = fd;
   return true;
 }
-static void persist_process_release(int dev) {  // the last model of this process on `dev` is gone
+static void persist_process_release(int dev) {  // called when a model of this process on `dev` is gone
   std::lock_guard<std::mutex> g(g_tok_mu);
   if (dev < 0 || dev >= 64) return;
+  {  // decided HERE, under the token mutex: a model created since the caller looked keeps the lock it may be using
+    std::lock_guard<std::mutex> gm(g_models_mu);
+    for (vits_model* o : g_models) if (o->device == dev) return;
+  }
   if (g_proc_lock[dev] > 0 && g_proc_lock_fd[dev] >= 0) { flock(g_proc_lock_fd[dev], LOCK_UN); close(g_proc_lock_fd[dev]); }
   g_proc_lock[dev] = 0; g_proc_lock_fd[dev] = -1;  // (a process that was denied asks again with its next model)
 }
@@ -817,7 +850,11 @@ static void persist_token_release(int dev) {
 // a host call that launches AND waits for its kernels: owns the token (when it is free) from here to its end
 struct PersistScope {
   int dev; bool own;
-  explicit PersistScope(int dev_) : dev(dev_), own(g_persist != 0 && persist_token_try(dev_)) { tl_persist = own ? g_persist : 0; }
+  explicit PersistScope(int dev_) : dev(dev_) {
+    const int cfg = persist_cfg();
+    own = cfg != 0 && persist_token_try(dev_);
+    tl_persist = own ? cfg : 0;
+  }
   void release() { tl_persist = -1; if (own) persist_token_release(dev); own = false; }  // (the caller has waited for its kernels)
   ~PersistScope() { release(); }
 };
@@ -1678,9 +1715,20 @@ static void run_encoder(vits_session* s, const EncoderW& E, float* x, const int*
 // call, not an error; asynchronous device sessions report VITS_ERR_DEVICE once.
 static thread_local bool tl_ps_timed_out = false;
 static int persist_timed_out() {
-  g_persist = 0;
+  const long long now = steady_ns();
+  long long iv = g_ps_rearm_ns.load();
+  const long long at = g_ps_rearmed_at_ns.load();
+  if (!iv || !at || now - at > 10 * iv) iv = g_ps_rearm_base_ns;          // first timeout, or the last re-arm held: start over
+  else if (iv < 64 * g_ps_rearm_base_ns) iv *= 2;                        // timed out again soon after a re-arm: back off
+  if (iv < 1) iv = 1;
+  g_ps_rearm_ns.store(iv);
+  g_ps_off_until_ns.store(now + iv);
+  const int n = g_ps_timeouts.fetch_add(1) + 1;
   tl_ps_timed_out = true;
-  return fail(VITS_ERR_DEVICE, "persistent kernel: exchange timed out (workgroups not co-resident?); disabled for this process");
+  if (!getenv("VITS_QUIET"))
+    fprintf(stderr, "[vits_mi355] persistent program: exchange timed out (workgroups not co-resident?) -- launch path for %.1f s, then re-armed (timeout #%d)\n",
+            iv * 1e-9, n);
+  return fail(VITS_ERR_DEVICE, "persistent kernel: exchange timed out (workgroups not co-resident?); off for %.1f s", iv * 1e-9);
 }
 
 static int check_err(vits_session* s) {
@@ -2241,7 +2289,7 @@ void vits_destroy(vits_model* m) {
   for (void* a : m->allocs) hipFree(a);
   const int dev = m->device;
   delete m;
-  if (last_on_device) { hipDeviceSynchronize(); persist_process_release(dev); }  // (nothing of this process runs a program there any more)
+  if (last_on_device) { hipDeviceSynchronize(); persist_process_release(dev); }  // (nothing of this process runs a program there any more; re-checked under the token mutex)
 }
 
 int vits_get_hparams(const vits_model* m, vits_hparams* out) {
@@ -3086,7 +3134,7 @@ int vits_session_create(vits_model* m, int32_t max_B, int32_t max_Tx, int32_t ma
   if (rc != VITS_OK) { session_free(s); return rc; }
   // the asynchronous entry point cannot hand the token back per call (nobody waits for the kernels): the first device session of a
   // device keeps it until it is destroyed; others (and host calls in the meantime) run the launch path
-  s->ps_owner = g_persist != 0 && persist_token_try(m->device);
+  s->ps_owner = g_persist != 0 && persist_token_try(m->device);  // (the token, not the mask: persist_cfg() decides per call)
   *out = s;
   return VITS_OK;
 }
@@ -3106,7 +3154,7 @@ int vits_session_synthesize_device(vits_session* s, const int64_t* d_ids, const 
   HIP_TRY(hipSetDevice(m->device));
   (void)stream;  // sessions run on their own stream; the argument is reserved
   TRY(session_reserve(s, B, Tx, Ty));
-  struct Mask { Mask(int v) { tl_persist = v; } ~Mask() { tl_persist = -1; } } mask(s->ps_owner ? g_persist : 0);
+  struct Mask { Mask(int v) { tl_persist = v; } ~Mask() { tl_persist = -1; } } mask(s->ps_owner ? persist_cfg() : 0);
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
   if (s->use_graph && !s->profile) {
     vits_session::GKey key(d_ids, d_lengths, d_sid, d_forced, d_audio, B, Tx, Ty, seed, scales[0], scales[1], scales[2], persist_mask());
@@ -3148,7 +3196,32 @@ void vits_debug_ks_waves(int nw) { g_ks_waves = nw; }
 void vits_debug_tail_impl(int impl) { g_tail_impl = impl; }
 void vits_debug_wn_fold(int on) { g_wn_fold = on; }
 void vits_debug_ln_stats(int on) { g_ln_stats = on; }
-void vits_debug_persist(int on) { g_persist = on; }
+void vits_debug_persist(int on) {  // (also arms the programs at once: a test that switches them on means now)
+  g_persist = on;
+  g_ps_off_until_ns.store(0); g_ps_rearm_ns.store(0); g_ps_rearmed_at_ns.store(0);
+}
+void vits_debug_persist_rearm_ms(int ms) {
+  g_ps_rearm_base_ns = (ms > 0 ? (long long)ms : (getenv("VITS_PERSIST_REARM_MS") ? atoll(getenv("VITS_PERSIST_REARM_MS")) : 1000)) * 1000000LL;
+}
+// State of the persistent programs of this process (a server logs it; tests assert the re-arm).
+int vits_persist_state(vits_model* m, vits_persist_info* out) {
+  if (!out) return fail(VITS_ERR_ARG, "null out");
+  memset(out, 0, sizeof *out);
+  out->configured_mask = g_persist;
+  const long long until = g_ps_off_until_ns.load(), now = steady_ns();
+  out->active_mask = (until && now < until) ? 0 : g_persist;
+  out->off_for_ms = (until && now < until) ? (int32_t)((until - now + 999999) / 1000000) : 0;
+  out->timeouts = g_ps_timeouts.load();
+  out->rearms = g_ps_rearms.load();
+  out->launches = -1;
+  out->process_owns_device = -1;
+  if (m) {
+    out->launches = vits_debug_persist_runs(m);
+    std::lock_guard<std::mutex> g(g_tok_mu);
+    if (m->device >= 0 && m->device < 64) out->process_owns_device = g_proc_lock[m->device];
+  }
+  return VITS_OK;
+}
 // The limit lives in a device word the kernel reads at run time, so graphs captured before or after the call follow it alike.
 void vits_debug_persist_spin(int limit) {
   g_ps_spin_limit = limit > 0 ? limit : 0;

@@ -762,9 +762,21 @@ static void persist_build_back(vits_session* s, vits_session::PersistProg& pp) {
 // before must not look like a cell of a later forward); the epoch block survives re-plans, so epochs only ever grow.
 // A failure here (allocation, upload) is not an error of the call: the affected programs stay !ok and their stages run on launches.
 static void persist_plan(vits_session* s) {
-  s->ps_enc.ok = s->ps_sdp.ok = s->ps_flow.ok = false;
+  // EVERY program of the previous layout dies here, the composite ones included: their records point into the arena as it was laid
+  // out before (a session that served an eligible shape and is then reserved for one beyond PS_MAX_T must not find a stale `ok`)
+  auto clear_all = [&]() {
+    s->ps_enc.ok = s->ps_sdp.ok = s->ps_flow.ok = s->ps_back.ok = false;
+    for (int k = 0; k < 2; ++k) s->ps_front[k].ok = s->ps_full[k].ok = false;
+  };
+  clear_all();
   if (!s->ps_enc.cells && !s->ps_sdp.cells && !s->ps_flow.cells) return;
-  auto give_up = [&]() { s->ps_enc.ok = s->ps_sdp.ok = s->ps_flow.ok = false; (void)hipGetLastError(); };
+  auto give_up = [&]() {
+    clear_all();
+    const hipError_t e = hipGetLastError();
+    static std::atomic<bool> said{false};  // (once per process: the reserve does not fail, so say why single utterances are slower)
+    if (!said.exchange(true) && !getenv("VITS_QUIET"))
+      fprintf(stderr, "[vits_mi355] persistent programs could not be built (%s): their stages run the launch path\n", hipGetErrorString(e));
+  };
   if (!s->ps_ctl) {
     if (hipMalloc((void**)&s->ps_ctl, sizeof(PersistCtl)) != hipSuccess) { s->ps_ctl = nullptr; return give_up(); }
     if (hipMemsetAsync(s->ps_ctl, 0, sizeof(PersistCtl), s->stream) != hipSuccess) return give_up();
@@ -775,8 +787,6 @@ static void persist_plan(vits_session* s) {
   if (s->ps_enc.cells && s->ps_enc.ll) persist_build_enc(s);
   if (s->ps_sdp.cells && s->ps_sdp.ll) persist_build_sdp(s);
   if (s->ps_flow.cells && s->ps_flow.ll) persist_build_flow(s);
-  for (int k = 0; k < 2; ++k) { s->ps_front[k].ok = false; s->ps_full[k].ok = false; }
-  s->ps_back.ok = false;
   if (s->ps_x.cells && s->ps_x.ll) {
     const bool enc = s->ps_enc.ok, sdp = s->ps_sdp.ok, flow = s->ps_flow.ok;
     if (enc) {

@@ -1111,7 +1111,7 @@ int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* leng
   s->ragged = B > 1;
   struct RaggedOff { vits_session* s; ~RaggedOff() { s->ragged = false; s->tile_tabs = nullptr; s->tile_keys.clear(); } } ragged_off{s};
   const unsigned long long* d_seeds = nullptr;
-  if (opts && opts->item_seeds) {
+  if (opts && (opts->flags & STTS_FLAG_ITEM_SEEDS) && opts->item_seeds) {
     d_seeds = call.up(reinterpret_cast<const unsigned long long*>(opts->item_seeds), (size_t)B);
     if (!d_seeds) return fail(VITS_ERR_NOMEM, "device alloc failed");
   }

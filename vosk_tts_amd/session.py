@@ -12,12 +12,15 @@ is no CPU path.  Thread-safe: the gRPC server shares one Synth across worker thr
 (server/tts_server.py:39-40) and ctypes releases the GIL during the call.
 """
 import itertools
+import logging
 import os
 import threading
 
 import numpy as np
 
 from .capi import VitsLib
+
+log = logging.getLogger(__name__)
 
 
 class _Pending:
@@ -53,6 +56,7 @@ class RequestCoalescer:
         self.calls = 0        # engine calls issued
         self.requests = 0     # requests served
         self.largest = 0      # largest batch so far
+        self.split_retries = 0  # merged batches that failed and were re-run member by member
 
     def submit(self, key, ids, sid, seed):
         me = _Pending(key, ids, sid, seed)
@@ -76,9 +80,21 @@ class RequestCoalescer:
                 outs = self._run_batch(batch[0].key, [(p.ids, p.sid, p.seed) for p in batch])
                 for p, o in zip(batch, outs):
                     p.result = o
-            except BaseException as e:  # every member of the batch sees the failure
+            except Exception as e:
+                if len(batch) == 1:
+                    me.error = e
+                else:
+                    # a merged batch failed: one bad request (token / speaker id out of range, ...) must not fail the unrelated
+                    # requests it was merged with -- run the members one by one, each gets its own result or its own exception
+                    self.split_retries += 1
+                    for p in batch:
+                        try:
+                            p.result = self._run_batch(p.key, [(p.ids, p.sid, p.seed)])[0]
+                        except Exception as e1:
+                            p.error = e1
+            except BaseException as e:  # KeyboardInterrupt / SystemExit in the leader: nobody may be left waiting
                 for p in batch:
-                    p.error = e
+                    p.error = RuntimeError(f"batch leader interrupted: {e!r}") if p is not me else e
         finally:
             with self._lock:
                 self.calls += 1
@@ -129,11 +145,41 @@ class VitsSession:
             # programs); merging only starts beyond that, which also bounds the workspaces and streams a burst can pin
             max_inflight = int(os.environ.get("VITS_COALESCE_INFLIGHT", "8"))
         self.coalescer = RequestCoalescer(self._run_solo_batch, max_batch, max_inflight) if coalesce else None
+        self._ps_timeouts = 0  # persistent-program timeouts already reported (persist_state)
+
+    def persist_state(self, with_device=True):
+        """State of the single-utterance persistent programs in this process (vits_persist_state): a poll timeout -- the device shared
+        with another process, a transient -- puts single utterances on the ~1.5x slower launch path for a bounded interval, after which
+        the programs are re-armed.  Logged at WARNING whenever the timeout count has grown since the last look."""
+        st = self._model.persist_state(with_device)
+        if st["timeouts"] > self._ps_timeouts:
+            log.warning("persistent programs timed out %d time(s) so far (re-armed %d time(s)); launch path for another %d ms; "
+                        "this process %s the device's program lock", st["timeouts"], st["rearms"], st["off_for_ms"],
+                        {1: "holds", -1: "was denied", 0: "has not asked for"}.get(st["process_owns_device"], "?"))
+            self._ps_timeouts = st["timeouts"]
+        return st
+
+    def _watch(self):
+        # cheap (process-wide counters, no device access): read through the C ABI every 256 requests
+        self._n_req = getattr(self, "_n_req", 0) + 1
+        if self._n_req & 255 == 0 and self._lib.is_device:
+            try:
+                self.persist_state(with_device=False)
+            except Exception:  # diagnostics must never cost a request
+                pass
 
     def _coalescable(self, feed, ids):
-        """plain single-utterance requests only: no injected tensors, no pinned durations, no caller-chosen batch semantics"""
-        return (self.coalescer is not None and ids.shape[0] == 1 and self.hp.bert_dim == 0 and
-                not any(k in feed for k in ("vits.noise_dp", "vits.noise_prior", "vits.forced_durations", "vits.solo", "vits.item_seeds", "bert")))
+        """plain single-utterance requests only: no injected tensors, no pinned durations, no caller-chosen batch semantics.
+        Returns the request's token count (> 0) when it may be merged, 0 otherwise -- a length outside (0, T] is NOT sliced here:
+        such a request takes the direct call, whose C-side check answers VITS_ERR_ARG as it always did."""
+        if not (self.coalescer is not None and ids.shape[0] == 1 and self.hp.bert_dim == 0 and
+                not any(k in feed for k in ("vits.noise_dp", "vits.noise_prior", "vits.forced_durations", "vits.solo", "vits.item_seeds", "bert"))):
+            return 0
+        lens = np.asarray(feed["input_lengths"]).reshape(-1)
+        if lens.shape[0] != 1:
+            return 0
+        n = int(lens[0])
+        return n if 0 < n <= ids.shape[1] else 0
 
     def _run_solo_batch(self, key, reqs):
         """reqs: [(ids [1,T] int64, sid, seed)] -> per request (audio-or-pcm [1,S_b], lengths [1]); one request: the plain call"""
@@ -212,8 +258,9 @@ class VitsSession:
 
     def run(self, output_names, input_feed, run_options=None):
         feed, ids, sid, seed = self._validated(output_names, input_feed)
-        if self._coalescable(feed, ids):
-            n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
+        self._watch()
+        n = self._coalescable(feed, ids)
+        if n:
             key = ("f32", tuple(float(v) for v in np.asarray(feed["scales"], np.float32).reshape(-1)), 1.0)
             audio, lengths = self.coalescer.submit(key, np.ascontiguousarray(ids[:, :n], np.int64), int(sid[0]), int(seed))
             self.last_lengths = lengths
@@ -232,8 +279,9 @@ class VitsSession:
         float output with numpy, half the bytes over PCIe.  return_lengths: also return the per-item sample counts
         (concurrent callers must take them from the call, not from the shared `last_lengths` attribute)."""
         feed, ids, sid, seed = self._validated(None, input_feed)
-        if self._coalescable(feed, ids):
-            n = int(np.asarray(feed["input_lengths"]).reshape(-1)[0])
+        self._watch()
+        n = self._coalescable(feed, ids)
+        if n:
             key = ("pcm", tuple(float(v) for v in np.asarray(feed["scales"], np.float32).reshape(-1)), float(scale))
             pcm, lengths = self.coalescer.submit(key, np.ascontiguousarray(ids[:, :n], np.int64), int(sid[0]), int(seed))
             self.last_lengths = lengths
