@@ -334,6 +334,7 @@ def dry_run(args, torch, dist, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))  # ranks differ on purpose: the line must carry the slowest one
+    own = time.perf_counter() - t0
     barrier()
     el = time.perf_counter() - t0
     seen = 1
@@ -345,8 +346,24 @@ def dry_run(args, torch, dist, rank, world):
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         seen = int(c.item())
     samples = 38400
+    # the per-rank fields of the real line travel the same way (all_gather of one float per rank) ...
+    rank_ms, rank_persist = [round(own / args.steps * 1e3, 4)], [1.0]
+    if dist is not None:
+        g = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([rank_ms[0], 1.0], dtype=torch.float64))
+        rank_ms = [round(float(x[0].item()), 4) for x in g]
+        rank_persist = [float(x[1].item()) for x in g]
+    # ... and configs[3]'s request list is dealt to the ranks exactly as the real batch256_sharded leg deals it
+    _, c4_len, _ = make_workload("c4", np.random.default_rng(1234), rank, world)
+    shard = torch.tensor([float(len(c4_len))], dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(shard, op=dist.ReduceOp.SUM)
+    # the order of the legs that open devices: every rank but 0 lets go of its device before rank 0's in-process multi-device leg
+    barrier()  # "ranks > 0 have closed their models"
+    barrier()  # "rank 0 is done with all devices"
     if rank == 0:
         print(json.dumps({"metric": "audio_samples_per_sec", "value": round(samples * world * args.steps / el, 1), "unit": "samples/s", "n_gpus": world,
+                          "rank_ms": rank_ms, "rank_persistent_launches_per_forward": rank_persist, "batch256_requests_seen": int(shard.item()),
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": seen,
                           "launched_by": "bench.py" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if dist is not None else "single process"),
@@ -649,14 +666,16 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         job_samples = valid_samples * world
         rank_ms = [float(np.median(own_times)) / steps * 1e3]
+        rank_persist = [round(persistent_per_step, 3)]
         if dist is not None:
             tt = torch.tensor([float(valid_samples), 1.0], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             job_samples = int(tt[0].item())
             assert int(tt[1].item()) == world
-            g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(g, torch.tensor(rank_ms, dtype=torch.float64))
-            rank_ms = [round(float(x.item()), 4) for x in g]
+            g = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(g, torch.tensor([rank_ms[0], persistent_per_step], dtype=torch.float64))
+            rank_ms = [round(float(x[0].item()), 4) for x in g]
+            rank_persist = [round(float(x[1].item()), 3) for x in g]
         total_samples = job_samples * steps
         value = total_samples / elapsed
         audio_sec_per_step = job_samples / SAMPLE_RATE
@@ -780,7 +799,7 @@ def main():
         return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
                     ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales,
                     timed_region_s=timed_region_s, blocks=len(blocks), launches=graph_nodes or sum(v[0] for v in rep.values()) // nprof,
-                    rank_ms=rank_ms, finite_checked=finite_checked, persistent_per_step=persistent_per_step)
+                    rank_ms=rank_ms, finite_checked=finite_checked, persistent_per_step=persistent_per_step, rank_persist=rank_persist)
 
     R = measure(args.workload, args.steps, args.warmup, args.min_seconds)
     B, Tx, Ty, lengths, ids, dur = R["B"], R["Tx"], R["Ty"], R["lengths"], R["ids"], R["dur"]
@@ -828,14 +847,6 @@ def main():
                     "rank_ms": R5["rank_ms"], "imbalance": round(max(R5["rank_ms"]) / max(min(R5["rank_ms"]), 1e-9), 4),
                     "workload": "c4: 256 ragged requests (20..200 tokens, durations pinned 3/token) sharded over the ranks by "
                                 "vosk_tts_amd.batching.plan_shards, one padded batch per rank, fp32"}
-        if rank == 0:
-            all_len = np.random.default_rng(1234).integers(20, 201, size=256)
-            try:
-                mds_leg = multi_device_synth_leg(hp, all_len, min(world, torch.cuda.device_count()))
-            except Exception as e:  # the leg must never take the line down
-                mds_leg = {"error": repr(e)}
-        if dist is not None:
-            dist.barrier()
 
     streaming = None
     if rank == 0 and (args.workload == "c5" or (args.workload == "c2" and not args.no_extras)):
@@ -896,6 +907,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = vits_cpu_baseline(blob, hp, ids, lengths, dur, args.workload, args.cpu_seconds)
 
+    # The in-process front door over ALL the job's devices (rank 0 opens one Model replica per device): last, and only after every
+    # other rank has let go of its device -- its model closed, so neither its weights nor its persistent-program lock are in the way
+    # and nobody sits in a barrier holding a model while rank 0 opens `world` more.
+    if args.workload == "c2" and not args.no_batch32:
+        if rank != 0:
+            model.close()
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            all_len = np.random.default_rng(1234).integers(20, 201, size=256)
+            try:
+                mds_leg = multi_device_synth_leg(hp, all_len, min(world, torch.cuda.device_count()))
+            except Exception as e:  # the leg must never take the line down
+                mds_leg = {"error": repr(e)}
+        if dist is not None:
+            dist.barrier()
+
     if rank == 0:
         line = {
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
@@ -904,6 +932,7 @@ def main():
             "rtf": round(rtf, 6), "x_realtime": round(1.0 / rtf, 1),
             "timed_region_s": round(R["timed_region_s"], 3), "timed_blocks": R["blocks"], "launches_per_forward": R["launches"],
             "persistent_launches_per_forward": round(R["persistent_per_step"], 3),
+            "rank_persistent_launches_per_forward": R["rank_persist"],
             "config": {"workload": f"{args.workload}: MB-iSTFT-VITS2 (ru-0.9-multi-shaped, SEEDED SYNTHETIC weights: timings are shape-exact, "
                                    f"dynamic range of a trained voice untested), B={B} T_x={Tx} (lengths {int(lengths.min())}..{int(lengths.max())}), "
                                    f"durations pinned 3/token -> T_y={Ty} with the duration predictor executed, "

@@ -218,8 +218,9 @@ def run_reference_stages(net, ids, lengths, sid, scales, noise_dp, noise_prior_f
 
 def build_reference_mas():
     """Compiles the reference's own Cython MAS core (training/vits2/monotonic_align/core.pyx) from where it lies
-    under /root/reference into oracle/_ref/mas/ (git-ignored) with the installed Cython + gcc, and returns the
-    module (exposes maximum_path_c).  Container-only, used by gen_golden.py."""
+    under /root/reference into oracle/_ref/mas/ (git-ignored; the built module travels to the GPU box with the snapshot like the
+    other prebuilt .so files) with the installed Cython + gcc, and returns the module (exposes maximum_path_c).  Building is
+    container-only (needs /root/reference); used by gen_golden.py and, where the module exists, by the MAS tests."""
     import importlib.util
     import subprocess
     import sysconfig
@@ -229,11 +230,19 @@ def build_reference_mas():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "mas")
     os.makedirs(out, exist_ok=True)
     pyx = os.path.join(REF_VITS2, "monotonic_align", "core.pyx")
-    c_file = os.path.join(out, "core.c")
     so = os.path.join(out, "core" + sysconfig.get_config_var("EXT_SUFFIX"))
+    stale = os.path.join(out, "core.c")  # (earlier rounds left Cython's C output here: it quotes the .pyx text in comments)
+    if os.path.exists(stale):
+        os.remove(stale)
     if not os.path.exists(so):
-        subprocess.check_call([sys.executable, "-m", "cython", "-3", pyx, "-o", c_file])
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fopenmp", "-I" + sysconfig.get_paths()["include"], c_file, "-o", so])
+        import tempfile
+
+        # only the compiled module is kept under oracle/_ref: Cython's generated C quotes the reference's .pyx source as comments,
+        # so it lives in a temporary directory for the length of the gcc call
+        with tempfile.TemporaryDirectory() as td:
+            c_file = os.path.join(td, "core.c")
+            subprocess.check_call([sys.executable, "-m", "cython", "-3", pyx, "-o", c_file])
+            subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-fopenmp", "-I" + sysconfig.get_paths()["include"], c_file, "-o", so])
     spec = importlib.util.spec_from_file_location("core", so)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

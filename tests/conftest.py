@@ -90,8 +90,9 @@ def assert_close(name, ref, got, rtol, atol_frac=None):
 
 
 def load_reference_mas():
-    """the reference's own compiled MAS core (oracle/_ref/mas/, built by __graft_entry__.build() where /root/reference exists;
-    it does not travel to the GPU box) or None"""
+    """the reference's own compiled MAS core (oracle/_ref/mas/core*.so, built by __graft_entry__.build() in the container, where
+    /root/reference exists; git-ignored, travels to the GPU box with the snapshot like every prebuilt .so) or None where it was
+    never built -- the committed fixture tests/golden/mas.npz pins the kernel either way"""
     import glob
     import importlib.util
 

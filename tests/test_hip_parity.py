@@ -488,8 +488,8 @@ def _bench_workload(name, rank=0, world=1):
 def _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, n_oracle_items, seed):
     """A full-size ragged batch (B = 32, up to 200 tokens / 600 frames) through vits_synthesize with the bench's pinned
     durations.  The oracle cannot run the whole batch in seconds, so (the decoder has no masks, an item of a
-    padded batch differs from its solo run only within the decoder's receptive field of its end): a few items (shortest,
-    longest, two mid) are compared with the oracle's run of that item alone on the samples at least 32 frames before the
+    padded batch differs from its solo run only within the decoder's receptive field of its end): n_oracle_items items (shortest,
+    longest, evenly spaced ranks in between) are compared with the oracle's run of that item alone on the samples at least 32 frames before the
     item's end; the longest item -- whose end is the batch's end -- on all samples; all other items through the
     size-independent properties: finite, exact lengths, defined zeros beyond len + 32 frames, and equality with the same
     item synthesized in a different batch composition (first half of the batch alone)."""
@@ -505,7 +505,8 @@ def _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, n_ora
         assert np.all(a_hip[b, (int(ylens[b]) + 33) * hop:] == 0.0)
         assert np.abs(a_hip[b, :int(ylens[b]) * hop]).max() > 1e-4
     order = np.argsort(ylens)
-    picks = sorted({int(order[0]), int(order[-1]), int(order[B // 3]), int(order[2 * B // 3])})[:n_oracle_items]
+    # shortest, longest and evenly spaced ranks in between (n_oracle_items of the B items)
+    picks = sorted({int(order[round(k * (B - 1) / max(n_oracle_items - 1, 1))]) for k in range(n_oracle_items)})
     # the oracle runs item b alone with the SAME noise the batch drew for it: Philox stream rows are (b*I + c), so build the
     # batch's prior noise for that item by a 1-item call is not possible -> inject explicit noise on both sides instead
     rng = np.random.default_rng(seed)
@@ -533,7 +534,28 @@ def test_c3_full_size_batch_parity(hip_default, oracle_default):
     """BASELINE configs[2] at full size: the exact batch bench.py times as "c3" (B = 32, 20..200 tokens, 3 frames/token)."""
     ids, lengths, dur = _bench_workload("c3")
     assert ids.shape[0] == 32 and 20 <= lengths.min() and lengths.max() <= 200
-    _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 4, seed=7)
+    _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 8, seed=7)
+
+
+def test_padded_batch_of_8_by_200_tokens_equals_the_oracle_on_the_same_padded_batch(hip_default, oracle_default):
+    """SURVEY A11 above B = 6: the decoder has no masks, so an item of a padded batch continues into the batch's padding.  The
+    engine's ragged path must give, on every valid sample, what the reference's arithmetic gives on the SAME padded batch -- checked
+    here against the oracle run on the whole padded batch (8 items, 200 tokens / 600 frames at most, lengths down to 60 tokens), not
+    against solo runs."""
+    rng = np.random.default_rng(88)
+    B, T = 8, 200
+    lengths = np.array([200, 187, 160, 133, 121, 97, 74, 60], np.int64)
+    ids = rng.integers(1, 62, size=(B, T)).astype(np.int64) * (np.arange(T)[None] < lengths[:, None])
+    sid = np.array([0, 1, 2, 3, 4, 5, 6, 2], np.int64)
+    scales = np.array([0.667, 1.0, 0.8], np.float32)
+    dur = np.where(np.arange(T)[None] < lengths[:, None], 3, 0).astype(np.int32)
+    noise = rng.standard_normal((B, 192, 3 * T)).astype(np.float32)
+    a_hip, l_hip = hip_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+    a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+    assert np.array_equal(l_hip, l_ref) and np.array_equal(l_ref, lengths * 3 * 256)
+    for b in range(B):
+        n = int(l_ref[b])
+        assert_close(f"item {b} ({int(lengths[b])} tokens) vs the oracle on the same padded batch", a_ref[b, :n], a_hip[b, :n], E2E_TOL)
 
 
 @pytest.mark.gpu
@@ -628,7 +650,7 @@ def test_c4_shard_parity(hip_default, oracle_default):
     """BASELINE configs[3]: 256 requests sharded over 8 GPUs by plan_shards; rank 3's shard of 32 through the same path."""
     ids, lengths, dur = _bench_workload("c4", rank=3, world=8)
     assert ids.shape[0] == 32
-    _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 3, seed=11)
+    _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 8, seed=11)
     # the shards partition the request list: every request appears in exactly one shard
     from vosk_tts_amd.batching import plan_shards
 

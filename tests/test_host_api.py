@@ -381,6 +381,47 @@ def test_driver_timed_configuration_equals_the_host_path(hip_default, workload):
 
 
 @pytest.mark.gpu
+def test_one_device_session_across_eligible_and_ineligible_shapes(hip_default):
+    """One VitsDeviceSession re-used across shapes: (1, 50, 150) runs the merged persistent program; (1, 200, 600) lies beyond the
+    programs' column limit, so the re-plan builds none -- and must not leave the previous layout's program marked usable (its records
+    point into the re-laid-out arena); then the small shape again.  Every call equals the host entry point."""
+    import ctypes
+
+    import torch
+
+    from vosk_tts_amd.capi import VitsDeviceSession
+
+    rng = np.random.default_rng(21)
+    scales = np.array([0.8, 1.0, 0.8], np.float32)
+    sid = np.array([3], np.int64)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    runs_fn = hip_default.lib.lib.vits_debug_persist_runs
+    runs_fn.restype = ctypes.c_int
+    runs_fn.argtypes = [ctypes.c_void_p]
+    s = VitsDeviceSession(hip_default, 1, 200, 600)
+    s.set_options(use_graph=True, profile=False)
+    s.set_sdp_always(True)
+    expect_runs = {50: 1, 200: 0}
+    for Tx in (50, 200, 50, 200, 50):
+        ids = rng.integers(1, 62, size=(1, Tx)).astype(np.int64)
+        lengths = np.array([Tx], np.int64)
+        dur = np.full((1, Tx), 3, np.int32)
+        Ty = 3 * Tx
+        want, wl = hip_default.synthesize(ids, lengths, scales, sid, forced_durations=dur, seed=7)
+        d_ids, d_len, d_sid, d_dur = t(ids), t(lengths), t(sid), t(dur)
+        d_audio = torch.zeros((1, Ty * 256), dtype=torch.float32, device=dev)
+        r0 = int(runs_fn(hip_default._h))
+        for rep in range(2):
+            d_audio.zero_()
+            s.synthesize_device(d_ids.data_ptr(), d_len.data_ptr(), 1, Tx, scales, d_sid.data_ptr(), d_dur.data_ptr(), Ty, 7, d_audio.data_ptr(), Ty * 256)
+            s.sync()
+            assert_close(f"T_x {Tx} call {rep}", want[0, :wl[0]], d_audio.cpu().numpy()[0, :wl[0]], 2e-6)
+        assert int(runs_fn(hip_default._h)) - r0 == 2 * expect_runs[Tx], f"T_x {Tx}: persistent launches"
+    s.close()
+
+
+@pytest.mark.gpu
 def test_multi_device_synth_on_two_devices(tmp_path):
     """MultiDeviceSynth with one replica per DEVICE (not two replicas on device 0): runs the day a box has two GPUs; the result of
     a request must not depend on which device it landed on."""

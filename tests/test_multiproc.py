@@ -171,3 +171,30 @@ def test_bench_multi_rank_entry_point_dry_run(launcher):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
     assert d["ms_per_step"] >= 2.0  # the slower rank (2 ms per step), not the faster one
     assert d["launched_by"] == ("bench.py" if launcher == "self" else "torch.distributed.run")
+    assert d["rank_ms"][1] > d["rank_ms"][0] >= 1.0 and d["rank_persistent_launches_per_forward"] == [1.0, 1.0]
+    assert d["batch256_requests_seen"] == 256  # configs[3]'s list dealt over the ranks: every request on exactly one rank
+
+
+def test_bench_eight_rank_dry_run():
+    """The driver's 8-GPU form (`--gpus 8`, here self-launched and on CPU): eight ranks rendezvous on 127.0.0.1, meet at the host-side
+    barriers, and rank 0's line carries all eight per-rank timings, the slowest rank's time, the 256 requests of configs[3] dealt
+    32 per rank, and per-rank persistent-launch counts."""
+    import json
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "10", "--warmup", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and len(d["rank_ms"]) == 8 and len(d["rank_persistent_launches_per_forward"]) == 8
+    assert d["ms_per_step"] >= 8.0 and d["rank_ms"][7] >= 8.0 > d["rank_ms"][0]
+    assert d["batch256_requests_seen"] == 256
+    import bench as B
+
+    for rank in range(8):  # the real leg's shard of every rank: 32 requests each, all 256 covered
+        ids, lens, dur = B.make_workload("c4", np.random.default_rng(1234), rank, 8)
+        assert ids.shape[0] == 32 and (dur.sum(1) == 3 * lens).all()
