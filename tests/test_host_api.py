@@ -382,8 +382,8 @@ def test_driver_timed_configuration_equals_the_host_path(hip_default, workload):
 
 @pytest.mark.gpu
 def test_one_device_session_across_eligible_and_ineligible_shapes(hip_default):
-    """One VitsDeviceSession re-used across shapes: (1, 50, 150) runs the merged persistent program; (1, 200, 600) lies beyond the
-    programs' column limit, so the re-plan builds none -- and must not leave the previous layout's program marked usable (its records
+    """One VitsDeviceSession re-used across shapes: (1, 50, 150) runs the merged persistent program; (1, 600, 1800) lies beyond the
+    programs' column limit on both sides, so the re-plan builds none -- and must not leave the previous layout's program marked usable (its records
     point into the re-laid-out arena); then the small shape again.  Every call equals the host entry point."""
     import ctypes
 
@@ -399,11 +399,11 @@ def test_one_device_session_across_eligible_and_ineligible_shapes(hip_default):
     runs_fn = hip_default.lib.lib.vits_debug_persist_runs
     runs_fn.restype = ctypes.c_int
     runs_fn.argtypes = [ctypes.c_void_p]
-    s = VitsDeviceSession(hip_default, 1, 200, 600)
+    s = VitsDeviceSession(hip_default, 1, 600, 1800)
     s.set_options(use_graph=True, profile=False)
     s.set_sdp_always(True)
-    expect_runs = {50: 1, 200: 0}
-    for Tx in (50, 200, 50, 200, 50):
+    expect_runs = {50: 1, 600: 0}
+    for Tx in (50, 600, 50, 600, 50):
         ids = rng.integers(1, 62, size=(1, Tx)).astype(np.int64)
         lengths = np.array([Tx], np.int64)
         dur = np.full((1, Tx), 3, np.int32)

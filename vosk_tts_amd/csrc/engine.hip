@@ -1397,6 +1397,14 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
     macs += (double)(epi == EPI_GATE ? 2 * P.H : P.Cout) * P.Cin * P.g[g].K;
   }
   ProfScope ps(s, name, 2.0 * macs * (double)P.Tout * P.B);
+  if (ps.on) {  // tools/profile_ops.py with VITS_PROF_SHAPES=1: one report line per distinct launch shape
+    static const bool shapes = getenv("VITS_PROF_SHAPES") != nullptr;
+    if (shapes) {
+      char sh[96];
+      snprintf(sh, sizeof sh, "/M%d.K%dx%d.N%dx%d.g%d", P.M, P.Cin, P.g[0].K, P.B, P.Tout, P.n_groups);
+      s->prof.back().name += sh;
+    }
+  }
 #ifdef CONV_TIMING
   hipStream_t st = s->stream;
   // timing build only: VITS_DBG_LAUNCH=<i> attaches the phase-stamp buffer to the i-th conv launch of the process
