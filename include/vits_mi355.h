@@ -336,6 +336,9 @@ int vits_debug_persist_runs(vits_model* m);
 void vits_debug_wn_fold(int on);
 /* Test hook: wave-pipelined decoder conv kernel (conv_wp_kernel): 0 = by size (default), 1 = never, 2 = whenever eligible. */
 void vits_debug_conv_wp(int mode);
+/* Test hook: software-pipelined 64 x 64 conv kernel (conv_sp_kernel, csrc/conv_sp.hip.h): -1 = environment / default (by grid size),
+ * 0 = never, 1 = by grid size, 2 = wherever a launch is eligible for it. */
+void vits_debug_conv_sp(int mode);
 /* Test hook: 1 = a conv_precision == 1 model runs its fp32 kernels instead of the split-bf16 variant (same weights, A/B). */
 void vits_debug_no_bf16x3(int on);
 /* Test hook: 0 = fused exp/sin + iSTFT + PQMF tail kernel (default), 1 = the separate istft / pqmf kernels. */

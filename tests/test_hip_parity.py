@@ -86,6 +86,61 @@ def test_conv1d_randomised_shapes_on_every_kernel(hip_lib, oracle_lib, mode):
         hip_lib.lib.vits_debug_force_tile(0)
 
 
+def test_software_pipelined_conv_kernel(hip_lib, hip_default, oracle_lib, oracle_default):
+    """conv_sp_kernel (csrc/conv_sp.hip.h: the 64 x 64 tile as a software-pipelined loop -- 64-channel stages, 4-slot weight ring, two
+    accumulators) forced wherever a launch is eligible (vits_debug_conv_sp(2)): random conv shapes (C_in multiples of 64, 1..11 taps,
+    dilations to the halo limit, ragged tile edges, padded rows), then every stage and the end-to-end call of a ragged batch -- its
+    RESSKIP / COUPLE epilogues, masks, Flip-folded channel order, grouped decoder launches and ragged tile maps -- against the oracle."""
+    from vosk_tts_amd.capi import op_conv1d
+
+    rng = np.random.default_rng(4242)
+    hip_lib.lib.vits_debug_conv_sp(2)
+    try:
+        for _ in range(24):
+            K = int(rng.choice([1, 2, 3, 5, 7, 11]))
+            dil = int(rng.integers(1, max(1, 60 // max(K - 1, 1)) + 1)) if K > 1 else 1
+            dil = min(dil, 9)
+            Cin = 64 * int(rng.integers(1, 6))
+            Cout = int(rng.choice([1, 17, 32, 50, 64, 72, 96, 130, 192, 256]))
+            T = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 128, 129, 200, 513, 1000]))
+            B = int(rng.integers(1, 4))
+            slope = float(rng.choice([1.0, 0.1, 0.01]))
+            x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+            w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+            bias = rng.standard_normal(Cout).astype(np.float32) if rng.random() < 0.7 else None
+            want = op_conv1d(oracle_lib, x, w, bias, dil, slope)
+            got = op_conv1d(hip_lib, x, w, bias, dil, slope)
+            assert_close(f"conv_sp B={B} Cin={Cin} Cout={Cout} T={T} K={K} dil={dil} slope={slope}", want, got, 2e-5)
+        B, T = 6, 70
+        lengths = np.array([70, 64, 51, 33, 17, 5], np.int64)
+        ids = rng.integers(1, 62, size=(B, T)).astype(np.int64) * (np.arange(T)[None] < lengths[:, None])
+        sid = np.array([0, 1, 2, 3, 4, 5], np.int64)
+        scales = np.array([0.667, 1.0, 0.8], np.float32)
+        for fold in (1, 0):  # folded WaveNet tail (STORE convs only) and the per-layer RESSKIP epilogue
+            hip_lib.lib.vits_debug_wn_fold(fold)
+            x, m_p, logs_p = hip_default.text_encoder(ids, lengths, sid)
+            xr, mr, lr = oracle_default.text_encoder(ids, lengths, sid)
+            assert_close("x", xr, x, STAGE_TOL); assert_close("m_p", mr, m_p, STAGE_TOL); assert_close("logs_p", lr, logs_p, STAGE_TOL)
+            dur = np.where(np.arange(T)[None] < lengths[:, None], 3, 0).astype(np.int32)
+            Ty = 3 * T
+            noise = rng.standard_normal((B, 192, Ty)).astype(np.float32)
+            _, ylen, zpr = oracle_default.regulate(None, dur, lengths, 1.0, mr, lr, noise, 0.667, Ty)
+            z = hip_default.flow(zpr, ylen, sid)
+            zr = oracle_default.flow(zpr, ylen, sid)
+            assert_close(f"z (wn fold {fold})", zr, z, STAGE_TOL)
+            mask = (np.arange(Ty)[None, :] < ylen[:, None])[:, None, :]
+            audio, _ = hip_default.decoder(zr * mask)
+            audio_r, _ = oracle_default.decoder(zr * mask)
+            assert_close("audio (decoder stage)", audio_r, audio, STAGE_TOL)
+            a_hip, l_hip = hip_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+            a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+            assert np.array_equal(l_hip, l_ref)
+            assert_close(f"waveform (wn fold {fold})", _valid(a_ref, l_ref), _valid(a_hip, l_hip), E2E_TOL)
+    finally:
+        hip_lib.lib.vits_debug_wn_fold(1)
+        hip_lib.lib.vits_debug_conv_sp(-1)
+
+
 @pytest.mark.parametrize("nw", [4, 8, 16])
 def test_ksplit_kernel_wave_counts(hip_lib, hip_default, hip_tiny, oracle_lib, oracle_default, oracle_tiny, nw):
     """The K-split kernel splits the contraction over 4, 8 or 16 waves at tap granularity (launch heuristic:

@@ -536,6 +536,16 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);
   nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
   const ConvGroup& G = P.g[grp];
+  CONV_DBG_DO(if (P.dbg && tid == 0 && blockIdx.x < 4000) {  // block trace (timing build): wall-clock start, hardware id, XCC id
+    P.dbg[128 + blockIdx.x * 4 + 0] = wall_clock64();
+    P.dbg[128 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(63492);
+    P.dbg[128 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 20);
+  })
+#ifdef CONV_TIMING
+#define BT_BLOCK_END() do { if (P.dbg && tid == 0 && blockIdx.x < 4000) P.dbg[128 + blockIdx.x * 4 + 1] = wall_clock64(); } while (0)
+#else
+#define BT_BLOCK_END() do { } while (0)
+#endif
 
   const int ROW = P.row_len;
   const int n0 = nt * N_T, m0 = mt * M_T;
@@ -732,11 +742,13 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
         for (int i = 0; i < 4; ++i) { at[i] = acc[0][ni][e0 + i]; as[i] = acc[MI - 1][ni][e0 + i]; }
         conv_epilogue_gate<4>(P, G, b, j * 32 + 4 * h, e0, n0 + wn * (NI * 32) + ni * 32 + l31, at, as);
       }
+    BT_BLOCK_END();
     return;
   }
   if (EPI == EPI_STORE && conv_epilogue_store_fast_ok(P, G)) {  // block-uniform
     conv_epilogue_store_fragments<MI, NI>(P, G, b, lenb, m0 + wm * MI * 32, n0 + wn * (NI * 32), h, l31, acc);
     CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 4] = __builtin_readcyclecounter() - dbg_t0;)
+    BT_BLOCK_END();
     return;
   }
 #pragma unroll
@@ -753,6 +765,7 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
     }
   }
   CONV_DBG_DO(if (P.dbg && blockIdx.x == 0 && lane == 0) P.dbg[wave * 8 + 4] = __builtin_readcyclecounter() - dbg_t0;)
+  BT_BLOCK_END();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@
 #include "../../include/vits_mi355.h"
 #include "conv_mfma.hip.h"
 #include "conv_small.hip.h"
+#include "conv_sp.hip.h"
 #include "conv_bf3.hip.h"
 #include "kernels_misc.hip.h"
 #include "persist.hip.h"
@@ -1384,6 +1385,43 @@ static bool conv_takes_c16(const ConvParams& P, int epi) {
   return c16_waves(P, epi) != 0;
 }
 
+// ---- software-pipelined 64 x 64 kernel (conv_sp.hip.h): stands in for conv_mfma_kernel<2,2,1,1,*> on launches that leave a CU with
+// few workgroups.  VITS_SP: 0 = never, 1 = by size (default), 2 = whenever eligible (A/B, tests); VITS_SP_MAXBLK: largest grid it takes.
+static int g_sp_mode = -1;
+static int sp_mode() {
+  static const int env = getenv("VITS_SP") ? atoi(getenv("VITS_SP")) : 1;
+  return g_sp_mode >= 0 ? g_sp_mode : env;
+}
+static bool conv_sp_ok(const ConvParams& P, int epi, int halo) {
+  if (sp_mode() == 0 || epi == EPI_GATE) return false;
+  if (P.Cin % SP_STAGE_CH || P.ups_u || P.reflect || P.x_split || P.ln_g || P.dds_y2 || P.ln_stat_out || 64 + halo > 128 || P.Tin < 2) return false;
+  for (int g = 0; g < P.n_groups; ++g)
+    if (P.g[g].x2 || P.g[g].x3) return false;
+  return true;
+}
+template <int EPI>
+static void launch_sp(vits_session* s, ConvParams& P, int halo) {
+  attach_tile_table(s, P, 64);
+  P.ntiles_m = cdiv(P.M, 64);
+  P.ntiles_n = cdiv(P.Tout, 64);
+  P.row_len = 64 + halo;
+  const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
+  const size_t lds = (size_t)2 * 4 * P.row_len * SP_PITCH * sizeof(float);  // two stage buffers of four chunks [column][SP_PITCH]
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> done1{0}, done2{0};  // once per (instantiation, device)
+    if (P.row_len <= 64) { if (big_lds_needed(done1)) hipFuncSetAttribute((const void*)conv_sp_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    else if (big_lds_needed(done2)) hipFuncSetAttribute((const void*)conv_sp_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (P.row_len <= 64) hipLaunchKernelGGL((conv_sp_kernel<EPI, 1>), dim3(nblk), dim3(256), lds, s->stream, P);
+  else hipLaunchKernelGGL((conv_sp_kernel<EPI, 2>), dim3(nblk), dim3(256), lds, s->stream, P);
+}
+// the 64 x 64 tile of a launch that was routed to conv_mfma_kernel<2,2,1,1,EPI>: the pipelined kernel when the grid is small
+static bool sp_takes(const ConvParams& P, int epi, int halo) {
+  static const long max_blk = getenv("VITS_SP_MAXBLK") ? atol(getenv("VITS_SP_MAXBLK")) : 2048;
+  const long nblk = (long)cdiv(P.M, 64) * cdiv(P.Tout, 64) * P.B * P.n_groups;
+  return conv_sp_ok(P, epi, halo) && (sp_mode() == 2 || nblk <= max_blk);
+}
+
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
 // Large problems (>= 2 workgroups per CU with 64x64 tiles) use the big-tile kernel (more operand
 // reuse); everything smaller uses the K-split kernel so that one utterance still fills the chip.
@@ -1468,6 +1506,14 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
       return;
     }
   }
+  if (sp_mode() == 2 && g_force_tile == 0 && conv_sp_ok(P, epi, halo)) {  // A/B: the pipelined kernel wherever it is eligible
+    static const char* names[4] = {"conv_sp_kernel<STORE>", "-", "conv_sp_kernel<RESSKIP>", "conv_sp_kernel<COUPLE>"};
+    ps.set_kernel(names[epi]);
+    if (epi == EPI_STORE) launch_sp<EPI_STORE>(s, P, halo);
+    else if (epi == EPI_RESSKIP) launch_sp<EPI_RESSKIP>(s, P, halo);
+    else launch_sp<EPI_COUPLE>(s, P, halo);
+    return;
+  }
   if (epi == EPI_GATE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<2,1,GATE,1>"); launch_ks<2, 1, EPI_GATE>(s, P, halo, &ps); }
     else if (!g_no_bf3 && P.g[0].wb && P.n_groups == 1 && P.M % 128 == 0 && P.x_ch_sign == 1 && !P.x_ch_off && !P.g[0].x2 && !P.ln_g &&
@@ -1488,11 +1534,13 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   }
   if (epi == EPI_RESSKIP) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,RESSKIP,1>"); launch_ks<1, 1, EPI_RESSKIP>(s, P, halo, &ps); }
+    else if (g_force_tile == 0 && sp_takes(P, epi, halo)) { ps.set_kernel("conv_sp_kernel<RESSKIP>"); launch_sp<EPI_RESSKIP>(s, P, halo); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,RESSKIP>"); launch_cfg<2, 2, 1, 1, EPI_RESSKIP>(s, P, halo); }
     return;
   }
   if (epi == EPI_COUPLE) {
     if (small) { ps.set_kernel("conv_mfma_ks_kernel<1,1,COUPLE,1>"); launch_ks<1, 1, EPI_COUPLE>(s, P, halo, &ps); }
+    else if (g_force_tile == 0 && sp_takes(P, epi, halo)) { ps.set_kernel("conv_sp_kernel<COUPLE>"); launch_sp<EPI_COUPLE>(s, P, halo); }
     else { ps.set_kernel("conv_mfma_kernel<2,2,1,1,COUPLE>"); launch_cfg<2, 2, 1, 1, EPI_COUPLE>(s, P, halo); }
     return;
   }
@@ -1549,6 +1597,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   if (P.M % 64 == 0 && (long)cdiv(P.M, 64) * cdiv(P.Tout, 128) * P.B * P.n_groups >= 256 && bf3_ok()) { bf3_go(1); return; }
   // (64 x 128 fp32 tiles for these convs were measured on the c3 batch in round 4: 2.21 - 2.42 ms against 2.17 ms per forward for the
   //  64 x 64 tiles -- profiles/r4_c3_tile_ab.txt; not a tile-shape problem)
+  if (g_force_tile == 0 && sp_takes(P, epi, halo)) { ps.set_kernel("conv_sp_kernel<STORE>"); launch_sp<EPI_STORE>(s, P, halo); return; }
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
   launch_cfg<2, 2, 1, 1, EPI_STORE>(s, P, halo);
 }
@@ -3250,6 +3299,7 @@ int vits_debug_persist_runs(vits_model* m) {
   return v[1];
 }
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
+void vits_debug_conv_sp(int mode) { g_sp_mode = mode; }
 void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
 
@@ -3322,7 +3372,8 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
     P.in_slope = slope;
     const char* dbg_env = getenv("VITS_CONV_DBG");
     long long* d_dbg = nullptr;
-    if (dbg_env) { hipMalloc((void**)&d_dbg, 128 * sizeof(long long)); hipMemset(d_dbg, 0, 128 * sizeof(long long)); P.dbg = d_dbg; }
+    constexpr size_t dbg_n = 128 + 4 * 4000;  // phase stamps + block trace (timing build)
+    if (dbg_env) { hipMalloc((void**)&d_dbg, dbg_n * sizeof(long long)); hipMemset(d_dbg, 0, dbg_n * sizeof(long long)); P.dbg = d_dbg; }
     const int reps = dbg_env ? atoi(dbg_env) : 1;
     hipEvent_t e0, e1, ea; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&ea);
     for (int r = 0; r < reps; ++r) {
@@ -3360,6 +3411,14 @@ int vits_op_conv1d(int device, const float* x, const float* w, const float* bias
       for (int w = 0; w < 16; ++w)  // stamps relative to wave 0's start; HW_ID: simd = bits 5:4, cu = bits 11:8, se = bits 15:13
         if (h[w * 8]) fprintf(stderr, "   wave %2d simd %lld cu %lld: start %+lld | +%lld  +%lld  +%lld  +%lld  +%lld  +%lld\n", w, (h[w * 8 + 7] >> 4) & 3, (h[w * 8 + 7] >> 8) & 15,
                 h[w * 8] - h[0], h[w * 8 + 1] - h[w * 8], h[w * 8 + 2] - h[w * 8], h[w * 8 + 3] - h[w * 8], h[w * 8 + 4] - h[w * 8], h[w * 8 + 5] - h[w * 8], h[w * 8 + 6] - h[w * 8]);
+    }
+    if (d_dbg && rc == VITS_OK && getenv("VITS_CONV_BT")) {  // block trace of the LAST launch (timing build): "blk id start end hw xcc", 10 ns units
+      std::vector<long long> t(4 * 4000);
+      hipMemcpy(t.data(), d_dbg + 128, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      long long t0 = 0;
+      for (int i = 0; i < 4000; ++i) if (t[4 * i] && (!t0 || t[4 * i] < t0)) t0 = t[4 * i];
+      for (int i = 0; i < 4000; ++i)
+        if (t[4 * i]) fprintf(stderr, "blk %d %lld %lld %lld %lld\n", i, t[4 * i] - t0, t[4 * i + 1] ? t[4 * i + 1] - t0 : -1, t[4 * i + 2], t[4 * i + 3]);
     }
     if (d_dbg) hipFree(d_dbg);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ea);
