@@ -34,8 +34,10 @@ with tempfile.TemporaryDirectory() as d:
                 log.append((t0, t1, len(reqs)))
     co._run_batch = timed
 
-    def run(inflight):
+    def run(inflight, gather_us=0.0):
         co.max_inflight = inflight
+        co.gather_us = gather_us
+        g0 = co.gathered
         for _ in range(4):
             synth.synth_audio(text, speaker_id=2)
         for timed_leg in (False, True):
@@ -63,9 +65,9 @@ with tempfile.TemporaryDirectory() as d:
         for a, b, n in log:
             by.setdefault(n, []).append(b - a)
         sizes = " ".join(f"{n}:{len(v)}x{np.median(v)*1e3:.2f}ms" for n, v in sorted(by.items()))
-        print(f"inflight {inflight:2d}: {sum(cnt)/el:7.1f} req/s  calls {len(log):4d}  mean batch {sum(n for _,_,n in log)/max(len(log),1):.2f}  "
+        print(f"inflight {inflight:2d} gather {gather_us:5.0f} us ({co.gathered - g0} waits): {sum(cnt)/el:7.1f} req/s  calls {len(log):4d}  mean batch {sum(n for _,_,n in log)/max(len(log),1):.2f}  "
               f">=1 call running {busy1/el:.2f}  >=2 {busy2/el:.2f}  | size:count x median call: {sizes}", flush=True)
 
-    for k in (1, 2, 3, 4, 8, 16):
-        run(k)
+    for k, g in ((8, 0.0), (1, 400.0), (2, 400.0), (2, 800.0), (3, 400.0), (4, 400.0), (8, 400.0)):
+        run(k, g)
     sess.close()

@@ -38,42 +38,118 @@ class RequestCoalescer:
     """Merges concurrent single-utterance requests into solo batches (server shape: one Synth shared by a thread pool,
     server/tts_server.py:35-57 -- N threads each calling .run() for ONE utterance).
 
-    Natural batching, no timer: a request that finds fewer than `max_inflight` engine calls running runs at once, alone (the first of
-    them on the persistent single-utterance path; nothing added to its latency).  Requests that arrive while `max_inflight` calls are in
-    flight queue up; when one of those calls returns, its thread hands the queue's compatible requests (same scales / output kind / conversion scale, at most `max_batch`) to the first waiter,
-    which runs them as ONE padded VITS_FLAG_SOLO_BATCH call with per-request item seeds -- every item of a solo batch is its own
-    single-utterance synthesis (own Philox streams, zeros beyond its own end), so what a request gets does not depend on what it was
-    batched with -- and scatters the results.  Without this, N concurrent calls run N - 1 of them on the launch-per-layer path
-    (one persistent program owner per device) and the GPU executes N small forwards one after the other."""
+    Natural batching: a request that finds fewer than `max_inflight` engine calls running runs at once (the first of them on the
+    persistent single-utterance path; nothing added to a lone client's latency).  Requests that arrive while `max_inflight` calls are in
+    flight queue up; when one of those calls returns, its thread hands the queue's compatible requests (same scales / output kind /
+    conversion scale, at most `max_batch`) to the first waiter, which runs them as ONE padded VITS_FLAG_SOLO_BATCH call with per-request
+    item seeds -- every item of a solo batch is its own single-utterance synthesis (own Philox streams, zeros beyond its own end), so
+    what a request gets does not depend on what it was batched with -- and scatters the results.
 
-    def __init__(self, run_batch, max_batch=32, max_inflight=1):
+    Gathering (`gather_us` > 0): a pool of N closed-loop clients otherwise settles into two alternating half-size batches (the clients of
+    the batch that just returned are still on their way back when the next one is launched), and a batch of 8 costs 0.39 ms per request on
+    the device where a batch of 16 costs 0.33.  So a leader that is about to launch FEWER requests than were recently present at the same
+    time (`_peak`: the largest number of requests in flight + queued during the last 50 ms) waits up to `gather_us` for the stragglers.
+    A lone client never waits (peak 1), a burst waits at most once per batch."""
+
+    def __init__(self, run_batch, max_batch=32, max_inflight=1, gather_us=0):
         self._run_batch = run_batch  # (key, [(ids, sid, seed), ...]) -> list of per-request results
         self.max_batch = int(max_batch)
         self.max_inflight = max(1, int(max_inflight))  # engine calls that may run at the same time (the GPU overlaps a few small forwards)
+        self.gather_us = float(gather_us)
         self._lock = threading.Lock()
+        self._cond = threading.Condition(self._lock)  # a gathering leader sleeps here; arrivals notify
         self._busy = 0
         self._queue = []
+        self._in_calls = 0     # requests inside engine calls right now
+        self._gathering = False  # a leader is waiting for stragglers: arrivals join its queue instead of starting calls of their own
+        self._peak = 1         # most requests present at once (in calls + queued) recently ...
+        self._peak_t = 0.0     # ... and when that was last seen
         self.calls = 0        # engine calls issued
         self.requests = 0     # requests served
         self.largest = 0      # largest batch so far
         self.split_retries = 0  # merged batches that failed and were re-run member by member
+        self.gathered = 0     # launches that waited for stragglers
+
+    # (lock held)
+    def _note_presence(self, now):
+        present = self._in_calls + len(self._queue)
+        if present >= self._peak or now - self._peak_t > 0.05:
+            self._peak, self._peak_t = max(present, 1), now
+
+    def _gather(self, me, batch):
+        """(lock held) `batch` (containing `me`) is about to be launched: wait for stragglers while it is smaller than the recent peak.
+        Returns the batch to launch."""
+        if self.gather_us <= 0:
+            return batch
+        import time
+
+        now = time.perf_counter()
+        self._note_presence(now)
+        target = min(self.max_batch, self._peak - self._in_calls)
+        if len(batch) >= target:
+            return batch
+        deadline = now + self.gather_us * 1e-6
+        self.gathered += 1
+        self._gathering = True
+        try:
+            return self._gather_wait(me, batch, target, deadline)
+        finally:
+            self._gathering = False
+
+    def _gather_wait(self, me, batch, target, deadline):
+        import time
+
+        while True:
+            more = [p for p in self._queue if p.key == me.key][:max(target, 1) - len(batch)]
+            if more:
+                taken = set(map(id, more))
+                self._queue = [p for p in self._queue if id(p) not in taken]
+                batch = batch + more
+            now = time.perf_counter()
+            if len(batch) >= target or now >= deadline:
+                return batch
+            self._cond.wait(deadline - now)
+
+    def _promote(self):
+        """(lock held) a leader has just taken its batch: requests it left in the queue (beyond its target, or of another key) must not
+        wait for a call to finish when a call slot is free -- the queue's head becomes a leader of its own (and gathers in turn)."""
+        if not self._queue or self._busy >= self.max_inflight or self._gathering:
+            return None
+        head = self._queue.pop(0)
+        self._busy += 1
+        head.lead = [head]
+        return head
 
     def submit(self, key, ids, sid, seed):
+        import time
+
         me = _Pending(key, ids, sid, seed)
+        promote = None
         with self._lock:
-            if self._busy >= self.max_inflight:
+            if self._busy >= self.max_inflight or self._gathering:
                 self._queue.append(me)
+                self._note_presence(time.perf_counter())
+                self._cond.notify_all()
                 batch = None
             else:
                 self._busy += 1
-                batch = [me]
+                batch = self._gather(me, [me])
+                self._in_calls += len(batch)
+                promote = self._promote()
+        if batch is not None and promote is not None:
+            promote.event.set()
         if batch is None:
             me.event.wait()
             if me.lead is None:  # somebody else ran it
                 if me.error is not None:
                     raise me.error
                 return me.result
-            batch = me.lead
+            with self._lock:
+                batch = self._gather(me, me.lead)
+                self._in_calls += len(batch)
+                promote = self._promote()
+            if promote is not None:
+                promote.event.set()
         # this thread leads `batch` (which contains its own request)
         try:
             try:
@@ -100,6 +176,7 @@ class RequestCoalescer:
                 self.calls += 1
                 self.requests += len(batch)
                 self.largest = max(self.largest, len(batch))
+                self._in_calls -= len(batch)
                 nxt = None
                 if self._queue:
                     head = self._queue[0]
@@ -144,7 +221,8 @@ class VitsSession:
             # 8: 2200, no coalescing: 2110 -- the device overlaps a handful of single-utterance forwards (one of them on the persistent
             # programs); merging only starts beyond that, which also bounds the workspaces and streams a burst can pin
             max_inflight = int(os.environ.get("VITS_COALESCE_INFLIGHT", "8"))
-        self.coalescer = RequestCoalescer(self._run_solo_batch, max_batch, max_inflight) if coalesce else None
+        gather_us = float(os.environ.get("VITS_COALESCE_GATHER_US", "0"))
+        self.coalescer = RequestCoalescer(self._run_solo_batch, max_batch, max_inflight, gather_us) if coalesce else None
         self._ps_timeouts = 0  # persistent-program timeouts already reported (persist_state)
 
     def persist_state(self, with_device=True):
