@@ -527,6 +527,47 @@ def concurrency_leg(hp, device, seconds=0.4):
     return out
 
 
+def bert_voice_leg(hp, device, seconds=0.4):
+    """What a request costs on a BERT-conditioned VITS voice (vosk_tts/synth.py:25-44,88-99): per request the WordPiece tokenizer and the
+    BERT encoder run in front of the synthesis (get_word_bert: 12-layer BERT-base geometry here, hidden_states[-3] -> 10 layers executed,
+    on the device through stts_bert_encode), then g2p fans the word vectors out to the phonemes and the bert [1,768,T] feed goes through
+    enc_p.bert_proj.  One thread, text -> int16 PCM on the host, free-running durations; `bert_ms` is get_word_bert alone."""
+    import tempfile
+
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_bert_dir, write_toy_model
+
+    hp_t = W.default_hparams(n_vocab=len(PHONEMES))
+    hp_t.conv_precision = hp.conv_precision
+    text = "привет мир привет мир."
+    with tempfile.TemporaryDirectory() as d:
+        write_toy_model(d, hp_t, bert=True)
+        write_bert_dir(os.path.join(d, "bert"), 1234, n_layers=12)  # BERT-base depth (the toy default is 4 layers)
+        model = Model(model_path=d, device=device)
+        synth = Synth(model)
+        for _ in range(6):
+            synth.synth_audio(text, speaker_id=2)
+        lat, bert_lat, samples = [], [], 0
+        stop = time.perf_counter() + seconds
+        while time.perf_counter() < stop or len(lat) < 30:
+            t0 = time.perf_counter()
+            pcm = synth.synth_audio(text, speaker_id=2)
+            lat.append(time.perf_counter() - t0)
+            samples += int(pcm.shape[-1])
+        for _ in range(30):
+            t0 = time.perf_counter()
+            rows = synth.get_word_bert(text)
+            bert_lat.append(time.perf_counter() - t0)
+        n_tok = len(synth.g2p(text, rows)[0])
+        model.onnx.close()
+    tot = float(np.sum(lat))
+    return {"requests": len(lat), "tokens": n_tok, "bert_layers_run": 10, "ms_median": round(float(np.median(lat)) * 1e3, 4), "ms_p90": round(float(np.percentile(lat, 90)) * 1e3, 4),
+            "bert_ms_median": round(float(np.median(bert_lat)) * 1e3, 4), "requests_per_s": round(len(lat) / tot, 1),
+            "x_realtime": round(samples / SAMPLE_RATE / tot, 1),
+            "what": "Synth.synth_audio on a BERT-conditioned VITS voice (synthetic weights, BERT-base geometry): tokenizer + BERT encoder + g2p + synthesis per request, one thread"}
+
+
 def _workload_name(v):
     import argparse
     if v in ("c1", "c2", "c3", "c4", "c5", "m2", "m3", "s8", "s16") or (v[:1] == "u" and v[1:].isdigit() and 1 <= int(v[1:]) <= 4000):
@@ -894,6 +935,10 @@ def main():
                 host_api["concurrent"] = concurrency_leg(hp, local_rank)
             except Exception as e:  # the leg must never take the line down
                 host_api["concurrent"] = {"error": repr(e)}
+            try:
+                host_api["bert_voice"] = bert_voice_leg(hp, local_rank)
+            except Exception as e:
+                host_api["bert_voice"] = {"error": repr(e)}
 
     multistream = None
     if args.workload == "c2" and not args.no_batch32:
