@@ -82,9 +82,9 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
   if (P.rag) {
-    const int rl = P.rag[b];
-    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
-    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    const int rl = P.rag[b], rc = P.rag[P.B];  // rag[B]: where the padded batch tensor ends (frames): no limit reaches beyond it
+    if (n0 >= conv_rag_limit(rl, rc, P.rag_out_mul, P.rag_out_add, P.rag_out_cap_add)) return;  // whole tile is padding of this item (block-uniform)
+    const int il = conv_rag_limit(rl, rc, P.rag_in_mul, P.rag_in_add);
     t_lim = il < t_lim ? il : t_lim;
   }
   if (P.skip_len && n0 >= P.len[b]) return;

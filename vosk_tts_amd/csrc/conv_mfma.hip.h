@@ -130,11 +130,14 @@ struct ConvParams {
   const float* ln_stat_in; float* ln_stat_out; int ln_nmb;
   int row_len;        // LDS row = N_T + halo
   long long* dbg;     // optional phase cycle stamps (tools/ only); null in production
-  // Ragged batches: item b only needs columns up to rag[b] frames (its length + a halo wider than the
-  // decoder's receptive field); input columns >= rag[b]*rag_in_mul + rag_in_add read as 0 and output tiles
-  // starting at or beyond rag[b]*rag_out_mul + rag_out_add are skipped.  null = dense (reference-padded).
+  // Ragged batches (the mask-free decoder): rag[b] = item b's length in frames, rag[B] = where the padded batch tensor ends.  Input columns
+  // >= min(rag[b]*rag_in_mul + rag_in_add, rag[B]*rag_in_mul) read as 0 and output tiles starting at or beyond
+  // min(rag[b]*rag_out_mul + rag_out_add, rag[B]*rag_out_mul) are skipped: the adds are what THIS layer still has to produce beyond the
+  // item's end for every later layer's receptive field (engine.hip run_decoder).  null = dense (reference-padded).
   const int* rag;
   int rag_in_mul, rag_in_add, rag_out_mul, rag_out_add;
+  int rag_tab_add;      // host only: the add the launch's compact tile map is built with (>= rag_out_add; one map per decoder stage instead of one per layer)
+  int rag_out_cap_add;  // output columns that exist beyond rag[B] * rag_out_mul (1 for the reflection-padded conv_post: T + 1 columns)
   // Masked stages (encoder / duration predictor / flow) of a ragged batch: every consumer of this conv's
   // output is either column-local or masks its input at len[b], so tiles that start at or beyond len[b]
   // are not computed at all (their memory keeps whatever it held; see DESIGN.md "ragged batches").
@@ -144,6 +147,12 @@ struct ConvParams {
   // block ids so they are dispatched first and spread over all CUs; ids >= tile_start[B] * ... exit at once.
   const int* tile_start;
 };
+
+// limit of a ragged launch in columns: rag[b] * mul + add, capped where the padded batch tensor ends (rag[B] frames)
+__device__ __forceinline__ int conv_rag_limit(int rl, int rcap, int mul, int add, int cap_add = 0) {
+  const int v = rl * mul + add, c = rcap * mul + cap_add;
+  return v < c ? v : c;
+}
 
 // Kernel-argument warm-up.  ConvParams travels by value (~700 bytes = 11 scalar-cache lines) and hipcc fetches its fields lazily,
 // one s_load + s_waitcnt lgkmcnt(0) per region right before first use: measured (tools/ddsdbg.py stamps) 2.4 us pass between
@@ -556,9 +565,9 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
   if (P.rag) {
-    const int rl = P.rag[b];
-    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
-    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    const int rl = P.rag[b], rc = P.rag[P.B];  // rag[B]: where the padded batch tensor ends (frames): no limit reaches beyond it
+    if (n0 >= conv_rag_limit(rl, rc, P.rag_out_mul, P.rag_out_add, P.rag_out_cap_add)) return;  // whole tile is padding of this item (block-uniform)
+    const int il = conv_rag_limit(rl, rc, P.rag_in_mul, P.rag_in_add);
     t_lim = il < t_lim ? il : t_lim;
   }
   if (P.skip_len && n0 >= P.len[b]) return;  // masked stage: the whole tile lies in this item's padding
@@ -812,9 +821,9 @@ __global__ void __launch_bounds__(NW * 64) conv_mfma_ks_kernel(const ConvParams 
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
   if (P.rag) {
-    const int rl = P.rag[b];
-    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
-    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    const int rl = P.rag[b], rc = P.rag[P.B];  // rag[B]: where the padded batch tensor ends (frames): no limit reaches beyond it
+    if (n0 >= conv_rag_limit(rl, rc, P.rag_out_mul, P.rag_out_add, P.rag_out_cap_add)) return;  // whole tile is padding of this item (block-uniform)
+    const int il = conv_rag_limit(rl, rc, P.rag_in_mul, P.rag_in_add);
     t_lim = il < t_lim ? il : t_lim;
   }
   if (P.skip_len && n0 >= P.len[b]) return;  // masked stage: the whole tile lies in this item's padding

@@ -641,7 +641,8 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   asm volatile("" : "+v"(bi));
   int len_raw = 0x7fffffff, rag_raw = 0x7fffffff;
   if (P.in_mask || P.out_mask || P.skip_len) len_raw = P.len[bi];
-  if (P.rag) rag_raw = P.rag[bi];
+  int rag_cap = 0x7fffffff;
+  if (P.rag) { rag_raw = P.rag[bi]; rag_cap = P.rag[P.B]; }
 
   // slab geometry of this group: one load instruction = vector v16 (+ 16 in the second pass) of rows 4 j + r4: 4 instructions stage a
   // 16-row slab of up to 64 columns, 8 one of up to 96
@@ -706,8 +707,9 @@ __device__ __forceinline__ void conv_wp_body(const ConvParams& P, const ConvGrou
   if (P.skip_len && n0 >= __builtin_amdgcn_readfirstlane(len_raw)) return;  // masked stage: the whole tile lies in this item's padding
   if (P.rag) {
     const int rl = __builtin_amdgcn_readfirstlane(rag_raw);
-    if (n0 >= rl * P.rag_out_mul + P.rag_out_add) return;  // whole tile is padding of this item (block-uniform)
-    const int il = rl * P.rag_in_mul + P.rag_in_add;
+    const int rc = __builtin_amdgcn_readfirstlane(rag_cap);
+    if (n0 >= conv_rag_limit(rl, rc, P.rag_out_mul, P.rag_out_add, P.rag_out_cap_add)) return;  // whole tile is padding of this item (block-uniform)
+    const int il = conv_rag_limit(rl, rc, P.rag_in_mul, P.rag_in_add);
     t_lim = il < t_lim ? il : t_lim;
   }
   const bool interior = t_base >= 0 && t_base + 4 * nvec <= t_lim;

@@ -711,7 +711,7 @@ struct vits_session {
 
   // named views (valid after plan())
   int B = 0, Tx = 0, Ty = 0;
-  int *len_x = nullptr, *len_y = nullptr, *len_rag = nullptr, *dur = nullptr, *cum = nullptr;
+  int *len_x = nullptr, *len_y = nullptr, *len_rag = nullptr, *len_tail = nullptr, *dur = nullptr, *cum = nullptr;
   // compact tile maps of the current forward (ragged batches): built on demand, reused by every launch with the
   // same (length array, scale, cap, tile width); reset at the start of each forward
   int* tile_tabs = nullptr;
@@ -868,7 +868,7 @@ static void plan(vits_session* s, int B, int Tx, int Ty) {
   const size_t Tm = (size_t)(Tx > Ty ? Tx : Ty);
   s->arena_used = 0;
   s->B = B; s->Tx = Tx; s->Ty = Ty;
-  s->len_x = bump<int>(s, B); s->len_y = bump<int>(s, B); s->len_rag = bump<int>(s, B);
+  s->len_x = bump<int>(s, B); s->len_y = bump<int>(s, B); s->len_rag = bump<int>(s, B + 1); s->len_tail = bump<int>(s, B);
   s->ylen64 = bump<int64_t>(s, B);
   s->dur = bump<int>(s, (size_t)B * Tx); s->cum = bump<int>(s, (size_t)B * Tx);
   s->condv = bump<float>(s, (size_t)B * (s->m->cond_rows + 1));
@@ -1101,14 +1101,14 @@ static void persist_launch(vits_session* s, vits_session::PersistProg& pp, const
 }
 
 // compact tile map for a ragged launch (see conv_decode_block); nullptr when no table slot is left
-static const int* tile_table(vits_session* s, const int* len, int mul, int add, int cap, int tile) {
-  auto key = std::make_tuple(len, mul, add, cap, tile);
+static const int* tile_table(vits_session* s, const int* len, int mul, int add, int cap, int tile, int has_cap = 0, int cap_add = 0) {
+  auto key = std::make_tuple(len, mul, add + 100000 * cap_add, cap, tile);
   for (size_t i = 0; i < s->tile_keys.size(); ++i)
     if (s->tile_keys[i] == key) return s->tile_tabs + i * (s->B + 1);
   if (s->tile_keys.size() >= 32) return nullptr;
   int* tab = s->tile_tabs + s->tile_keys.size() * (s->B + 1);
   s->tile_keys.push_back(key);
-  hipLaunchKernelGGL(ragged_tiles_kernel, dim3(1), dim3(64), 0, s->stream, len, s->B, mul, add, cap, tile, tab);
+  hipLaunchKernelGGL(ragged_tiles_kernel, dim3(1), dim3(64), 0, s->stream, len, s->B, mul, add, cap, tile, tab, has_cap, cap_add);
   return tab;
 }
 
@@ -1117,7 +1117,7 @@ static void attach_tile_table(vits_session* s, ConvParams& P, int N_T) {
   if (!pair && !P.xcd_mode) P.xcd_mode = 12;
   P.tile_start = nullptr;
   if (!s || !s->arena || s->B == 1) return;  // a single utterance in a padded bucket: the few dead tiles exit early instead
-  if (P.rag) P.tile_start = tile_table(s, P.rag, P.rag_out_mul, P.rag_out_add, P.Tout, N_T);
+  if (P.rag) P.tile_start = tile_table(s, P.rag, P.rag_out_mul, P.rag_tab_add > P.rag_out_add ? P.rag_tab_add : P.rag_out_add, P.Tout, N_T, 1, P.rag_out_cap_add);  // (tiles the map lists beyond this launch's own limit exit at once)  // (the decoder's rag array carries its cap in rag[B])
   else if (P.skip_len) P.tile_start = tile_table(s, P.len, 1, 0, P.Tout, N_T);
 }
 
@@ -2074,11 +2074,53 @@ static float* run_flow(vits_session* s, int B, int Ty) {
 // frames, so with 32 every sample below len*hop is bit-identical to the dense padded run.
 #define VITS_RAGGED_HALO 32
 static void set_rag(ConvParams& P, const int* rag, int in_mul, int in_add, int out_mul, int out_add) {
-  P.rag = rag; P.rag_in_mul = in_mul; P.rag_in_add = in_add; P.rag_out_mul = out_mul; P.rag_out_add = out_add;
+  P.rag = rag; P.rag_in_mul = in_mul; P.rag_in_add = in_add; P.rag_out_mul = out_mul; P.rag_out_add = out_add; P.rag_out_cap_add = 0; P.rag_tab_add = 0;
 }
-// rag_halo >= 0 (with ragged): frames computed beyond each item's length.  VITS_RAGGED_HALO reproduces the reference's
-// padded-batch result on every valid sample; 0 decodes every item as if it were alone (zeros beyond its own end at every
-// stage), which is what a batch of independent utterances of the StableTTS path wants.
+// What each decoder layer still has to produce BEYOND an item's end in a ragged batch, in columns of its own output (round 5).  The
+// decoder has no masks: in the reference's padded batch an item's activations continue into the padding, and a valid sample depends on
+// that continuation over the receptive field that is left between a layer and the waveform -- 25 frames at conv_pre, 5 columns after
+// the last ResBlock.  Rounds 1-4 computed len + 32 frames at EVERY layer (10 % of the decoder's work at 330-frame items); now every
+// launch carries its own limit: out = what the layers behind it need, in = what its producer made.  Walked backwards from the tail.
+struct DecNeeds {
+  int pre_out = 0, post_out = 0, tail_cols = 0;
+  int ups_q[8] = {0};                       // polyphase launch: input positions q beyond len * rate_in
+  int c1_out[8][VITS_MAX_RESD] = {{0}}, c2_out[8][VITS_MAX_RESD] = {{0}};
+};
+static DecNeeds decoder_needs(const vits_hparams& hp, bool continuation) {
+  DecNeeds N;
+  if (!continuation) return N;  // halo 0: every item is decoded as if alone (zeros beyond its own end at every stage)
+  int need;  // columns the NEXT consumer wants beyond len * rate, at the current rate
+  if (hp.dec_type == 0) {
+    // iSTFT frame f feeds sub-band samples [f hop, f hop + n_fft); PQMF synthesis reaches (taps / 2) / subbands sub-band samples ahead
+    need = (hp.istft_n_fft + hp.istft_hop - 1) / hp.istft_hop + ((hp.pqmf_taps / 2 + hp.subbands - 1) / hp.subbands + hp.istft_hop - 1) / hp.istft_hop + 2;
+  } else {
+    need = 0;
+  }
+  N.tail_cols = need;              // the tail reads conv_post columns 0 .. len * rate + need INCLUSIVE ...
+  N.post_out = need + 1;           // ... so conv_post makes need + 1 of them beyond len * rate (it has T + 1 columns: the reflection pad)
+  need += 4;                       // conv_post, 7 taps (pad 4 with the reflection column, 3 without)
+  for (int i = hp.n_ups - 1; i >= 0; --i) {
+    for (int d = hp.n_resd - 1; d >= 0; --d) {
+      int h2 = 0, h1 = 0;
+      for (int j = 0; j < hp.n_resk; ++j) {
+        const int k = hp.res_kernels[j];
+        h2 = std::max(h2, (k - 1) / 2);
+        h1 = std::max(h1, (k - 1) * hp.res_dilations[j][d] / 2);
+      }
+      N.c2_out[i][d] = need; need += h2;
+      N.c1_out[i][d] = need; need += h1;
+    }
+    const int u = hp.up_rates[i], taps = (hp.up_kernels[i] + u - 1) / u;
+    N.ups_q[i] = (need + u - 1) / u + 1;  // output column c = u q + phase
+    need = N.ups_q[i] + taps / 2 + 2;      // input positions a polyphase output reads: q -+ taps / 2 (+ slack for the phase shifts)
+  }
+  N.pre_out = need;
+  return N;
+}
+// rag_halo > 0 (with ragged): the reference's padded-batch continuation -- every valid sample equals the dense padded run (the per-layer
+// limits above; the value only has to be >= the receptive field and is otherwise unused); 0 decodes every item as if it were alone
+// (zeros beyond its own end at every stage), which is what a batch of independent utterances wants (solo batches, the StableTTS path).
+// VITS_RAG_UNIFORM=1: the round-4 form (len + rag_halo frames at every layer), the A/B reference.
 static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, int Ty, float* d_audio, long long audio_bstride,
                         float* d_mb, bool ragged = false, int rag_halo = -1) {
   vits_model* m = s->m;
@@ -2086,18 +2128,28 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
   const vits_hparams& hp = m->hp;
   int C = hp.dec_initial_channel, T = Ty;
   const int* rag = nullptr;
+  const int* rag_tail = nullptr;
   int rate = 1;  // columns per frame at the current stage
   static const bool no_ragged_env = getenv("VITS_NO_RAGGED") != nullptr;
+  static const bool uniform = getenv("VITS_RAG_UNIFORM") && atoi(getenv("VITS_RAG_UNIFORM")) != 0;
+  int final_rate = 1;
+  for (int i = 0; i < hp.n_ups; ++i) final_rate *= hp.up_rates[i];
+  const bool layered = rag_halo > 0 && !uniform;
+  const DecNeeds ND = decoder_needs(hp, layered);
   if (ragged && (B > 1 || s->rag_b1) && !no_ragged_env) {
-    hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, B, Ty, rag_halo);
+    // uniform form: rag = len + halo, the tail may read (len + halo) * rate columns; layered form: rag = len, every launch adds its own need
+    hipLaunchKernelGGL(ragged_len_kernel, dim3(cdiv(B + 1, 64)), dim3(64), 0, s->stream, s->len_y, s->len_rag, s->len_tail, B, Ty,
+                       layered ? 0 : rag_halo, final_rate, layered ? ND.tail_cols : rag_halo * final_rate);
     rag = s->len_rag;
+    rag_tail = s->len_tail;
   }
   float* cur = s->dec_bufs[0];
   ConvParams P = conv_params(m->conv_pre, z, cur, B, Ty, 1, 3);
   if (mask_in) { P.in_mask = 1; P.len = s->len_y; }  // (z * y_mask) models.py:1703
   if (m->cond_dec_off >= 0) { P.bias_b = s->condv; P.bias_b_stride = m->cond_rows; P.bias_b_off = m->cond_dec_off; }  // + cond(g)
-  set_rag(P, rag, 1, 0, 1, 0);
+  set_rag(P, rag, 1, 0, 1, ND.pre_out);
   launch_conv(s, P, EPI_STORE, "dec.conv_pre");
+  int prod_add = ND.pre_out;  // columns (at the current rate) the tensor about to be consumed has beyond len * rate
   const float* in1 = cur; const float* in2 = nullptr; const float* in3 = nullptr;
   float in_scale = 1.f;
   for (int i = 0; i < hp.n_ups; ++i) {
@@ -2115,9 +2167,10 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     P.in_slope = 0.1f; P.in_scale = in_scale;
     P.ups_u = U.u; P.ups_cout = Co;
     for (int r = 0; r < U.u; ++r) P.ups_shift[r] = U.shift[r];
-    set_rag(P, rag, rate, 0, rate, 0);  // polyphase: output "columns" are input positions q
+    set_rag(P, rag, rate, prod_add, rate, ND.ups_q[i]);  // polyphase: output "columns" are input positions q
     launch_conv(s, P, EPI_STORE, "dec.ups", U.halo);
     C = Co; T = To; rate *= U.u;
+    prod_add = ND.ups_q[i] * U.u;
     // MRF: 3 ResBlock1 chains in grouped launches (modules.py:210-223)
     const int nk = hp.n_resk;
     // (Round 4 experiment, removed: the three chains as three branches of the captured graph -- one stream each, forked and joined
@@ -2135,7 +2188,8 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
       P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
       P.M = m->rb[(size_t)i * nk].c1[d].Mpad; P.Cout = C; P.Tout = T; P.Tout_stride = T; P.y_bstride = (long long)C * T;
       P.in_slope = 0.1f; P.in_scale = 1.f;
-      set_rag(P, rag, rate, 0, rate, 0);
+      set_rag(P, rag, rate, prod_add, rate, ND.c1_out[i][d]);
+      P.rag_tab_add = ND.c1_out[i][0];  // one compact tile map for the six launches of the stage (its widest limit)
       launch_conv(s, P, EPI_STORE, "dec.res_c1");
       for (int j = 0; j < nk; ++j) {  // x = c2(leaky_relu(xt)) + x
         const ResBlockW& R = m->rb[(size_t)i * nk + j];
@@ -2144,7 +2198,10 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
         P.g[j].res = d == 0 ? y : set[4 + j];
         P.g[j].K = R.K; P.g[j].dil = 1; P.g[j].pad_l = (R.K - 1) / 2; P.g[j].n_sg = R.c2[d].n_sg;
       }
+      set_rag(P, rag, rate, ND.c1_out[i][d], rate, ND.c2_out[i][d]);
+      P.rag_tab_add = ND.c1_out[i][0];
       launch_conv(s, P, EPI_STORE, "dec.res_c2");
+      prod_add = ND.c2_out[i][d];
     }
     in1 = set[4]; in2 = nk > 1 ? set[5] : nullptr; in3 = nk > 2 ? set[6] : nullptr;
     in_scale = 1.0f / (float)nk;  // x = xs / num_kernels (models.py:1036), folded into the next staging
@@ -2161,12 +2218,13 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
     P.M = m->conv_post.Mpad; P.Cout = Pc; P.Tout = Tp; P.Tout_stride = Tp; P.y_bstride = (long long)Pc * Tp;
     P.in_slope = 0.01f; P.in_scale = in_scale; P.reflect = 1;
-    set_rag(P, rag, rate, 0, rate, 1);
+    set_rag(P, rag, rate, prod_add, rate, layered ? ND.post_out : 1);
+    P.rag_out_cap_add = 1;  // T + 1 output columns
     launch_conv(s, P, EPI_STORE, "dec.conv_post");
     const int S = hp.subbands, N = hp.istft_n_fft, hop = hp.istft_hop, Tm = T * hop;
     if (g_tail_impl == 0) {  // one launch: exp/sin, iSTFT and PQMF through LDS
       ProfScope ps(s, "istft_pqmf", 0, "istft_pqmf_kernel");
-      TailParams tp{post, m->istft_basis, m->pqmf, mb, d_audio, S, N, hop, Tp, Tm, hp.pqmf_taps, audio_bstride, rag, rate * hop};
+      TailParams tp{post, m->istft_basis, m->pqmf, mb, d_audio, S, N, hop, Tp, Tm, hp.pqmf_taps, audio_bstride, rag_tail, hop};  // (rag_tail: conv_post columns that exist)
       const int HM = (hp.pqmf_taps / 2 + S - 1) / S + 1, nsub = TAIL_MB + 2 * HM, FR = (nsub + N) / hop + 2;
       const size_t lds = ((size_t)2 * S * (N / 2 + 1) * FR + (size_t)S * nsub + (size_t)(N + 2) * N + (size_t)S * (hp.pqmf_taps + 1)) * sizeof(float);
       hipLaunchKernelGGL(istft_pqmf_kernel, dim3(cdiv(Tm, TAIL_MB), B), dim3(256), lds, s->stream, tp);
@@ -2174,12 +2232,12 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
       {
         ProfScope ps(s, "istft", 0, "istft_kernel");
         hipLaunchKernelGGL(istft_kernel, dim3(cdiv(Tm, 256), S, B), dim3(256), 0, s->stream, post, m->istft_basis, mb, S, N, hop, Tp, Tm,
-                           rag, rate * hop);
+                           rag_tail, hop);
       }
       {
         ProfScope ps(s, "pqmf", 0, "pqmf_synthesis_kernel");
         hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3(cdiv(Tm * S, 256), B), dim3(256), 0, s->stream, mb, m->pqmf, d_audio, S,
-                           hp.pqmf_taps, Tm, audio_bstride, rag, rate * hop * S);
+                           hp.pqmf_taps, Tm, audio_bstride, rag_tail, hop * S);
       }
     }
   } else {
@@ -2190,9 +2248,9 @@ static void run_decoder(vits_session* s, const float* z, bool mask_in, int B, in
     P.B = B; P.Cin = C; P.x_ch_sign = 1; P.x_bstride = (long long)C * T; P.Tin = T; P.Tin_stride = T;
     P.M = m->conv_post.Mpad; P.Cout = 1; P.Tout = T; P.Tout_stride = T; P.y_bstride = T;
     P.in_slope = 0.01f; P.in_scale = in_scale;
-    set_rag(P, rag, rate, 0, rate, 0);
+    set_rag(P, rag, rate, prod_add, rate, layered ? ND.post_out : 0);
     launch_conv(s, P, EPI_STORE, "dec.conv_post");
-    hipLaunchKernelGGL(tanh_copy_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s->stream, post, d_audio, T, (long long)T, audio_bstride, rag, rate);
+    hipLaunchKernelGGL(tanh_copy_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s->stream, post, d_audio, T, (long long)T, audio_bstride, rag_tail, 1);
   }
 }
 

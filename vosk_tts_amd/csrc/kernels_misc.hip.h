@@ -890,9 +890,11 @@ __global__ void __launch_bounds__(256) expand_prior_kernel(const float* stats, c
 
 // tile_start[b] = sum_{b' < b} ceil(min(cap, len[b']*mul + add) / tile)  (B+1 entries): the compact tile map of
 // one ragged conv launch (conv_decode_block).  One thread; B <= a few hundred.
-__global__ void ragged_tiles_kernel(const int* len, int B, int mul, int add, int cap, int tile, int* tile_start) {
+// has_cap: len has B + 1 entries, len[B] = where the padded batch tensor ends in frames (the decoder's rag array, conv_rag_limit)
+__global__ void ragged_tiles_kernel(const int* len, int B, int mul, int add, int cap, int tile, int* tile_start, int has_cap, int cap_add) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int run = 0;
+  if (has_cap) { const int c = len[B] * mul + cap_add; cap = c < cap ? c : cap; }
   for (int b = 0; b < B; ++b) {
     tile_start[b] = run;
     int cols = len[b] * mul + add;
@@ -903,17 +905,21 @@ __global__ void ragged_tiles_kernel(const int* len, int B, int mul, int add, int
   tile_start[B] = run;
 }
 
-// rag[b] = min(T_end, len_y[b] + halo): frames each item of a ragged batch needs in the (mask-free) decoder, where
-// T_end = min(Ty, max_b len_y[b]) is where the reference's padded batch tensor ends (Ty may be a larger capacity bucket:
-// beyond the longest item the decoder must see the tensor edge, i.e. zeros, exactly like the exact-size run)
-__global__ void ragged_len_kernel(const int* len_y, int* rag, int B, int Ty, int halo) {
+// The decoder's ragged limits.  rag[b] = min(T_end, len_y[b] + halo) frames for b < B and rag[B] = T_end, where T_end = min(Ty, max_b len_y[b])
+// is where the reference's padded batch tensor ends (Ty may be a larger capacity bucket: beyond the longest item the decoder must
+// see the tensor edge, i.e. zeros, exactly like the exact-size run).  tail[b] = min(len_y[b] * tail_mul + tail_add, T_end * tail_mul):
+// the columns of the last conv's output that exist for item b (what the iSTFT / PQMF / tanh tail may read).
+__global__ void ragged_len_kernel(const int* len_y, int* rag, int* tail, int B, int Ty, int halo, int tail_mul, int tail_add) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  if (b > B) return;
   int mx = 0;
   for (int i = 0; i < B; ++i) mx = len_y[i] > mx ? len_y[i] : mx;
   const int end = mx < Ty ? mx : Ty;
+  if (b == B) { rag[B] = end; return; }
   const int v = len_y[b] + halo;
   rag[b] = v < end ? v : end;
+  const int t = len_y[b] * tail_mul + tail_add, tc = end * tail_mul;  // (an inclusive column index for the iSTFT: the last conv makes tail + 1 columns)
+  tail[b] = t < tc ? t : tc;
 }
 
 // Synth.audio_float_to_int16 after `audio * scale` (vosk_tts/synth.py:16-23,128-130) on the device:
