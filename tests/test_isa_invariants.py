@@ -64,3 +64,22 @@ def test_persistent_kernel_keeps_its_operands_out_of_loop_carried_registers(isa)
     and 85 VGPRs).  Budget with the operands requested at the top of the step: no scratch, well under the file."""
     k = isa["persist_kernel"]
     assert k["scratch"] == 0 and k["vgprs"] <= 216, (k["vgprs"], k["scratch"])
+
+
+def test_software_pipelined_conv_kernel_loop_shape(isa):
+    """conv_sp_kernel (csrc/conv_sp.hip.h): what makes it worth having at one to three workgroups per CU is the SHAPE of its tap loop --
+    three workgroups per CU without spills, B fragments as two ds_read_b128 per tap (the [column][channel] LDS layout; ds_read_b32
+    would mean the layout regressed to eight reads + eight address adds per tap), weight fragments on buffer addressing, and no
+    s_waitcnt vmcnt(0) inside the steady tap loop (a drained queue there means the 4-slot weight ring is being rotated through moves)."""
+    for name in ("conv_sp_kernel<0, 1>", "conv_sp_kernel<0, 2>", "conv_sp_kernel<2, 2>", "conv_sp_kernel<3, 2>"):
+        k = isa[name]
+        assert k["scratch"] == 0 and k["occupancy"] >= 3 and k["vgprs"] <= 168, (name, k["vgprs"], k["scratch"], k["occupancy"])
+    body = isa["conv_sp_kernel<0, 2>"]["body"]
+    blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+    loops = [b for b in blocks if b.count("v_mfma_f32_32x32x2_f32") >= 24]  # the steady group-of-four-taps loop (and the peeled group)
+    assert loops, "no block with >= 24 MFMAs: the tap groups are no longer unrolled by four"
+    for b in loops:
+        n_mfma = b.count("v_mfma_f32_32x32x2_f32")
+        assert b.count("ds_read_b128") * 4 >= n_mfma // 2 and "ds_read_b32" not in b, "B fragments must be two ds_read_b128 per tap"
+        assert "global_load_dwordx4" not in b and b.count("buffer_load_dwordx4") >= n_mfma // 8 * 2 - 2
+        assert not re.search(r"s_waitcnt vmcnt\(0\)", b), "the tap loop drains the memory queue"
