@@ -193,6 +193,21 @@ def test_bert_conditioned_vits_voice_end_to_end_on_gpu(tmp_path, oracle_lib, no_
     assert np.abs(other - got).max() > 1e-3
     with pytest.raises(ValueError, match="bert"):
         model.onnx.run(None, dict(feed, bert=None))
+    # round 5: the bert feed is an input of the graph-replayed host path (pinned block, bucketed T_x), not a reason for the eager path:
+    # both give the same samples, free-running durations included (text of another length: another bucket)
+    lib = model.onnx._lib.lib
+    for text in ("прив+ет, м+ир!", "м+ир прив+ет м+ир прив+ет прив+ет."):
+        f2, _ = synth._feed(text, 3, None, None, None, None)
+        f2 = dict(f2, **{"vits.seed": 11})
+        fast = model.onnx.run(None, f2)[0]
+        fast2 = model.onnx.run(None, f2)[0]  # replay
+        lib.vits_debug_fast_path(0)
+        try:
+            eager = model.onnx.run(None, f2)[0]
+        finally:
+            lib.vits_debug_fast_path(1)
+        assert fast.shape == eager.shape and np.array_equal(fast, fast2)
+        assert_close("BERT voice: graph-replayed path vs eager", eager, fast, 1e-5)
 
 
 @pytest.mark.gpu

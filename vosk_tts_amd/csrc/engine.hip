@@ -767,7 +767,7 @@ struct vits_session {
   bool rag_b1 = false;             // single utterance in a frame bucket: decoder sees zeros beyond the item's own end
   bool sdp_always = false;         // device-session option: run the duration predictor even when durations are forced
   char *io_h = nullptr, *io_d = nullptr;  // per-call inputs: pinned host mirror and device copy (SynthDev | lengths | sid | ids | forced)
-  size_t io_bytes = 0, io_len = 0, io_sid = 0, io_ids = 0, io_forced = 0, io_seeds = 0;
+  size_t io_bytes = 0, io_len = 0, io_sid = 0, io_ids = 0, io_forced = 0, io_seeds = 0, io_bert = 0;  // io_bert: float [B, bert_dim, TxB] (BERT-conditioned voices), 0 = none
   int64_t* h_ylen = nullptr;       // pinned [B] + one int error word behind it
   hipGraphExec_t g1[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [persist*4 + forced*2 + solo]
   std::map<int, vits_session*> backs;
@@ -2705,6 +2705,10 @@ static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
   s->io_forced = s->io_ids + align_up(sizeof(int64_t) * (size_t)B * TxB, 64);
   s->io_seeds = s->io_forced + align_up(sizeof(int32_t) * (size_t)B * TxB, 64);
   s->io_bytes = s->io_seeds + align_up(sizeof(unsigned long long) * B, 64);
+  if (m->hp.bert_dim > 0) {  // the `bert` feed of a BERT-conditioned voice (vosk_tts/synth.py:88-99) rides in the same block: [B, bert_dim, TxB]
+    s->io_bert = s->io_bytes;
+    s->io_bytes += align_up(sizeof(float) * (size_t)B * m->hp.bert_dim * TxB, 64);
+  }
   if (hipHostMalloc((void**)&s->io_h, s->io_bytes) != hipSuccess || hipMalloc((void**)&s->io_d, s->io_bytes) != hipSuccess ||
       hipHostMalloc((void**)&s->h_ylen, sizeof(int64_t) * (B + 1)) != hipSuccess) {
     session_free(s);
@@ -2833,12 +2837,13 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
     const int64_t* d_ids = reinterpret_cast<const int64_t*>(F->io_d + F->io_ids);
     const int32_t* d_forced = reinterpret_cast<const int32_t*>(F->io_d + F->io_forced);
     run_cond(F, d_sid, B, d_len, F->len_x, TxB);
-    if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && F->ps_front[forced ? 0 : 1].ok) {
-      // text encoder [+ duration predictor] + durations as one persistent launch
+    if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && F->ps_front[forced ? 0 : 1].ok && !F->io_bert) {
+      // text encoder [+ duration predictor] + durations as one persistent launch (the text-encoder program has no `bert` input:
+      // a BERT-conditioned voice runs its text side on launches inside the same captured graph)
       persist_launch(F, F->ps_front[forced ? 0 : 1], "front.persist", nullptr, 0.f, 0, d_ids, forced ? d_forced : nullptr, 1.f, 0.f);
       F->ea_pending = false;
     } else {
-      run_text_encoder(F, d_ids, B, TxB);
+      run_text_encoder(F, d_ids, B, TxB, F->io_bert ? reinterpret_cast<const float*>(F->io_d + F->io_bert) : nullptr);
       if (!forced) run_duration(F, F->x, nullptr, 0.f, 0, B, TxB, true);
       run_durations(F, forced ? d_forced : nullptr, 1.f, B, TxB, 0);
     }
@@ -2927,6 +2932,14 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
     if (forced) {
       memcpy(h_forced + (size_t)b * TxB, opts->forced_durations + (size_t)b * Tx, sizeof(int32_t) * Tx);
       for (int t = Tx; t < TxB; ++t) h_forced[(size_t)b * TxB + t] = 0;
+    }
+  }
+  if (F->io_bert) {  // [B, bert_dim, Tx] -> [B, bert_dim, TxB], bucket columns zero
+    float* h_bert = reinterpret_cast<float*>(F->io_h + F->io_bert);
+    const size_t rows = (size_t)B * hp.bert_dim;
+    for (size_t r = 0; r < rows; ++r) {
+      memcpy(h_bert + r * TxB, opts->bert + r * Tx, sizeof(float) * Tx);
+      for (int t = Tx; t < TxB; ++t) h_bert[r * TxB + t] = 0.f;
     }
   }
   // ---- phase 1 and the one host round trip
@@ -3030,7 +3043,11 @@ static int synth_dispatch(vits_model* m, const int64_t* ids, const int64_t* leng
   if (!m->acoustic) return fail(VITS_ERR_UNSUPPORTED, "vocoder-only model: only the decoder stage is available");
   for (int b = 0; b < B; ++b) if (lengths[b] < 0 || lengths[b] > Tx) return fail(VITS_ERR_ARG, "length out of range");
   static const bool env_off = getenv("VITS_NO_FASTPATH") != nullptr;
-  const bool injected = (opts && (opts->noise_dp || opts->noise_prior || opts->bert)) || m->hp.bert_dim > 0;
+  if (m->hp.bert_dim > 0 && (!opts || !opts->bert)) return fail(VITS_ERR_ARG, "this voice is BERT-conditioned: the bert feed [B,%d,T_x] is required", m->hp.bert_dim);
+  if (m->hp.bert_dim == 0 && opts && opts->bert) return fail(VITS_ERR_ARG, "the bert feed was given but this voice has no BERT projection (hparams.bert_dim == 0)");
+  // (round 5: the `bert` feed of a BERT-conditioned voice is an INPUT like the ids and goes through the graph-replayed path; only
+  //  injected noise tensors -- parity tests -- take the eager path)
+  const bool injected = opts && (opts->noise_dp || opts->noise_prior);
   for (int attempt = 0;; ++attempt) {
     tl_ps_timed_out = false;
     const int rc = (g_fast_path && !env_off && !injected)
