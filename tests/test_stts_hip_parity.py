@@ -206,6 +206,51 @@ def test_bert_encoder_vs_transformers_golden(hip_lib, name, hidden):
     enc.close()
 
 
+def test_bert_encoder_graph_replay_equals_eager(hip_lib):
+    """stts_bert_encode replays one captured forward per token-count bucket (multiples of 8, [PAD] columns beyond the sentence):
+    same rows as the exact-size eager launches for every length of a bucket, on the capturing call and on replays, with and
+    without token types, and from two threads at once (a busy bucket falls back to the eager form)."""
+    import threading
+
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd.capi_stts import BertEncoder
+
+    enc = BertEncoder(hip_lib, BW.synthetic_blob(BW.small_hparams(120, 768, 4), 1234))
+    rng = np.random.default_rng(12)
+    try:
+        for T in (1, 5, 7, 8, 9, 30, 31):
+            ids = rng.integers(0, 120, size=T)
+            types = rng.integers(0, 2, size=T) if T % 2 else None
+            a = enc.encode(ids, types)
+            a2 = enc.encode(ids, types)
+            hip_lib.lib.vits_debug_fast_path(0)
+            try:
+                e = enc.encode(ids, types)
+            finally:
+                hip_lib.lib.vits_debug_fast_path(1)
+            assert a.shape == (T, 768) and np.array_equal(a, a2)
+            assert_close(f"BERT rows, T = {T}: replayed vs eager", e, a, 1e-6)
+        ids = rng.integers(0, 120, size=14)
+        want = enc.encode(ids)
+        got, errs = [None] * 6, []
+
+        def work(k):
+            try:
+                for _ in range(20):
+                    got[k] = enc.encode(ids)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(ex)
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs
+        for k in range(6):
+            assert_close(f"thread {k}", want, got[k], 1e-6)
+    finally:
+        enc.close()
+
+
 def test_bert_base_geometry_vs_oracle(hip_lib, oracle_lib):
     """rubert-base geometry (12 x 768, 12 heads, 3072; 10 layers run for hidden_states[-3]) at 60 tokens, HIP vs oracle"""
     from vosk_tts_amd import weights_bert as BW

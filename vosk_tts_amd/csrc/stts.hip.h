@@ -1155,12 +1155,36 @@ int stts_synthesize_batch(stts_model* m, const int64_t* ids, const int64_t* leng
 // Linear is a 1x1 conv launch (q/k/v fused, GELU in the intermediate conv's epilogue), self-attention is the MFMA flash
 // kernel without relative tables, residual + LayerNorm(eps) is layernorm_c_kernel(a + b).
 struct BertLayerW { ConvW qkv, o, c1, c2; float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; };
+// One captured forward per token-count bucket (round 5): get_word_bert runs in front of EVERY request of a BERT-conditioned voice
+// (vosk_tts/synth.py:25-44), and 73 eager launches + two hipMalloc / hipFree per call were 0.9 ms of such a request.  A context owns its
+// session (stream + workspace laid out for the bucket), a pinned input block [ids | token types | length], the device copy, a pinned
+// output block and the graph: memcpy node in, the launches, memcpy node out.  Bucket columns beyond the sentence are [PAD] tokens whose
+// columns nothing valid reads: every op of the encoder is column-local except attention, which masks keys at the length.
+struct BertCtx {
+  vits_session* s = nullptr;
+  int Tb = 0;
+  char *io_h = nullptr, *io_d = nullptr;
+  float *out_h = nullptr, *ot = nullptr;
+  hipGraphExec_t g = nullptr;
+  bool busy = false;
+};
 struct bert_model {
   vits_model base;
   bert_hparams hp;
   float *we = nullptr, *pe = nullptr, *te = nullptr, *eg = nullptr, *eb = nullptr;
   std::vector<BertLayerW> layers;
+  std::mutex ctx_mu;
+  std::map<int, BertCtx*> ctx;  // by bucket
 };
+static void bert_ctx_free(BertCtx* c) {
+  if (!c) return;
+  if (c->g) hipGraphExecDestroy(c->g);
+  if (c->io_h) hipHostFree(c->io_h);
+  if (c->io_d) hipFree(c->io_d);
+  if (c->out_h) hipHostFree(c->out_h);
+  if (c->s) session_free(c->s);
+  delete c;
+}
 
 static ConvW bert_linear(vits_model* b, const char* name, int Cout, int Cin) {
   const float* w = tget(b, 2, Cout, Cin, -1, "%s.weight", name);
@@ -1243,6 +1267,7 @@ int stts_bert_create(const void* blob, size_t bytes, int device, bert_model** ou
 void stts_bert_destroy(bert_model* m) {
   if (!m) return;
   hipSetDevice(m->base.device);
+  for (auto& kv : m->ctx) bert_ctx_free(kv.second);
   for (vits_session* s : m->base.pool) session_free(s);
   for (void* a : m->base.allocs) hipFree(a);
   delete m;
@@ -1254,28 +1279,12 @@ int stts_bert_get_hparams(const bert_model* m, bert_hparams* out) {
   return VITS_OK;
 }
 
-int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, int32_t T, float* out) {
-  if (!m || !ids || !out || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
+// the encoder's launches on session s: ids / types int64 [T] and len int32 on the device -> ot [T][H]
+static void bert_forward(bert_model* m, vits_session* s, const int64_t* d_ids, const int64_t* d_ty, const int* d_len, int T, float* x, float* y, float* att,
+                         float* qkv, float* ff, float* ot) {
   const bert_hparams& hp = m->hp;
-  if (T > hp.max_position) return fail(VITS_ERR_ARG, "%d tokens exceed max_position %d", T, hp.max_position);
-  const int H = hp.hidden, F = hp.intermediate, nh = hp.n_heads;
-  HIP_TRY(hipSetDevice(m->base.device));
-  vits_session* s = nullptr;
-  TRY(pool_acquire(&m->base, &s));
-  struct Rel { vits_model* b; vits_session* s; std::vector<void*> tmp; ~Rel() { hipStreamSynchronize(s->stream); pool_release(b, s); for (void* p : tmp) hipFree(p); } } rel{&m->base, s, {}};
-  TRY(stts_arena(s, ((size_t)T * (H * 4 + 3 * H + F) + 64) * sizeof(float) + 64 * 1024));
-  float* x = bump<float>(s, (size_t)H * T); float* y = bump<float>(s, (size_t)H * T); float* att = bump<float>(s, (size_t)H * T);
-  float* qkv = bump<float>(s, (size_t)3 * H * T); float* ff = bump<float>(s, (size_t)F * T); float* ot = bump<float>(s, (size_t)H * T);
-  int* d_len = bump<int>(s, 1);
-  void* d_ids = nullptr; void* d_ty = nullptr;
-  if (hipMalloc(&d_ids, sizeof(int64_t) * T) != hipSuccess) return fail(VITS_ERR_NOMEM, "device alloc failed");
-  rel.tmp.push_back(d_ids);
-  if (types) { if (hipMalloc(&d_ty, sizeof(int64_t) * T) != hipSuccess) return fail(VITS_ERR_NOMEM, "device alloc failed"); rel.tmp.push_back(d_ty); }
-  HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int64_t) * T, hipMemcpyHostToDevice, s->stream));
-  if (types) HIP_TRY(hipMemcpyAsync(d_ty, types, sizeof(int64_t) * T, hipMemcpyHostToDevice, s->stream));
-  const int tl = T;
-  HIP_TRY(hipMemcpyAsync(d_len, &tl, sizeof(int), hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(bert_embed_kernel, dim3(cdiv(T, 64), H), dim3(64), 0, s->stream, (const int64_t*)d_ids, (const int64_t*)d_ty, m->we, m->pe, m->te, y, H, T,
+  const int H = hp.hidden, nh = hp.n_heads;
+  hipLaunchKernelGGL(bert_embed_kernel, dim3(cdiv(T, 64), H), dim3(64), 0, s->stream, d_ids, d_ty, m->we, m->pe, m->te, y, H, T,
                      hp.vocab_size, hp.type_vocab, s->d_err);
   {
     LNParams P{y, nullptr, nullptr, x, m->eg, m->eb, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr};
@@ -1295,6 +1304,92 @@ int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, in
     { LNParams Q{y, x, nullptr, x, L.g2, L.b2, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr}; launch_layernorm(s->stream, Q, 1); }
   }
   hipLaunchKernelGGL(transpose_ct_kernel, dim3(cdiv(H, 256), T), dim3(256), 0, s->stream, x, ot, H, T);
+}
+
+// graph-replayed form: returns 1 when it served the call, 0 when the caller should take the eager form (bucket busy in another
+// thread, allocation failure), < 0 on an error of the call itself
+static int bert_encode_graph(bert_model* m, const int64_t* ids, const int64_t* types, int T, float* out) {
+  static const bool off = getenv("VITS_NO_FASTPATH") != nullptr;
+  if (off || !g_fast_path) return 0;
+  const bert_hparams& hp = m->hp;
+  const int H = hp.hidden, F = hp.intermediate;
+  int Tb = (T + 7) / 8 * 8;
+  if (Tb > hp.max_position) Tb = hp.max_position;
+  BertCtx* c = nullptr;
+  {
+    std::lock_guard<std::mutex> g(m->ctx_mu);
+    auto it = m->ctx.find(Tb);
+    if (it != m->ctx.end()) {
+      if (it->second->busy) return 0;
+      c = it->second;
+    } else {
+      if (m->ctx.size() >= 64) return 0;
+      c = new BertCtx();
+      c->Tb = Tb;
+      const size_t io = (size_t)2 * Tb * sizeof(int64_t) + 64;
+      bool ok = session_new(&m->base, &c->s) == VITS_OK;
+      ok = ok && stts_arena(c->s, ((size_t)Tb * (H * 4 + 3 * H + F) + 64) * sizeof(float) + 64 * 1024) == VITS_OK;
+      ok = ok && hipHostMalloc((void**)&c->io_h, io) == hipSuccess && hipMalloc((void**)&c->io_d, io) == hipSuccess;
+      ok = ok && hipHostMalloc((void**)&c->out_h, sizeof(float) * (size_t)Tb * H) == hipSuccess;
+      if (!ok) { bert_ctx_free(c); (void)hipGetLastError(); return 0; }
+      m->ctx[Tb] = c;
+    }
+    c->busy = true;
+  }
+  struct Done { bert_model* m; BertCtx* c; ~Done() { std::lock_guard<std::mutex> g(m->ctx_mu); c->busy = false; } } done{m, c};
+  vits_session* s = c->s;
+  int64_t* h_ids = reinterpret_cast<int64_t*>(c->io_h);
+  int64_t* h_ty = h_ids + Tb;
+  int* h_len = reinterpret_cast<int*>(h_ty + Tb);
+  for (int t = 0; t < Tb; ++t) { h_ids[t] = t < T ? ids[t] : 0; h_ty[t] = (t < T && types) ? types[t] : 0; }
+  *h_len = T;
+  if (!c->g) {
+    s->arena_used = 0;
+    float* x = bump<float>(s, (size_t)H * Tb); float* y = bump<float>(s, (size_t)H * Tb); float* att = bump<float>(s, (size_t)H * Tb);
+    float* qkv = bump<float>(s, (size_t)3 * H * Tb); float* ff = bump<float>(s, (size_t)F * Tb);
+    c->ot = bump<float>(s, (size_t)H * Tb);
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    CaptureGuard cg(s->stream);
+    hipMemcpyAsync(c->io_d, c->io_h, (size_t)2 * Tb * sizeof(int64_t) + 64, hipMemcpyHostToDevice, s->stream);
+    const int64_t* d_ids = reinterpret_cast<const int64_t*>(c->io_d);
+    bert_forward(m, s, d_ids, d_ids + Tb, reinterpret_cast<const int*>(d_ids + 2 * Tb), Tb, x, y, att, qkv, ff, c->ot);
+    hipMemcpyAsync(c->out_h, c->ot, sizeof(float) * (size_t)Tb * H, hipMemcpyDeviceToHost, s->stream);
+    if (capture_end(s, &c->g, &cg) != VITS_OK) { c->g = nullptr; return 0; }
+  }
+  { const hipError_t le = hipGraphLaunch(c->g, s->stream); if (le != hipSuccess) return -fail(VITS_ERR_DEVICE, "hipGraphLaunch failed: %s", hipGetErrorString(le)); }
+  const int rc = check_err(s);  // (synchronises the stream; error codes are positive: handed back negated)
+  if (rc != VITS_OK) return -rc;
+  memcpy(out, c->out_h, sizeof(float) * (size_t)T * H);
+  return 1;
+}
+
+int stts_bert_encode(bert_model* m, const int64_t* ids, const int64_t* types, int32_t T, float* out) {
+  if (!m || !ids || !out || T <= 0) return fail(VITS_ERR_ARG, "bad argument");
+  const bert_hparams& hp = m->hp;
+  if (T > hp.max_position) return fail(VITS_ERR_ARG, "%d tokens exceed max_position %d", T, hp.max_position);
+  const int H = hp.hidden, F = hp.intermediate;
+  HIP_TRY(hipSetDevice(m->base.device));
+  {
+    const int gr = bert_encode_graph(m, ids, types, T, out);
+    if (gr == 1) return VITS_OK;
+    if (gr < 0) return -gr;
+  }
+  vits_session* s = nullptr;
+  TRY(pool_acquire(&m->base, &s));
+  struct Rel { vits_model* b; vits_session* s; std::vector<void*> tmp; ~Rel() { hipStreamSynchronize(s->stream); pool_release(b, s); for (void* p : tmp) hipFree(p); } } rel{&m->base, s, {}};
+  TRY(stts_arena(s, ((size_t)T * (H * 4 + 3 * H + F) + 64) * sizeof(float) + 64 * 1024));
+  float* x = bump<float>(s, (size_t)H * T); float* y = bump<float>(s, (size_t)H * T); float* att = bump<float>(s, (size_t)H * T);
+  float* qkv = bump<float>(s, (size_t)3 * H * T); float* ff = bump<float>(s, (size_t)F * T); float* ot = bump<float>(s, (size_t)H * T);
+  int* d_len = bump<int>(s, 1);
+  void* d_ids = nullptr; void* d_ty = nullptr;
+  if (hipMalloc(&d_ids, sizeof(int64_t) * T) != hipSuccess) return fail(VITS_ERR_NOMEM, "device alloc failed");
+  rel.tmp.push_back(d_ids);
+  if (types) { if (hipMalloc(&d_ty, sizeof(int64_t) * T) != hipSuccess) return fail(VITS_ERR_NOMEM, "device alloc failed"); rel.tmp.push_back(d_ty); }
+  HIP_TRY(hipMemcpyAsync(d_ids, ids, sizeof(int64_t) * T, hipMemcpyHostToDevice, s->stream));
+  if (types) HIP_TRY(hipMemcpyAsync(d_ty, types, sizeof(int64_t) * T, hipMemcpyHostToDevice, s->stream));
+  const int tl = T;
+  HIP_TRY(hipMemcpyAsync(d_len, &tl, sizeof(int), hipMemcpyHostToDevice, s->stream));
+  bert_forward(m, s, (const int64_t*)d_ids, (const int64_t*)d_ty, d_len, T, x, y, att, qkv, ff, ot);
   HIP_TRY(hipMemcpyAsync(out, ot, sizeof(float) * (size_t)T * H, hipMemcpyDeviceToHost, s->stream));
   return check_err(s);
 }
