@@ -200,7 +200,9 @@ def test_bert_conditioned_vits_voice_end_to_end_on_gpu(tmp_path, oracle_lib, no_
         f2, _ = synth._feed(text, 3, None, None, None, None)
         f2 = dict(f2, **{"vits.seed": 11})
         fast = model.onnx.run(None, f2)[0]
+        r0 = model.onnx.persist_state()["launches"]
         fast2 = model.onnx.run(None, f2)[0]  # replay
+        assert model.onnx.persist_state()["launches"] == r0 + 2, "a BERT-conditioned voice must run the persistent programs too (front incl. bert_proj, back)"
         lib.vits_debug_fast_path(0)
         try:
             eager = model.onnx.run(None, f2)[0]

@@ -752,6 +752,7 @@ struct vits_session {
                            // duration predictor, their backs the flow -- cells and records are only laid out / built for those
   bool ps_defer = false;   // the owner calls persist_plan itself after re-pointing shared tensors (backs): session_reserve skips it
   PersistCtl* ps_ctl = nullptr;
+  const float* ps_bert = nullptr;  // BERT-conditioned voices: the fixed device buffer [bert_dim][Tx] the text-encoder program reads (front sessions: io_d + io_bert)
   bool ps_owner = false;   // device sessions (asynchronous entry point): this session holds the device's persistent-path token for its lifetime
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled
   // session, so a steady stream of vits_synthesize calls does no hipMalloc / hipFree (both synchronise the device)
@@ -1824,7 +1825,7 @@ static void run_text_encoder(vits_session* s, const int64_t* d_ids, int B, int T
   vits_model* m = s->m;
   const vits_hparams& hp = m->hp;
   const int H = hp.hidden_channels;
-  if ((persist_mask() & PERSIST_ENC) && s->ps_enc.ok && B == 1 && Tx == s->Tx && !d_bert) {  // one persistent kernel instead of ~35 launches
+  if ((persist_mask() & PERSIST_ENC) && s->ps_enc.ok && B == 1 && Tx == s->Tx && (!d_bert || d_bert == s->ps_bert)) {  // one persistent kernel instead of ~35 launches
     persist_launch(s, s->ps_enc, "enc.persist", nullptr, 0.f, 0, d_ids);
     return;
   }
@@ -2696,9 +2697,8 @@ static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
   vits_session* s = nullptr;
   TRY(session_new(m, &s));
   s->ps_roles = PERSIST_ENC | PERSIST_SDP;
-  int rc = session_reserve(s, B, TxB, 1);
-  if (rc != VITS_OK) { session_free(s); return rc; }
   // per-call input block: [SynthDev | lengths int64 [B] | sid int64 [B] | ids int64 [B,TxB] | forced int32 [B,TxB]]
+  // (allocated BEFORE the workspace is laid out: the text-encoder program of a BERT-conditioned voice is resolved against io_d + io_bert)
   s->io_len = align_up(sizeof(SynthDev), 64);
   s->io_sid = s->io_len + align_up(sizeof(int64_t) * B, 64);
   s->io_ids = s->io_sid + align_up(sizeof(int64_t) * B, 64);
@@ -2707,7 +2707,7 @@ static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
   s->io_bytes = s->io_seeds + align_up(sizeof(unsigned long long) * B, 64);
   if (m->hp.bert_dim > 0) {  // the `bert` feed of a BERT-conditioned voice (vosk_tts/synth.py:88-99) rides in the same block: [B, bert_dim, TxB]
     s->io_bert = s->io_bytes;
-    s->io_bytes += align_up(sizeof(float) * (size_t)B * m->hp.bert_dim * TxB, 64);
+    s->io_bytes += align_up(sizeof(float) * (size_t)B * m->hp.bert_dim * TxB, 64) + 256;  // (+ slack: the program's operand window reads whole 16-column tiles)
   }
   if (hipHostMalloc((void**)&s->io_h, s->io_bytes) != hipSuccess || hipMalloc((void**)&s->io_d, s->io_bytes) != hipSuccess ||
       hipHostMalloc((void**)&s->h_ylen, sizeof(int64_t) * (B + 1)) != hipSuccess) {
@@ -2715,6 +2715,9 @@ static int front_acquire(vits_model* m, int B, int TxB, vits_session** out) {
     return fail(VITS_ERR_NOMEM, "fast-path staging buffers");
   }
   memset(s->io_h, 0, s->io_bytes);
+  if (s->io_bert && B == 1) s->ps_bert = reinterpret_cast<const float*>(s->io_d + s->io_bert);
+  const int rc = session_reserve(s, B, TxB, 1);
+  if (rc != VITS_OK) { session_free(s); return rc; }
   *out = s;
   return VITS_OK;
 }
@@ -2837,9 +2840,9 @@ static int phase1_launch(vits_session* F, bool forced, bool solo) {
     const int64_t* d_ids = reinterpret_cast<const int64_t*>(F->io_d + F->io_ids);
     const int32_t* d_forced = reinterpret_cast<const int32_t*>(F->io_d + F->io_forced);
     run_cond(F, d_sid, B, d_len, F->len_x, TxB);
-    if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && F->ps_front[forced ? 0 : 1].ok && !F->io_bert) {
-      // text encoder [+ duration predictor] + durations as one persistent launch (the text-encoder program has no `bert` input:
-      // a BERT-conditioned voice runs its text side on launches inside the same captured graph)
+    if (persist_mask() == (PERSIST_SDP | PERSIST_ENC | PERSIST_FLOW) && B == 1 && F->ps_front[forced ? 0 : 1].ok && (!F->io_bert || F->ps_bert)) {
+      // text encoder [+ duration predictor] + durations as one persistent launch (a BERT-conditioned voice: the program reads the
+      // `bert` tensor straight from the input block, two more steps)
       persist_launch(F, F->ps_front[forced ? 0 : 1], "front.persist", nullptr, 0.f, 0, d_ids, forced ? d_forced : nullptr, 1.f, 0.f);
       F->ea_pending = false;
     } else {

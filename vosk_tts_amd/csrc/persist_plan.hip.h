@@ -75,13 +75,18 @@ static size_t persist_enc_layer_cells(const vits_model* m, const EncoderW& E, si
 }
 static bool persist_enc_eligible(const vits_model* m, int B, int Tx) {
   const vits_hparams& hp = m->hp;
-  if (!persist_common_ok(m, B, Tx) || hp.bert_dim > 0 || !persist_encoder_ok(m, m->enc_p) || !persist_conv_ok(m->enc_proj) || m->enc_proj.K != 1) return false;
-  return 2 + 8 * (int)m->enc_p.layers.size() <= PS_MAX_STEPS;
+  if (!persist_common_ok(m, B, Tx) || !persist_encoder_ok(m, m->enc_p) || !persist_conv_ok(m->enc_proj) || m->enc_proj.K != 1) return false;
+  // BERT-conditioned flavour (round 5): x = (emb * sqrt(H) + bert_proj(bert)) * mask as two more steps (a K-sliced matrix step over the
+  // plain `bert` tensor + a summing column step); the program is only BUILT for sessions that own a fixed bert buffer (ps_bert)
+  if (hp.bert_dim > 0 && (!persist_conv_ok(m->bert_proj) || m->bert_proj.K != 1)) return false;
+  return 4 + 8 * (int)m->enc_p.layers.size() <= PS_MAX_STEPS;
 }
 static size_t persist_enc_cells(const vits_model* m, int B, int Tx) {
   if (!persist_enc_eligible(m, B, Tx)) return 0;
-  const size_t Tp = (size_t)cdiv(Tx, 16) * 16;
-  return Tp * m->hp.hidden_channels + m->enc_p.layers.size() * persist_enc_layer_cells(m, m->enc_p, Tp);
+  const size_t Tp = (size_t)cdiv(Tx, 16) * 16, H = m->hp.hidden_channels;
+  size_t bert = 0;
+  if (m->hp.bert_dim > 0) bert = Tp * H * (m->bert_proj.Cin / persist_slice(m->bert_proj.Cin, 1) + 1);  // K-slice partials + the sum
+  return Tp * H + bert + m->enc_p.layers.size() * persist_enc_layer_cells(m, m->enc_p, Tp);
 }
 
 // ---- flow (ResidualCouplingTransformersBlock reverse, folded WaveNet tail)
@@ -553,11 +558,27 @@ static const ll_t* seg_enc(vits_session* s, PBuild& b, ll_t* stats_cells) {
   const int H = hp.hidden_channels, n = (int)m->enc_p.layers.size();
   const int cond_layer = (m->use_g && m->cond_enc_off >= 0) ? hp.enc_cond_layer : -1;
   const float* vec = cond_layer >= 0 ? s->condv + m->cond_enc_off : nullptr;
+  const bool bert = hp.bert_dim > 0;  // (persist_plan builds this program for such a voice only when the session owns a bert buffer)
   PStep st = b.blank(PK_EMB);
-  b.col_par(st, H, nullptr, nullptr, nullptr, cond_layer == 0 ? vec : nullptr);
+  b.col_par(st, H, nullptr, nullptr, nullptr, (cond_layer == 0 && !bert) ? vec : nullptr);
   st.emb = m->emb; st.scale = sqrtf((float)H); st.n_vocab = hp.n_vocab;
   st.out = b.take_rows(H);
   const ll_t* x = b.push(st).out;
+  if (bert) {
+    // x = (emb * sqrt(H) + bert_proj(bert)) * mask  (vosk_tts/synth.py:88-99; run_text_encoder): bert is a PLAIN tensor [bert_dim][T_x
+    // bucket] the graph's memcpy node fills (front sessions of the host path); 768 channels = 3 K-slices, summed by a column step
+    st = b.mm(m->bert_proj, nullptr, hp.bert_dim);
+    st.bin_plain = s->ps_bert;
+    const int ks = st.ks;
+    st.yout = b.take_rows((size_t)ks * H);
+    st.ypitch = H;
+    const ll_t* part = b.push(st).yout;
+    st = b.blank(PK_LN);
+    b.col_par(st, H, nullptr, nullptr, ks > 1 ? m->bert_proj.bias : nullptr, cond_layer == 0 ? vec : nullptr);
+    st.np = ks; st.ln = 0; st.part = part; st.part_stride = (long long)b.Tp * H; st.res = x;
+    st.out = b.take_rows(H);
+    x = b.push(st).out;
+  }
   for (int i = 0; i < n; ++i)
     x = persist_encoder_layer(b, m->enc_p.layers[i], m->enc_p, x, (i + 1 == cond_layer) ? vec : nullptr, nullptr, i == n - 1 ? s->x : nullptr);
   // stats = proj(x * mask) * mask   (models.py:324-325)
@@ -784,7 +805,8 @@ static void persist_plan(vits_session* s) {
   for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow})
     if (pp->cells && pp->ll && hipMemsetAsync(pp->ll, 0, pp->cells * sizeof(ll_t), s->stream) != hipSuccess) return give_up();
   if (s->ps_x.cells && s->ps_x.ll && hipMemsetAsync(s->ps_x.ll, 0, s->ps_x.cells * sizeof(ll_t), s->stream) != hipSuccess) return give_up();
-  if (s->ps_enc.cells && s->ps_enc.ll) persist_build_enc(s);
+  const bool enc_buildable = s->m->hp.bert_dim == 0 || s->ps_bert;  // a BERT-conditioned voice: only sessions with a fixed bert buffer
+  if (s->ps_enc.cells && s->ps_enc.ll && enc_buildable) persist_build_enc(s);
   if (s->ps_sdp.cells && s->ps_sdp.ll) persist_build_sdp(s);
   if (s->ps_flow.cells && s->ps_flow.ll) persist_build_flow(s);
   if (s->ps_x.cells && s->ps_x.ll) {
