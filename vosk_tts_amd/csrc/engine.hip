@@ -3050,7 +3050,10 @@ static int synth_dispatch(vits_model* m, const int64_t* ids, const int64_t* leng
   if (m->hp.bert_dim == 0 && opts && opts->bert) return fail(VITS_ERR_ARG, "the bert feed was given but this voice has no BERT projection (hparams.bert_dim == 0)");
   // (round 5: the `bert` feed of a BERT-conditioned voice is an INPUT like the ids and goes through the graph-replayed path; only
   //  injected noise tensors -- parity tests -- take the eager path)
-  const bool injected = opts && (opts->noise_dp || opts->noise_prior);
+  bool injected = opts && (opts->noise_dp || opts->noise_prior);
+  // a large padded batch of a BERT-conditioned voice: its bert feed ([B, 768, T_x], tens of MB) would be pinned once per shape bucket --
+  // such calls keep the exact-size eager path (hipMemcpy from the caller's buffer)
+  if (m->hp.bert_dim > 0 && (size_t)B * m->hp.bert_dim * ((Tx + 7) / 8 * 8) * sizeof(float) > ((size_t)8 << 20)) injected = true;
   for (int attempt = 0;; ++attempt) {
     tl_ps_timed_out = false;
     const int rc = (g_fast_path && !env_off && !injected)
