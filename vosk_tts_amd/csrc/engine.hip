@@ -1357,6 +1357,14 @@ static void launch_conv_wp(vits_session* s, ConvParams& P, ProfScope& ps) {
     }
   }
   const dim3 grid(owned ? owned : P.ntiles_m * P.ntiles_n * P.B * P.n_groups);
+  // A/B (round 5, VITS_WP_NW4=1): four waves per workgroup where a contraction has only 8 chunks (the C = 128 decoder stage: one chunk per
+  // wave and an 8-way reduction with 8 waves).  Measured: see profiles/r5_wp_nw4.txt
+  static const bool nw4 = getenv("VITS_WP_NW4") && atoi(getenv("VITS_WP_NW4")) != 0;
+  if (nw4 && P.Cin / CONV_CI_T <= 8 && !owned) {
+    ps.set_kernel("conv_wp_kernel<4>");
+    hipLaunchKernelGGL(conv_wp_kernel<4>, grid, dim3(4 * 64), (size_t)4 * CONV_CI_T * WP_PITCH * sizeof(float), s->stream, P);
+    return;
+  }
   ps.set_kernel("conv_wp_kernel<8>");
   hipLaunchKernelGGL(conv_wp_kernel<NW>, grid, dim3(NW * 64), lds, s->stream, P);
 }
