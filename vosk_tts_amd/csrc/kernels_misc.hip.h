@@ -115,23 +115,28 @@ struct LNParams {
   // LayerNorm runs on x'
   const float* pre; float* pre_out;
 };
+template <int TL = LN_TL>
 __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
-  red[cg * LN_TL + tl] = v;
+  constexpr int CG = 256 / TL;
+  red[cg * TL + tl] = v;
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int g = 0; g < LN_CG; ++g) s += red[g * LN_TL + tl];
+  for (int g = 0; g < CG; ++g) s += red[g * TL + tl];
   __syncthreads();
   return s;
 }
-// MAXV = channels per thread (C <= 16 * MAXV): instantiated for 12 / 24 / 48 so narrow tensors do not issue dead loads
-template <int MAXV>
+// MAXV = channels per thread (C <= CG * MAXV): instantiated for 12 / 24 / 48 so narrow tensors do not issue dead loads.
+// TL = time lanes per block (CG = 256 / TL channel groups): 16 by default; 4 for tensors of a few columns (round 5: a 768 x 16 BERT
+// tensor was ONE block, a 384 x 304 estimator tensor 20 -- 9 us of latency per launch, 21 / 68 launches per request)
+template <int MAXV, int TL = LN_TL>
 __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
-  __shared__ float red[LN_CG * LN_TL];
+  constexpr int LN_CGT = 256 / TL;
+  __shared__ float red[256];
   kernarg_warm<sizeof(LNParams)>();
-  const int tl = threadIdx.x & (LN_TL - 1), cg = threadIdx.x >> 4, b = blockIdx.y;
-  if (P.skip_len && (int)(blockIdx.x * LN_TL) >= P.len[b]) return;  // block-uniform
-  const int t = blockIdx.x * LN_TL + tl;
+  const int tl = threadIdx.x & (TL - 1), cg = threadIdx.x / TL, b = blockIdx.y;
+  if (P.skip_len && (int)(blockIdx.x * TL) >= P.len[b]) return;  // block-uniform
+  const int t = blockIdx.x * TL + tl;
   const bool in = t < P.T;
   const long long o0 = (long long)b * P.C * P.T + (in ? t : 0);
   float v[MAXV];
@@ -141,13 +146,13 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   if (P.b) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+      const int c = cg + i * LN_CGT, cc = c < P.C ? c : P.C - 1;
       v[i] = P.a[o0 + (long long)cc * P.T] + P.b[o0 + (long long)cc * P.T];
     }
   } else {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+      const int c = cg + i * LN_CGT, cc = c < P.C ? c : P.C - 1;
       v[i] = P.a[o0 + (long long)cc * P.T];
     }
   }
@@ -155,25 +160,25 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
     const bool live = in && t < P.len[b];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+      const int c = cg + i * LN_CGT, cc = c < P.C ? c : P.C - 1;
       v[i] = live ? P.pre[cc] * v[i] + P.pre[P.C + cc] : 0.f;
       if (in && c < P.C) P.pre_out[o0 + (long long)c * P.T] = v[i];
     }
   }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = cg + i * LN_CG;
+    const int c = cg + i * LN_CGT;
     v[i] = (in && c < P.C) ? v[i] : 0.f;
     sum += v[i];
   }
-  const float mean = ln_group_sum(sum, red, tl, cg) / (float)P.C;
+  const float mean = ln_group_sum<TL>(sum, red, tl, cg) / (float)P.C;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = cg + i * LN_CG;
+    const int c = cg + i * LN_CGT;
     if (c < P.C) { const float d = v[i] - mean; sq += d * d; }
   }
-  const float rstd = 1.0f / sqrtf(ln_group_sum(sq, red, tl, cg) / (float)P.C + P.eps);
+  const float rstd = 1.0f / sqrtf(ln_group_sum<TL>(sq, red, tl, cg) / (float)P.C + P.eps);
   if (!in) return;
   const bool zero = P.mask && t >= P.len[b];
   const float* gp = P.gamma + (P.mod_stride ? (long long)b * P.mod_stride : 0);
@@ -182,13 +187,13 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
   float ga[MAXV], be[MAXV], ba[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = cg + i * LN_CG, cc = c < P.C ? c : P.C - 1;
+    const int c = cg + i * LN_CGT, cc = c < P.C ? c : P.C - 1;
     ga[i] = gp[cc]; be[i] = bp[cc];
     ba[i] = P.base ? P.base[o0 + (long long)cc * P.T] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = cg + i * LN_CG;
+    const int c = cg + i * LN_CGT;
     float x = (v[i] - mean) * rstd * (g1 + ga[i]) + be[i];
     if (P.gelu) x = gelu_erf(x);
     x += ba[i];
@@ -197,6 +202,13 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
 }
 
 static void launch_layernorm(hipStream_t st, const LNParams& P, int B) {
+  static const int small_blocks = getenv("VITS_LN_SMALL") ? atoi(getenv("VITS_LN_SMALL")) : 64;  // A/B: 0 = never the 4-lane form
+  if ((long)((P.T + LN_TL - 1) / LN_TL) * B < small_blocks && P.C <= 12 * 64) {  // few columns: 4 time lanes x 64 channel groups, 4 x the blocks
+    const dim3 g4((P.T + 3) / 4, B);
+    if (P.C <= 6 * 64) hipLaunchKernelGGL((layernorm_c_kernel<6, 4>), g4, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((layernorm_c_kernel<12, 4>), g4, dim3(256), 0, st, P);
+    return;
+  }
   const dim3 grid((P.T + LN_TL - 1) / LN_TL, B);
   if (P.C <= 12 * LN_CG) hipLaunchKernelGGL(layernorm_c_kernel<12>, grid, dim3(256), 0, st, P);
   else if (P.C <= 24 * LN_CG) hipLaunchKernelGGL(layernorm_c_kernel<24>, grid, dim3(256), 0, st, P);
