@@ -228,7 +228,7 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
                             "x_realtime": round(cs * n / t_cpu / SAMPLE_RATE, 2)}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        print(json.dumps({
+        emit_line({
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if getattr(args, "precision", "f32") == "f32" else "bf16x3", "data": "synthetic", "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
@@ -242,7 +242,7 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
                          "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                          "kernel": "whole forward (per-kernel breakdown: rocprofv3 --kernel-trace of this command)",
                          "forward": {"algorithmic_gflop": round(flops / 1e9, 3)}},
-            "cpu_baseline": cpu_baseline}))
+            "cpu_baseline": cpu_baseline})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -362,12 +362,12 @@ def dry_run(args, torch, dist, rank, world):
     barrier()  # "ranks > 0 have closed their models"
     barrier()  # "rank 0 is done with all devices"
     if rank == 0:
-        print(json.dumps({"metric": "audio_samples_per_sec", "value": round(samples * world * args.steps / el, 1), "unit": "samples/s", "n_gpus": world,
+        emit_line({"metric": "audio_samples_per_sec", "value": round(samples * world * args.steps / el, 1), "unit": "samples/s", "n_gpus": world,
                           "rank_ms": rank_ms, "rank_persistent_launches_per_forward": rank_persist, "batch256_requests_seen": int(shard.item()),
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": seen,
                           "launched_by": "bench.py" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if dist is not None else "single process"),
-                          "config": {"workload": "dry run: no GPU work, launch / barrier / aggregation only"}}))
+                          "config": {"workload": "dry run: no GPU work, launch / barrier / aggregation only"}})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -568,6 +568,18 @@ def bert_voice_leg(hp, device, seconds=0.4):
             "what": "Synth.synth_audio on a BERT-conditioned VITS voice (synthetic weights, BERT-base geometry): tokenizer + BERT encoder + g2p + synthesis per request, one thread"}
 
 
+_JSON_FD = None
+
+
+def emit_line(obj):
+    """the bench line: to the process's ORIGINAL stdout (main() points fd 1 at stderr so that library chatter cannot precede it)"""
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def _workload_name(v):
     import argparse
     if v in ("c1", "c2", "c3", "c4", "c5", "m2", "m3", "s8", "s16") or (v[:1] == "u" and v[1:].isdigit() and 1 <= int(v[1:]) <= 4000):
@@ -602,6 +614,13 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (c10d's "[Gloo] Rank 0 is connected to ..." at
+    # rendezvous, for one), so from here on file descriptor 1 points at stderr and the line is written to the saved descriptor
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -991,7 +1010,7 @@ def main():
             "value_is": "device-resident session (inputs in HBM when the timed region starts, as the bench contract requires); the drop-in host "
                         "path (ids on the host -> int16 on the host, free-running) is host_api",
         }
-        print(json.dumps(line))
+        emit_line(line)
     if dist is not None:
         dist.destroy_process_group()
 
