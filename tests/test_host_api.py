@@ -522,6 +522,56 @@ def test_request_coalescer_batches_concurrent_requests_and_routes_results():
     assert co.requests == 10 and co.largest == max(sizes) and co._busy == 0 and not co._queue
 
 
+def test_request_coalescer_gather_window_and_promotion():
+    """RequestCoalescer with the opt-in gather window (no GPU needed; fake engine: 2 ms + 0.2 ms per request).  One key, one call in
+    flight: a closed-loop pool of 12 threads settles into two alternating half-size batches without the window and is served in
+    (nearly) full batches with it.  Two keys, several calls in flight: every request gets ITS result exactly once, nobody starves
+    (leftovers beyond a leader's target are promoted to leaders of their own), the bookkeeping returns to idle.  A lone client
+    never waits."""
+    import threading
+    import time
+
+    from vosk_tts_amd.session import RequestCoalescer
+
+    def run_batch(key, reqs):
+        time.sleep(0.002 + 0.0002 * len(reqs))
+        return [("out", key, r[2]) for r in reqs]
+
+    def pool(inflight, gather, keys):
+        co = RequestCoalescer(run_batch, 32, inflight, gather)
+        stop = time.perf_counter() + 0.35
+        cnt, bad = [0] * 12, []
+
+        def worker(k):
+            i = 0
+            while time.perf_counter() < stop:
+                key = keys[k % len(keys)]
+                r = co.submit(key, None, 0, (k, i))
+                if r != ("out", key, (k, i)):
+                    bad.append((k, i, r))
+                i += 1
+                cnt[k] += 1
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+        [t.start() for t in th]
+        [t.join(10) for t in th]
+        assert not any(t.is_alive() for t in th), f"stuck threads (in flight {inflight}, gather {gather})"
+        assert not bad and min(cnt) >= 5 and co.requests == sum(cnt), (inflight, gather, min(cnt))
+        assert co._busy == 0 and not co._queue and co._in_calls == 0 and not co._gathering and not any(co._in_key.values())
+        return co
+
+    plain, windowed = pool(1, 0, ["a"]), pool(1, 400, ["a"])
+    assert plain.gathered == 0 and windowed.gathered > 0
+    assert windowed.requests / windowed.calls > 1.3 * plain.requests / plain.calls, (plain.requests / plain.calls, windowed.requests / windowed.calls)
+    for inflight in (1, 2, 4):
+        pool(inflight, 400, ["a", "a", "a", "b"])  # a leader only ever takes its own key; the peak it gathers up to is per key
+    lone = RequestCoalescer(run_batch, 32, 1, 5000)
+    t0 = time.perf_counter()
+    for i in range(20):
+        assert lone.submit("a", None, 0, i) == ("out", "a", i)
+    assert (time.perf_counter() - t0) / 20 < 0.0045 and lone.gathered == 0, "a lone client must never wait for stragglers"
+
+
 def test_session_does_not_slice_by_an_unvalidated_length():
     """VitsSession._coalescable (no GPU needed): input_lengths outside (0, T] must not be used to slice the ids -- such a request is
     not merged and takes the direct call, whose C-side check answers VITS_ERR_ARG."""

@@ -62,19 +62,23 @@ class RequestCoalescer:
         self._queue = []
         self._in_calls = 0     # requests inside engine calls right now
         self._gathering = False  # a leader is waiting for stragglers: arrivals join its queue instead of starting calls of their own
-        self._peak = 1         # most requests present at once (in calls + queued) recently ...
-        self._peak_t = 0.0     # ... and when that was last seen
+        self._in_key = {}      # ... per key
+        self._peaks = {}       # key -> (most requests of that key present at once recently, when that was last seen)
         self.calls = 0        # engine calls issued
         self.requests = 0     # requests served
         self.largest = 0      # largest batch so far
         self.split_retries = 0  # merged batches that failed and were re-run member by member
         self.gathered = 0     # launches that waited for stragglers
 
-    # (lock held)
-    def _note_presence(self, now):
-        present = self._in_calls + len(self._queue)
-        if present >= self._peak or now - self._peak_t > 0.05:
-            self._peak, self._peak_t = max(present, 1), now
+    # (lock held) requests of `key` present at once (inside engine calls + queued): a leader only ever takes its own key, so the
+    # stragglers it may wait for are counted per key
+    def _note_presence(self, now, key):
+        present = self._in_key.get(key, 0) + sum(1 for p in self._queue if p.key == key)
+        peak, t = self._peaks.get(key, (1, 0.0))
+        if present >= peak or now - t > 0.05:
+            self._peaks[key] = (max(present, 1), now)
+        if len(self._peaks) > 64:  # (keys are (kind, scales, scale) tuples: bounded in practice, bounded here for good)
+            self._peaks = {key: self._peaks[key]}
 
     def _gather(self, me, batch):
         """(lock held) `batch` (containing `me`) is about to be launched: wait for stragglers while it is smaller than the recent peak.
@@ -84,8 +88,8 @@ class RequestCoalescer:
         import time
 
         now = time.perf_counter()
-        self._note_presence(now)
-        target = min(self.max_batch, self._peak - self._in_calls)
+        self._note_presence(now, me.key)
+        target = min(self.max_batch, self._peaks[me.key][0] - self._in_key.get(me.key, 0))
         if len(batch) >= target:
             return batch
         deadline = now + self.gather_us * 1e-6
@@ -128,13 +132,14 @@ class RequestCoalescer:
         with self._lock:
             if self._busy >= self.max_inflight or self._gathering:
                 self._queue.append(me)
-                self._note_presence(time.perf_counter())
+                self._note_presence(time.perf_counter(), key)
                 self._cond.notify_all()
                 batch = None
             else:
                 self._busy += 1
                 batch = self._gather(me, [me])
                 self._in_calls += len(batch)
+                self._in_key[key] = self._in_key.get(key, 0) + len(batch)
                 promote = self._promote()
         if batch is not None and promote is not None:
             promote.event.set()
@@ -147,6 +152,7 @@ class RequestCoalescer:
             with self._lock:
                 batch = self._gather(me, me.lead)
                 self._in_calls += len(batch)
+                self._in_key[key] = self._in_key.get(key, 0) + len(batch)
                 promote = self._promote()
             if promote is not None:
                 promote.event.set()
@@ -177,6 +183,7 @@ class RequestCoalescer:
                 self.requests += len(batch)
                 self.largest = max(self.largest, len(batch))
                 self._in_calls -= len(batch)
+                self._in_key[batch[0].key] = self._in_key.get(batch[0].key, 0) - len(batch)
                 nxt = None
                 if self._queue:
                     head = self._queue[0]
