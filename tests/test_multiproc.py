@@ -171,6 +171,7 @@ def test_bench_multi_rank_entry_point_dry_run(launcher):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
     assert d["ms_per_step"] >= 2.0  # the slower rank (2 ms per step), not the faster one
     assert d["launched_by"] == ("bench.py" if launcher == "self" else "torch.distributed.run")
+    assert r.stdout.strip() == lines[0], "stdout must carry the one JSON line and nothing else (c10d's [Gloo] messages used to precede it)"
     assert d["rank_ms"][1] > d["rank_ms"][0] >= 1.0 and d["rank_persistent_launches_per_forward"] == [1.0, 1.0]
     assert d["batch256_requests_seen"] == 256  # configs[3]'s list dealt over the ranks: every request on exactly one rank
 
