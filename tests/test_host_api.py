@@ -923,11 +923,13 @@ _CHILD_PROCESS = r"""
 import ctypes, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 from vosk_tts_amd import weights as W
-from vosk_tts_amd.capi import VitsLib
+from vosk_tts_amd.capi import VitsLib, VitsDeviceSession
 lib = VitsLib()
 m = lib.create(W.synthetic_blob(W.default_hparams(), 1234), 0)
 lib.lib.vits_debug_persist_runs.restype = ctypes.c_int
 lib.lib.vits_debug_persist_runs.argtypes = [ctypes.c_void_p]
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+sess = VitsDeviceSession(m, 1, 40, 120) if mode == "hold" else None   # an asynchronous device session keeps the device's programs for its lifetime
 rng = np.random.default_rng(5)
 ids = rng.integers(1, 62, size=(1, 40)).astype(np.int64)
 args = (ids, np.array([40], np.int64), np.array([0.667, 1.0, 0.8], np.float32), np.array([2], np.int64))
@@ -936,28 +938,32 @@ a2, _ = m.synthesize(*args, seed=77)
 assert np.array_equal(a, a2)
 np.save(sys.argv[2], a)
 print("RUNS", int(lib.lib.vits_debug_persist_runs(m._h)), flush=True)
-if len(sys.argv) > 3 and sys.argv[3] == "hold":   # keep the model (and with it the device's lock) until told to let go
+if mode in ("hold", "idle"):   # hold: a device session (and with it the lock) until told to let go; idle: only a model, no call in flight
     sys.stdin.readline()
-    m.close()
+    if sess is not None:
+        sess.close()
     print("RELEASED", flush=True)
     sys.stdin.readline()
+    m.close()
 """
 
 
 @pytest.mark.gpu
-def test_a_second_process_on_the_device_leaves_the_persistent_programs_to_the_first(tmp_path):
+def test_processes_share_the_persistent_programs_of_a_device_call_by_call(tmp_path):
     """Two PROCESSES on one device (two bench ranks on a one-GPU box, a server with several workers per GPU): the persistent programs
-    need all their workgroups co-resident, so only the process that holds the device's lock (flock on a file named after the PCI bus
-    id, engine.hip persist_process_owns) runs them; the other one takes the launch path -- same samples, no timeout -- and gets the
-    programs once the first process has destroyed its last model on the device.  (Own lock directory: independent of what this
-    test process itself holds.)"""
+    need all their workgroups co-resident, so they run under an advisory lock (flock on a file named after the PCI bus id, engine.hip
+    persist_process_lock) that a process holds for exactly as long as it holds the device's token: one host call, or the lifetime of
+    a device session.  (1) A process that merely HAS a model on the device -- idle -- blocks nobody (round 5; the lock used to be kept
+    while a model existed).  (2) While another process keeps a device session, this one runs the launch path -- same samples, no
+    timeout.  (3) When that session is gone the programs are available again.  (Own lock directory: independent of what this test
+    process itself holds.)"""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "child.py"
     script.write_text(_CHILD_PROCESS)
-    env = dict(os.environ, VITS_PERSIST_LOCK_DIR=str(tmp_path))
+    env = dict(os.environ, VITS_PERSIST_LOCK_DIR=str(tmp_path), VITS_QUIET="1")
 
     def run_child(tag):
         out = tmp_path / f"{tag}.npy"
@@ -965,16 +971,35 @@ def test_a_second_process_on_the_device_leaves_the_persistent_programs_to_the_fi
         assert r.returncode == 0, r.stderr[-2000:]
         return int([x for x in r.stdout.splitlines() if x.startswith("RUNS")][-1].split()[1]), np.load(out)
 
-    first = subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "first.npy"), "hold"], env=env, stdin=subprocess.PIPE,
+    def start(mode):
+        p = subprocess.Popen([sys.executable, str(script), root, str(tmp_path / f"{mode}.npy"), mode], env=env, stdin=subprocess.PIPE,
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    try:
-        line = first.stdout.readline()
+        line = p.stdout.readline()
         while line and not line.startswith("RUNS"):
-            line = first.stdout.readline()
-        assert line.startswith("RUNS") and int(line.split()[1]) > 0, (line, first.stderr.read()[-2000:] if not line else "")
-        mine = np.load(tmp_path / "first.npy")
-        runs_b, audio_b = run_child("while_owned")
-        assert runs_b == 0, "the second process ran persistent programs on a device another process owns"
+            line = p.stdout.readline()
+        assert line.startswith("RUNS"), p.stderr.read()[-2000:]
+        return p, int(line.split()[1])
+
+    def finish(p):
+        try:
+            p.stdin.write("\n\n"); p.stdin.flush()
+        except Exception:
+            pass
+        p.wait(timeout=60)
+
+    idle, runs_idle = start("idle")
+    try:
+        assert runs_idle > 0
+        mine = np.load(tmp_path / "idle.npy")
+        runs_a, audio_a = run_child("next_to_an_idle_process")
+        assert runs_a > 0, "a process that is idle (a model, no call in flight) must not keep the device's programs"
+        assert np.abs(audio_a - mine).max() <= 5e-4 * np.abs(mine).max()
+    finally:
+        finish(idle)
+    first, _ = start("hold")
+    try:
+        runs_b, audio_b = run_child("while_a_device_session_exists")
+        assert runs_b == 0, "the second process ran persistent programs while another process's device session held them"
         assert audio_b.shape == mine.shape and np.abs(audio_b - mine).max() <= 5e-4 * np.abs(mine).max()
         first.stdin.write("\n"); first.stdin.flush()
         line = first.stdout.readline()
@@ -982,11 +1007,7 @@ def test_a_second_process_on_the_device_leaves_the_persistent_programs_to_the_fi
             line = first.stdout.readline()
         assert line.startswith("RELEASED")
         runs_c, audio_c = run_child("after_release")
-        assert runs_c > 0, "the lock was not released with the first process's last model"
+        assert runs_c > 0, "the lock was not released with the other process's device session"
         assert np.abs(audio_c - mine).max() <= 5e-4 * np.abs(mine).max()
     finally:
-        try:
-            first.stdin.write("\n"); first.stdin.flush()
-        except Exception:
-            pass
-        first.wait(timeout=60)
+        finish(first)

@@ -794,60 +794,67 @@ static T* bump(vits_session* s, size_t n) {
 
 static inline int persist_mask() { return tl_persist >= 0 ? tl_persist : 0; }
 // ... and across PROCESSES: two processes that run the persistent programs on one device at the same time starve each other into the
-// poll timeout just the same (seen with two bench ranks on one device: "exchange timed out").  The first process that wants the programs
-// on a device takes an advisory lock -- flock on a file named after the device's PCI bus id, kept while the process has a model on
-// that device -- and every other process runs the launch path there.  Processes that do not share the lock directory (containers
-// with their own /tmp) are not covered; the bounded poll loops and the launch-path fallback still are.
+// poll timeout just the same (seen with two bench ranks on one device: "exchange timed out").  The token therefore includes an advisory
+// lock -- flock on a file named after the device's PCI bus id -- taken for exactly as long as the token is held: the length of ONE host
+// call (which launches and waits for its kernels), or the lifetime of an asynchronous device session.  Round 5: it used to be held for
+// as long as the process had a model on the device, which pinned every other process on that GPU to the launch path even while the
+// owner was idle; now an idle process holds nothing, and two busy processes share the programs call by call (a call that finds the
+// lock taken runs on launches: slower, never wrong).  Processes that do not share the lock directory (containers with their own /tmp)
+// are not covered; the bounded poll loops and the launch-path fallback still are.
 // VITS_PERSIST_LOCK=0: no lock; VITS_PERSIST_LOCK_DIR: directory of the lock files (default /tmp).
-static int g_proc_lock[64];     // 0 = not tried, 1 = this process owns the device's programs (or no lock is used), -1 = another process does
-static int g_proc_lock_fd[64];
-static std::chrono::steady_clock::time_point g_proc_lock_tried[64];
-static bool persist_process_owns(int dev) {  // (g_tok_mu held)
-  if (g_proc_lock[dev] > 0) return true;
-  const auto now = std::chrono::steady_clock::now();
-  // denied: ask again once a second (the owner may have exited; one non-blocking flock)
-  if (g_proc_lock[dev] < 0 && now - g_proc_lock_tried[dev] < std::chrono::seconds(1)) return false;
-  g_proc_lock_tried[dev] = now;
-  g_proc_lock_fd[dev] = -1;
-  if (getenv("VITS_PERSIST_LOCK") && atoi(getenv("VITS_PERSIST_LOCK")) == 0) { g_proc_lock[dev] = 1; return true; }
-  char bus[64] = "dev";
-  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
-  for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-  char path[512];
-  snprintf(path, sizeof path, "%s/vits_mi355_persist_%s.lock", getenv("VITS_PERSIST_LOCK_DIR") ? getenv("VITS_PERSIST_LOCK_DIR") : "/tmp", bus);
-  // read-only: another user's process can open it too (flock does not care); O_NOFOLLOW: a symlink planted under the predictable name
-  // in a shared directory is refused, not followed (then: no lock, as without a lock directory)
-  const int fd = open(path, O_CREAT | O_RDONLY | O_CLOEXEC | O_NOFOLLOW, 0644);
-  if (fd < 0) { g_proc_lock[dev] = 1; return true; }                // no lock directory: as before
-  if (flock(fd, LOCK_EX | LOCK_NB) != 0) {
-    close(fd);
-    if (g_proc_lock[dev] == 0 && !getenv("VITS_QUIET"))  // once per (process, device, model generation)
-      fprintf(stderr, "[vits_mi355] device %d: another process owns the persistent programs (%s): single utterances run the launch path here\n", dev, path);
+static int g_proc_lock[64];     // last outcome per device: 0 = not asked yet, 1 = got it (or no lock is used), -1 = another process had it
+static int g_proc_lock_fd[64];  // 0 = not opened yet (fd 0 is never ours), -1 = no lock in use, > 0 = the lock file
+static bool persist_process_lock(int dev) {  // (g_tok_mu held)
+  if (g_proc_lock_fd[dev] == 0) {
+    g_proc_lock_fd[dev] = -1;
+    if (!(getenv("VITS_PERSIST_LOCK") && atoi(getenv("VITS_PERSIST_LOCK")) == 0)) {
+      char bus[64] = "dev";
+      if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+      for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+      char path[512];
+      snprintf(path, sizeof path, "%s/vits_mi355_persist_%s.lock", getenv("VITS_PERSIST_LOCK_DIR") ? getenv("VITS_PERSIST_LOCK_DIR") : "/tmp", bus);
+      // read-only: another user's process can open it too (flock does not care); O_NOFOLLOW: a symlink planted under the predictable
+      // name in a shared directory is refused, not followed (then: no lock, as without a lock directory)
+      const int fd = open(path, O_CREAT | O_RDONLY | O_CLOEXEC | O_NOFOLLOW, 0644);
+      if (fd > 0) g_proc_lock_fd[dev] = fd;
+      else if (fd == 0) close(fd);
+    }
+  }
+  if (g_proc_lock_fd[dev] < 0) { g_proc_lock[dev] = 1; return true; }  // no lock directory / switched off: as without other processes
+  if (flock(g_proc_lock_fd[dev], LOCK_EX | LOCK_NB) != 0) {
+    if (g_proc_lock[dev] >= 0 && !getenv("VITS_QUIET"))  // (once per change of fortune)
+      fprintf(stderr, "[vits_mi355] device %d: another process is running the persistent programs: this call takes the launch path\n", dev);
     g_proc_lock[dev] = -1;
     return false;
   }
-  g_proc_lock[dev] = 1; g_proc_lock_fd[dev] = fd;
+  g_proc_lock[dev] = 1;
   return true;
+}
+static void persist_process_unlock(int dev) {  // (g_tok_mu held)
+  if (g_proc_lock_fd[dev] > 0) flock(g_proc_lock_fd[dev], LOCK_UN);
 }
 static void persist_process_release(int dev) {  // called when a model of this process on `dev` is gone
   std::lock_guard<std::mutex> g(g_tok_mu);
   if (dev < 0 || dev >= 64) return;
-  {  // decided HERE, under the token mutex: a model created since the caller looked keeps the lock it may be using
+  {  // decided HERE, under the token mutex: a model created since the caller looked keeps the file it may be using
     std::lock_guard<std::mutex> gm(g_models_mu);
     for (vits_model* o : g_models) if (o->device == dev) return;
   }
-  if (g_proc_lock[dev] > 0 && g_proc_lock_fd[dev] >= 0) { flock(g_proc_lock_fd[dev], LOCK_UN); close(g_proc_lock_fd[dev]); }
-  g_proc_lock[dev] = 0; g_proc_lock_fd[dev] = -1;  // (a process that was denied asks again with its next model)
+  if (g_tok_busy[dev]) return;  // (a call in flight still holds the lock; it is unlocked with the token)
+  if (g_proc_lock_fd[dev] > 0) close(g_proc_lock_fd[dev]);
+  g_proc_lock_fd[dev] = 0; g_proc_lock[dev] = 0;
 }
 static bool persist_token_try(int dev) {
   std::lock_guard<std::mutex> g(g_tok_mu);
-  if (dev < 0 || dev >= 64 || g_tok_busy[dev] || !persist_process_owns(dev)) return false;
+  if (dev < 0 || dev >= 64 || g_tok_busy[dev] || !persist_process_lock(dev)) return false;
   g_tok_busy[dev] = true;
   return true;
 }
 static void persist_token_release(int dev) {
   std::lock_guard<std::mutex> g(g_tok_mu);
-  if (dev >= 0 && dev < 64) g_tok_busy[dev] = false;
+  if (dev < 0 || dev >= 64) return;
+  persist_process_unlock(dev);
+  g_tok_busy[dev] = false;
 }
 // a host call that launches AND waits for its kernels: owns the token (when it is free) from here to its end
 struct PersistScope {
