@@ -752,6 +752,7 @@ struct vits_session {
                            // duration predictor, their backs the flow -- cells and records are only laid out / built for those
   bool ps_defer = false;   // the owner calls persist_plan itself after re-pointing shared tensors (backs): session_reserve skips it
   PersistCtl* ps_ctl = nullptr;
+  std::vector<std::pair<std::vector<long long>, const float*>> ps_pending;  // parameter packs built by the plan in progress (persist_pack), published after its one stream sync
   const float* ps_bert = nullptr;  // BERT-conditioned voices: the fixed device buffer [bert_dim][Tx] the text-encoder program reads (front sessions: io_d + io_bert)
   bool ps_owner = false;   // device sessions (asynchronous entry point): this session holds the device's persistent-path token for its lifetime
   // staging area of the host-buffer entry points (inputs, noise, audio): a bump allocator that lives with the pooled

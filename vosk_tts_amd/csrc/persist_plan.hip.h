@@ -182,20 +182,33 @@ static const float* persist_pack(vits_session* s, const float* const (&src)[8], 
   std::vector<long long> key;
   for (int k = 0; k < 8; ++k) { key.push_back((long long)(uintptr_t)src[k]); key.push_back(add[k]); }
   key.push_back(len); key.push_back(rows);
-  std::lock_guard<std::mutex> g(m->pack_mu);
-  auto it = m->packs.find(key);
-  if (it != m->packs.end()) return it->second;
+  for (auto& pk : s->ps_pending)  // built earlier in this plan, on this session's stream: usable by this plan's programs, not yet published
+    if (pk.first == key) return pk.second;
   float* dst = nullptr;
-  if (hipMalloc((void**)&dst, sizeof(float) * 8 * (size_t)rows) != hipSuccess) return nullptr;
-  m->allocs.push_back(dst);
+  {
+    std::lock_guard<std::mutex> g(m->pack_mu);
+    auto it = m->packs.find(key);
+    if (it != m->packs.end()) return it->second;
+    if (hipMalloc((void**)&dst, sizeof(float) * 8 * (size_t)rows) != hipSuccess) return nullptr;
+    m->allocs.push_back(dst);
+  }
   PsPackArgs a;
   for (int k = 0; k < 8; ++k) { a.src[k] = src[k] == m->zeros ? nullptr : src[k]; a.add[k] = add[k]; a.len[k] = len; }
   hipLaunchKernelGGL(ps_pack_kernel, dim3(cdiv(rows * 8, 256)), dim3(256), 0, s->stream, dst, a, rows);
-  // published only once it is written: another thread planning a session on ITS stream would otherwise find the entry and launch a
-  // program that reads the pack before this stream has run the kernel (once per distinct pack per model)
-  if (hipStreamSynchronize(s->stream) != hipSuccess) return nullptr;
-  m->packs[key] = dst;
+  // Published (persist_publish_packs) only once it is written: another thread planning a session on ITS stream would otherwise find the
+  // entry and launch a program that reads the pack before this stream has run the kernel.  Round 5: ONE synchronisation per plan (the
+  // one persist_plan ends with) instead of one per pack under the model's mutex; two threads that plan the same model at the same time may
+  // each build a pack -- the first to publish wins, the other copy stays with the model's allocations (a few KB, once).
+  s->ps_pending.emplace_back(std::move(key), dst);
   return dst;
+}
+// after the stream that ran the pack kernels has been synchronised
+static void persist_publish_packs(vits_session* s, bool ok) {
+  if (ok && !s->ps_pending.empty()) {
+    std::lock_guard<std::mutex> g(s->m->pack_mu);
+    for (auto& pk : s->ps_pending) s->m->packs.emplace(pk.first, pk.second);  // (emplace keeps an entry another thread published first)
+  }
+  s->ps_pending.clear();
 }
 
 // ------------------------------------------------------------------------------------------------ program builders
@@ -793,6 +806,7 @@ static void persist_plan(vits_session* s) {
   if (!s->ps_enc.cells && !s->ps_sdp.cells && !s->ps_flow.cells) return;
   auto give_up = [&]() {
     clear_all();
+    s->ps_pending.clear();
     const hipError_t e = hipGetLastError();
     static std::atomic<bool> said{false};  // (once per process: the reserve does not fail, so say why single utterances are slower)
     if (!said.exchange(true) && !getenv("VITS_QUIET"))
@@ -822,5 +836,7 @@ static void persist_plan(vits_session* s) {
     }
   }
   // the programs live in pageable memory of the session: the copies must not outlive this call's view
-  if (hipStreamSynchronize(s->stream) != hipSuccess) give_up();
+  const bool synced = hipStreamSynchronize(s->stream) == hipSuccess;
+  persist_publish_packs(s, synced);
+  if (!synced) give_up();
 }
