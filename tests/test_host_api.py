@@ -213,6 +213,37 @@ def test_bert_conditioned_vits_voice_end_to_end_on_gpu(tmp_path, oracle_lib, no_
 
 
 @pytest.mark.gpu
+def test_warmup_takes_the_capture_cost_off_the_first_request(tmp_path):
+    """Model.warmup() (extension): after it the first real request of a warmed size costs what a steady-state request costs, not the
+    workspace layout + program build + two graph captures of its bucket; results are unaffected."""
+    import time
+
+    from vosk_tts_amd import Model, Synth
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), W.default_hparams(n_vocab=len(PHONEMES)))
+    text = "прив+ет, м+ир! прив+ет, м+ир."
+
+    def first_request(warm):
+        model = Model(model_path=d, device=0)
+        synth = Synth(model)
+        if warm:
+            calls, secs = model.warmup(max_tokens=96)
+            assert calls >= 12 * 2 and secs > 0
+        t0 = time.perf_counter()
+        pcm = synth.synth_audio(text, speaker_id=2, duration_noise_level=0.0)
+        dt = time.perf_counter() - t0
+        model.onnx.close()
+        return dt, pcm
+
+    cold, a = first_request(False)
+    warm, b = first_request(True)
+    assert a.shape == b.shape and np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+    assert warm < 0.5 * cold, f"first request after warmup {warm * 1e3:.2f} ms vs cold {cold * 1e3:.2f} ms"
+
+
+@pytest.mark.gpu
 def test_model_synth_end_to_end_on_gpu(tmp_path, oracle_lib):
     from vosk_tts_amd import Model, Synth
     from vosk_tts_amd import weights as W

@@ -133,6 +133,12 @@ class Model:
             else:
                 logging.warning("bert/vocab.txt found without bert/model.bertw or bert/model.onnx: BERT conditioning disabled")
 
+    def warmup(self, **kw):
+        """Pre-builds workspaces, persistent programs and captured graphs of the common request sizes (VitsSession.warmup); a no-op for
+        session types without it.  Not part of the reference API: call it once after loading when first-request latency matters."""
+        fn = getattr(self.onnx, "warmup", None)
+        return fn(**kw) if fn is not None else (0, 0.0)
+
     def get_model_path(self, model_name, lang):
         if model_name is None:
             return self.get_model_by_lang(lang)

@@ -396,5 +396,34 @@ class VitsSession:
             forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed,
             bert=None if bert is None else np.ascontiguousarray(np.asarray(bert, np.float32)[:, :, :n]))
 
+    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0):
+        """Pay the one-off costs of the graph-replayed host path before the first real request does (extension; onnxruntime has the same
+        need and no such call): for every T_x bucket (multiples of 8) up to `max_tokens`, every frame bucket (multiples of 32) between
+        frames_per_token[0] and [1] frames per token is synthesized once with pinned durations -- which lays out the workspaces, builds
+        the persistent programs and captures the front / back graphs of those (T_x, T_y) buckets -- plus one free-running call.
+        Returns (calls, seconds).  Requests outside the warmed buckets still work; they pay their bucket's capture (tens of
+        milliseconds) on first use."""
+        import time
+
+        t0 = time.perf_counter()
+        calls = 0
+        scales = np.array([0.8, 1.0, 0.8], np.float32)
+        sid = np.array([speaker_id], np.int64)
+        lo, hi = float(frames_per_token[0]), float(frames_per_token[1])
+        for tx in range(8, max(int(max_tokens), 8) + 1, 8):
+            ids = np.ones((1, tx), np.int64)
+            lens = np.array([tx], np.int64)
+            bert = np.zeros((1, self.hp.bert_dim, tx), np.float32) if self.hp.bert_dim > 0 else None
+            first = max(32, (int(lo * tx) + 31) // 32 * 32)
+            last = max(first, (int(hi * tx) + 31) // 32 * 32)
+            for ty in list(range(first, last + 1, 32)) + [None]:
+                dur = None
+                if ty is not None:  # exactly ty frames over the tx tokens
+                    dur = np.full((1, tx), ty // tx, np.int32)
+                    dur[0, :ty % tx] += 1
+                self._model.synthesize_pcm16(ids, lens, scales, sid, forced_durations=dur, seed=1, bert=bert)
+                calls += 1
+        return calls, time.perf_counter() - t0
+
     def close(self):
         self._model.close()
