@@ -223,16 +223,21 @@ def test_warmup_takes_the_capture_cost_off_the_first_request(tmp_path):
     from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
 
     d = write_toy_model(str(tmp_path / "m"), W.default_hparams(n_vocab=len(PHONEMES)))
-    text = "прив+ет, м+ир! прив+ет, м+ир."
+    text = "прив+ет, м+ир! прив+ет, м+ир. прив+ет, м+ир! прив+ет, м+ир."
 
     def first_request(warm):
         model = Model(model_path=d, device=0)
         synth = Synth(model)
         if warm:
-            calls, secs = model.warmup(max_tokens=96)
-            assert calls >= 12 * 2 and secs > 0
+            calls, secs = model.warmup(max_tokens=64)
+            assert calls >= 8 * 2 and secs > 0
+        # a request whose buckets the warm-up covered: 37 tokens -> T_x bucket 40, durations 3 / token -> 111 frames -> bucket 128
+        ids = np.array([synth.g2p_noembed(text)], np.int64)[:, :37]
+        feed = {"input": ids, "input_lengths": np.array([37], np.int64), "scales": np.array([0.8, 1.0, 0.8], np.float32),
+                "sid": np.array([2], np.int64), "bert": None, "phone_duration_extra": None,
+                "vits.forced_durations": np.full((1, 37), 3, np.int32), "vits.seed": 4}
         t0 = time.perf_counter()
-        pcm = synth.synth_audio(text, speaker_id=2, duration_noise_level=0.0)
+        pcm = model.onnx.run_pcm16(feed, 1.0)
         dt = time.perf_counter() - t0
         model.onnx.close()
         return dt, pcm
