@@ -266,6 +266,32 @@ def test_bert_base_geometry_vs_oracle(hip_lib, oracle_lib):
     hip.close()
 
 
+def test_bert_ffn_k_sliced_launch_equals_the_single_launch(hip_lib):
+    """Sentence-sized BERT calls run the 3072 -> 768 FFN matrix as three K-slices in one grouped conv_wp launch whose partial tensors the
+    LayerNorm sums (stts.hip.h bert_forward); with the kernel choice forced (vits_debug_force_tile) the same layer runs as one launch
+    of the K-split kernel.  Same rows up to the summation order, for one and for two column tiles."""
+    from vosk_tts_amd import weights_bert as BW
+    from vosk_tts_amd.capi_stts import BertEncoder
+
+    enc = BertEncoder(hip_lib, BW.synthetic_blob(BW.base_hparams(300), 11))
+    rng = np.random.default_rng(5)
+    try:
+        for T in (6, 16, 41):
+            ids = rng.integers(0, 300, size=T)
+            hip_lib.lib.vits_debug_fast_path(0)  # (graphs captured under one choice would replay it)
+            try:
+                sliced = enc.encode(ids)
+                hip_lib.lib.vits_debug_force_tile(2)
+                single = enc.encode(ids)
+            finally:
+                hip_lib.lib.vits_debug_force_tile(0)
+                hip_lib.lib.vits_debug_fast_path(1)
+            assert_close(f"T = {T}: K-sliced vs single launch", single, sliced, 2e-6)
+            assert_close(f"T = {T}: replayed", sliced, enc.encode(ids), 2e-6)
+    finally:
+        enc.close()
+
+
 def test_stts_batch_items_equal_their_single_utterance_calls(stts_pair):
     """stts_synthesize_batch: B = 4 ragged utterances (different lengths, speakers, BERT vectors, forced pauses) in one
     pass; every item must equal its own single-utterance call with seed + b (same kernels, per-item masks / zero padding

@@ -5,7 +5,6 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: F401,E402
 from vosk_tts_amd import weights_bert as BW  # noqa: E402
 from vosk_tts_amd.capi import VitsLib  # noqa: E402
 from vosk_tts_amd.capi_stts import BertEncoder  # noqa: E402

@@ -114,6 +114,9 @@ struct LNParams {
   // mapped to x' = (pre[c] * x + pre[C + c]) * [t < len[b]], x' is written to pre_out (the block's residual stream) and the
   // LayerNorm runs on x'
   const float* pre; float* pre_out;
+  // K-sliced producer (round 5, the BERT encoder's second FFN matrix: stts.hip.h bert_forward): `a` is the first of np partial tensors
+  // pstride floats apart, summed here in fixed order before everything else (0 / 1: a is the whole tensor)
+  int np; long long pstride;
 };
 template <int TL = LN_TL>
 __device__ __forceinline__ float ln_group_sum(float v, float* red, int tl, int cg) {
@@ -154,6 +157,15 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const LNParams P) {
     for (int i = 0; i < MAXV; ++i) {
       const int c = cg + i * LN_CGT, cc = c < P.C ? c : P.C - 1;
       v[i] = P.a[o0 + (long long)cc * P.T];
+    }
+  }
+  if (P.np > 1) {  // kernel-uniform
+    for (int j = 1; j < P.np; ++j) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = cg + i * LN_CGT, cc = c < P.C ? c : P.C - 1;
+        v[i] += P.a[(long long)j * P.pstride + o0 + (long long)cc * P.T];
+      }
     }
   }
   if (P.pre) {

@@ -1290,6 +1290,11 @@ static void bert_forward(bert_model* m, vits_session* s, const int64_t* d_ids, c
     LNParams P{y, nullptr, nullptr, x, m->eg, m->eb, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr};
     launch_layernorm(s->stream, P, 1);
   }
+  // (round 5) sentence-sized calls: the 3072 -> 768 matrix of the FFN is the one launch of a layer that ran on 24 CUs (21 us of a 75 us
+  // layer, profiles/r5_bert_ffn2.txt); VITS_BERT_KSLICE=0: the single launch (A/B)
+  static const bool kslice_env = !(getenv("VITS_BERT_KSLICE") && atoi(getenv("VITS_BERT_KSLICE")) == 0);
+  const bool ffn2_slices = kslice_env && g_force_tile == 0 && T <= 64 && T >= 4 && hp.intermediate % (3 * CONV_CI_T) == 0 && hp.intermediate / 3 >= 8 * CONV_CI_T &&
+                           H % 32 == 0 && !m->layers.empty() && m->layers[0].c2.K == 1;
   for (const BertLayerW& L : m->layers) {
     ConvParams P = conv_params(L.qkv, x, qkv, 1, T, 1, 0);
     launch_conv(s, P, EPI_STORE, "bert.qkv");
@@ -1300,8 +1305,29 @@ static void bert_forward(bert_model* m, vits_session* s, const int64_t* d_ids, c
     P = conv_params(L.c1, x, ff, 1, T, 1, 0); P.relu = 3;
     launch_conv(s, P, EPI_STORE, "bert.ffn1");
     P = conv_params(L.c2, ff, y, 1, T, 1, 0);
-    launch_conv(s, P, EPI_STORE, "bert.ffn2");
-    { LNParams Q{y, x, nullptr, x, L.g2, L.b2, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr}; launch_layernorm(s->stream, Q, 1); }
+    if (ffn2_slices) {
+      // K-sliced: three contiguous thirds of the 3072 input channels as the three groups of ONE conv_wp launch (72 workgroups of 8 waves,
+      // each streaming 128 KB of weights) instead of the K-split kernel's 24 workgroups x 384 KB; the partial tensors land in the qkv
+      // buffer (dead since the attention, exactly 3 x [H, T]) and the LayerNorm behind sums them
+      const int Cs = hp.intermediate / 3;
+      P.n_groups = 3; P.Cin = Cs; P.x_bstride = (long long)Cs * T;
+      for (int j = 0; j < 3; ++j) {
+        P.g[j] = P.g[0];
+        P.g[j].x = ff + (size_t)j * Cs * T;
+        P.g[j].w = L.c2.w + (size_t)j * (Cs / CONV_CI_T) * 2 * 64 * 4;  // packed [m-block][chunk][2 step groups][64 lanes][4]: the m-block stride (n_sg) stays the whole matrix's
+        P.g[j].w16 = nullptr; P.g[j].wb = nullptr;
+        P.g[j].bias = j == 0 ? L.c2.bias : nullptr;
+        P.g[j].y = qkv + (size_t)j * H * T;
+      }
+      ProfScope ps(s, "bert.ffn2", 2.0 * H * hp.intermediate * (double)T);
+      launch_conv_wp(s, P, ps);
+    } else {
+      launch_conv(s, P, EPI_STORE, "bert.ffn2");
+    }
+    {
+      LNParams Q{ffn2_slices ? qkv : y, x, nullptr, x, L.g2, L.b2, nullptr, H, T, 0, 0, 0, 0, hp.ln_eps, nullptr, nullptr, ffn2_slices ? 3 : 0, (long long)H * T};
+      launch_layernorm(s->stream, Q, 1);
+    }
   }
   hipLaunchKernelGGL(transpose_ct_kernel, dim3(cdiv(H, 256), T), dim3(256), 0, s->stream, x, ot, H, T);
 }
