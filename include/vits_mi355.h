@@ -336,6 +336,12 @@ int vits_debug_persist_runs(vits_model* m);
 void vits_debug_wn_fold(int on);
 /* Test hook: wave-pipelined decoder conv kernel (conv_wp_kernel): 0 = by size (default), 1 = never, 2 = whenever eligible. */
 void vits_debug_conv_wp(int mode);
+/* Test hook, host arithmetic only (no device is touched): the per-layer limits of the decoder in a ragged batch whose items continue into
+ * the padding like the reference's padded batch (engine.hip decoder_needs) -- how many columns beyond an item's end each launch still
+ * produces.  out[0] = frames of z the decoder reads beyond an item's end, [1] conv_pre's output limit, [2] conv_post's, [3] columns the
+ * iSTFT / PQMF tail reads, then per upsampling stage: the polyphase launch's limit (input positions), c1 limits [n_resd], c2 limits
+ * [n_resd].  Returns the number of values (at most `cap` are written), or a negative error. */
+int vits_debug_decoder_needs(const vits_hparams* hp, int32_t* out, int32_t cap);
 /* Test hook: software-pipelined 64 x 64 conv kernel (conv_sp_kernel, csrc/conv_sp.hip.h): -1 = environment / default (by grid size),
  * 0 = never, 1 = by grid size, 2 = wherever a launch is eligible for it. */
 void vits_debug_conv_sp(int mode);

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -227,3 +228,45 @@ def test_product_package_never_touches_the_oracle():
                 assert "libvits_oracle" not in src or f == "capi.py", f
                 assert "vits_oracle.c" not in src, f
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.parametrize("which", ["tiny", "default"])
+def test_decoder_ragged_limits_cover_the_oracle_decoders_dependency_cone(hip_lib, oracle_lib, tiny_blob, default_blob, which):
+    """The per-layer limits a ragged batch decodes with (engine.hip decoder_needs, exported as host arithmetic by
+    vits_debug_decoder_needs) against the ORACLE decoder's measured one-sided dependency: frames of z at or beyond an item's end + k
+    are re-drawn and the first len * hop samples compared bit for bit.  The limits must cover every frame that changes a valid
+    sample (else a ragged batch differs from the reference's padded batch) and should not cover many more (they are the tiles saved).
+    Also: the limits grow monotonically from the waveform back to z, layer by layer, at every stage."""
+    m = oracle_lib.create(tiny_blob if which == "tiny" else default_blob)
+    hp = m.hp
+    need = hip_lib.decoder_needs(hp)
+    L, T = 12, 12 + need["z_frames"] + 8
+    rng = np.random.default_rng(17)
+    z = rng.standard_normal((1, hp.inter_channels, T)).astype(np.float32)
+    sid = np.array([0], np.int64)
+    base, _ = m.decoder(z, want_mb=False, sid=sid)
+    valid = L * hp.hop_length
+
+    def changes(k):  # do frames >= L + k reach the item's own samples?
+        z2 = z.copy()
+        z2[:, :, L + k:] = rng.standard_normal((1, hp.inter_channels, T - L - k)).astype(np.float32)
+        a, _ = m.decoder(z2, want_mb=False, sid=sid)
+        return not np.array_equal(a[:, :valid], base[:, :valid])
+
+    assert changes(0) and not changes(need["z_frames"]), "frames beyond the limit reach valid samples"
+    lo, hi = 0, need["z_frames"]  # changes(lo), not changes(hi)
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        lo, hi = (mid, hi) if changes(mid) else (lo, mid)
+    true_frames = hi  # frames L .. L + hi - 1 are needed
+    assert true_frames <= need["z_frames"] <= true_frames + 6, (true_frames, need)
+    # layer by layer, towards z: every limit at least what its consumer needs, scaled by the stage's rate
+    prev = need["post_out"]
+    assert need["post_out"] == need["tail_cols"] + 1
+    for st, u in zip(reversed(need["stages"]), reversed(list(hp.up_rates[:hp.n_ups]))):
+        for c2, c1 in zip(reversed(st["c2_out"]), reversed(st["c1_out"])):
+            assert c2 >= prev and c1 > c2, (need, prev)
+            prev = c1
+        assert st["ups_q"] * u >= prev
+        prev = st["ups_q"]
+    assert need["pre_out"] > prev and need["z_frames"] == need["pre_out"] + 3

@@ -128,6 +128,7 @@ class VitsLib:
                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64,
                 ctypes.c_void_p]
             f("session_last_ms").argtypes = [ctypes.c_void_p, c_f32p]
+            f("debug_decoder_needs").argtypes = [ctypes.POINTER(HParams), c_i32p, ctypes.c_int32]
             f("stream_open").argtypes = [ctypes.c_void_p, c_i64p, ctypes.c_int32, c_f32p, ctypes.c_int64,
                                          ctypes.POINTER(SynthOpts), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), c_i64p]
             f("stream_open_latent").argtypes = [ctypes.c_void_p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32,
@@ -156,6 +157,21 @@ class VitsLib:
 
     def create(self, blob, device=0):
         return VitsModel(self, blob, device)
+
+    def decoder_needs(self, hp):
+        """vits_debug_decoder_needs (host arithmetic, no device): the decoder's per-layer limits in a ragged batch for the hparams struct
+        `hp` -> dict(z_frames, pre_out, post_out, tail_cols, stages=[dict(ups_q, c1_out=[...], c2_out=[...])])"""
+        buf = np.zeros(4 + 4 * 9, np.int32)
+        n = self._fn("debug_decoder_needs")(ctypes.byref(hp), _p(buf, c_i32p), buf.shape[0])
+        if n < 0:
+            raise VitsError(-n, self._fn("last_error")().decode(errors="replace"))
+        v = buf[:n].tolist()
+        out = dict(z_frames=v[0], pre_out=v[1], post_out=v[2], tail_cols=v[3], stages=[])
+        k, nd = 4, hp.n_resd
+        for _ in range(hp.n_ups):
+            out["stages"].append(dict(ups_q=v[k], c1_out=v[k + 1:k + 1 + nd], c2_out=v[k + 1 + nd:k + 1 + 2 * nd]))
+            k += 1 + 2 * nd
+        return out
 
     def mas_maximum_path(self, values, t_ys, t_xs, device=0):
         """monotonic_align.maximum_path_c (core.pyx:35-42): values float32 [B,T_y,T_x] -> paths int32 [B,T_y,T_x]."""

@@ -3396,6 +3396,24 @@ int vits_debug_persist_runs(vits_model* m) {
   return v[1];
 }
 void vits_debug_conv_wp(int mode) { g_wp_mode = mode; }
+// Host arithmetic only (no device): the per-layer limits decoder_needs derives for a padded-batch continuation.  Layout: [0] frames of z
+// read beyond an item's end (conv_pre's output limit + its 3 taps to the right), [1] pre_out, [2] post_out, [3] tail_cols, then per
+// upsampling stage: ups_q, c1_out[0..n_resd), c2_out[0..n_resd).  Returns the number of values (written up to cap).
+int vits_debug_decoder_needs(const vits_hparams* hp, int32_t* out, int32_t cap) {
+  if (!hp || !out || hp->n_ups < 0 || hp->n_ups > VITS_MAX_UPS || hp->n_resd < 0 || hp->n_resd > VITS_MAX_RESD || hp->n_resk < 0 || hp->n_resk > VITS_MAX_RESK)
+    return -fail(VITS_ERR_ARG, "decoder_needs: bad arguments");
+  for (int i = 0; i < hp->n_ups; ++i) if (hp->up_rates[i] < 1) return -fail(VITS_ERR_ARG, "decoder_needs: bad up_rates");
+  if (hp->dec_type == 0 && (hp->istft_hop < 1 || hp->subbands < 1)) return -fail(VITS_ERR_ARG, "decoder_needs: bad tail geometry");
+  const DecNeeds N = decoder_needs(*hp, true);
+  std::vector<int32_t> v = {N.pre_out + 3, N.pre_out, N.post_out, N.tail_cols};
+  for (int i = 0; i < hp->n_ups; ++i) {
+    v.push_back(N.ups_q[i]);
+    for (int d = 0; d < hp->n_resd; ++d) v.push_back(N.c1_out[i][d]);
+    for (int d = 0; d < hp->n_resd; ++d) v.push_back(N.c2_out[i][d]);
+  }
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
 void vits_debug_conv_sp(int mode) { g_sp_mode = mode; }
 void vits_debug_no_bf16x3(int on) { g_no_bf3 = on; }
 void vits_debug_poison_workspace(int on) { g_poison = on; }
