@@ -31,6 +31,7 @@ The default run (c2) also measures c3 and reports it under "batch32" in the same
 BASELINE.json quotes the metric at "batch=1 and 32".
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -50,6 +51,17 @@ PROFILE_ROUND = "r5"  # prefix of the committed rocprofv3 / PMC summaries under 
 REFERENCE_PYTORCH_CPU = {"x_realtime": [7.0, 7.5], "samples_per_s": 1.6e5, "cores": 8, "infer_s": [0.23, 0.25],
                          "what": "reference PyTorch modules, eager CPU, torch.set_num_threads(8), B=1 50 tokens -> 150 frames",
                          "source": "BASELINE.md section 3 (measured in the survey container, not on the GPU box)"}
+
+
+def settle_gc():
+    """Called in front of every timed region.  CPython's cyclic collector stops THIS process for 25-60 ms per older-generation pass --
+    the heap of a process that imported torch and generated synthetic weights is a few million objects -- which is longer than most
+    timed regions here (measured with tools/m2_steps.py, profiles/r5_m2_gc.txt: calls 12 and 105 of the 4.2 ms m2 loop took 25 and
+    42-61 ms, none with the collector off; where the passes fall moves with every unrelated allocation).  Everything allocated so far is
+    collected once and moved to the permanent generation -- gc.freeze(), what a pre-fork server does after loading its models -- and the
+    collector STAYS ENABLED during the timed steps: it only has the steps' own garbage to look at."""
+    gc.collect()
+    gc.freeze()
 
 
 def make_workload(name, rng, rank=0, world=1):
@@ -169,6 +181,7 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
 
     for i in range(args.warmup):
         step(i)
+    settle_gc()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -392,6 +405,7 @@ def multi_device_synth_leg(hp, lengths_all, n_devices, reps=3):
         try:
             mds.synth_tokens(tokens[:2 * n_devices], speaker_ids=2)  # graphs / workspaces warm
             mds.synth_tokens(tokens, speaker_ids=2)
+            settle_gc()
             times, samples = [], 0
             for _ in range(reps):
                 t0 = time.perf_counter()
@@ -412,6 +426,7 @@ def streaming_leg(model, ids, lengths, dur, chunk=128, reps=5):
     sc = np.array([0.8, 1.0, 0.8], np.float32)
     ttfa, total, oneshot = [], [], []
     Ty = int(dur[:1].sum())
+    settle_gc()
     for it in range(reps + 1):
         t0 = time.perf_counter()
         g = model.stream(ids[:1], sc, 2, chunk_frames=chunk, forced_durations=dur[:1], seed=7)
@@ -485,6 +500,7 @@ def concurrency_leg(hp, device, seconds=0.4):
                     [t.start() for t in wt]
                     [t.join() for t in wt]
                 lat, samples = [[] for _ in range(n_threads)], [0] * n_threads
+                settle_gc()
                 stop = time.perf_counter() + seconds
                 c0 = (co.calls, co.requests) if co is not None else (0, 0)
                 r0 = runs()
@@ -549,6 +565,7 @@ def bert_voice_leg(hp, device, seconds=0.4):
         for _ in range(6):
             synth.synth_audio(text, speaker_id=2)
         lat, bert_lat, samples = [], [], 0
+        settle_gc()
         stop = time.perf_counter() + seconds
         while time.perf_counter() < stop or len(lat) < 30:
             t0 = time.perf_counter()
@@ -689,6 +706,7 @@ def main():
         persist_r0, persist_steps = persist_runs(), 0
 
         def timed_block():
+            settle_gc()
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -929,6 +947,7 @@ def main():
             lat, samples = [], 0
             for i in range(8):
                 model.synthesize_pcm16(ids, lengths, sc, [2], forced_durations=forced, seed=1000 + i)
+            settle_gc()
             t_all = time.perf_counter()
             i = 0
             while i < 50 or time.perf_counter() - t_all < 0.5:
