@@ -396,13 +396,17 @@ class VitsSession:
             forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed,
             bert=None if bert is None else np.ascontiguousarray(np.asarray(bert, np.float32)[:, :, :n]))
 
-    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0):
+    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0, freeze_gc=False):
         """Pay the one-off costs of the graph-replayed host path before the first real request does (extension; onnxruntime has the same
         need and no such call): for every T_x bucket (multiples of 8) up to `max_tokens`, every frame bucket (multiples of 32) between
         frames_per_token[0] and [1] frames per token is synthesized once with pinned durations -- which lays out the workspaces, builds
         the persistent programs and captures the front / back graphs of those (T_x, T_y) buckets -- plus one free-running call.
         Returns (calls, seconds).  Requests outside the warmed buckets still work; they pay their bucket's capture (tens of
-        milliseconds) on first use."""
+        milliseconds) on first use.
+        freeze_gc=True additionally runs gc.collect() + gc.freeze() at the end: CPython's older-generation passes over the heap of a
+        process that has loaded its models stop every thread for tens of milliseconds (25-60 ms measured beside 1 ms requests,
+        profiles/r5_m2_gc.txt); frozen, that heap is no longer traversed and the collector only looks at what requests allocate.
+        Process-wide, hence opt-in."""
         import time
 
         t0 = time.perf_counter()
@@ -423,6 +427,11 @@ class VitsSession:
                     dur[0, :ty % tx] += 1
                 self._model.synthesize_pcm16(ids, lens, scales, sid, forced_durations=dur, seed=1, bert=bert)
                 calls += 1
+        if freeze_gc:
+            import gc
+
+            gc.collect()
+            gc.freeze()
         return calls, time.perf_counter() - t0
 
     def close(self):
