@@ -216,6 +216,7 @@ def test_bert_conditioned_vits_voice_end_to_end_on_gpu(tmp_path, oracle_lib, no_
 def test_warmup_takes_the_capture_cost_off_the_first_request(tmp_path):
     """Model.warmup() (extension): after it the first real request of a warmed size costs what a steady-state request costs, not the
     workspace layout + program build + two graph captures of its bucket; results are unaffected."""
+    import gc
     import time
 
     from vosk_tts_amd import Model, Synth
@@ -229,16 +230,24 @@ def test_warmup_takes_the_capture_cost_off_the_first_request(tmp_path):
         model = Model(model_path=d, device=0)
         synth = Synth(model)
         if warm:
-            calls, secs = model.warmup(max_tokens=64)
+            try:
+                calls, secs = model.warmup(max_tokens=64, freeze_gc=True)  # (the opt-in heap freeze: exercised, then undone for the other tests)
+            finally:
+                gc.unfreeze()
             assert calls >= 8 * 2 and secs > 0
         # a request whose buckets the warm-up covered: 37 tokens -> T_x bucket 40, durations 3 / token -> 111 frames -> bucket 128
         ids = np.array([synth.g2p_noembed(text)], np.int64)[:, :37]
         feed = {"input": ids, "input_lengths": np.array([37], np.int64), "scales": np.array([0.8, 1.0, 0.8], np.float32),
                 "sid": np.array([2], np.int64), "bert": None, "phone_duration_extra": None,
                 "vits.forced_durations": np.full((1, 37), 3, np.int32), "vits.seed": 4}
-        t0 = time.perf_counter()
-        pcm = model.onnx.run_pcm16(feed, 1.0)
-        dt = time.perf_counter() - t0
+        gc.collect()
+        gc.disable()  # (a collector pass over this process's heap is 25-60 ms, profiles/r5_m2_gc.txt: not what is being timed)
+        try:
+            t0 = time.perf_counter()
+            pcm = model.onnx.run_pcm16(feed, 1.0)
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         model.onnx.close()
         return dt, pcm
 
@@ -602,10 +611,18 @@ def test_request_coalescer_gather_window_and_promotion():
     for inflight in (1, 2, 4):
         pool(inflight, 400, ["a", "a", "a", "b"])  # a leader only ever takes its own key; the peak it gathers up to is per key
     lone = RequestCoalescer(run_batch, 32, 1, 5000)
-    t0 = time.perf_counter()
-    for i in range(20):
-        assert lone.submit("a", None, 0, i) == ("out", "a", i)
-    assert (time.perf_counter() - t0) / 20 < 0.0045 and lone.gathered == 0, "a lone client must never wait for stragglers"
+    import gc
+
+    gc.collect()
+    gc.disable()  # (a collector pass inside the 20 calls would read as waiting)
+    try:
+        t0 = time.perf_counter()
+        for i in range(20):
+            assert lone.submit("a", None, 0, i) == ("out", "a", i)
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    assert dt / 20 < 0.0045 and lone.gathered == 0, "a lone client must never wait for stragglers"
 
 
 def test_session_does_not_slice_by_an_unvalidated_length():
