@@ -27,6 +27,8 @@ for spec in sys.argv[1].split(";"):
         print(r.stderr[-1500:]); continue
     end = max(b[2] for b in blk)
     def cu_of(hw, xcc): return (xcc & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)
+    clk = sorted((x >> 8) / ((e - s) * 10.0) for _, s, e, _, x in blk if (x >> 8) and e > s)  # shader-clock cycles / wall ns (big-tile kernel only)
+    if clk: print(f"   shader clock over a workgroup's life (s_memtime cycles / wall time), GHz: p10 {clk[len(clk)//10]:.3f} p50 {clk[len(clk)//2]:.3f} p90 {clk[len(clk)*9//10]:.3f}")
     by = collections.defaultdict(list)
     for i, s, e, hw, xcc in blk: by[cu_of(hw, xcc)].append((s, e, i))
     durs = sorted(e - s for _, s, e, _, _ in blk)

@@ -525,11 +525,16 @@ __device__ __forceinline__ void conv_epilogue_store_fragments(const ConvParams& 
 }
 
 template <int WM, int WN, int MI, int NI, int EPI>
-__global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {  // 3 workgroups per CU
-  static_assert(WM * WN == 4, "256-thread workgroups");
+__global__ void __launch_bounds__(WM * WN * 64, 3) conv_mfma_kernel(const ConvParams P) {  // 3 waves per SIMD: 3 workgroups of 4 waves per CU, or 6 of 2
+  // 256-thread workgroups, or (round 6) TWO-wave workgroups: the same wave tile on half the columns, so that a launch of 1 - 3 four-wave
+  // workgroups per CU becomes 2 - 6 two-wave ones and quantises half as coarsely over the 256 CUs (the WaveNet gate conv of a 32-item
+  // batch: 580 tiles of 128 x 64 = 2.27 per CU, 3 on the critical CUs -> 1160 of 128 x 32 = 4.5 / 5)
+  static_assert(WM * WN == 4 || WM * WN == 2, "256- or 128-thread workgroups");
+  constexpr int NWV = WM * WN;          // waves per workgroup
+  constexpr int RPW = CONV_CI_T / NWV;  // chunk rows a wave stages
   constexpr int M_T = WM * MI * 32;
   constexpr int N_T = WN * NI * 32;
-  constexpr int JT = (N_T + CONV_MAX_HALO + 63) / 64;
+  constexpr int JT = N_T < 64 ? 1 : (N_T + CONV_MAX_HALO + 63) / 64;  // 32-column tiles: N_T + halo <= 64 (launcher's condition)
   static_assert(64 * (JT - 1) <= N_T, "staging column groups");
   extern __shared__ float lds[];
   kernarg_warm<sizeof(ConvParams)>();
@@ -545,13 +550,16 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);
   nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
   const ConvGroup& G = P.g[grp];
-  CONV_DBG_DO(if (P.dbg && tid == 0 && blockIdx.x < 4000) {  // block trace (timing build): wall-clock start, hardware id, XCC id
+  CONV_DBG_DO(long long bt_c0 = 0; if (P.dbg && tid == 0 && blockIdx.x < 4000) {  // block trace (timing build): wall-clock start, hardware id, XCC id
     P.dbg[128 + blockIdx.x * 4 + 0] = wall_clock64();
     P.dbg[128 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(63492);
     P.dbg[128 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 20);
+    bt_c0 = __builtin_readcyclecounter();
   })
 #ifdef CONV_TIMING
-#define BT_BLOCK_END() do { if (P.dbg && tid == 0 && blockIdx.x < 4000) P.dbg[128 + blockIdx.x * 4 + 1] = wall_clock64(); } while (0)
+  // (round 6) the shader-clock cycles the workgroup lived go into bits 8.. of the XCC word: cycles / wall time = the clock this CU ran at
+#define BT_BLOCK_END() do { if (P.dbg && tid == 0 && blockIdx.x < 4000) { P.dbg[128 + blockIdx.x * 4 + 1] = wall_clock64(); \
+    P.dbg[128 + blockIdx.x * 4 + 3] |= (__builtin_readcyclecounter() - bt_c0) << 8; } } while (0)
 #else
 #define BT_BLOCK_END() do { } while (0)
 #endif
@@ -572,8 +580,8 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   }
   if (P.skip_len && n0 >= P.len[b]) return;  // masked stage: the whole tile lies in this item's padding
 
-  // ---- staging: wave w owns chunk rows w, w+4, w+8, w+12; lanes stride over columns
-  float stg[4][JT];
+  // ---- staging: wave w owns chunk rows w, w + NWV, ...; lanes stride over columns
+  float stg[RPW][JT];
   const float* xb = G.x + (long long)b * P.x_bstride;
   const float* xb2 = G.x2 ? G.x2 + (long long)b * P.x_bstride : nullptr;
   const float* xb3 = G.x3 ? G.x3 + (long long)b * P.x_bstride : nullptr;
@@ -586,27 +594,27 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   for (int j = 0; j < JT; ++j) tob[j] = (unsigned)toff[j] * 4u;
   const __amdgpu_buffer_rsrc_t rx = bt_rsrc(xb), rx2 = bt_rsrc(xb2 ? xb2 : xb), rx3 = bt_rsrc(xb3 ? xb3 : xb);
   auto load_chunk = [&](int c) {
-    unsigned roff[4];  // byte offset of the chunk's rows inside the item (wave-uniform; < 2^31 by the arena's size limits)
+    unsigned roff[RPW];  // byte offset of the chunk's rows inside the item (wave-uniform; < 2^31 by the arena's size limits)
     // channel-concatenated second input (x_split): chunks at or beyond the split read g.x2 at channel ci - x_split
     const bool second = P.x_split && c * CONV_CI_T >= P.x_split;  // block-uniform
     const int cb = second ? c * CONV_CI_T - P.x_split : c * CONV_CI_T;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) roff[rr] = (unsigned)((long long)(P.x_ch_off + (cb + wave + 4 * rr) * P.x_ch_sign) * P.Tin_stride * 4);
+    for (int rr = 0; rr < RPW; ++rr) roff[rr] = (unsigned)((long long)(P.x_ch_off + (cb + wave + NWV * rr) * P.x_ch_sign) * P.Tin_stride * 4);
     if (P.x_split) {
       const __amdgpu_buffer_rsrc_t rs = second ? rx2 : rx;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+      for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
         for (int j = 0; j < JT; ++j) stg[rr][j] = bt_ld(rs, tob[j], roff[rr]);
     } else if (xb2) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+      for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
         for (int j = 0; j < JT; ++j)
           stg[rr][j] = bt_ld(rx, tob[j], roff[rr]) + bt_ld(rx2, tob[j], roff[rr]) + (xb3 ? bt_ld(rx3, tob[j], roff[rr]) : 0.f);
     } else {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+      for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
         for (int j = 0; j < JT; ++j) stg[rr][j] = bt_ld(rx, tob[j], roff[rr]);
     }
@@ -616,12 +624,12 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_kernel(const ConvParams P) {
   auto store_chunk = [&](int buf) {
     float* dst = lds + buf * (CONV_CI_T * ROW);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < RPW; ++rr) {
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
         const int col = lane + 64 * j;
         const float v = tok[j] ? conv_act_in(stg[rr][j], in_scale, in_slope) : 0.f;
-        if (j < JT - 1 || col < ROW) dst[(wave + 4 * rr) * ROW + col] = v;  // 64 (JT - 1) <= N_T <= ROW: only the last group needs the test
+        if (j < JT - 1 || col < ROW) dst[(wave + NWV * rr) * ROW + col] = v;  // 64 (JT - 1) <= N_T <= ROW: only the last group needs the test
       }
     }
   };

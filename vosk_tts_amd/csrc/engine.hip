@@ -31,6 +31,7 @@
 #include "conv_mfma.hip.h"
 #include "conv_small.hip.h"
 #include "conv_sp.hip.h"
+#include "conv_w1.hip.h"
 #include "conv_bf3.hip.h"
 #include "kernels_misc.hip.h"
 #include "persist.hip.h"
@@ -1140,7 +1141,7 @@ static void launch_cfg(vits_session* s, ConvParams& P, int halo) {
   P.row_len = N_T + halo;
   const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
   const size_t lds = (size_t)2 * CONV_CI_T * P.row_len * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MI, NI, EPI>), dim3(nblk), dim3(256), lds, st, P);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MI, NI, EPI>), dim3(nblk), dim3(WM * WN * 64), lds, st, P);
 }
 
 // waves per workgroup of the K-split kernel: 0 = heuristic (ks_pick_waves), else forced (tests / tools: VITS_KS_WAVES)
@@ -1439,6 +1440,33 @@ static bool sp_takes(const ConvParams& P, int epi, int halo) {
   return conv_sp_ok(P, epi, halo) && (sp_mode() == 2 || nblk <= max_blk);
 }
 
+// ---- independent-wave 64 x 64 tiles (conv_w1.hip.h): stands in for conv_mfma_kernel<2,2,2,2,STORE> (the ResBlock convs of a batch).
+// MEASURED (profiles/r6_w1_ab.txt): parity green, 1.3 % SLOWER than the four-wave kernel on c3 / c4 (20.40 -> 20.66 ms, 127.3 -> 129.1) --
+// the barrier was not what the 128 x 128 kernel loses: its launches run at a shader clock of 1.86 - 2.11 GHz instead of 2.4
+// (profiles/r6_bt_clock.txt) with the matrix pipe ~90 % busy at THAT clock, and this form moves 2.6 x the activation bytes through L2.
+// Kept as an A/B (like the producer / consumer split-bf16 kernel): VITS_W1=1 takes the launches the 128 x 128 kernel would; default off.
+static int w1_mode() {
+  static const int env = getenv("VITS_W1") ? atoi(getenv("VITS_W1")) : 0;
+  return env;
+}
+static bool conv_w1_ok(const ConvParams& P, int epi, int halo) {
+  if (w1_mode() == 0 || epi != EPI_STORE) return false;
+  if (P.M % 64 || P.Cin % CONV_CI_T || P.ups_u || P.reflect || P.x_split || P.ln_g || P.dds_y2 || P.ln_stat_out || 64 + halo > W1_PITCH || P.Tin < 2) return false;
+  for (int g = 0; g < P.n_groups; ++g)
+    if (P.g[g].x2 || P.g[g].x3) return false;
+  return true;
+}
+static void launch_w1(vits_session* s, ConvParams& P, int halo) {
+  attach_tile_table(s, P, 64);
+  P.ntiles_m = cdiv(P.M, 64);
+  P.ntiles_n = cdiv(P.Tout, 64);
+  P.row_len = 64 + halo;
+  const int nblk = P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
+  const size_t lds = (size_t)CONV_CI_T * W1_PITCH * sizeof(float);
+  if (P.row_len <= 64) hipLaunchKernelGGL((conv_w1_kernel<EPI_STORE, 1>), dim3(nblk), dim3(64), lds, s->stream, P);
+  else hipLaunchKernelGGL((conv_w1_kernel<EPI_STORE, 2>), dim3(nblk), dim3(64), lds, s->stream, P);
+}
+
 // dispatch on epilogue + problem size.  halo = max over groups of (K-1)*dil (or the polyphase spread).
 // Large problems (>= 2 workgroups per CU with 64x64 tiles) use the big-tile kernel (more operand
 // reuse); everything smaller uses the K-split kernel so that one utterance still fills the chip.
@@ -1545,7 +1573,16 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
       if (bf3_pc()) hipLaunchKernelGGL((conv_bf3pc_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(384), lds, s->stream, P);
       else hipLaunchKernelGGL((conv_bf3_kernel<2, EPI_GATE>), dim3(P.ntiles_m * P.ntiles_n * P.B), dim3(256), lds, s->stream, P);
     } else {  // (128 x 128 tiles for the gate conv: 2.30 against 1.77 ms per c3 forward, round 4, profiles/r4_c3_tile_ab.txt)
-      ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo);
+      // Round 6: a grid of 1 - 3 four-wave workgroups per CU (all resident at once) lasts as long as the CU with the most of them; the
+      // same wave tiles in TWO-wave workgroups of 128 x 32 halve the quantum (c3: 580 tiles -> 1160).  VITS_GATE2W: 0 = never,
+      // 1 = by grid size (default), 2 = whenever the window fits (A/B)
+      static const int g2w = getenv("VITS_GATE2W") ? atoi(getenv("VITS_GATE2W")) : 1;
+      const long nblk64 = (long)cdiv(P.M, 128) * cdiv(P.Tout, 64) * P.B;
+      if (g_force_tile == 0 && g2w && 32 + halo <= 64 && (g2w == 2 || nblk64 <= 1536)) {
+        ps.set_kernel("conv_mfma_kernel<2,1,2,1,GATE>"); launch_cfg<2, 1, 2, 1, EPI_GATE>(s, P, halo);
+      } else {
+        ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo);
+      }
     }
     return;
   }
@@ -1608,6 +1645,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   static const long big_min = getenv("VITS_BIG_BLOCKS") ? atol(getenv("VITS_BIG_BLOCKS")) : 512;
   if (m_fits && big_blocks >= big_min) {
     if (bf3_ok()) { bf3_go(2); return; }
+    if (g_force_tile == 0 && conv_w1_ok(P, epi, halo)) { ps.set_kernel("conv_w1_kernel<STORE>"); launch_w1(s, P, halo); return; }
     ps.set_kernel("conv_mfma_kernel<2,2,2,2,STORE>"); launch_cfg<2, 2, 2, 2, EPI_STORE>(s, P, halo); return;
   }
   // 64-row multiples at batch size (encoder / flow STORE convs: 192, 576, 768 rows) of a conv_precision == 1 model
