@@ -877,6 +877,27 @@ def main():
                 pass
         roofline["committed"] = committed
 
+        # Shader clock while this workload runs (round 6): fp32 MFMA convs with their LDS / L2 / HBM traffic do not hold the 2.4 GHz the
+        # 157.3 TFLOP/s peak is quoted at (profiles/r6_bt_clock.txt: 1.86 - 2.11 GHz inside the batch ResBlock kernel; a pure-MFMA loop
+        # holds 2.39, profiles/r6_mfmapower.txt).  A burst of forwards is enqueued on the session stream (asynchronous graph replays) and
+        # a probe of one-wave workgroups on a stream of its own compares s_memtime with the 100 MHz wall clock next to them.
+        try:
+            sess.set_options(use_graph=not args.no_graph, profile=False)
+            n_burst = int(max(8, min(400, 0.06 / max(elapsed / steps, 1e-5))))  # ~60 ms of forwards
+            for _ in range(n_burst):
+                step()
+            ghz = lib.clock_probe(device=local_rank, duration_us=int(0.5 * n_burst * (elapsed / steps) * 1e6), n=64)
+            sess.sync()
+            clk = ghz[len(ghz) // 2]
+            roofline["clock"] = {"shader_ghz_median_during_forwards": round(clk, 3), "p10": round(ghz[len(ghz) // 10], 3), "p90": round(ghz[len(ghz) * 9 // 10], 3),
+                                 "nominal_ghz": 2.4, "peak_at_measured_clock": round(kpeak * clk / 2.4, 1),
+                                 "frac_at_measured_clock": round(achieved / (kpeak * clk / 2.4), 4),
+                                 "forward_frac_at_measured_clock": round(flops_fwd / (elapsed / steps) / 1e12 / (PEAK_FP32_MFMA_TFLOPS * clk / 2.4), 4),
+                                 "how": "vits_debug_clock_probe: 64 one-wave workgroups on their own stream for half of a burst of forwards, s_memtime / s_memrealtime; "
+                                        "the whole forward's average (every kernel and the gaps between them), not the dominant kernel's alone"}
+        except Exception as e:  # a probe failure must not cost the bench line
+            roofline["clock"] = {"error": str(e)[:200]}
+
         sess.close()
         return dict(B=B, Tx=Tx, Ty=Ty, lengths=lengths, ids=ids, dur=dur, valid_samples=valid_samples, job_samples=job_samples,
                     ms_per_step=ms_per_step, value=value, rtf=rtf, roofline=roofline, scales=scales,
@@ -894,7 +915,7 @@ def main():
                    "samples_per_step_per_gpu": R3["valid_samples"],
                    "workload": "c3: B=32 ragged 20..200 tokens padded, durations pinned 3/token, fp32",
                    "timed_region_s": round(R3["timed_region_s"], 3),
-                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "forward", "committed") if k in R3["roofline"]}}
+                   "roofline": {k: R3["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_valid", "flops_are", "traffic", "kernel", "avg_launch_us", "forward", "clock", "committed") if k in R3["roofline"]}}
 
     # BASELINE configs[2] as written ("bf16 acoustic + fp32 vocoder" is allowed there): the same batch on a model created with
     # hparams.conv_precision = 1, i.e. the decoder's ResBlock convs as split-bf16 (3 bf16 MFMAs per product, fp32-class accuracy:
@@ -909,7 +930,7 @@ def main():
                           "x_realtime": round(1.0 / R4["rtf"], 1), "batch": R4["B"], "T_x": R4["Tx"], "T_y": R4["Ty"],
                           "workload": "c3 as batch32, ResBlock, encoder / flow STORE and WaveNet gate convs split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate), the rest fp32",
                           "timed_region_s": round(R4["timed_region_s"], 3),
-                          "roofline": {k: R4["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us", "forward", "by_kernel_ms_per_forward") if k in R4["roofline"]}}
+                          "roofline": {k: R4["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us", "forward", "clock", "by_kernel_ms_per_forward") if k in R4["roofline"]}}
         # the whole-forward fraction of THIS line is priced against its own ceiling: split-bf16 issues 3 bf16 MFMAs per product
         fw = dict(batch32_bf16x3["roofline"].get("forward", {}))
         if fw:

@@ -1,0 +1,77 @@
+/* vits_mi355_debug.h -- TEST HOOKS of libvits_mi355.so.  NOT part of the installed ABI: a deployment ships include/vits_mi355.h and
+ * include/stts_mi355.h only; this header exists for tests/, tools/ and bench.py.
+ *
+ * Scope of a hook (round 6):
+ *   - kernel-selection / path switches (force_tile, attention_impl, fast_path, ks_waves, ln_stats, wn_fold, conv_wp, conv_sp,
+ *     no_bf16x3, tail_impl, poison_workspace) are THREAD-LOCAL: they change what the CALLING thread's engine calls launch and nothing
+ *     another thread is running (the engine runs every call on the caller's thread);
+ *   - the persistent-program switches (persist, persist_spin, persist_rearm_ms) are process-wide on purpose: the programs are a
+ *     per-device resource with one owner at a time; they are atomics and take effect for calls that start afterwards.
+ */
+#ifndef VITS_MI355_DEBUG_H
+#define VITS_MI355_DEBUG_H
+#include "vits_mi355.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: 0 = choose the conv kernel by problem size (default), 1 = always the big-tile kernel,
+ * 2 = always the K-split small-N kernel, 3 = the small-tile (16x16x4 MFMA, LDS-staged) kernel wherever a launch is
+ * eligible for it.  Process-wide. */
+void vits_debug_force_tile(int mode);
+/* Test hook: 0 = by sequence length (default: 16-query MFMA kernel up to T = 512, 32-query MFMA flash kernel beyond),
+ * 1 = the scalar-VALU attention kernel, 2 = always the 32-query kernel, 3 = always the 16-query kernel. */
+void vits_debug_attention_impl(int impl);
+/* Test hook: 1 (default) = vits_synthesize replays captured hipGraphs over bucketed shapes when no noise tensor is
+ * injected; 0 = always the eager path (one launch per kernel, exact-size workspace).  Both give the same samples. */
+void vits_debug_fast_path(int on);
+/* Test hook: waves per workgroup of the K-split conv kernel: 0 = size heuristic (default), 4 / 8 / 16 forced. */
+void vits_debug_ks_waves(int nw);
+/* Test hook: 1 (default) = the folded encoder LayerNorms take their channel statistics from the producing conv's epilogue,
+ * 0 = every consumer workgroup recomputes them. */
+void vits_debug_ln_stats(int on);
+/* Bit mask of the single-utterance stages (B = 1, T <= 256) that run as ONE persistent kernel each, with in-band ("LL cell")
+ * exchange between their steps (csrc/persist.hip.h): 1 duration predictor, 2 text encoder, 4 flow.  Default 7; 0: the launch-per-layer
+ * path everywhere (the A/B reference, and the batch path).  Setting the mask also ends a timeout's off interval at once. */
+void vits_debug_persist(int mask);
+/* Test hook: poll rounds after which a worker of a persistent program gives up (0 = the default bound, 2^18).  A timeout
+ * switches the persistent programs off for a bounded interval (below) and the host entry points run the call again on the launch
+ * path (the caller sees a slower call, not an error); an asynchronous device session reports VITS_ERR_DEVICE once. */
+void vits_debug_persist_spin(int limit);
+/* Test hook: base re-arm interval in milliseconds (0 = VITS_PERSIST_REARM_MS or 1000). */
+void vits_debug_persist_rearm_ms(int ms);
+/* Test hook: persistent-program launches of this model that ran to completion (no timeout) since vits_create; -1 on error.
+ * (The bound of vits_debug_persist_spin is a device word the kernel reads at run time: captured graphs follow it.) */
+int vits_debug_persist_runs(vits_model* m);
+/* Test hook: 1 (default) = WaveNet tail of the coupling layers in folded form (gate outputs of all layers kept, one conv =
+ * post o sum of skip halves), 0 = per-layer res/skip accumulation + post as the reference executes it.  Same results to rounding. */
+void vits_debug_wn_fold(int on);
+/* Test hook: wave-pipelined decoder conv kernel (conv_wp_kernel): 0 = by size (default), 1 = never, 2 = whenever eligible. */
+void vits_debug_conv_wp(int mode);
+/* Test hook, host arithmetic only (no device is touched): the per-layer limits of the decoder in a ragged batch whose items continue into
+ * the padding like the reference's padded batch (engine.hip decoder_needs) -- how many columns beyond an item's end each launch still
+ * produces.  out[0] = frames of z the decoder reads beyond an item's end, [1] conv_pre's output limit, [2] conv_post's, [3] columns the
+ * iSTFT / PQMF tail reads, then per upsampling stage: the polyphase launch's limit (input positions), c1 limits [n_resd], c2 limits
+ * [n_resd].  Returns the number of values (at most `cap` are written), or a negative error. */
+int vits_debug_decoder_needs(const vits_hparams* hp, int32_t* out, int32_t cap);
+/* Test hook: software-pipelined 64 x 64 conv kernel (conv_sp_kernel, csrc/conv_sp.hip.h): -1 = environment / default (by grid size),
+ * 0 = never, 1 = by grid size, 2 = wherever a launch is eligible for it. */
+void vits_debug_conv_sp(int mode);
+/* Test hook: 1 = a conv_precision == 1 model runs its fp32 kernels instead of the split-bf16 variant (same weights, A/B). */
+void vits_debug_no_bf16x3(int on);
+/* Test hook: 0 = fused exp/sin + iSTFT + PQMF tail kernel (default), 1 = the separate istft / pqmf kernels. */
+void vits_debug_tail_impl(int impl);
+/* Test hook: fill every newly laid-out workspace with NaN bit patterns (stale-padding detector). */
+void vits_debug_poison_workspace(int on);
+
+/* Shader clock under load (round 6): launches `n` one-wave workgroups on a private stream that sit on the device for `duration_us` and
+ * compare the shader-clock counter (s_memtime) with the constant 100 MHz wall clock (s_memrealtime); ghz[i] = the clock workgroup i's
+ * CU ran at while whatever else is on the device (a bench loop on another stream) was running.  Blocks until the probe is done.
+ * Returns the number of values written or a negative error.  (fp32 MFMA convs do not hold the 2.4 GHz the peak is quoted at:
+ * profiles/r6_bt_clock.txt.) */
+int vits_debug_clock_probe(int device, int32_t duration_us, double* ghz, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,6 +30,16 @@ def test_product_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.is_device
 
 
+def test_debug_hooks_live_in_their_own_header_and_are_exported(hip_lib):
+    """Round 6: the installed header carries no test hook; include/vits_mi355_debug.h (tests / tools / bench only) declares them all
+    and the library exports every one."""
+    assert not [n for n in _header_functions() if n.startswith("vits_debug_")]
+    hooks = _header_functions("vits_mi355_debug.h")
+    assert len([n for n in hooks if n.startswith("vits_debug_")]) >= 17 and "vits_debug_clock_probe" in hooks
+    missing = [n for n in hooks if not hasattr(hip_lib.lib, n)]
+    assert not missing, f"libvits_mi355.so lacks {missing}"
+
+
 def test_stts_header_surface_is_exported_by_product_library_and_oracle(hip_lib, oracle_lib):
     """include/stts_mi355.h (StableTTS / Matcha family): every declared entry point exists in libvits_mi355.so, and the
     oracle exports the same surface under sttsref_; the hparams mirror has the header's size."""
@@ -120,7 +130,7 @@ def _header_prototypes():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     protos = {}
-    for h in ("vits_mi355.h", "stts_mi355.h"):
+    for h in ("vits_mi355.h", "vits_mi355_debug.h", "stts_mi355.h"):
         text = open(os.path.join(root, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
         for m in re.finditer(r"\b(?:int|void|double|const\s+char\s*\*)\s*((?:vits|stts|bert)_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):

@@ -137,6 +137,8 @@ class VitsLib:
             f("stream_close").argtypes = [ctypes.c_void_p]
             f("stream_close").restype = None
             f("persist_state").argtypes = [ctypes.c_void_p, ctypes.POINTER(PersistInfo)]
+            if self.has("debug_clock_probe"):
+                f("debug_clock_probe").argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.c_int32]
 
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -157,6 +159,15 @@ class VitsLib:
 
     def create(self, blob, device=0):
         return VitsModel(self, blob, device)
+
+    def clock_probe(self, device=0, duration_us=20000, n=64):
+        """vits_debug_clock_probe (include/vits_mi355_debug.h): shader clock in GHz seen by `n` one-wave workgroups that sit on the device
+        for `duration_us` NEXT to whatever the caller has in flight on other streams -> sorted list.  Blocks for the duration."""
+        out = (ctypes.c_double * n)()
+        rc = self._fn("debug_clock_probe")(device, duration_us, out, n)
+        if rc < 0:
+            raise VitsError(-rc, self._fn("last_error")().decode(errors="replace"))
+        return sorted(float(v) for v in out[:rc])
 
     def decoder_needs(self, hp):
         """vits_debug_decoder_needs (host arithmetic, no device): the decoder's per-layer limits in a ragged batch for the hparams struct

@@ -227,27 +227,17 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
   // one tap: prefetch the next step into the other slot, read this tap's B fragments, 12 MFMAs
   auto tap = [&](auto slot_, const char* lk0, const char* lk1) {
     constexpr int S = decltype(slot_)::value;
-#ifndef BF3_EXP_NOW  // (time-only experiment switches, tools/ab_build.sh: results are garbage)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       a[(S + NS - 1) % NS][mi][0] = wload(wq[mi], ws);
       a[(S + NS - 1) % NS][mi][1] = wload(wq[mi], ws + 1024);
     }
     ws += 2048;
-#else
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) { a[(S + NS - 1) % NS][mi][0] = a[S][mi][1]; a[(S + NS - 1) % NS][mi][1] = a[S][mi][0]; }
-#endif
     bf16x8 bh[2], bl[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-#ifndef BF3_EXP_NOB
       bh[ni] = *reinterpret_cast<const bf16x8*>(lk0 + ni * 32 * (BF3_PITCH * 2));
       bl[ni] = *reinterpret_cast<const bf16x8*>(lk1 + ni * 32 * (BF3_PITCH * 2));
-#else
-      bh[ni] = a[S][ni % MI][0]; bl[ni] = a[S][ni % MI][1];
-      asm volatile("" : "+v"(bh[ni]), "+v"(bl[ni]));
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);  // loads of the next step and this tap's B reads in flight before the first MFMA
     // lo*hi + hi*lo + hi*hi, the four accumulators interleaved (no back-to-back dependent MFMAs)
@@ -316,9 +306,7 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
     // activation loads waits for those too (conv_mfma.hip.h, same rule).  They are requested TWO chunks ahead: a chunk's taps
     // take 1.2 k (3 taps) .. 4.2 k (11 taps) MFMA cycles per wave, less than an HBM round trip under load.
     tap(bf3_int<0>{}, lk0, lk1);
-#if !defined(BF3_EXP_NOSTG) && !defined(BF3_EXP_NOLOAD)
     if constexpr (!PC) { if (c + 2 < nchunks) load_chunk(c + 2, stn); }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     lk0 += dstep;
     lk1 += dstep;
@@ -338,19 +326,8 @@ static __device__ __forceinline__ void conv_bf3_body(const ConvParams& P, const 
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) a[0][mi][pc] = a[1][mi][pc];
     }
-#if defined(BF3_EXP_NOSTORE)
-    if constexpr (!PC) {  // keep the loads (and the wait for them) alive without the split / LDS stores
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) asm volatile("" :: "v"(stg[rr][j]));
-    }
-#elif !defined(BF3_EXP_NOSTG)
     if constexpr (!PC) { if (c + 1 < nchunks) store_chunk((c + 1) & 1); }
-#endif
-#ifndef BF3_EXP_NOBAR
     __syncthreads();
-#endif
     if constexpr (!PC) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)

@@ -133,9 +133,6 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
   auto request = [&](auto SLOT) {
     constexpr int slot = decltype(SLOT)::value;
     const int sgc = sg < n_sg ? sg : n_sg - 2;  // clamped: a fixed number of loads per tap keeps the waits counted
-#ifdef SP_EXP_SAMEW
-    (void)sgc; a[slot][0] = bt_ld4(wp, lane16, 0u); a[slot][1] = bt_ld4(wp, lane16, 1024u); sg += 2; return;  // timing experiment: every tap re-reads the first fragments (L1 / L2 hits)
-#endif
     a[slot][0] = bt_ld4(wp, lane16, (unsigned)sgc * 1024u);
     a[slot][1] = bt_ld4(wp, lane16, (unsigned)sgc * 1024u + 1024u);
     sg += 2;
@@ -148,9 +145,6 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
   __syncthreads();
 
   f32x4 bv[2][2];
-#ifdef SP_EXP_NOB
-  bv[0][0] = bv[0][1] = bv[1][0] = bv[1][1] = f32x4{1.f, 2.f, 3.f, 4.f};
-#endif
   const float* lb = nullptr;  // this lane's eight B values of column (tile column + tap shift 0) of the stage's first chunk
   int kk = 0, jrow = 0;       // tap inside the chunk / float offset of the chunk inside the stage
   // B fragments of the tap at (jrow, kk) -- or, for the tap after a stage's last one (`valid` false, wave-uniform), a harmless re-read of
@@ -158,9 +152,6 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
   auto read_b = [&](auto SET, bool valid) {
     constexpr int set = decltype(SET)::value;
     const f32x4* lk = reinterpret_cast<const f32x4*>(lb + (valid ? jrow + kk * dil * SP_PITCH : 0));
-#ifdef SP_EXP_NOB
-    (void)lk; return;  // timing experiment: no B-fragment reads (garbage results)
-#endif
     bv[set][0] = lk[0];
     bv[set][1] = lk[1];
   };
@@ -203,12 +194,8 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
     read_b(S0{}, true);
     // group 0, peeled: the next stage's activation loads go out with its first tap (straight-line code: exactly counted waits)
     const bool next = s + 1 < nstages;
-#ifdef SP_EXP_NOSTAGE
-    tap(S0{}, VW{}, true, nothing);  // timing experiment: no activation loads / staging stores / barriers after the first stage
-#else
     if (next) tap(S0{}, VS{}, true, [&]() { load_stage(s + 1); });
     else tap(S0{}, VW{}, true, nothing);
-#endif
     tap(S1{}, VW{}, true, nothing);
     tap(S2{}, VW{}, true, nothing);
     tap(S3{}, VW{}, ngroups > 1, nothing);
@@ -219,10 +206,8 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
       tap(S2{}, VW{}, true, nothing);
       tap(S3{}, VW{}, g + 1 < ngroups, nothing);
     }
-#ifndef SP_EXP_NOSTAGE
     if (next) store_stage((s + 1) & 1);
     __syncthreads();
-#endif
   }
 
   // ---- epilogue (shared with conv_mfma_kernel)

@@ -1491,3 +1491,15 @@ __global__ void __launch_bounds__(NW * 64) relpos_attention16_kernel(const float
     if (i < T) ob[(long long)d * T + i] = active ? a * inv : 0.f;
   }
 }
+
+// ---- shader clock under load (vits_debug_clock_probe, include/vits_mi355_debug.h): one wave per workgroup sleeps on its CU for
+// `ticks` of the constant 100 MHz clock and reports shader-clock cycles per wall nanosecond over that interval.  s_memtime counts the
+// shader clock of the CU's XCD whether or not this wave is issuing, so the figure is the clock the kernels running NEXT to the probe
+// (another stream) see.  (Round 6: the batch ResBlock kernel runs at 1.86 - 2.11 GHz, not at the 2.4 GHz its peak is quoted at.)
+__global__ void __launch_bounds__(64) clock_probe_kernel(double* ghz, long long ticks) {
+  const long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+  long long w1 = w0;
+  while (w1 - w0 < ticks) { __builtin_amdgcn_s_sleep(64); w1 = wall_clock64(); }
+  const long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) ghz[blockIdx.x] = (double)(c1 - c0) / ((double)(w1 - w0) * 10.0);  // 100 MHz ticks -> ns
+}

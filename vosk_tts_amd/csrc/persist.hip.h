@@ -164,12 +164,7 @@ typedef int ps_i4 __attribute__((ext_vector_type(4)));
 #define PR_P(T, rv, k) ((PS_G T*)(((unsigned long long)(unsigned)PR_I(rv, 5 + 2 * (k)) << 32) | (unsigned long long)(unsigned)PR_I(rv, 4 + 2 * (k))))
 #define PR_B(rv, k) PR_I(rv, 24 + (k))
 
-// time-only experiment switches for tools/ab_build.sh (results are garbage): -DPS_EXP_NOGELU, -DPS_EXP_NOPOLL
-#ifdef PS_EXP_NOGELU
-#define PS_GELU(v) (v)
-#else
 #define PS_GELU(v) c16_gelu(v)
-#endif
 
 struct PsCtx {
   unsigned epoch;
@@ -180,9 +175,6 @@ struct PsCtx {
 };
 // one more round of a poll loop: true = keep polling.  `pending` is wave-uniform (a ballot).
 __device__ __forceinline__ bool ps_again(PsCtx& cx, bool pending) {
-#ifdef PS_EXP_NOPOLL
-  return false;
-#endif
   // The poll state is wave-uniform by construction, but hipcc's uniformity analysis gives up on it (it is carried around the step
   // loop through every kind's control flow) and kept `aborted` / `spins` as per-lane values: the exit test of every poll loop was a
   // vector compare under an exec mask.  readfirstlane at the point of use puts the test back on the scalar unit.
