@@ -53,6 +53,10 @@ REFERENCE_PYTORCH_CPU = {"x_realtime": [7.0, 7.5], "samples_per_s": 1.6e5, "core
                          "source": "BASELINE.md section 3 (measured in the survey container, not on the GPU box)"}
 
 
+GC_NOTE = ("heap frozen before every timed region (gc.collect + gc.freeze: what Model.warmup(freeze_gc=True) does for a server), collector "
+           "enabled during the steps; a default server without that call sees 25-60 ms older-generation pauses (profiles/r5_m2_gc.txt)")
+
+
 def settle_gc():
     """Called in front of every timed region.  CPython's cyclic collector stops THIS process for 25-60 ms per older-generation pass --
     the heap of a process that imported torch and generated synthetic weights is a few million objects -- which is longer than most
@@ -244,7 +248,7 @@ def bench_multistream(args, torch, rank, world, local_rank, dist, as_object=Fals
         emit_line({
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if getattr(args, "precision", "f32") == "f32" else "bf16x3", "data": "synthetic", "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
+            "dtype": "f32" if getattr(args, "precision", "f32") == "f32" else "bf16x3", "data": "synthetic", "gc": GC_NOTE, "rtf": round(ms * 1e-3 / (S_ / SAMPLE_RATE), 6), "x_realtime": round(S_ / SAMPLE_RATE / (ms * 1e-3), 1),
             "config": {"workload": f"{args.workload}: StableTTS/Matcha multistream graph (seeded synthetic weights) + bundled HiFi-GAN V1, "
                                    + (f"B=32 ragged {int(lengths.min())}..{int(lengths.max())} symbols" if batched else f"B=1, {Tx} symbols") + " x 5 streams, "
                                    f"zero BERT vectors, durations pinned 3/symbol -> T_y<={Ty}, {hp.n_timesteps} Euler steps with guidance {hp.guidance_scale:g}, "
@@ -371,14 +375,28 @@ def dry_run(args, torch, dist, rank, world):
     shard = torch.tensor([float(len(c4_len))], dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(shard, op=dist.ReduceOp.SUM)
+    # what the first real N-GPU run can be checked against: the work plan_shards deals to every rank (valid frames = 3 x tokens here,
+    # and padded frames = shard size x its longest item, what a dense padded batch would execute), slowest rank over the mean
+    own_work = torch.tensor([float(c4_len.sum()) * 3.0, float(len(c4_len)) * float(c4_len.max()) * 3.0], dtype=torch.float64)
+    work = [own_work]
+    if dist is not None:
+        work = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(work, own_work)
+    valid_fr = [float(w[0].item()) for w in work]
+    padded_fr = [float(w[1].item()) for w in work]
+    predicted = {"valid_frames_per_rank": [int(v) for v in valid_fr], "padded_frames_per_rank": [int(v) for v in padded_fr],
+                 "imbalance_valid_max_over_mean": round(max(valid_fr) / (sum(valid_fr) / len(valid_fr)), 4),
+                 "imbalance_padded_max_over_mean": round(max(padded_fr) / (sum(padded_fr) / len(padded_fr)), 4),
+                 "reads": "batch256_sharded is strong scaling: value = all samples / the slowest rank; with ragged decoding a rank's time follows its "
+                          "VALID frames (plus ~30 halo frames per item), so expect the real line's max(rank_ms) / mean(rank_ms) near imbalance_valid"}
     # the order of the legs that open devices: every rank but 0 lets go of its device before rank 0's in-process multi-device leg
     barrier()  # "ranks > 0 have closed their models"
     barrier()  # "rank 0 is done with all devices"
     if rank == 0:
         emit_line({"metric": "audio_samples_per_sec", "value": round(samples * world * args.steps / el, 1), "unit": "samples/s", "n_gpus": world,
                           "rank_ms": rank_ms, "rank_persistent_launches_per_forward": rank_persist, "batch256_requests_seen": int(shard.item()),
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": seen,
+                          "batch256_predicted": predicted, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "gc": GC_NOTE, "dry_run": True, "ranks_seen": seen,
                           "launched_by": "bench.py" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if dist is not None else "single process"),
                           "config": {"workload": "dry run: no GPU work, launch / barrier / aggregation only"}})
     if dist is not None:
@@ -1036,7 +1054,7 @@ def main():
         line = {
             "metric": "audio_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if args.workload == "c4" else "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
+            "scaling": "strong" if args.workload == "c4" else "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic", "gc": GC_NOTE,
             "rtf": round(rtf, 6), "x_realtime": round(1.0 / rtf, 1),
             "timed_region_s": round(R["timed_region_s"], 3), "timed_blocks": R["blocks"], "launches_per_forward": R["launches"],
             "persistent_launches_per_forward": round(R["persistent_per_step"], 3),

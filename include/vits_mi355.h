@@ -299,7 +299,8 @@ typedef struct vits_persist_info {
   int32_t timeouts;            /* poll timeouts since the library was loaded */
   int32_t rearms;              /* re-arms since the library was loaded */
   int32_t launches;            /* persistent launches of `m` that ran to completion (-1 without a model) */
-  int32_t process_owns_device; /* this process holds the cross-process lock of m's device: 1 yes, -1 another process does, 0 not asked yet */
+  int32_t process_owns_device; /* outcome of the LAST call's lease of the cross-process lock of m's device (the lock is taken per call, not
+                                * held): 1 got it, -1 was refused (another process had it), 0 not asked yet; -1 without a model */
   int32_t reserved;
 } vits_persist_info;
 int vits_persist_state(vits_model* m, vits_persist_info* out);

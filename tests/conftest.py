@@ -18,6 +18,7 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "libvits_oracle.so")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "nightly: long GPU tests (minutes of CPU oracle time); they skip unless VITS_NIGHTLY=1")
 
 
 def golden(name):

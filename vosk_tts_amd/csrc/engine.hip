@@ -82,8 +82,16 @@ static std::atomic<int> g_ps_spin_limit{0};  // test hook (vits_debug_persist_sp
 // device could each hold half of the CUs and wait forever (the bounded poll loops turn that into an error, not a hang -- but it must
 // not happen in normal operation).  So at most ONE caller per device owns the persistent path at a time (a token); everybody else
 // takes the launch path for that call.  persist_mask() is what the stage launchers test: the owner's mask, 0 for everybody else.
+#define PERSIST_OWNERS_DEFAULT 1
 static std::mutex g_tok_mu;
-static bool g_tok_busy[64];
+static int g_tok_busy[64];  // owners of the device's persistent path right now (round 6: up to persist_owners() of them, was a flag)
+// How many callers may run persistent programs on ONE device at the same time.  A program's 256 workgroups (512 threads, ~60 KB of LDS,
+// <= 128 registers per thread) fill exactly HALF of every CU, so two programs are co-resident on the whole chip and neither waits for the
+// other; a third could only be placed where one of them has finished.  VITS_PERSIST_OWNERS (1..4); measured in profiles/r6_owners.txt.
+static int persist_owners() {
+  static const int n = getenv("VITS_PERSIST_OWNERS") ? atoi(getenv("VITS_PERSIST_OWNERS")) : PERSIST_OWNERS_DEFAULT;
+  return n < 1 ? 1 : (n > 4 ? 4 : n);
+}
 static thread_local int tl_persist = -1;  // >= 0: this thread's mask for the call in progress
 static std::atomic<int> g_persist{getenv("VITS_NO_PERSIST") ? 0 : (getenv("VITS_PERSIST") ? atoi(getenv("VITS_PERSIST")) : 7)};  // mask: 1 duration predictor, 2 text encoder, 4 flow (environment switches: A/B runs of bench.py and tools/)
 // A poll timeout (persist_timed_out) switches the programs off for a BOUNDED interval, not for the life of the process: a server that

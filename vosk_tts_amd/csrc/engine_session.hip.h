@@ -168,15 +168,15 @@ static void persist_process_release(int dev) {  // called when a model of this p
 }
 static bool persist_token_try(int dev) {
   std::lock_guard<std::mutex> g(g_tok_mu);
-  if (dev < 0 || dev >= 64 || g_tok_busy[dev] || !persist_process_lock(dev)) return false;
-  g_tok_busy[dev] = true;
+  if (dev < 0 || dev >= 64 || g_tok_busy[dev] >= persist_owners()) return false;
+  if (g_tok_busy[dev] == 0 && !persist_process_lock(dev)) return false;  // the process lease is taken by the first owner, dropped by the last
+  ++g_tok_busy[dev];
   return true;
 }
 static void persist_token_release(int dev) {
   std::lock_guard<std::mutex> g(g_tok_mu);
   if (dev < 0 || dev >= 64) return;
-  persist_process_unlock(dev);
-  g_tok_busy[dev] = false;
+  if (g_tok_busy[dev] > 0 && --g_tok_busy[dev] == 0) persist_process_unlock(dev);
 }
 // a host call that launches AND waits for its kernels: owns the token (when it is free) from here to its end
 struct PersistScope {

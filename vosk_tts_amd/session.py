@@ -132,14 +132,16 @@ class RequestCoalescer:
         with self._lock:
             if self._busy >= self.max_inflight or self._gathering:
                 self._queue.append(me)
-                self._note_presence(time.perf_counter(), key)
+                if self.gather_us > 0:
+                    self._note_presence(time.perf_counter(), key)
                 self._cond.notify_all()
                 batch = None
             else:
                 self._busy += 1
                 batch = self._gather(me, [me])
                 self._in_calls += len(batch)
-                self._in_key[key] = self._in_key.get(key, 0) + len(batch)
+                if self.gather_us > 0:
+                    self._in_key[key] = self._in_key.get(key, 0) + len(batch)
                 promote = self._promote()
         if batch is not None and promote is not None:
             promote.event.set()
@@ -152,7 +154,8 @@ class RequestCoalescer:
             with self._lock:
                 batch = self._gather(me, me.lead)
                 self._in_calls += len(batch)
-                self._in_key[key] = self._in_key.get(key, 0) + len(batch)
+                if self.gather_us > 0:
+                    self._in_key[key] = self._in_key.get(key, 0) + len(batch)
                 promote = self._promote()
             if promote is not None:
                 promote.event.set()
@@ -169,11 +172,16 @@ class RequestCoalescer:
                     # a merged batch failed: one bad request (token / speaker id out of range, ...) must not fail the unrelated
                     # requests it was merged with -- run the members one by one, each gets its own result or its own exception
                     self.split_retries += 1
-                    for p in batch:
-                        try:
-                            p.result = self._run_batch(p.key, [(p.ids, p.sid, p.seed)])[0]
-                        except Exception as e1:
-                            p.error = e1
+                    try:
+                        for p in batch:
+                            try:
+                                p.result = self._run_batch(p.key, [(p.ids, p.sid, p.seed)])[0]
+                            except Exception as e1:
+                                p.error = e1
+                    except BaseException as e2:  # interrupted in the middle of the retries (the sibling handler below does not cover this one)
+                        for p in batch:
+                            if p.result is None and p.error is None:
+                                p.error = RuntimeError(f"batch leader interrupted: {e2!r}") if p is not me else e2
             except BaseException as e:  # KeyboardInterrupt / SystemExit in the leader: nobody may be left waiting
                 for p in batch:
                     p.error = RuntimeError(f"batch leader interrupted: {e!r}") if p is not me else e
@@ -183,7 +191,15 @@ class RequestCoalescer:
                 self.requests += len(batch)
                 self.largest = max(self.largest, len(batch))
                 self._in_calls -= len(batch)
-                self._in_key[batch[0].key] = self._in_key.get(batch[0].key, 0) - len(batch)
+                if self.gather_us > 0:  # (the per-key presence count only feeds the gather window)
+                    left = self._in_key.get(batch[0].key, 0) - len(batch)
+                    if left > 0:
+                        self._in_key[batch[0].key] = left
+                    else:
+                        self._in_key.pop(batch[0].key, None)  # a server that forwards client-chosen speech rates sees unboundedly many keys
+                for p in batch:
+                    if p.result is None and p.error is None:  # whatever happened above: a member never wakes up with nothing
+                        p.error = RuntimeError("coalesced batch ended without a result for this request")
                 nxt = None
                 if self._queue:
                     head = self._queue[0]
@@ -202,6 +218,9 @@ class RequestCoalescer:
         if me.error is not None:
             raise me.error
         return me.result
+
+# frame-bucket ("back") contexts the engine keeps per T_x bucket before it evicts the least recently used one (csrc/engine_fastpath.hip.h back_get)
+BACK_SESSIONS_PER_FRONT = 6
 
 _GRAPH_INPUTS = ("input", "input_lengths", "scales", "sid")
 _OPTIONAL_NONE = ("bert", "phone_duration_extra")
@@ -238,9 +257,12 @@ class VitsSession:
         the programs are re-armed.  Logged at WARNING whenever the timeout count has grown since the last look."""
         st = self._model.persist_state(with_device)
         if st["timeouts"] > self._ps_timeouts:
-            log.warning("persistent programs timed out %d time(s) so far (re-armed %d time(s)); launch path for another %d ms; "
-                        "this process %s the device's program lock", st["timeouts"], st["rearms"], st["off_for_ms"],
-                        {1: "holds", -1: "was denied", 0: "has not asked for"}.get(st["process_owns_device"], "?"))
+            # process_owns_device is the outcome of the LAST call's lock lease (1 got it, -1 was refused, 0 not asked yet) and is only
+            # known with a model handle: the periodic watcher (with_device=False) says nothing about it
+            lock = (", last call " + {1: "got", -1: "was refused", 0: "has not asked for"}.get(st["process_owns_device"], "?") +
+                    " the device's program lock") if with_device else ""
+            log.warning("persistent programs timed out %d time(s) so far (re-armed %d time(s)); launch path for another %d ms%s",
+                        st["timeouts"], st["rearms"], st["off_for_ms"], lock)
             self._ps_timeouts = st["timeouts"]
         return st
 
@@ -396,10 +418,11 @@ class VitsSession:
             forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed,
             bert=None if bert is None else np.ascontiguousarray(np.asarray(bert, np.float32)[:, :, :n]))
 
-    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0, freeze_gc=False):
+    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0, freeze_gc=False, typical_frames_per_token=3.0):
         """Pay the one-off costs of the graph-replayed host path before the first real request does (extension; onnxruntime has the same
-        need and no such call): for every T_x bucket (multiples of 8) up to `max_tokens`, every frame bucket (multiples of 32) between
-        frames_per_token[0] and [1] frames per token is synthesized once with pinned durations -- which lays out the workspaces, builds
+        need and no such call): for every T_x bucket (multiples of 8) up to `max_tokens`, the frame buckets (multiples of 32) between
+        frames_per_token[0] and [1] frames per token that lie closest to `typical_frames_per_token` -- at most BACK_SESSIONS_PER_FRONT - 1
+        of them, the engine's per-T_x cap less one -- are synthesized once with pinned durations -- which lays out the workspaces, builds
         the persistent programs and captures the front / back graphs of those (T_x, T_y) buckets -- plus one free-running call.
         Returns (calls, seconds).  Requests outside the warmed buckets still work; they pay their bucket's capture (tens of
         milliseconds) on first use.
@@ -420,7 +443,14 @@ class VitsSession:
             bert = np.zeros((1, self.hp.bert_dim, tx), np.float32) if self.hp.bert_dim > 0 else None
             first = max(32, (int(lo * tx) + 31) // 32 * 32)
             last = max(first, (int(hi * tx) + 31) // 32 * 32)
-            for ty in list(range(first, last + 1, 32)) + [None]:
+            # The engine keeps at most BACK_SESSIONS_PER_FRONT frame-bucket contexts per T_x bucket and evicts the least recently used
+            # (engine_fastpath.hip.h back_get): warming more than that frees the first ones again (from T_x = 64 on there are 7+
+            # buckets between 2 and 5 frames per token).  So: the buckets closest to `typical_frames_per_token`, at most one fewer
+            # than the cap (the free-running call below may open one more), walked from the farthest to the closest -- the
+            # likeliest bucket is the most recently used one when warm-up ends.
+            centre = typical_frames_per_token * tx
+            buckets = sorted(range(first, last + 1, 32), key=lambda ty: abs(ty - centre))[:BACK_SESSIONS_PER_FRONT - 1]
+            for ty in sorted(buckets, key=lambda ty: -abs(ty - centre)) + [None]:
                 dur = None
                 if ty is not None:  # exactly ty frames over the tx tokens
                     dur = np.full((1, tx), ty // tx, np.int32)
