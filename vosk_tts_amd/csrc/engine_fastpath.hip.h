@@ -262,7 +262,8 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   const int TxB = (Tx + 7) / 8 * 8;
   const bool forced = opts && opts->forced_durations, solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
   // (declared before the session guard: the call's last stream synchronisation happens before this scope ends)
-  PersistScope pscope(B == 1 ? m->device : -1);  // a single utterance takes the persistent stages when no other call on this device holds them
+  InFlight inflight(m->device);
+  PersistScope pscope(B == 1 ? m->device : -1, inflight.before == 0);  // a single utterance takes the persistent stages when it starts alone on its device
   vits_session* F = nullptr;
   {
     int rc = front_acquire(m, B, TxB, &F);
