@@ -64,11 +64,14 @@ void vits_debug_tail_impl(int impl);
 /* Test hook: fill every newly laid-out workspace with NaN bit patterns (stale-padding detector). */
 void vits_debug_poison_workspace(int on);
 
-/* Shader clock under load (round 6): launches `n` one-wave workgroups on a private stream that sit on the device for `duration_us` and
- * compare the shader-clock counter (s_memtime) with the constant 100 MHz wall clock (s_memrealtime); ghz[i] = the clock workgroup i's
- * CU ran at while whatever else is on the device (a bench loop on another stream) was running.  Blocks until the probe is done.
- * Returns the number of values written or a negative error.  (fp32 MFMA convs do not hold the 2.4 GHz the peak is quoted at:
- * profiles/r6_bt_clock.txt.) */
+/* Shader clock under load (round 6): launches `n` one-wave workgroups on a stream of the library's own that sit on the device for
+ * `duration_us` and compare the shader-clock counter (s_memtime) with the constant 100 MHz wall clock (s_memrealtime); ghz[i] = the clock
+ * workgroup i's CU ran at while whatever else is on the device (a bench loop on another stream) was running.  Blocks until the probe is
+ * done; the first call per device creates the probe's stream and buffer (call it once BEFORE the work it is to watch: allocation waits
+ * for work in flight).  Returns the number of values written or a negative error.
+ * What it found (profiles/r6_bt_clock.txt, r6_clock_in_forward.txt): back-to-back dense conv launches on N(0,1) operands pull the clock
+ * down to 1.86 - 2.11 GHz, the forwards of the bench (synthetic weights of trained-model scale) run at 2.35 - 2.40: the 2.4 GHz peak is
+ * the right yardstick for the bench lines, and a microbenchmark on random data is not a proxy for them. */
 int vits_debug_clock_probe(int device, int32_t duration_us, double* ghz, int32_t n);
 
 #ifdef __cplusplus

@@ -601,17 +601,23 @@ int vits_debug_decoder_needs(const vits_hparams* hp, int32_t* out, int32_t cap) 
 }
 void vits_debug_conv_sp(int mode) { g_sp_mode = mode; }
 int vits_debug_clock_probe(int device, int32_t duration_us, double* ghz, int32_t n) {
-  if (!ghz || n < 1 || n > 1024 || duration_us < 1 || duration_us > 2000000) return fail(VITS_ERR_ARG, "clock probe: bad arguments");
+  if (!ghz || n < 1 || n > 1024 || duration_us < 1 || duration_us > 2000000 || device < 0 || device >= 64) return fail(VITS_ERR_ARG, "clock probe: bad arguments");
   HIP_TRY(hipSetDevice(device));
-  hipStream_t st = nullptr;
-  double* d = nullptr;
-  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));  // its own hardware queue: runs NEXT to whatever the caller has in flight
-  if (hipMalloc((void**)&d, sizeof(double) * n) != hipSuccess) { hipStreamDestroy(st); return fail(VITS_ERR_NOMEM, "clock probe: device alloc failed"); }
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(n), dim3(64), 0, st, d, (long long)duration_us * 100);
-  hipError_t e = hipStreamSynchronize(st);
-  if (e == hipSuccess) e = hipMemcpy(ghz, d, sizeof(double) * n, hipMemcpyDeviceToHost);
-  hipFree(d);
-  hipStreamDestroy(st);
+  // stream and result buffer are created ONCE per device and kept: hipMalloc / hipStreamCreate wait for the device's work in flight, and
+  // the probe exists to run NEXT to that work (call it once before the burst it is to watch)
+  static std::mutex mu;
+  static hipStream_t st[64];
+  static double* buf[64];
+  std::lock_guard<std::mutex> g(mu);
+  if (!st[device]) {
+    HIP_TRY(hipStreamCreateWithFlags(&st[device], hipStreamNonBlocking));  // its own hardware queue
+    if (hipMalloc((void**)&buf[device], sizeof(double) * 1024) != hipSuccess) { buf[device] = nullptr; return fail(VITS_ERR_NOMEM, "clock probe: device alloc failed"); }
+  }
+  if (!buf[device]) return fail(VITS_ERR_NOMEM, "clock probe: no buffer");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(n), dim3(64), 0, st[device], buf[device], (long long)duration_us * 100);
+  hipError_t e = hipStreamSynchronize(st[device]);
+  if (e == hipSuccess) e = hipMemcpyAsync(ghz, buf[device], sizeof(double) * n, hipMemcpyDeviceToHost, st[device]);
+  if (e == hipSuccess) e = hipStreamSynchronize(st[device]);
   if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "clock probe failed: %s", hipGetErrorString(e));
   return n;
 }

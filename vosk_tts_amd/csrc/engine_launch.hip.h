@@ -393,10 +393,10 @@ static bool sp_takes(const ConvParams& P, int epi, int halo) {
 }
 
 // ---- independent-wave 64 x 64 tiles (conv_w1.hip.h): stands in for conv_mfma_kernel<2,2,2,2,STORE> (the ResBlock convs of a batch).
-// MEASURED (profiles/r6_w1_ab.txt): parity green, 1.3 % SLOWER than the four-wave kernel on c3 / c4 (20.40 -> 20.66 ms, 127.3 -> 129.1) --
-// the barrier was not what the 128 x 128 kernel loses: its launches run at a shader clock of 1.86 - 2.11 GHz instead of 2.4
-// (profiles/r6_bt_clock.txt) with the matrix pipe ~90 % busy at THAT clock, and this form moves 2.6 x the activation bytes through L2.
-// Kept as an A/B (like the producer / consumer split-bf16 kernel): VITS_W1=1 takes the launches the 128 x 128 kernel would; default off.
+// MEASURED (profiles/r6_w1_ab.txt): parity green, 1.3 % SLOWER than the four-wave kernel on c3 / c4 (20.40 -> 20.66 ms, 127.3 -> 129.1):
+// the chunk barrier is not what the 128 x 128 kernel loses -- an independent-wave form with no barrier at all lands on the same plateau
+// (and moves 2.6 x the activation bytes through L2).  Kept as an A/B (like the producer / consumer split-bf16 kernel): VITS_W1=1 takes
+// the launches the 128 x 128 kernel would; default off.
 static int w1_mode() {
   static const int env = getenv("VITS_W1") ? atoi(getenv("VITS_W1")) : 0;
   return env;

@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(NW * 64) relpos_attention16_kernel(const float
 // ---- shader clock under load (vits_debug_clock_probe, include/vits_mi355_debug.h): one wave per workgroup sleeps on its CU for
 // `ticks` of the constant 100 MHz clock and reports shader-clock cycles per wall nanosecond over that interval.  s_memtime counts the
 // shader clock of the CU's XCD whether or not this wave is issuing, so the figure is the clock the kernels running NEXT to the probe
-// (another stream) see.  (Round 6: the batch ResBlock kernel runs at 1.86 - 2.11 GHz, not at the 2.4 GHz its peak is quoted at.)
+// (another stream) see.  (Round 6: dense conv launches on N(0,1) operands run at 1.86 - 2.11 GHz, the bench's forwards at 2.35 - 2.40.)
 __global__ void __launch_bounds__(64) clock_probe_kernel(double* ghz, long long ticks) {
   const long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
   long long w1 = w0;
