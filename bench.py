@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide; the headline figures with 2:1 sparsity are not used)
 SAMPLE_RATE = 22050
-PROFILE_ROUND = "r5"  # prefix of the committed rocprofv3 / PMC summaries under profiles/ quoted beside the live figures
+PROFILE_ROUND = "r6"  # prefix of the committed rocprofv3 / PMC summaries under profiles/ quoted beside the live figures
 # the reference's own PyTorch modules (SynthesizerTrn.infer, eager, fp32) on the survey container's 8 vCPU
 # Xeon @ 2.1 GHz for the c2 shape (50 tokens -> 150 frames, durations pinned): the only executable form of the reference.
 REFERENCE_PYTORCH_CPU = {"x_realtime": [7.0, 7.5], "samples_per_s": 1.6e5, "cores": 8, "infer_s": [0.23, 0.25],

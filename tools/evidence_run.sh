@@ -4,7 +4,7 @@
 # EVIDENCE_HEAD=<git sha of the tree that is measured> is written to ${RD}_HEAD.txt (the GPU box has no .git): bench.py prints it beside
 # every figure it reads from the committed profiles.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; mkdir -p $O
-RD=${ROUND:-r5}   # prefix of the files (= PROFILE_ROUND in bench.py)
+RD=${ROUND:-r6}   # prefix of the files (= PROFILE_ROUND in bench.py)
 cd $R
 echo "${EVIDENCE_HEAD:-unknown}" > $O/${RD}_HEAD.txt
 bf16x3_profiles() {
