@@ -1254,6 +1254,7 @@ def test_batch_on_another_stream_does_not_starve_the_persistent_programs(hip_lib
     lens1 = np.array([50], np.int64); sid1 = np.array([2], np.int64)
     lib = hip_lib.lib
     lib.vits_debug_persist(7)
+    lib.vits_debug_persist_when(0)  # the rounds 3-5 rule (programs whenever the token is free): THIS is the case that must not starve
     want1, _ = hip_default.synthesize(ids1, lens1, sc, sid1, seed=3)
     wantb, wl = hip_default.synthesize(ids_b, lens_b, sc, sid_b, seed=4)
     st0 = hip_default.persist_state()
@@ -1282,7 +1283,60 @@ def test_batch_on_another_stream_does_not_starve_the_persistent_programs(hip_lib
     finally:
         stop.set()
         th.join(120)
+        lib.vits_debug_persist_when(1)
     assert not errs, errs
     st1 = hip_default.persist_state()
     assert st1["timeouts"] == st0["timeouts"], "a persistent program timed out next to a batch on another stream"
     assert st1["launches"] >= st0["launches"] + 2 * n1, "every single-utterance call must have completed its two persistent launches"
+
+
+def test_a_call_takes_the_persistent_programs_only_when_it_starts_alone(hip_lib, hip_default):
+    """Round 6 (profiles/r6_owners.txt): with the default rule a single-utterance host call runs the programs when no other host call is
+    in flight on its device, and the launch path when one is -- same samples either way (1e-4: other kernels, other summation order)."""
+    import threading
+
+    rng = np.random.default_rng(6)
+    sc = np.array([0.667, 1.0, 0.8], np.float32)
+    ids1 = rng.integers(1, 62, size=(1, 50)).astype(np.int64)
+    lens1 = np.array([50], np.int64); sid1 = np.array([2], np.int64)
+    B, T = 16, 200
+    ids_b = rng.integers(1, 62, size=(B, T)).astype(np.int64)
+    lens_b = np.full(B, T, np.int64); sid_b = np.zeros(B, np.int64)
+    lib = hip_lib.lib
+    lib.vits_debug_persist(7)
+    lib.vits_debug_persist_when(1)
+    want1, _ = hip_default.synthesize(ids1, lens1, sc, sid1, seed=3)  # (also warms the buckets)
+    hip_default.synthesize(ids_b, lens_b, sc, sid_b, seed=4)
+    st0 = hip_default.persist_state()
+    for _ in range(5):
+        got, _ = hip_default.synthesize(ids1, lens1, sc, sid1, seed=3)
+        assert np.array_equal(got, want1)
+    st1 = hip_default.persist_state()
+    assert st1["launches"] == st0["launches"] + 10, "alone: two persistent launches per call"
+    stop = threading.Event()
+    errs = []
+
+    def batches():
+        try:
+            while not stop.is_set():
+                hip_default.synthesize(ids_b, lens_b, sc, sid_b, seed=4)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=batches)
+    th.start()
+    try:
+        import time
+
+        time.sleep(0.05)  # the batch loop is running: (almost) every single call now starts next to a batch call
+        n1 = 60
+        for _ in range(n1):
+            got, _ = hip_default.synthesize(ids1, lens1, sc, sid1, seed=3)
+            assert_close("single utterance next to a batch (launch path or programs)", want1, got, 2e-4)
+    finally:
+        stop.set()
+        th.join(120)
+    assert not errs, errs
+    st2 = hip_default.persist_state()
+    assert st2["timeouts"] == st1["timeouts"]
+    assert st2["launches"] - st1["launches"] <= n1, "next to a batch call most single calls must have taken the launch path"

@@ -189,10 +189,8 @@ struct InFlight {
   explicit InFlight(int dev_) : dev(dev_ >= 0 && dev_ < 64 ? dev_ : -1), before(0) { if (dev >= 0) before = g_calls_inflight[dev].fetch_add(1); }
   ~InFlight() { if (dev >= 0) g_calls_inflight[dev].fetch_sub(1); }
 };
-static bool persist_only_alone() {
-  static const bool v = !(getenv("VITS_PERSIST_WHEN") && atoi(getenv("VITS_PERSIST_WHEN")) == 0);
-  return v;
-}
+static std::atomic<int> g_persist_when{getenv("VITS_PERSIST_WHEN") ? atoi(getenv("VITS_PERSIST_WHEN")) : 1};  // 1: alone only; 0: whenever the token is free
+static bool persist_only_alone() { return g_persist_when.load(std::memory_order_relaxed) != 0; }
 // a host call that launches AND waits for its kernels: owns the token (when it is free) from here to its end
 struct PersistScope {
   int dev; bool own;
