@@ -530,7 +530,9 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
       // 1 = by grid size (default), 2 = whenever the window fits (A/B)
       static const int g2w = getenv("VITS_GATE2W") ? atoi(getenv("VITS_GATE2W")) : 1;
       const long nblk64 = (long)cdiv(P.M, 128) * cdiv(P.Tout, 64) * P.B;
-      if (g_force_tile == 0 && g2w && 32 + halo <= 64 && (g2w == 2 || nblk64 <= 1536)) {
+      // (only where the four-wave grid is 2 - 6 workgroups per CU: a 6000-frame single utterance -- 282 four-wave workgroups, about one
+      //  per CU -- is 3 % SLOWER on two-wave tiles, profiles/r6_gate2w_ab.txt)
+      if (g_force_tile == 0 && g2w && 32 + halo <= 64 && (g2w == 2 || (nblk64 >= 512 && nblk64 <= 1536))) {
         ps.set_kernel("conv_mfma_kernel<2,1,2,1,GATE>"); launch_cfg<2, 1, 2, 1, EPI_GATE>(s, P, halo);
       } else {
         ps.set_kernel("conv_mfma_kernel<2,2,2,1,GATE>"); launch_cfg<2, 2, 2, 1, EPI_GATE>(s, P, halo);
