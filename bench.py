@@ -558,12 +558,13 @@ def concurrency_leg(hp, device, seconds=0.4):
                 if co is not None:
                     co.max_inflight = keep_inflight
 
-        out["coalesced"] = [leg(n, True) for n in (1, 4, 16)]
+        threads = tuple(int(v) for v in os.environ.get("BENCH_THREADS", "1,4,16").split(","))  # (tools: other client counts; the line's shape is 1 / 4 / 16)
+        out["coalesced"] = [leg(n, True) for n in threads]
         out["uncoalesced_16_threads"] = leg(16, False)
         if os.environ.get("BENCH_COALESCE_SWEEP"):  # tools: engine calls allowed in flight at once
             out["inflight_sweep_16_threads"] = {str(k): leg(16, True, k) for k in (2, 3, 4, 8)}
         one = out["coalesced"][0]["requests_per_s"]
-        out["speedup_16_threads_over_1"] = round(out["coalesced"][2]["requests_per_s"] / max(one, 1e-9), 2)
+        out["speedup_16_threads_over_1"] = round(out["coalesced"][-1]["requests_per_s"] / max(one, 1e-9), 2)
         sess.close()
     return out
 

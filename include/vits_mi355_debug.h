@@ -38,11 +38,13 @@ void vits_debug_persist(int mask);
  * switches the persistent programs off for a bounded interval (below) and the host entry points run the call again on the launch
  * path (the caller sees a slower call, not an error); an asynchronous device session reports VITS_ERR_DEVICE once. */
 void vits_debug_persist_spin(int limit);
-/* WHEN a host call takes the persistent programs (process-wide; environment VITS_PERSIST_WHEN): 1 (default, round 6) = only a call that
- * starts while no other host call is in flight on its device -- next to other calls' kernels a program is placed late and its spinning
- * workers slow everybody down (profiles/r6_owners.txt: 4 clients 1910 -> 2030 requests/s, p50 2.4 -> 1.9 ms); 0 = whenever the device's
- * program token is free (rounds 3-5).  Device sessions (vits_session_*) take the token for their lifetime either way. */
-void vits_debug_persist_when(int alone_only);
+/* WHEN a host call takes the persistent programs (process-wide; environment VITS_PERSIST_WHEN): a single-utterance call runs them when at
+ * most `max_others_in_flight` OTHER host calls are in flight on its device as it starts (and the device's program token is free).  Default 1
+ * (round 6): next to several other calls' kernels a program is placed late and its spinning workers slow everybody down -- 4 clients
+ * 1910 -> 2030 requests/s, p50 2.4 -> 1.9 ms on launches only -- while with 2 clients "one on the programs, one on launches" wins (1460
+ * against 1240 requests/s); profiles/r6_owners.txt.  0 = only a call that starts alone; -1 = whenever the token is free (rounds 3-5).
+ * Device sessions (vits_session_*) take the token for their lifetime either way. */
+void vits_debug_persist_when(int max_others_in_flight);
 /* Test hook: base re-arm interval in milliseconds (0 = VITS_PERSIST_REARM_MS or 1000). */
 void vits_debug_persist_rearm_ms(int ms);
 /* Test hook: persistent-program launches of this model that ran to completion (no timeout) since vits_create; -1 on error.

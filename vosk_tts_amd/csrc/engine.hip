@@ -538,7 +538,7 @@ void vits_debug_persist(int on) {  // (also arms the programs at once: a test th
   g_persist = on;
   g_ps_off_until_ns.store(0); g_ps_rearm_ns.store(0); g_ps_rearmed_at_ns.store(0);
 }
-void vits_debug_persist_when(int alone_only) { g_persist_when = alone_only ? 1 : 0; }
+void vits_debug_persist_when(int max_others_in_flight) { g_persist_when = max_others_in_flight < -1 ? -1 : max_others_in_flight; }
 void vits_debug_persist_rearm_ms(int ms) {
   g_ps_rearm_base_ns = (ms > 0 ? (long long)ms : (getenv("VITS_PERSIST_REARM_MS") ? atoll(getenv("VITS_PERSIST_REARM_MS")) : 1000)) * 1000000LL;
 }

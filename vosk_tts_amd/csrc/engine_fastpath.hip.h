@@ -263,7 +263,7 @@ static int synth_fast(vits_model* m, const int64_t* ids, const int64_t* lengths,
   const bool forced = opts && opts->forced_durations, solo = opts && (opts->flags & VITS_FLAG_SOLO_BATCH);
   // (declared before the session guard: the call's last stream synchronisation happens before this scope ends)
   InFlight inflight(m->device);
-  PersistScope pscope(B == 1 ? m->device : -1, inflight.before == 0);  // a single utterance takes the persistent stages when it starts alone on its device
+  PersistScope pscope(B == 1 ? m->device : -1, inflight.before);  // a single utterance takes the persistent stages when the device is quiet enough as it starts
   vits_session* F = nullptr;
   {
     int rc = front_acquire(m, B, TxB, &F);

@@ -181,22 +181,26 @@ static void persist_token_release(int dev) {
 // Host calls in flight per device (graph-replayed entry points, every batch size).  Round 6 (profiles/r6_owners.txt): a persistent program
 // needs every CU's whole register file for one of its workgroups, so next to other calls' kernels it is placed late, polls long and --
 // once resident -- keeps 256 CUs' issue slots busy with its spinning workers: with 4 closed-loop clients the launch path alone serves
-// 2040 requests/s at p50 1.9 ms, "one call on the programs, three on launches" 1910 at 2.4 ms.  So a call takes the programs only when
-// it starts ALONE on its device (VITS_PERSIST_WHEN=0: whenever the token is free, the rounds 3-5 rule).
+// 2040 requests/s at p50 1.9 ms, "one call on the programs, three on launches" 1910 at 2.4 ms; with 2 clients it is the other way round
+// (1460 against 1240 requests/s).  So a call takes the programs when at most `g_persist_when` OTHER host calls are in flight on its
+// device as it starts (default 1; VITS_PERSIST_WHEN / vits_debug_persist_when; -1: whenever the token is free, the rounds 3-5 rule).
 static std::atomic<int> g_calls_inflight[64];
 struct InFlight {
   int dev; int before;
   explicit InFlight(int dev_) : dev(dev_ >= 0 && dev_ < 64 ? dev_ : -1), before(0) { if (dev >= 0) before = g_calls_inflight[dev].fetch_add(1); }
   ~InFlight() { if (dev >= 0) g_calls_inflight[dev].fetch_sub(1); }
 };
-static std::atomic<int> g_persist_when{getenv("VITS_PERSIST_WHEN") ? atoi(getenv("VITS_PERSIST_WHEN")) : 1};  // 1: alone only; 0: whenever the token is free
-static bool persist_only_alone() { return g_persist_when.load(std::memory_order_relaxed) != 0; }
+static std::atomic<int> g_persist_when{getenv("VITS_PERSIST_WHEN") ? atoi(getenv("VITS_PERSIST_WHEN")) : 1};
+static bool persist_quiet_enough(int others_in_flight) {
+  const int t = g_persist_when.load(std::memory_order_relaxed);
+  return t < 0 || others_in_flight <= t;
+}
 // a host call that launches AND waits for its kernels: owns the token (when it is free) from here to its end
 struct PersistScope {
   int dev; bool own;
-  explicit PersistScope(int dev_, bool alone = true) : dev(dev_) {
+  explicit PersistScope(int dev_, int others_in_flight = 0) : dev(dev_) {
     const int cfg = persist_cfg();
-    own = cfg != 0 && (alone || !persist_only_alone()) && persist_token_try(dev_);
+    own = cfg != 0 && persist_quiet_enough(others_in_flight) && persist_token_try(dev_);
     tl_persist = own ? cfg : 0;
   }
   void release() { tl_persist = -1; if (own) persist_token_release(dev); own = false; }  // (the caller has waited for its kernels)
