@@ -64,6 +64,10 @@ int vits_debug_decoder_needs(const vits_hparams* hp, int32_t* out, int32_t cap);
 /* Test hook: software-pipelined 64 x 64 conv kernel (conv_sp_kernel, csrc/conv_sp.hip.h): -1 = environment / default (by grid size),
  * 0 = never, 1 = by grid size, 2 = wherever a launch is eligible for it. */
 void vits_debug_conv_sp(int mode);
+/* Test hook: stream-K schedule of the 64 x 64 pipelined tile (conv_sk_kernel, csrc/conv_sk.hip.h; a measured prototype, 8-17 % SLOWER than
+ * the plain launch on s8 / s16, profiles/r6_sk_ab.txt): -1 = environment VITS_SK (default 0 = off), 0 = off, 1 = the launches conv_sp_kernel<STORE>
+ * takes by size, 2 = wherever it is eligible.  A session gets the kernel's exchange buffers the next time its workspace is laid out. */
+void vits_debug_conv_sk(int mode);
 /* Test hook: 1 = a conv_precision == 1 model runs its fp32 kernels instead of the split-bf16 variant (same weights, A/B). */
 void vits_debug_no_bf16x3(int on);
 /* Test hook: 0 = fused exp/sin + iSTFT + PQMF tail kernel (default), 1 = the separate istft / pqmf kernels. */

@@ -619,6 +619,32 @@ def test_full_size_batches_every_item_against_the_oracle(hip_default, oracle_def
     _check_full_size_batch(hip_default, oracle_default, ids, lengths, dur, 32, seed=7 if wl == "c3" else 11)
 
 
+def test_stream_k_prototype_gives_the_plain_launch_results(hip_lib, default_blob, oracle_default):
+    """conv_sk_kernel (csrc/conv_sk.hip.h, round 6: a stream-K schedule of the 64 x 64 pipelined tile -- persistent workgroups, equal-cost
+    contiguous ranges over (tile, stage), partial accumulators exchanged as {value, epoch} cells and added in workgroup order).  A measured
+    prototype that LOSES (profiles/r6_sk_ab.txt) and is off by default; forced here wherever it is eligible: a ragged batch of 8 must equal
+    the oracle, twice (the second forward runs on the epoch the first one published)."""
+    rng = np.random.default_rng(77)
+    hip_lib.lib.vits_debug_conv_sk(2)
+    try:
+        model = hip_lib.create(default_blob, 0)  # fresh sessions: the exchange buffers are allocated when a workspace is laid out
+        ids, lengths = _synthetic_batch(rng, 8, 30, 70)
+        B, Tx = ids.shape
+        sid = rng.integers(0, 200, size=B).astype(np.int64)
+        scales = np.array([0.667, 1.0, 0.8], np.float32)
+        dur = rng.integers(1, 5, size=(B, Tx)).astype(np.int32)
+        Ty = int((dur * (np.arange(Tx)[None] < lengths[:, None])).sum(1).max())
+        noise = rng.standard_normal((B, 192, Ty)).astype(np.float32)
+        a_ref, l_ref = oracle_default.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+        for rep in range(2):
+            a_hip, l_hip = model.synthesize(ids, lengths, scales, sid, noise_prior=noise, forced_durations=dur)
+            assert np.array_equal(l_ref, l_hip)
+            assert_close(f"waveform, stream-K convs (forward {rep})", _valid(a_ref, l_ref), _valid(a_hip, l_hip), E2E_TOL)
+        model.close()
+    finally:
+        hip_lib.lib.vits_debug_conv_sk(-1)
+
+
 def test_padded_batch_of_8_by_200_tokens_equals_the_oracle_on_the_same_padded_batch(hip_default, oracle_default):
     """SURVEY A11 above B = 6: the decoder has no masks, so an item of a padded batch continues into the batch's padding.  The
     engine's ragged path must give, on every valid sample, what the reference's arithmetic gives on the SAME padded batch -- checked

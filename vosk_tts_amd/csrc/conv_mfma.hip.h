@@ -187,16 +187,18 @@ __device__ __forceinline__ void kernarg_warm() {
 // M-tiles of a column tile, which stage the same activation window) would land on ntiles_m different L2s and each fetch the
 // window over the fabric.  Inside every run of 8 * ntiles_m ids, XCD x takes ids [x * ntiles_m, (x + 1) * ntiles_m) in its own
 // dispatch order; the tail that does not fill a run keeps the identity.  The spread of tiles over the XCDs is unchanged.
-__device__ __forceinline__ int conv_pair_mtiles(int ntiles_m) {
-  const int L = blockIdx.x, run = 8 * ntiles_m;
-  if (ntiles_m < 2 || L >= (int)(gridDim.x / run) * run) return L;
+__device__ __forceinline__ int conv_pair_mtiles(int ntiles_m, int L = blockIdx.x, int nblk = gridDim.x) {
+  const int run = 8 * ntiles_m;
+  if (ntiles_m < 2 || L >= (nblk / run) * run) return L;
   const int base = L / run * run, r = L - base, x = r & 7, w = r >> 3;  // w-th workgroup of XCD x inside this run
   return base + x * ntiles_m + w;
 }
-__device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, int& grp, int& nt, int& b) {
+// (Lb / nblk: the block id and grid size to decode for -- the launch's own by default; a persistent kernel that walks VIRTUAL blocks
+//  passes its own, conv_sk.hip.h)
+__device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, int& grp, int& nt, int& b, int Lb = blockIdx.x, int nblk_ = gridDim.x) {
   if (P.tile_start) {
     // plain dispatch order (no XCD-contiguous remap: working tiles must be spread over all XCDs), M-tiles paired per XCD
-    int id = P.xcd_mode == 12 ? (int)blockIdx.x : conv_pair_mtiles(P.ntiles_m);
+    int id = P.xcd_mode == 12 ? Lb : conv_pair_mtiles(P.ntiles_m, Lb, nblk_);
     mt = id % P.ntiles_m; id /= P.ntiles_m;
     const int total = P.tile_start[P.B];
     int q;
@@ -214,7 +216,7 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
     // after the other (profiles/r3_blocktrace_c2.txt), the w-th and (w + 32)-th workgroup of an XCD's stream are CU mates, and the
     // launch lasts as long as the CU with the heaviest pair.  XCD x takes tiles x, x + 8, ... of every group in an order that puts a
     // 3-tap tile under every 11-tap one (14 units) and 7-tap tiles under each other (14) instead of 11 + 7 (18).
-    const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+    const int x = Lb & 7, w = Lb >> 3;
     const int per = P.ntiles_m * P.ntiles_n, n = (per - x + 7) >> 3;  // tiles of one group on this XCD
     const int a = n < 32 ? n : 32;            // first pass over the 32 CUs: 11-tap tiles, then 7-tap ones
     const int b7 = 32 - a < n ? 32 - a : n;   // 7-tap tiles that fit in the first pass
@@ -234,14 +236,14 @@ __device__ __forceinline__ bool conv_decode_block(const ConvParams& P, int& mt, 
   {
     // bijective XCD remap: block L runs on XCD L%8; give each XCD a contiguous range of logical ids so
     // tiles sharing an activation window share an L2
-    const int nblk = gridDim.x, L = blockIdx.x;
+    const int nblk = nblk_, L = Lb;
     const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, within = L >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
   if (P.n_groups > 1) {
     // grouped launch (k = 11/7/3 ResBlocks, sorted heaviest first by the launcher): plain dispatch order
     // with the group outermost, so the long blocks start first and the launch tail is made of short ones
-    id = (P.B > 1 && P.xcd_mode != 12) ? conv_pair_mtiles(P.ntiles_m) : (int)blockIdx.x;  // (one utterance: an XCD keeps its M-tile's weight rows, profiles/r3_xcd_map.txt)
+    id = (P.B > 1 && P.xcd_mode != 12) ? conv_pair_mtiles(P.ntiles_m, Lb, nblk_) : Lb;  // (one utterance: an XCD keeps its M-tile's weight rows, profiles/r3_xcd_map.txt)
     mt = id % P.ntiles_m; id /= P.ntiles_m;
     nt = id % P.ntiles_n; id /= P.ntiles_n;
     b = id % P.B;

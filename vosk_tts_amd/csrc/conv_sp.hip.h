@@ -34,39 +34,27 @@
 // (profiles/r5_conv_sp.txt).  Pitch 20: the 16 lanes of a ds_read_b128 group land on 16 distinct 4-bank groups (20 i mod 64).
 #define SP_PITCH 20
 
-template <int EPI, int JT>
-__global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
+// One 64 x 64 tile's contraction over the stages [s_begin, s_end) of 64 channels (the whole tile: 0 .. C_in / 64; stream-K segments,
+// conv_sk.hip.h: any sub-range) -> the two accumulators of this wave.  false: the tile lies in an item's padding (block-uniform).
+template <int JT>
+__device__ __forceinline__ bool conv_sp_tile(const ConvParams& P, const ConvGroup& G, float* lds, int mt, int nt, int b, int s_begin, int s_end,
+                                             f32x16 (&acc)[2]) {
   constexpr int N_T = 64, M_T = 64;
-  extern __shared__ float lds[];
-  kernarg_warm<sizeof(ConvParams)>();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
-
-  int mt, grp, nt, b;
-  if (!conv_decode_block(P, mt, grp, nt, b)) return;
-  mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);
-  nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
-  const ConvGroup& G = P.g[grp];
-  CONV_DBG_DO(if (P.dbg && tid == 0 && blockIdx.x < 4000) {
-    P.dbg[128 + blockIdx.x * 4 + 0] = wall_clock64();
-    P.dbg[128 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(63492);
-    P.dbg[128 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 20);
-  })
-
   const int ROW = P.row_len;
   const int n0 = nt * N_T, m0 = mt * M_T;
   const int K = G.K, dil = G.dil;
-  const int nstages = P.Cin / SP_STAGE_CH;
   int t_lim = P.Tin;
   if (P.in_mask) { int lb = P.len[b]; t_lim = lb < t_lim ? lb : t_lim; }
   if (P.rag) {
     const int rl = P.rag[b], rc = P.rag[P.B];
-    if (n0 >= conv_rag_limit(rl, rc, P.rag_out_mul, P.rag_out_add, P.rag_out_cap_add)) return;
+    if (n0 >= conv_rag_limit(rl, rc, P.rag_out_mul, P.rag_out_add, P.rag_out_cap_add)) return false;
     const int il = conv_rag_limit(rl, rc, P.rag_in_mul, P.rag_in_add);
     t_lim = il < t_lim ? il : t_lim;
   }
-  if (P.skip_len && n0 >= P.len[b]) return;
+  if (P.skip_len && n0 >= P.len[b]) return false;
 
   // ---- staging: wave w owns stage rows w, w + 4, ..., w + 60; lanes stride over the ROW columns.  With one wave on a SIMD nothing hides
   // a staging pass (it was 30 % of such a workgroup's time, profiles/r5_conv_sp.txt), so the per-element work is cut to what the tile
@@ -116,7 +104,6 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
     }
   };
 
-  f32x16 acc[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
 
@@ -129,7 +116,7 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
 
   // ---- weight ring: slot u holds tap (4 g + u); taps 0..2 requested here, tap q + 3 at tap q
   f32x4 a[4][2];
-  int sg = 0;  // step-group of the next tap to request (2 per tap)
+  int sg = s_begin * 8 * K;  // step-group of the next tap to request (2 per tap, 4 K taps per stage)
   auto request = [&](auto SLOT) {
     constexpr int slot = decltype(SLOT)::value;
     const int sgc = sg < n_sg ? sg : n_sg - 2;  // clamped: a fixed number of loads per tap keeps the waits counted
@@ -140,8 +127,8 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
   using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
   request(S0{}); request(S1{}); request(S2{});
-  load_stage(0);
-  store_stage(0);
+  load_stage(s_begin);
+  store_stage(s_begin & 1);
   __syncthreads();
 
   f32x4 bv[2][2];
@@ -188,12 +175,12 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
   using VS = std::integral_constant<int, (16 * JT + 2 + 7) / 8>;  // + the next stage's 16 JT activation loads
 
   const int ngroups = K;  // 4 K taps per stage, in groups of four
-  for (int s = 0; s < nstages; ++s) {
+  for (int s = s_begin; s < s_end; ++s) {
     lb = lds + (s & 1) * buf_f + (wn * 32 + l31) * SP_PITCH + h * 8;
     kk = 0; jrow = 0;
     read_b(S0{}, true);
     // group 0, peeled: the next stage's activation loads go out with its first tap (straight-line code: exactly counted waits)
-    const bool next = s + 1 < nstages;
+    const bool next = s + 1 < s_end;
     if (next) tap(S0{}, VS{}, true, [&]() { load_stage(s + 1); });
     else tap(S0{}, VW{}, true, nothing);
     tap(S1{}, VW{}, true, nothing);
@@ -210,10 +197,16 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
     __syncthreads();
   }
 
-  // ---- epilogue (shared with conv_mfma_kernel)
-  f32x16 accs[1][1];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) accs[0][0][e] = acc[0][e] + acc[1][e];
+  return true;
+}
+
+// the tile's epilogue on the summed accumulator (shared with conv_mfma_kernel)
+template <int EPI>
+__device__ __forceinline__ void conv_sp_epilogue(const ConvParams& P, const ConvGroup& G, int mt, int nt, int b, f32x16 (&accs)[1][1]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int n0 = nt * 64, m0 = mt * 64;
   const int lenb = (P.out_mask || EPI == EPI_RESSKIP || EPI == EPI_COUPLE) ? P.len[b] : 0x7fffffff;
   if (EPI == EPI_STORE && conv_epilogue_store_fast_ok(P, G)) {
     conv_epilogue_store_fragments<1, 1>(P, G, b, lenb, m0 + wm * 32, n0 + wn * 32, h, l31, accs);
@@ -226,5 +219,29 @@ __global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
       conv_epilogue_frag<EPI, 4>(P, G, b, lenb, m0 + wm * 32 + 4 * h, e0, n0 + wn * 32 + l31, v);
     }
   }
+}
+
+template <int EPI, int JT>
+__global__ void __launch_bounds__(256, 3) conv_sp_kernel(const ConvParams P) {
+  extern __shared__ float lds[];
+  kernarg_warm<sizeof(ConvParams)>();
+  const int tid = threadIdx.x;
+  int mt, grp, nt, b;
+  if (!conv_decode_block(P, mt, grp, nt, b)) return;
+  mt = __builtin_amdgcn_readfirstlane(mt); grp = __builtin_amdgcn_readfirstlane(grp);
+  nt = __builtin_amdgcn_readfirstlane(nt); b = __builtin_amdgcn_readfirstlane(b);
+  const ConvGroup& G = P.g[grp];
+  CONV_DBG_DO(if (P.dbg && tid == 0 && blockIdx.x < 4000) {
+    P.dbg[128 + blockIdx.x * 4 + 0] = wall_clock64();
+    P.dbg[128 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(63492);
+    P.dbg[128 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 20);
+  })
+  f32x16 acc[2];
+  if (!conv_sp_tile<JT>(P, G, lds, mt, nt, b, 0, P.Cin / SP_STAGE_CH, acc)) return;
+  f32x16 accs[1][1];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accs[0][0][e] = acc[0][e] + acc[1][e];
+  conv_sp_epilogue<EPI>(P, G, mt, nt, b, accs);
   CONV_DBG_DO(if (P.dbg && tid == 0 && blockIdx.x < 4000) P.dbg[128 + blockIdx.x * 4 + 1] = wall_clock64();)
+  (void)tid;
 }

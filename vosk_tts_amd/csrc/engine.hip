@@ -36,6 +36,7 @@
 #include "conv_bf3.hip.h"
 #include "kernels_misc.hip.h"
 #include "persist.hip.h"
+#include "conv_sk.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512];
@@ -601,6 +602,7 @@ int vits_debug_decoder_needs(const vits_hparams* hp, int32_t* out, int32_t cap) 
   return (int)v.size();
 }
 void vits_debug_conv_sp(int mode) { g_sp_mode = mode; }
+void vits_debug_conv_sk(int mode) { g_sk_mode = mode; }
 int vits_debug_clock_probe(int device, int32_t duration_us, double* ghz, int32_t n) {
   if (!ghz || n < 1 || n > 1024 || duration_us < 1 || duration_us > 2000000 || device < 0 || device >= 64) return fail(VITS_ERR_ARG, "clock probe: bad arguments");
   HIP_TRY(hipSetDevice(device));

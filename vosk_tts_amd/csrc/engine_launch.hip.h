@@ -385,6 +385,30 @@ static void launch_sp(vits_session* s, ConvParams& P, int halo) {
   if (P.row_len <= 64) hipLaunchKernelGGL((conv_sp_kernel<EPI, 1>), dim3(nblk), dim3(256), lds, s->stream, P);
   else hipLaunchKernelGGL((conv_sp_kernel<EPI, 2>), dim3(nblk), dim3(256), lds, s->stream, P);
 }
+// stream-K schedule of the same tile (conv_sk.hip.h; prototype, VITS_SK): G persistent workgroups, equal-cost contiguous ranges
+static bool sk_takes(vits_session* s, const ConvParams& P, int epi, int halo) {
+  return sk_mode() && epi == EPI_STORE && s && s->sk_ws && s->sk_ctl && conv_sp_ok(P, epi, halo);
+}
+static void launch_sk(vits_session* s, ConvParams& P, int halo) {
+  attach_tile_table(s, P, 64);
+  P.ntiles_m = cdiv(P.M, 64);
+  P.ntiles_n = cdiv(P.Tout, 64);
+  P.row_len = 64 + halo;
+  const long nblk = (long)P.ntiles_m * P.ntiles_n * P.B * P.n_groups;
+  static const int gmax = getenv("VITS_SK_G") ? atoi(getenv("VITS_SK_G")) : 0;
+  long G = gmax > 0 ? gmax : 2L * s->m->n_cu;  // two workgroups per CU are co-resident at every halo (73 KB of LDS at the widest)
+  if (G > SK_SLOTS) G = SK_SLOTS;
+  if (G > nblk) G = nblk;
+  const size_t lds = (size_t)2 * 4 * P.row_len * SP_PITCH * sizeof(float);
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> done1{0}, done2{0};
+    if (P.row_len <= 64) { if (big_lds_needed(done1)) hipFuncSetAttribute((const void*)conv_sk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    else if (big_lds_needed(done2)) hipFuncSetAttribute((const void*)conv_sk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const SkArgs A{s->sk_ctl, s->sk_ws, 1 << 22};
+  if (P.row_len <= 64) hipLaunchKernelGGL((conv_sk_kernel<1>), dim3((unsigned)G), dim3(256), lds, s->stream, P, A);
+  else hipLaunchKernelGGL((conv_sk_kernel<2>), dim3((unsigned)G), dim3(256), lds, s->stream, P, A);
+}
 // the 64 x 64 tile of a launch that was routed to conv_mfma_kernel<2,2,1,1,EPI>: the pipelined kernel when the grid is small
 static bool sp_takes(const ConvParams& P, int epi, int halo) {
   static const long max_blk = getenv("VITS_SP_MAXBLK") ? atol(getenv("VITS_SP_MAXBLK")) : 2048;
@@ -606,6 +630,7 @@ static void launch_conv(vits_session* s, ConvParams& P, int epi, const char* nam
   if (P.M % 64 == 0 && (long)cdiv(P.M, 64) * cdiv(P.Tout, 128) * P.B * P.n_groups >= 256 && bf3_ok()) { bf3_go(1); return; }
   // (64 x 128 fp32 tiles for these convs were measured on the c3 batch in round 4: 2.21 - 2.42 ms against 2.17 ms per forward for the
   //  64 x 64 tiles -- profiles/r4_c3_tile_ab.txt; not a tile-shape problem)
+  if (g_force_tile == 0 && sk_takes(s, P, epi, halo) && (sk_mode() == 2 || sp_takes(P, epi, halo))) { ps.set_kernel("conv_sk_kernel<STORE>"); launch_sk(s, P, halo); return; }
   if (g_force_tile == 0 && sp_takes(P, epi, halo)) { ps.set_kernel("conv_sp_kernel<STORE>"); launch_sp<EPI_STORE>(s, P, halo); return; }
   ps.set_kernel("conv_mfma_kernel<2,2,1,1,STORE>");
   launch_cfg<2, 2, 1, 1, EPI_STORE>(s, P, halo);

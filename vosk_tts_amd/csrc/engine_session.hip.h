@@ -3,6 +3,13 @@
 // planner / launch selection / stages / host paths can be read on their own.
 #pragma once
 // ------------------------------------------------------------------------------------ sessions
+// stream-K prototype switch (conv_sk.hip.h): VITS_SK=1 the launches conv_sp_kernel<STORE> would take by size, 2 wherever it is eligible
+#define SK_SLOTS 1024
+static thread_local int g_sk_mode = -1;  // vits_debug_conv_sk: -1 = environment
+static int sk_mode() {
+  static const int v = getenv("VITS_SK") ? atoi(getenv("VITS_SK")) : 0;
+  return g_sk_mode >= 0 ? g_sk_mode : v;
+}
 // A session owns one HIP stream and a bump-allocated activation workspace sized for
 // (B, T_x, T_y).  vits_synthesize() borrows one from the model's pool, so concurrent calls from
 // the gRPC server's worker threads (server/tts_server.py:39-40,57) never share buffers.
@@ -73,6 +80,9 @@ struct vits_session {
                            // duration predictor, their backs the flow -- cells and records are only laid out / built for those
   bool ps_defer = false;   // the owner calls persist_plan itself after re-pointing shared tensors (backs): session_reserve skips it
   PersistCtl* ps_ctl = nullptr;
+  // stream-K prototype (conv_sk.hip.h, VITS_SK=1): partial-accumulator cells of SK_SLOTS workgroups and the launch epoch block
+  ll_t* sk_ws = nullptr;
+  SkCtl* sk_ctl = nullptr;
   std::vector<std::pair<std::vector<long long>, const float*>> ps_pending;  // parameter packs built by the plan in progress (persist_pack), published after its one stream sync
   const float* ps_bert = nullptr;  // BERT-conditioned voices: the fixed device buffer [bert_dim][Tx] the text-encoder program reads (front sessions: io_d + io_bert)
   bool ps_owner = false;   // device sessions (asynchronous entry point): this session holds the device's persistent-path token for its lifetime
@@ -324,6 +334,14 @@ static int session_reserve(vits_session* s, int B, int Tx, int Ty) {
     hipMemsetAsync(s->arena, 0xFF, s->arena_bytes, s->stream);
     hipStreamSynchronize(s->stream);
   }
+  if (sk_mode() && !s->sk_ws) {  // (outside any capture: the stream-K kernel's exchange buffers, once per session)
+    void* p = nullptr; void* c = nullptr;
+    if (hipMalloc(&p, sizeof(ll_t) * (size_t)SK_SLOTS * SK_CELLS) == hipSuccess && hipMalloc(&c, sizeof(SkCtl)) == hipSuccess) {
+      hipMemsetAsync(p, 0, sizeof(ll_t) * (size_t)SK_SLOTS * SK_CELLS, s->stream);
+      hipMemsetAsync(c, 0, sizeof(SkCtl), s->stream);
+      s->sk_ws = static_cast<ll_t*>(p); s->sk_ctl = static_cast<SkCtl*>(c);
+    } else { if (p) hipFree(p); if (c) hipFree(c); (void)hipGetLastError(); }
+  }
   if (!s->ps_defer) persist_plan(s);  // never fails the reserve: a program that cannot be built leaves its stage on the launch path
   return VITS_OK;
 }
@@ -361,6 +379,8 @@ static void session_free(vits_session* s) {
   for (auto& r : s->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   if (s->arena) hipFree(s->arena);
   if (s->ps_ctl) hipFree(s->ps_ctl);
+  if (s->sk_ws) hipFree(s->sk_ws);
+  if (s->sk_ctl) hipFree(s->sk_ctl);
   for (vits_session::PersistProg* pp : {&s->ps_enc, &s->ps_sdp, &s->ps_flow, &s->ps_front[0], &s->ps_front[1], &s->ps_back, &s->ps_full[0], &s->ps_full[1]}) {
     if (pp->d) hipFree(pp->d);
     if (pp->recs_d) hipFree(pp->recs_d);
