@@ -457,8 +457,9 @@ def streaming_leg(model, ids, lengths, dur, chunk=128, reps=5, warm=4):
         c1 = time.perf_counter()
         assert n == a.shape[1]
         # The first iterations are warm-up: the stream runs the eager stage path on a pooled session and alternates here with the
-        # graph-replayed one-shot call of the same size; until both own their workspaces (2 - 4 opens, tools/stream_warm_probe.py) an open
-        # costs 20 - 30 ms instead of 5 (round 6: with one warm-up iteration the median of five flipped between 5 and 26 ms from run to
+        # graph-replayed one-shot call of the same size; the first opens pay the workspace allocations (11 + 28 ms at this size) and the
+        # first open AFTER the first graph-replayed call pays ~20 ms once more in its first eager launches (tools/stream_warm_probe.py:
+        # VitsSession.warmup(stream_chunk_frames=...) takes both off a server's first requests); an open then costs 5 ms (round 6: with one warm-up iteration the median of five flipped between 5 and 26 ms from run to
         # run).  `warmup_ms` keeps those iterations visible.
         if it >= warm:
             ttfa.append((t1 - t0) * 1e3); total.append((t2 - t0) * 1e3); oneshot.append((c1 - c0) * 1e3)

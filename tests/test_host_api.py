@@ -213,6 +213,47 @@ def test_bert_conditioned_vits_voice_end_to_end_on_gpu(tmp_path, oracle_lib, no_
 
 
 @pytest.mark.gpu
+def test_warmup_can_take_the_first_stream_opens_too(tmp_path):
+    """VitsSession.warmup(stream_chunk_frames=...) (round 6): a stream runs the eager stage path on a pooled session, whose first two opens
+    of a size cost 15 - 40 ms; warmed, the first real stream of that size delivers its first chunk in steady-state time, and its chunks
+    are what the unwarmed model streams."""
+    import gc
+    import time
+
+    from vosk_tts_amd import Model
+    from vosk_tts_amd import weights as W
+    from vosk_tts_amd.toymodel import PHONEMES, write_toy_model
+
+    d = write_toy_model(str(tmp_path / "m"), W.default_hparams(n_vocab=len(PHONEMES)))
+    ids = (np.arange(40, dtype=np.int64)[None] % 20) + 1
+    dur = np.full((1, 40), 3, np.int32)
+    sc = np.array([0.8, 1.0, 0.8], np.float32)
+
+    def first_stream(warm):
+        model = Model(model_path=d, device=0)
+        if warm:
+            calls, _ = model.warmup(max_tokens=40, stream_chunk_frames=32)
+            assert calls >= 5 * (2 + 2)  # five T_x buckets: at least two one-shot calls and two stream opens each
+        gc.collect()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            g = model.onnx._model.stream(ids, sc, 2, chunk_frames=32, forced_durations=dur, seed=4)
+            first = next(g)
+            dt = time.perf_counter() - t0
+            rest = [first] + list(g)
+        finally:
+            gc.enable()
+        model.onnx.close()
+        return dt, np.concatenate(rest)
+
+    cold, a_cold = first_stream(False)
+    warm, a_warm = first_stream(True)
+    assert np.array_equal(a_cold, a_warm)
+    assert warm < 0.6 * cold and warm < 0.01, f"first chunk of the first stream: cold {cold * 1e3:.1f} ms, after warm-up {warm * 1e3:.1f} ms"
+
+
+@pytest.mark.gpu
 def test_warmup_takes_the_capture_cost_off_the_first_request(tmp_path):
     """Model.warmup() (extension): after it the first real request of a warmed size costs what a steady-state request costs, not the
     workspace layout + program build + two graph captures of its bucket; results are unaffected."""

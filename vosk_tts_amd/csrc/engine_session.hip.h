@@ -395,30 +395,10 @@ static void session_free(vits_session* s) {
   delete s;
 }
 
-// Pooled sessions of the eager host entry points (stage calls, noise-injected calls, streams).  Round 6: the caller says which layout it is
-// about to reserve and gets an idle session that already HAS it when there is one -- a server that alternates streams and one-shot eager
-// calls of one utterance size used to re-plan (and re-build the persistent programs of) the one pooled session on every call, ~20 ms each
-// (seen in bench.py's streaming leg: 26 ms to first audio instead of 5 for the first three or four iterations).  Without a match a new
-// session is created while the pool holds fewer than POOL_KEEP idle ones; beyond that the OLDEST idle session is re-planned.
-#define POOL_KEEP 4
-static int pool_acquire(vits_model* m, vits_session** out, int B = 0, int Tx = 0, int Ty = 0, int roles = -1) {
+static int pool_acquire(vits_model* m, vits_session** out) {
   {
     std::lock_guard<std::mutex> g(m->pool_mu);
-    if (B > 0)
-      for (size_t i = m->pool.size(); i-- > 0;) {
-        vits_session* c = m->pool[i];
-        if (c->arena && c->B == B && c->Tx == Tx && c->Ty == Ty && (roles < 0 || c->ps_planned_roles == roles)) {
-          m->pool.erase(m->pool.begin() + (long)i);
-          *out = c;
-          return VITS_OK;
-        }
-      }
-    if (!m->pool.empty() && (B <= 0 || m->pool.size() >= POOL_KEEP)) {
-      const size_t i = B <= 0 ? m->pool.size() - 1 : 0;  // (no layout given: most recently used, as before; else the oldest)
-      *out = m->pool[i];
-      m->pool.erase(m->pool.begin() + (long)i);
-      return VITS_OK;
-    }
+    if (!m->pool.empty()) { *out = m->pool.back(); m->pool.pop_back(); return VITS_OK; }
   }
   return session_new(m, out);
 }

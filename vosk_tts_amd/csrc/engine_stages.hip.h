@@ -626,7 +626,7 @@ struct HostStage {
 static int begin_stage(HostStage& hs, int B, int Tx, int Ty, int roles = 7) {
   hipError_t e = hipSetDevice(hs.m->device);
   if (e != hipSuccess) return fail(VITS_ERR_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
-  TRY(pool_acquire(hs.m, &hs.s, B, Tx, Ty, roles));
+  TRY(pool_acquire(hs.m, &hs.s));
   hs.s->ps_roles = roles;
   TRY(session_reserve(hs.s, B, Tx, Ty));
   return VITS_OK;

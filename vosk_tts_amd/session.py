@@ -418,7 +418,8 @@ class VitsSession:
             forced_durations=None if fd is None else np.asarray(fd)[:, :n], seed=seed,
             bert=None if bert is None else np.ascontiguousarray(np.asarray(bert, np.float32)[:, :, :n]))
 
-    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0, freeze_gc=False, typical_frames_per_token=3.0):
+    def warmup(self, max_tokens=128, frames_per_token=(2.0, 5.0), speaker_id=0, freeze_gc=False, typical_frames_per_token=3.0,
+               stream_chunk_frames=None):
         """Pay the one-off costs of the graph-replayed host path before the first real request does (extension; onnxruntime has the same
         need and no such call): for every T_x bucket (multiples of 8) up to `max_tokens`, the frame buckets (multiples of 32) between
         frames_per_token[0] and [1] frames per token that lie closest to `typical_frames_per_token` -- at most BACK_SESSIONS_PER_FRONT - 1
@@ -426,6 +427,9 @@ class VitsSession:
         the persistent programs and captures the front / back graphs of those (T_x, T_y) buckets -- plus one free-running call.
         Returns (calls, seconds).  Requests outside the warmed buckets still work; they pay their bucket's capture (tens of
         milliseconds) on first use.
+        stream_chunk_frames=<n> also opens and drains a stream (run_stream's engine path) of every T_x bucket TWICE, at the typical frame
+        count: streams run the eager stage path on a pooled session, and the first two opens of a size cost 15 - 40 ms instead of the
+        steady 5 (workspace allocation, then one more slow open after the first graph-replayed call: tools/stream_warm_probe.py).
         freeze_gc=True additionally runs gc.collect() + gc.freeze() at the end: CPython's older-generation passes over the heap of a
         process that has loaded its models stop every thread for tens of milliseconds (25-60 ms measured beside 1 ms requests,
         profiles/r5_m2_gc.txt); frozen, that heap is no longer traversed and the collector only looks at what requests allocate.
@@ -457,6 +461,14 @@ class VitsSession:
                     dur[0, :ty % tx] += 1
                 self._model.synthesize_pcm16(ids, lens, scales, sid, forced_durations=dur, seed=1, bert=bert)
                 calls += 1
+            if stream_chunk_frames:
+                ty = max(1, int(round(typical_frames_per_token * tx)))
+                dur = np.full((1, tx), ty // tx, np.int32)
+                dur[0, :ty % tx] += 1
+                for _ in range(2):
+                    for _chunk in self._model.stream(ids, scales, speaker_id, chunk_frames=int(stream_chunk_frames), forced_durations=dur, seed=1, bert=bert):
+                        pass
+                    calls += 1
         if freeze_gc:
             import gc
 
