@@ -668,6 +668,51 @@ def test_request_coalescer_gather_window_and_promotion():
     assert dt / 20 < 0.0045 and lone.gathered == 0, "a lone client must never wait for stragglers"
 
 
+def test_warmup_walks_at_most_the_engines_frame_bucket_cap_and_ends_on_the_likeliest_bucket():
+    """Round-5 advisor finding (CPU: a stub model records the calls): the engine keeps 6 frame-bucket contexts per T_x bucket and evicts the
+    least recently used, so warming every bucket between 2 and 5 frames per token (13 at T_x = 128) freed the first ones again.  warmup now
+    warms at most BACK_SESSIONS_PER_FRONT - 1 pinned buckets per T_x, the ones closest to `typical_frames_per_token`, farthest first, then
+    one free-running call; with stream_chunk_frames two stream opens per T_x bucket follow."""
+    from vosk_tts_amd import session as S
+
+    class Stub:
+        def __init__(self):
+            self.calls = []
+
+        def synthesize_pcm16(self, ids, lens, scales, sid, forced_durations=None, seed=0, bert=None):
+            self.calls.append(("pcm", ids.shape[1], None if forced_durations is None else int(forced_durations.sum())))
+
+        def stream(self, ids, scales, sid, chunk_frames=64, forced_durations=None, seed=0, bert=None):
+            self.calls.append(("stream", ids.shape[1], int(forced_durations.sum()), chunk_frames))
+            return iter(())
+
+    class HP:
+        bert_dim = 0
+
+    sess = object.__new__(S.VitsSession)
+    sess._model, sess.hp = Stub(), HP()
+    calls, _ = sess.warmup(max_tokens=128)
+    per_tx = {}
+    for kind, tx, ty in sess._model.calls:
+        per_tx.setdefault(tx, []).append(ty)
+    assert sorted(per_tx) == list(range(8, 129, 8)) and calls == len(sess._model.calls)
+    for tx, tys in per_tx.items():
+        pinned = tys[:-1]
+        assert tys[-1] is None, "the free-running call comes last"
+        assert 1 <= len(pinned) <= S.BACK_SESSIONS_PER_FRONT - 1
+        assert all(ty % 32 == 0 and ty >= 32 for ty in pinned)
+        dist = [abs(ty - 3.0 * tx) for ty in pinned]
+        assert dist == sorted(dist, reverse=True), "farthest bucket first, the likeliest one most recently used"
+        assert dist[-1] <= 32, "the bucket around 3 frames per token is among them"
+    assert len(per_tx[128]) == S.BACK_SESSIONS_PER_FRONT  # 13 candidate buckets at T_x = 128: five pinned + the free-running call
+    # streams: two opens per T_x bucket at the typical frame count, after that bucket's one-shot calls
+    sess._model.calls.clear()
+    sess.warmup(max_tokens=16, stream_chunk_frames=32)
+    kinds = [c[0] for c in sess._model.calls]
+    assert kinds.count("stream") == 4 and kinds[-2:] == ["stream", "stream"]
+    assert [c for c in sess._model.calls if c[0] == "stream"][0][1:] == (8, 24, 32)
+
+
 def test_session_does_not_slice_by_an_unvalidated_length():
     """VitsSession._coalescable (no GPU needed): input_lengths outside (0, T] must not be used to slice the ids -- such a request is
     not merged and takes the direct call, whose C-side check answers VITS_ERR_ARG."""
