@@ -194,6 +194,11 @@ def test_bench_eight_rank_dry_run():
     assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and len(d["rank_ms"]) == 8 and len(d["rank_persistent_launches_per_forward"]) == 8
     assert d["ms_per_step"] >= 8.0 and d["rank_ms"][7] >= 8.0 > d["rank_ms"][0]
     assert d["batch256_requests_seen"] == 256
+    # round 6: the work plan_shards deals to every rank, so that the first real 8-GPU run can be checked against it
+    pr = d["batch256_predicted"]
+    assert len(pr["valid_frames_per_rank"]) == 8 and len(pr["padded_frames_per_rank"]) == 8
+    assert 1.0 <= pr["imbalance_valid_max_over_mean"] < 1.01 and 1.0 <= pr["imbalance_padded_max_over_mean"] < 1.05
+    assert "gc" in d
     import bench as B
 
     for rank in range(8):  # the real leg's shard of every rank: 32 requests each, all 256 covered
